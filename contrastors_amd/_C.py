@@ -1,0 +1,134 @@
+"""ctypes binding of libcontrastors_hip.so (the C-ABI declared in include/contrastors_hip.h).
+
+There is NO fallback: if the shared object is missing or a symbol is absent, importing/using this module raises.
+The product path never routes through oracle/ or any CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("CONTRASTORS_HIP_LIB", _PKG / "lib" / "libcontrastors_hip.so"))
+
+CX_OK = 0
+_ERR = {-1: "CX_ERR_SHAPE", -2: "CX_ERR_ALIGN", -3: "CX_ERR_ARG", -4: "CX_ERR_LAUNCH"}
+
+vp = C.c_void_p
+i32 = C.c_int
+i64 = C.c_long
+f32 = C.c_float
+
+
+class CxLayerWeights(C.Structure):
+    _fields_ = (
+        [(n, vp) for n in ("Wqkv", "Wout", "Wfc1", "Wfc2", "WqkvT", "WoutT", "Wfc1T", "Wfc2T")]
+        + [(n, vp) for n in ("bqkv", "bout", "bfc1", "bfc2")]
+        + [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+        + [(n, vp) for n in ("gWqkv", "gWout", "gWfc1", "gWfc2")]
+        + [(n, vp) for n in ("gbqkv", "gbout", "gbfc1", "gbfc2")]
+        + [(n, vp) for n in ("gln1_g", "gln1_b", "gln2_g", "gln2_b")]
+    )
+
+
+class CxEncoderDesc(C.Structure):
+    _fields_ = [
+        ("n_layer", i32), ("d", i32), ("n_head", i32), ("d_inner", i32), ("gated", i32),
+        ("vocab", i32), ("max_pos", i32), ("padding_idx", i32),
+        ("ln_eps", f32), ("softmax_scale", f32),
+        ("word_emb", vp), ("type_emb", vp), ("pos_emb", vp),
+        ("emb_ln_g", vp), ("emb_ln_b", vp),
+        ("gword_emb", vp), ("gtype_emb", vp), ("gpos_emb", vp), ("gemb_ln_g", vp), ("gemb_ln_b", vp),
+        ("rot_cos", vp), ("rot_sin", vp),
+        ("layers", C.POINTER(CxLayerWeights)),
+        ("pool_mode", i32), ("normalize", i32),
+    ]
+
+
+class CxChunkBuffers(C.Structure):
+    _fields_ = [("T_cap", i64)] + [
+        (n, vp)
+        for n in (
+            "h0", "emb_mean", "emb_rstd", "qkv", "ctx", "lse", "z1", "h1", "mean1", "rstd1", "yg", "act", "z2",
+            "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
+        )
+    ]
+
+
+# name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.
+_SIGS = {
+    "cx_abi_version": (i32, []),
+    "cx_build_info": (C.c_char_p, []),
+    "cx_error_string": (C.c_char_p, [i32]),
+    "cx_gemm_bf16_nt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "cx_gemm_set_glds": (None, [i32]),
+    "cx_gemm_get_glds": (i32, []),
+    "cx_transpose_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
+    "cx_cast_transpose_f32_to_bf16": (i32, [vp, vp, i32, i32, vp]),
+    "cx_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
+    "cx_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "cx_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "cx_embed_ln_bwd": (i32, [vp] * 15 + [i32, i32, i32, i32, vp]),
+    "cx_swiglu_fwd": (i32, [vp, vp, i32, i32, vp]),
+    "cx_swiglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cx_bias_gelu_fwd": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cx_bias_gelu_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
+    "cx_rotary_qkv_inplace": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_pool_normalize_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cx_pool_normalize_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cx_infonce_ws_floats": (i64, [i32, i32]),
+    "cx_infonce_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_infonce_bwd": (i32, [vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_sgemm_nt": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "cx_transpose_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "cx_encoder_forward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
+                                 i32, i32, vp, vp]),
+    "cx_encoder_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
+                                  i32, vp, vp, vp]),
+    "cx_probe_mfma_layout": (i32, [vp, vp]),
+    "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library with typed entry points.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m contrastors_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        h = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != CX_OK:
+        raise RuntimeError(f"contrastors_hip: {what or 'call'} failed with {_ERR.get(rc, rc)}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def cur_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

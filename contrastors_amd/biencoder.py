@@ -1,0 +1,153 @@
+"""BiEncoder / LogitScale / DualEncoder on the native engine (host-side mirror of
+sc/models/biencoder/modeling_biencoder.py:30-41,44-49,79-90,282-319, configuration_biencoder.py and
+sc/models/dual_encoder/modeling_dual_encoder.py:36-68).
+
+`BiEncoder(config).forward(input_ids, attention_mask, normalize)` -> {"embedding": (B,d) fp32}: same call and
+result contract as the reference; trunk + pooling + L2-normalise are one native call (NomicBertEngine).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .distributed import gather_with_grad
+from .nomic_bert import NomicBertConfig, NomicBertEngine, VarlenBatch, _EncodeFn
+
+
+@dataclass
+class BiEncoderConfig:
+    """sc/models/biencoder/configuration_biencoder.py:4-31 (same field names and defaults)."""
+
+    model_name: str = "nomic-ai/nomic-bert-2048"
+    projection_dim: Optional[int] = None
+    logit_scale: float = 1 / 0.07
+    use_fused_kernels: bool = True
+    pooling: str = "last"
+    nomic_encoder: bool = False
+    freeze: bool = False
+    trainable_logit_scale: bool = False
+    hamming: bool = False
+    pretrained: bool = False
+    gradient_checkpointing: bool = False
+    encoder: bool = True
+    seq_len: int = 2048
+    trunk_config: Optional[NomicBertConfig] = None  # no hub access: the architecture is given explicitly
+
+
+class LogitScale(torch.nn.Module):
+    """x * exp(log_scale) (sc/models/biencoder/modeling_biencoder.py:30-41)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.logit_scale = torch.nn.Parameter(torch.ones([]) * np.log(config.logit_scale),
+                                              requires_grad=config.trainable_logit_scale)
+        # host copy of a frozen scale: lets the fused loss avoid a device sync per step
+        self._const_scale = None if config.trainable_logit_scale else float(config.logit_scale)
+
+    def forward(self, x):
+        return x * self.logit_scale.exp()
+
+    def __repr__(self):
+        return f"LogitScale(logit_scale={self.logit_scale.exp().item()}, trainable={self.logit_scale.requires_grad})"
+
+
+def _default_trunk_config(name: str) -> NomicBertConfig:
+    if "nomic" in name:
+        return NomicBertConfig.nomic_bert_2048()
+    if "bert-base" in name:
+        return NomicBertConfig.bert_base_uncased()
+    raise ValueError(f"no offline architecture table entry for {name!r}; pass BiEncoderConfig.trunk_config")
+
+
+class BiEncoder(torch.nn.Module):
+    def __init__(self, config: BiEncoderConfig, device="cuda", seed: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        if not config.encoder:
+            raise NotImplementedError("decoder trunks are out of the hot-path scope (SURVEY.md §2a #15)")
+        if config.pooling not in ("mean", "cls"):
+            raise NotImplementedError(f"pooling={config.pooling!r}")
+        trunk_cfg = config.trunk_config or _default_trunk_config(config.model_name)
+        self.trunk = NomicBertEngine(trunk_cfg, device=device, pooling=config.pooling, normalize=True, seed=seed)
+        self.frozen_trunk = bool(config.freeze)
+        if self.frozen_trunk:
+            self.trunk.eval()
+            for p in self.trunk.parameters():
+                p.requires_grad = False
+        d = trunk_cfg.n_embd
+        self.proj = torch.nn.Linear(d, config.projection_dim).to(device) if config.projection_dim else torch.nn.Identity()
+        self.hamming = bool(config.hamming)
+
+    @property
+    def device(self):
+        return self.trunk.device_
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if self.frozen_trunk:
+            self.trunk.eval()
+        return self
+
+    def forward(self, input_ids, attention_mask=None, is_padded_inputs=True, normalize=True, binarize=False,
+                seqlens=None, **kwargs):
+        plain = (not self.hamming) and isinstance(self.proj, torch.nn.Identity) and not binarize
+        eng_norm = bool(normalize) and plain
+        if seqlens is not None:
+            vb = VarlenBatch.from_lengths(input_ids, seqlens)
+        else:
+            vb = VarlenBatch.from_mask(input_ids, attention_mask)
+        if torch.is_grad_enabled() and self.training and not self.frozen_trunk:
+            emb = _EncodeFn.apply(self.trunk.flat_decay, self.trunk, vb, eng_norm)
+        else:
+            emb, _ = self.trunk.forward_chunk(vb, False, eng_norm)
+        if not plain:
+            if self.hamming:  # LayerNorm without affine on the pooled vector (modeling_biencoder.py:282-285,307)
+                emb = F.layer_norm(emb, (emb.shape[-1],))
+            emb = self.proj(emb)
+            if binarize:
+                emb = (emb > 0).float()
+            elif normalize:
+                emb = F.normalize(emb, dim=-1)
+        return {"embedding": emb, "router_logits": None, "router_loss": None, "tokens_per_expert": None}
+
+    # ---- data-parallel plumbing (what DDP does for the reference, sc/trainers/text_text.py:163-180) -------------
+    def sync_gradients(self):
+        """Average the flat gradient buffer over ranks: ONE all-reduce over RCCL/xGMI per optimizer step."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            W = dist.get_world_size()
+            dist.all_reduce(self.trunk.flat_grad, op=dist.ReduceOp.SUM)
+            self.trunk.flat_grad.div_(W)
+            for p in self.proj.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                    p.grad.div_(W)
+
+    def broadcast_parameters(self, src: int = 0):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.trunk.flat_param, src)
+            for p in self.proj.parameters():
+                dist.broadcast(p.data, src)
+            self.trunk.sync_shadows()
+
+    def no_sync(self):  # API parity with DDP-wrapped towers (sc/loss.py:151); reduction is explicit here
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def param_groups(self, weight_decay: float):
+        """decay / no-decay groups of sc/optimizer.py:16-25 over the flat buffers."""
+        groups = [{"params": [self.trunk.flat_decay], "weight_decay": weight_decay},
+                  {"params": [self.trunk.flat_nodecay], "weight_decay": 0.0}]
+        proj_w = [p for n, p in self.proj.named_parameters() if p.ndim >= 2]
+        proj_b = [p for n, p in self.proj.named_parameters() if p.ndim < 2]
+        if proj_w:
+            groups[0]["params"] += proj_w
+        if proj_b:
+            groups[1]["params"] += proj_b
+        return groups

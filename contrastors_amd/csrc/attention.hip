@@ -1,0 +1,598 @@
+// attention.hip -- K1/K2 (+K11 fused) of SURVEY.md §2b: non-causal variable-length self-attention forward and
+// backward for head_dim 64 on CDNA4 matrix cores.  Replaces flash_attn_varlen_qkvpacked_func at
+// sc/layers/attention.py:172-182 and the rotary pass sc/layers/embedding.py:685-706 (rotation is applied while
+// the Q/K tiles are staged into LDS, so q/k never make an extra HBM round trip).
+//
+// Layout idea (all three kernels): the softmax row index is kept in the LANE dimension of every MFMA result.
+//   forward / dQ:  S^T[key][q] = mfma(A=K rows, B=Q rows)   -> lane = q, 16 keys per lane in registers
+//                  O^T[d][q]  += mfma(A=V^T rows, B=P)       -> lane = q again: rescale/LSE are lane-local
+//   dK/dV:         S[q][key]   = mfma(A=Q rows, B=K rows)    -> lane = key, accumulate dK^T/dV^T[d][key]
+// The MFMA accumulator register r of lane-half hi holds row (r&3)+8*(r>>2)+4*hi; feeding registers 8h..8h+7
+// straight back as the next MFMA's B fragment only permutes the reduction index, provided the A fragment is
+// read with the same permutation: rows {4hi..4hi+3, 8+4hi..8+4hi+3} (+16h) of a TRANSPOSED LDS tile
+// (two ds_read_b64).  Transposed tiles are built while staging (pairs of rows packed into 32-bit LDS writes).
+#include "cx_common.h"
+#include "../../include/contrastors_hip.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int TSTRIDE = 136;  // bytes per row of a transposed [64 d][64 idx] tile (+8 B pad: conflict-free b64 reads)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+CX_DEVICE void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = bf16lo_to_f32(v.x); f[1] = bf16hi_to_f32(v.x);
+    f[2] = bf16lo_to_f32(v.y); f[3] = bf16hi_to_f32(v.y);
+    f[4] = bf16lo_to_f32(v.z); f[5] = bf16hi_to_f32(v.z);
+    f[6] = bf16lo_to_f32(v.w); f[7] = bf16hi_to_f32(v.w);
+}
+CX_DEVICE uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+CX_DEVICE uint16_t elem16(const uint4& v, int e) {
+    const uint32_t w = (e < 2) ? v.x : (e < 4) ? v.y : (e < 6) ? v.z : v.w;
+    return (uint16_t)((e & 1) ? (w >> 16) : (w & 0xffffu));
+}
+
+// Load chunks cp and cp+4 (8 bf16 each) of one 64-wide head row and apply the non-interleaved rotation at
+// position `pos` (fp32 math, one bf16 rounding -- same as the reference op).
+CX_DEVICE void load_row_pair(const bf16_t* row, int cp, const float* cosv, const float* sinv, int pos, uint4& lo,
+                             uint4& hi) {
+    lo = *reinterpret_cast<const uint4*>(row + cp * 8);
+    hi = *reinterpret_cast<const uint4*>(row + 32 + cp * 8);
+    if (cosv) {
+        float x1[8], x2[8], o1[8], o2[8];
+        unpack8(lo, x1);
+        unpack8(hi, x2);
+        const float* c = cosv + (size_t)pos * 32 + cp * 8;
+        const float* s = sinv + (size_t)pos * 32 + cp * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o1[e] = x1[e] * c[e] - x2[e] * s[e];
+            o2[e] = x2[e] * c[e] + x1[e] * s[e];
+        }
+        lo = pack8(o1);
+        hi = pack8(o2);
+    }
+}
+
+// Write the 8 columns [c8, c8+8) of rows (2*kp, 2*kp+1) into a transposed tile: T[d][idx] at byte d*TSTRIDE+idx*2.
+CX_DEVICE void write_transposed_pair(char* tile, int kp, int c8, const uint4& r0, const uint4& r1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w = (uint32_t)elem16(r0, e) | ((uint32_t)elem16(r1, e) << 16);
+        *reinterpret_cast<uint32_t*>(tile + (c8 + e) * TSTRIDE + kp * 4) = w;
+    }
+}
+
+// A-fragment of a transposed tile for reduction block `blk16` (16 indices): lane (d, hi) gets indices
+// base+{0..3} and base+8+{0..3}, base = blk16*16 + 4*hi  (matches accumulator registers 8h..8h+7, see header).
+CX_DEVICE bf16x8_t read_transposed_frag(const char* tile, int d, int blk16, int hi) {
+    const char* p = tile + d * TSTRIDE + (blk16 * 16 + 4 * hi) * 2;
+    union {
+        uint2 u[2];
+        bf16x8_t v;
+    } x;
+    x.u[0] = *reinterpret_cast<const uint2*>(p);
+    x.u[1] = *reinterpret_cast<const uint2*>(p + 16);
+    return x.v;
+}
+
+// accumulator registers 8*half .. 8*half+7 -> bf16 B fragment
+CX_DEVICE bf16x8_t pack_frag(const float (&v)[16], int half) {
+    union {
+        uint32_t u[4];
+        bf16x8_t v;
+    } x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x.u[e] = pack_bf16x2(v[8 * half + 2 * e], v[8 * half + 2 * e + 1]);
+    return x.v;
+}
+
+struct AttnParams {
+    const bf16_t* qkv;     // (T,3,H,64)
+    const int32_t* cu;
+    const float* cosv;
+    const float* sinv;
+    bf16_t* out;           // (T,H,64)            [fwd out / bwd: forward output]
+    float* lse;            // (H,T)
+    const bf16_t* dout;    // (T,H,64)
+    float* delta;          // (H,T)
+    bf16_t* dqkv;          // (T,3,H,64)
+    int H, T;
+    float scale;
+};
+
+// ---------------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[16384 + 8192 + 64 * TSTRIDE];
+    char* Qs = smem;
+    char* Ks = smem + 16384;
+    char* Vt = smem + 16384 + 8192;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= len) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+
+    // stage (rotated) Q tile
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        const int r = pss * 64 + (tid >> 2), cp = tid & 3;
+        int tq = q0 + r;
+        tq = tq < len ? tq : len - 1;
+        uint4 lo, hi4;
+        load_row_pair(qbase + (size_t)(t0 + tq) * tok_stride, cp, p.cosv, p.sinv, tq, lo, hi4);
+        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = lo;
+        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = hi4;
+    }
+    __syncthreads();
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
+
+    const float sc2 = p.scale * LOG2E;
+    float m_run = -1e30f, l_run = 0.f;
+    f32x16_t acc_o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+
+    for (int kv0 = 0; kv0 < len; kv0 += 64) {
+        {   // K tile (rotated, row-major): 64 rows x 4 chunk pairs = one item per thread
+            const int r = tid >> 2, cp = tid & 3;
+            int tk = kv0 + r;
+            tk = tk < len ? tk : len - 1;
+            uint4 lo, hi4;
+            load_row_pair(kbase + (size_t)(t0 + tk) * tok_stride, cp, p.cosv, p.sinv, tk, lo, hi4);
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
+        }
+        {   // V tile, transposed: thread = (key pair, 8-column chunk)
+            const int kp = tid >> 3, c = tid & 7;
+            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
+            k0i = k0i < len ? k0i : len - 1;
+            k1i = k1i < len ? k1i : len - 1;
+            const uint4 r0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k0i) * tok_stride + c * 8);
+            const uint4 r1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k1i) * tok_stride + c * 8);
+            write_transposed_pair(Vt, kp, c * 8, r0, r1);
+        }
+        __syncthreads();
+
+        float s[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + kb * 32 + acc_row(r, hi);
+                s[kb][r] = key < len ? a[r] * sc2 : -INFINITY;
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[kb][r] = exp2f(s[kb][r] - m_new);
+                psum += s[kb][r];
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8_t pf = pack_frag(s[kb], half);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    acc_o[db] =
+                        mfma_bf16_32x32x16(read_transposed_frag(Vt, db * 32 + l31, kb * 2 + half, hi), pf, acc_o[db]);
+            }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    const int q = q0 + wave * 32 + l31;
+    if (q < len) {
+        bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
+                pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
+            }
+        if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (m_run + log2f(l_tot)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------- delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+    const long total = (long)p.T * p.H * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long th = i >> 3;
+        const int c = (int)(i & 7);
+        float a[8], bq[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.dout + th * DH + c * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(p.out + th * DH + c * 8), bq);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += a[e] * bq[e];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (c == 0) {
+            const long t = th / p.H;
+            const int hh = (int)(th - t * p.H);
+            p.delta[(size_t)hh * p.T + t] = s;
+        }
+    }
+}
+
+// Inverse rotation of a gradient held as acc[0] (d < 32) / acc[1] (d >= 32), then scaled bf16 store of one head row.
+CX_DEVICE void store_unrotated(bf16_t* row, const f32x16_t (&acc)[2], float scale, const float* cosv,
+                               const float* sinv, int pos, int hi) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const int d = 8 * qd + 4 * hi;
+        float lo[4], hh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = acc[0][4 * qd + e] * scale;
+            hh[e] = acc[1][4 * qd + e] * scale;
+        }
+        if (cosv) {
+            const float4 c = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + d);
+            const float4 s = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + d);
+            const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gl = lo[e], gh = hh[e];
+                lo[e] = gl * cc[e] + gh * ss[e];
+                hh[e] = gh * cc[e] - gl * ss[e];
+            }
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(lo[0], lo[1]);
+        pk.y = pack_bf16x2(lo[2], lo[3]);
+        *reinterpret_cast<uint2*>(row + d) = pk;
+        pk.x = pack_bf16x2(hh[0], hh[1]);
+        pk.y = pack_bf16x2(hh[2], hh[3]);
+        *reinterpret_cast<uint2*>(row + 32 + d) = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- dQ
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+    // Qs/dOs are only needed to build the loop-invariant register fragments; the K/V/Kt tiles alias them.
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= len) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const size_t o_stride = (size_t)p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const bf16_t* dobase = p.dout + (size_t)h * DH;
+
+    {
+        char* Qs = smem;
+        char* dOs = smem + 16384;
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int r = pss * 64 + (tid >> 2), cp = tid & 3;
+            int tq = q0 + r;
+            tq = tq < len ? tq : len - 1;
+            uint4 lo, hi4;
+            load_row_pair(qbase + (size_t)(t0 + tq) * tok_stride, cp, p.cosv, p.sinv, tq, lo, hi4);
+            *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = hi4;
+            load_row_pair(dobase + (size_t)(t0 + tq) * o_stride, cp, nullptr, nullptr, 0, lo, hi4);
+            *reinterpret_cast<uint4*>(dOs + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(dOs + tile64_off(r, cp + 4)) = hi4;
+        }
+    }
+    __syncthreads();
+    bf16x8_t qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = lds_read_frag(smem, tile64_off(wave * 32 + l31, ks * 2 + hi));
+        dof[ks] = lds_read_frag(smem + 16384, tile64_off(wave * 32 + l31, ks * 2 + hi));
+    }
+    __syncthreads();
+
+    char* Ks = smem;
+    char* Vs = smem + 8192;
+    char* Kt = smem + 16384;
+    const int q = q0 + wave * 32 + l31;
+    const int qc = q < len ? q : len - 1;
+    const float lse2 = p.lse[(size_t)h * p.T + t0 + qc] * LOG2E;
+    const float dl = p.delta[(size_t)h * p.T + t0 + qc];
+    const float sc2 = p.scale * LOG2E;
+
+    f32x16_t acc_dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
+
+    for (int kv0 = 0; kv0 < len; kv0 += 64) {
+        if (wave < 2) {  // K: rotated, row-major + transposed.  item = (key pair, chunk pair)
+            const int kp = tid >> 2, cp = tid & 3;
+            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
+            k0i = k0i < len ? k0i : len - 1;
+            k1i = k1i < len ? k1i : len - 1;
+            uint4 a_lo, a_hi, b_lo, b_hi;
+            load_row_pair(kbase + (size_t)(t0 + k0i) * tok_stride, cp, p.cosv, p.sinv, k0i, a_lo, a_hi);
+            load_row_pair(kbase + (size_t)(t0 + k1i) * tok_stride, cp, p.cosv, p.sinv, k1i, b_lo, b_hi);
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp)) = a_lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp + 4)) = a_hi;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp)) = b_lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp + 4)) = b_hi;
+            write_transposed_pair(Kt, kp, cp * 8, a_lo, b_lo);
+            write_transposed_pair(Kt, kp, 32 + cp * 8, a_hi, b_hi);
+        } else {  // V row-major: 64 rows x 8 chunks over 128 threads
+            const int t2 = tid - 128;
+#pragma unroll
+            for (int pss = 0; pss < 4; ++pss) {
+                const int r = pss * 16 + (t2 >> 3), c = t2 & 7;
+                int tk = kv0 + r;
+                tk = tk < len ? tk : len - 1;
+                *reinterpret_cast<uint4*>(Vs + tile64_off(r, c)) =
+                    *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + tk) * tok_stride + c * 8);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t a_s, a_dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                a_s = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a_s);
+                a_dp = mfma_bf16_32x32x16(lds_read_frag(Vs, tile64_off(kb * 32 + l31, ks * 2 + hi)), dof[ks], a_dp);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + kb * 32 + acc_row(r, hi);
+                const float pr = key < len ? exp2f(a_s[r] * sc2 - lse2) : 0.f;
+                ds[r] = pr * (a_dp[r] - dl);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8_t dsf = pack_frag(ds, half);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    acc_dq[db] = mfma_bf16_32x32x16(read_transposed_frag(Kt, db * 32 + l31, kb * 2 + half, hi), dsf,
+                                                    acc_dq[db]);
+            }
+        }
+        __syncthreads();
+    }
+    if (q < len)
+        store_unrotated(p.dqkv + (size_t)(t0 + q) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, q,
+                        hi);
+}
+
+// ---------------------------------------------------------------------------------------------------- dK, dV
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+    // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | Qt | dOt | lse[64] | delta[64]
+    __shared__ __attribute__((aligned(16))) char smem[16384 + 2 * 64 * TSTRIDE + 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    const int k0 = blockIdx.x * 128;
+    if (k0 >= len) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const size_t o_stride = (size_t)p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const bf16_t* dobase = p.dout + (size_t)h * DH;
+
+    {
+        char* Ks = smem;
+        char* Vs = smem + 16384;
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int r = pss * 64 + (tid >> 2), cp = tid & 3;
+            int tk = k0 + r;
+            tk = tk < len ? tk : len - 1;
+            uint4 lo, hi4;
+            load_row_pair(kbase + (size_t)(t0 + tk) * tok_stride, cp, p.cosv, p.sinv, tk, lo, hi4);
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
+            load_row_pair(vbase + (size_t)(t0 + tk) * tok_stride, cp, nullptr, nullptr, 0, lo, hi4);
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp + 4)) = hi4;
+        }
+    }
+    __syncthreads();
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = lds_read_frag(smem, tile64_off(wave * 32 + l31, ks * 2 + hi));
+        vf[ks] = lds_read_frag(smem + 16384, tile64_off(wave * 32 + l31, ks * 2 + hi));
+    }
+    __syncthreads();
+
+    char* Qs = smem;
+    char* dOs = smem + 8192;
+    char* Qt = smem + 16384;
+    char* dOt = Qt + 64 * TSTRIDE;
+    float* lse_s = reinterpret_cast<float*>(dOt + 64 * TSTRIDE);
+    float* dl_s = lse_s + 64;
+
+    const int key = k0 + wave * 32 + l31;
+    const bool key_ok = key < len;
+    const float sc2 = p.scale * LOG2E;
+    f32x16_t acc_dk[2], acc_dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
+
+    for (int q0 = 0; q0 < len; q0 += 64) {
+        if (wave < 2) {  // Q rotated: row-major + transposed; item = (row pair, chunk pair)
+            const int rp = tid >> 2, cp = tid & 3;
+            int r0i = q0 + 2 * rp, r1i = r0i + 1;
+            r0i = r0i < len ? r0i : len - 1;
+            r1i = r1i < len ? r1i : len - 1;
+            uint4 a_lo, a_hi, b_lo, b_hi;
+            load_row_pair(qbase + (size_t)(t0 + r0i) * tok_stride, cp, p.cosv, p.sinv, r0i, a_lo, a_hi);
+            load_row_pair(qbase + (size_t)(t0 + r1i) * tok_stride, cp, p.cosv, p.sinv, r1i, b_lo, b_hi);
+            *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp)) = a_lo;
+            *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp + 4)) = a_hi;
+            *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp)) = b_lo;
+            *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
+            write_transposed_pair(Qt, rp, cp * 8, a_lo, b_lo);
+            write_transposed_pair(Qt, rp, 32 + cp * 8, a_hi, b_hi);
+        } else {  // dO: row-major + transposed
+            const int t2 = tid - 128;
+            const int rp = t2 >> 2, cp = t2 & 3;
+            int r0i = q0 + 2 * rp, r1i = r0i + 1;
+            r0i = r0i < len ? r0i : len - 1;
+            r1i = r1i < len ? r1i : len - 1;
+            uint4 a_lo, a_hi, b_lo, b_hi;
+            load_row_pair(dobase + (size_t)(t0 + r0i) * o_stride, cp, nullptr, nullptr, 0, a_lo, a_hi);
+            load_row_pair(dobase + (size_t)(t0 + r1i) * o_stride, cp, nullptr, nullptr, 0, b_lo, b_hi);
+            *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp)) = a_lo;
+            *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp + 4)) = a_hi;
+            *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp)) = b_lo;
+            *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
+            write_transposed_pair(dOt, rp, cp * 8, a_lo, b_lo);
+            write_transposed_pair(dOt, rp, 32 + cp * 8, a_hi, b_hi);
+        }
+        if (tid < 64) {
+            int r = q0 + tid;
+            const bool ok = r < len;
+            r = ok ? r : len - 1;
+            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
+            lse_s[tid] = ok ? p.lse[(size_t)h * p.T + t0 + r] * LOG2E : INFINITY;
+            dl_s[tid] = p.delta[(size_t)h * p.T + t0 + r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t a_s, a_dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                a_s = mfma_bf16_32x32x16(lds_read_frag(Qs, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
+                a_dp = mfma_bf16_32x32x16(lds_read_frag(dOs, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
+            }
+            float pr[16], ds[16];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int row = qb * 32 + 8 * qd + 4 * hi;
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + row);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const float pv = key_ok ? exp2f(a_s[r] * sc2 - ll[e]) : 0.f;
+                    pr[r] = pv;
+                    ds[r] = pv * (a_dp[r] - dd[e]);
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    acc_dv[db] = mfma_bf16_32x32x16(read_transposed_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf,
+                                                    acc_dv[db]);
+                    acc_dk[db] = mfma_bf16_32x32x16(read_transposed_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf,
+                                                    acc_dk[db]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (key_ok) {
+        bf16_t* krow = p.dqkv + (size_t)(t0 + key) * tok_stride + (size_t)(p.H + h) * DH;
+        bf16_t* vrow = krow + (size_t)p.H * DH;
+        store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, key, hi);
+        store_unrotated(vrow, acc_dv, 1.f, nullptr, nullptr, 0, hi);
+    }
+}
+
+inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
+                       uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
+                       void* stream) {
+    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
+    if (!qkv || !cu_seqlens || !out || !lse) return CX_ERR_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
+    p.H = H; p.T = T; p.scale = softmax_scale;
+    dim3 grid((max_seqlen + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
+int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
+                       const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
+                       uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream) {
+    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
+    if (!dout || !qkv || !out || !lse || !cu_seqlens || !delta || !dqkv) return CX_ERR_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin;
+    p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
+    p.dout = dout; p.delta = delta; p.dqkv = dqkv;
+    p.H = H; p.T = T; p.scale = softmax_scale;
+    long nthreads = (long)T * H * 8;
+    int g = (int)((nthreads + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    dim3 grid((max_seqlen + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
+}  // extern "C"

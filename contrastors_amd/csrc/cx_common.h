@@ -1,0 +1,83 @@
+// cx_common.h -- device-side helpers shared by every gfx950 kernel in this library.
+//
+// Everything here is written for CDNA4 only (wave64, MFMA 32x32x16 bf16, 64-bank LDS);
+// there is deliberately no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; all bf16 tensors cross the C-ABI as uint16_t*
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define CX_DEVICE __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32
+// ---------------------------------------------------------------------------------------------
+CX_DEVICE float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+CX_DEVICE float bf16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
+CX_DEVICE float bf16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// round-to-nearest-even, NaN preserved (quiet)
+CX_DEVICE bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+CX_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+CX_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+CX_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tile layout used by every MFMA kernel for K-contiguous operands:
+//   a tile is [rows][64 bf16] = 128 B per row = 8 chunks of 16 B.  Chunk c of row r lives at
+//   byte  r*128 + ((c ^ ((r>>1)&7)) << 4).
+// With this XOR the 16-lane service groups of ds_read_b128 (rows distinct mod 16, same c) hit 16
+// distinct 16-B slots of the 256-B bank row: conflict free (see DESIGN.md "LDS layouts").
+// ---------------------------------------------------------------------------------------------
+CX_DEVICE int tile64_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// MFMA wrappers ---------------------------------------------------------------------------------
+// D(32x32) += A(32x16) * B(16x32).  Lane l supplies A[i=l&31][k=8*(l>>5)+e] and B[k=8*(l>>5)+e][j=l&31],
+// e=0..7.  Result: lane l holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] in register r.
+CX_DEVICE f32x16_t mfma_bf16_32x32x16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// Row index held by accumulator register r of a 32x32 MFMA result for lane-half hi.
+CX_DEVICE int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+CX_DEVICE bf16x8_t lds_read_frag(const char* lds, int byte_off) {
+    return *reinterpret_cast<const bf16x8_t*>(lds + byte_off);
+}
+
+// XCD-aware remap of a linear workgroup id: the dispatcher places block b on XCD b%8, so give each
+// XCD a contiguous run of logical tiles (shared operand panels then hit the same 4 MiB L2).
+// Bijective for any nwg (guide T1, bijective variant).
+CX_DEVICE int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,238 @@
+// gemm_bf16.hip -- K9 of SURVEY.md §2b: the FusedDense contraction  Out[m][n] = sum_k X[m][k] * W[n][k]
+// (+ bias[n]) on CDNA4 matrix cores.  Replaces flash_attn.ops.fused_dense (cuBLASLt) at the call sites
+// contrastors/layers/attention.py:82-85,112-114,243 and contrastors/layers/mlp.py:24-28,61-83.
+//
+// One kernel serves forward (X=activations, W=weight), dgrad (X=dY, W=W^T shadow) and wgrad
+// (X=dY^T, W=act^T, fp32 atomic accumulate, split-K over tokens): both operands are always
+// K-contiguous ("NT"), which is the layout MFMA fragments want (8 consecutive k per lane = one 16-B load).
+//
+// Structure (v1, "step-3" of the guide's ladder): 128x128x64 block tile, 4 waves in 2x2, each wave a 64x64
+// sub-tile = 2x2 MFMA 32x32x16 accumulators; LDS double buffer (64 KiB -> 2 blocks/CU); operand tiles either
+// DMA'd straight into LDS (global_load_lds, 16 B/lane, swizzle applied on the SOURCE address) or staged through
+// registers; XCD-aware tile order.  The MFMA is issued with A := W-fragment and B := X-fragment so that each
+// lane ends up holding 4 consecutive n for one m -> 8/16-byte epilogue stores.
+#include "cx_common.h"
+#include "../../include/contrastors_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ATOMIC = 2 };
+
+struct GemmParams {
+    const bf16_t* X;
+    const bf16_t* W;
+    void* Out;
+    const float* bias;  // fp32[N] or nullptr
+    int M, N, K;
+    int ldx, ldw, ldo;
+    int tiles_m, tiles_n, split_k;
+    float alpha;
+};
+
+// Staging registers as a plain struct of named members: an indexed array here is not scalarised by the compiler
+// (it lands in scratch / promoted LDS).
+struct StageRegs { uint4 r0, r1, r2, r3; };
+
+CX_DEVICE uint4 stage_load(const bf16_t* __restrict__ base, int ld, int row0, int nrows, int k0, int tid, int p) {
+    const int r = p * 32 + (tid >> 3);
+    int gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;
+    return *reinterpret_cast<const uint4*>(base + (size_t)gr * ld + k0 + (tid & 7) * 8);
+}
+
+template <bool GLDS>
+CX_DEVICE void stage_tile(const bf16_t* __restrict__ base, int ld, int row0, int nrows, int k0, char* lds_tile,
+                          int tid, StageRegs& regs) {
+    if constexpr (GLDS) {
+        // LDS destination of one wave-instruction is  M0 + lane*16 : 1 KiB = 8 tile rows.  The swizzle of
+        // tile64_off() is an involution on the chunk index within a row, so fetching chunk (s ^ key(r)) into
+        // linear slot s produces exactly the swizzled image (guide §5.4 rule 21).
+        const int lane = tid & 63;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = j * 32 + w * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = row0 + r;
+            gr = gr < nrows ? gr : nrows - 1;
+            const bf16_t* g = base + (size_t)gr * ld + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(lds_tile + (j * 4 + w) * 1024), 16, 0, 0);
+        }
+    } else {
+        regs.r0 = stage_load(base, ld, row0, nrows, k0, tid, 0);
+        regs.r1 = stage_load(base, ld, row0, nrows, k0, tid, 1);
+        regs.r2 = stage_load(base, ld, row0, nrows, k0, tid, 2);
+        regs.r3 = stage_load(base, ld, row0, nrows, k0, tid, 3);
+    }
+}
+
+CX_DEVICE void commit_tile(char* lds_tile, int tid, const StageRegs& regs) {
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint4*>(lds_tile + tile64_off(r, c)) = regs.r0;
+    *reinterpret_cast<uint4*>(lds_tile + tile64_off(r + 32, c)) = regs.r1;
+    *reinterpret_cast<uint4*>(lds_tile + tile64_off(r + 64, c)) = regs.r2;
+    *reinterpret_cast<uint4*>(lds_tile + tile64_off(r + 96, c)) = regs.r3;
+}
+
+template <bool GLDS, int OUT_MODE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][X|W]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tn = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tm = lid % p.tiles_m;
+    const int sk = lid / p.tiles_m;
+
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_total = p.K / BK;
+    const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
+    const int kt_end = (int)(((long)nk_total * (sk + 1)) / p.split_k);
+    const int nk = kt_end - kt_begin;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    StageRegs xr = {}, wr = {};
+    if (nk > 0) {
+        stage_tile<GLDS>(p.X, p.ldx, m0, p.M, kt_begin * BK, smem, tid, xr);
+        stage_tile<GLDS>(p.W, p.ldw, n0, p.N, kt_begin * BK, smem + TILE_BYTES, tid, wr);
+        if constexpr (!GLDS) {
+            commit_tile(smem, tid, xr);
+            commit_tile(smem + TILE_BYTES, tid, wr);
+        }
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nk; ++it) {
+        char* cur = smem + (it & 1) * 2 * TILE_BYTES;
+        char* nxt = smem + ((it + 1) & 1) * 2 * TILE_BYTES;
+        const bool more = (it + 1) < nk;
+        if (more) {
+            const int k0 = (kt_begin + it + 1) * BK;
+            stage_tile<GLDS>(p.X, p.ldx, m0, p.M, k0, nxt, tid, xr);
+            stage_tile<GLDS>(p.W, p.ldw, n0, p.N, k0, nxt + TILE_BYTES, tid, wr);
+        }
+        const char* xs = cur;
+        const char* ws = cur + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t wf[2], xf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                wf[b] = lds_read_frag(ws, tile64_off(wn * 64 + b * 32 + l31, ks * 2 + hi));
+                xf[b] = lds_read_frag(xs, tile64_off(wm * 64 + b * 32 + l31, ks * 2 + hi));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
+        }
+        if constexpr (!GLDS) {
+            if (more) {
+                commit_tile(nxt, tid, xr);
+                commit_tile(nxt + TILE_BYTES, tid, wr);
+            }
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  acc[a][b][r] = Out[m][n] with m = m0 + wm*64 + b*32 + l31, n = n0 + wn*64 + a*32 + acc_row(r,hi)
+    const bool add_bias = (p.bias != nullptr) && (sk == 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = m0 + wm * 64 + b * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * hi;
+                if (n >= p.N) continue;  // N % 4 == 0 (launcher): a quad is all-in or all-out
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e] * p.alpha;
+                if (add_bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if constexpr (OUT_MODE == OUT_BF16) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = pk;
+                } else if constexpr (OUT_MODE == OUT_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.Out) + (size_t)m * p.ldo + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    float* o = reinterpret_cast<float*>(p.Out) + (size_t)m * p.ldo + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
+                }
+            }
+        }
+    }
+}
+
+int g_use_glds = 1;
+
+template <bool GLDS>
+hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    dim3 grid(nwg), block(256);
+    switch (out_mode) {
+        case OUT_BF16: hipLaunchKernelGGL((gemm_bf16_nt_kernel<GLDS, OUT_BF16>), grid, block, 0, stream, p); break;
+        case OUT_F32: hipLaunchKernelGGL((gemm_bf16_nt_kernel<GLDS, OUT_F32>), grid, block, 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_bf16_nt_kernel<GLDS, OUT_F32_ATOMIC>), grid, block, 0, stream, p); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }
+int cx_gemm_get_glds(void) { return g_use_glds; }
+
+int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float* bias, int M, int N, int K, int ldx,
+                    int ldw, int ldo, int out_mode, int split_k, float alpha, void* stream) {
+    if (M <= 0 || N <= 0) return CX_OK;
+    if (K <= 0 || (K % BK) != 0 || (N % 4) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (out_mode < 0 || out_mode > 2) return CX_ERR_ARG;
+    if (out_mode == OUT_BF16 && (ldo % 4) != 0) return CX_ERR_ALIGN;
+    if (out_mode != OUT_BF16 && (ldo % 4) != 0) return CX_ERR_ALIGN;
+    GemmParams p;
+    p.X = X; p.W = W; p.Out = Out; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+    const int nk = K / BK;
+    if (split_k < 1) split_k = 1;
+    if (split_k > nk) split_k = nk;
+    if (out_mode != OUT_F32_ATOMIC) split_k = 1;  // only the accumulating epilogue can combine K slices
+    p.split_k = split_k;
+    p.alpha = alpha;
+    hipError_t e = g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
+                              : launch_mode<false>(p, out_mode, (hipStream_t)stream);
+    return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+}  // extern "C"

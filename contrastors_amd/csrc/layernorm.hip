@@ -1,0 +1,383 @@
+// layernorm.hip -- K5/K6 of SURVEY.md §2b: fused (residual add +) LayerNorm forward/backward, and the
+// BertEmbeddings gather fused with the embedding LayerNorm (a11).  HBM-bound: one wave per row, every lane owns
+// 4 consecutive columns per 256-column chunk (8-B bf16 / 16-B fp32 accesses), statistics in fp32, one pass over
+// the row held in registers.  Replaces flash_attn.ops.layer_norm.{dropout_add_layer_norm, layer_norm} at
+// sc/layers/block.py:422-431,453-462 and sc/models/encoder/modeling_nomic_bert.py:534 (dropout p = 0).
+#include "cx_common.h"
+#include "../../include/contrastors_hip.h"
+
+namespace {
+
+CX_DEVICE void load4_bf16(const bf16_t* p, float (&v)[4]) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = bf16lo_to_f32(u.x); v[1] = bf16hi_to_f32(u.x);
+    v[2] = bf16lo_to_f32(u.y); v[3] = bf16hi_to_f32(u.y);
+}
+CX_DEVICE void store4_bf16(bf16_t* p, const float (&v)[4]) {
+    uint2 u;
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+CX_DEVICE void load4_f32(const float* p, float (&v)[4]) {
+    const float4 u = *reinterpret_cast<const float4*>(p);
+    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+}
+
+template <int NCH>
+CX_DEVICE void row_stats(const float (&z)[NCH][4], int d, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += z[i][e];
+    mean = wave_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float c = z[i][e] - mean;
+            v += c * c;
+        }
+    rstd = rsqrtf(wave_sum(v) / (float)d + eps);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ res,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                     bf16_t* z_out, float* __restrict__ mean_o,
+                                                     float* __restrict__ rstd_o, int rows, float eps) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][4], b[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
+        load4_f32(beta + (i * 64 + lane) * 4, b[i]);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float z[NCH][4];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            load4_bf16(x0 + off, z[i]);
+            if (res) {
+                float r[4];
+                load4_bf16(res + off, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[i][e] += r[e];
+            }
+        }
+        float mean, rstd;
+        row_stats<NCH>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (z[i][e] - mean) * rstd * g[i][e] + b[i][e];
+            store4_bf16(out + off, o);
+            if (z_out) store4_bf16(z_out + off, z[i]);
+        }
+        if (lane == 0) {
+            mean_o[row] = mean;
+            rstd_o[row] = rstd;
+        }
+    }
+}
+
+// Shared tail of both backward kernels: fold the per-wave dgamma/dbeta partials of one block and atomically add.
+template <int NCH>
+CX_DEVICE void flush_param_grads(float (&dg)[NCH][4], float (&db)[NCH][4], float* dgamma, float* dbeta,
+                                 float* smem /* [2][4][D] */) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            smem[(0 * 4 + wave) * D + (i * 64 + lane) * 4 + e] = dg[i][e];
+            smem[(1 * 4 + wave) * D + (i * 64 + lane) * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sg += smem[(0 * 4 + w) * D + c];
+            sb += smem[(1 * 4 + w) * D + c];
+        }
+        if (dgamma) unsafeAtomicAdd(dgamma + c, sg);
+        if (dbeta) unsafeAtomicAdd(dbeta + c, sb);
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
+                                                     const bf16_t* __restrict__ z, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i,
+                                                     const bf16_t* __restrict__ dz_extra, bf16_t* __restrict__ dz,
+                                                     float* dgamma, float* dbeta, int rows) {
+    constexpr int D = NCH * 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][4], dg[NCH][4], db[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float dy[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            load4_bf16(da + off, dy[i]);
+            if (dbb) {
+                float t[4];
+                load4_bf16(dbb + off, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dy[i][e] += t[e];
+            }
+            float zz[4];
+            load4_bf16(z + off, zz);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (zz[e] - mean) * rstd;
+                const float wdy = g[i][e] * dy[i][e];
+                s1 += wdy * xh[i][e];
+                s2 += wdy;
+                dg[i][e] += dy[i][e] * xh[i][e];
+                db[i][e] += dy[i][e];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (g[i][e] * dy[i][e] - s1 * xh[i][e] - s2) * rstd;
+            if (dz_extra) {
+                float t[4];
+                load4_bf16(dz_extra + off, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += t[e];
+            }
+            store4_bf16(dz + off, o);
+        }
+    }
+    flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ indices,
+                                                           const float* __restrict__ word,
+                                                           const float* __restrict__ type0,
+                                                           const float* __restrict__ pos_emb,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                           int T, int S, float eps) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][4], b[NCH][4], ty[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
+        load4_f32(beta + (i * 64 + lane) * 4, b[i]);
+        load4_f32(type0 + (i * 64 + lane) * 4, ty[i]);
+    }
+    for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
+        const int flat = indices[t];
+        const long id = ids[flat];
+        const int pos = flat % S;
+        float z[NCH][4];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            load4_f32(word + (size_t)id * D + col, z[i]);
+            // reference order: word + pos + type (sc/layers/embedding.py:601-614)
+            if (pos_emb) {
+                float pe[4];
+                load4_f32(pos_emb + (size_t)pos * D + col, pe);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[i][e] += pe[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[i][e] += ty[i][e];
+        }
+        float mean, rstd;
+        row_stats<NCH>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (z[i][e] - mean) * rstd * g[i][e] + b[i][e];
+            store4_bf16(out + (size_t)t * D + (i * 64 + lane) * 4, o);
+        }
+        if (lane == 0) {
+            mean_o[t] = mean;
+            rstd_o[t] = rstd;
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
+    const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb, const int64_t* __restrict__ ids,
+    const int32_t* __restrict__ indices, const float* __restrict__ word, const float* __restrict__ type0,
+    const float* __restrict__ pos_emb, const float* __restrict__ gamma, const float* __restrict__ mean_i,
+    const float* __restrict__ rstd_i, float* dword, float* dtype0, float* dpos, float* dgamma, float* dbeta, int T,
+    int S, int padding_idx) {
+    constexpr int D = NCH * 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][4], ty[NCH][4], dg[NCH][4], db[NCH][4], dty[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
+        load4_f32(type0 + (i * 64 + lane) * 4, ty[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = dty[i][e] = 0.f;
+    }
+    for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
+        const int flat = indices[t];
+        const long id = ids[flat];
+        const int pos = flat % S;
+        const float mean = mean_i[t], rstd = rstd_i[t];
+        float dy[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            load4_bf16(da + (size_t)t * D + col, dy[i]);
+            if (dbb) {
+                float tt[4];
+                load4_bf16(dbb + (size_t)t * D + col, tt);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dy[i][e] += tt[e];
+            }
+            float zz[4];
+            load4_f32(word + (size_t)id * D + col, zz);
+            if (pos_emb) {
+                float pe[4];
+                load4_f32(pos_emb + (size_t)pos * D + col, pe);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zz[e] += pe[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                zz[e] += ty[i][e];
+                xh[i][e] = (zz[e] - mean) * rstd;
+                const float wdy = g[i][e] * dy[i][e];
+                s1 += wdy * xh[i][e];
+                s2 += wdy;
+                dg[i][e] += dy[i][e] * xh[i][e];
+                db[i][e] += dy[i][e];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int col = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float o = (g[i][e] * dy[i][e] - s1 * xh[i][e] - s2) * rstd;
+                dty[i][e] += o;
+                // nn.Embedding(padding_idx=...) gives that row no gradient (sc/layers/embedding.py:581)
+                if (dword && id != padding_idx) unsafeAtomicAdd(dword + (size_t)id * D + col + e, o);
+                if (dpos) unsafeAtomicAdd(dpos + (size_t)pos * D + col + e, o);
+            }
+        }
+    }
+    flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
+    __syncthreads();
+    // type-embedding row 0 receives the sum over every token: reuse the same block fold.
+    float zero[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zero[i][e] = 0.f;
+    flush_param_grads<NCH>(dty, zero, dtype0, nullptr, smem);
+}
+
+inline int ln_grid(int rows) {
+    int g = (rows + 3) / 4;
+    if (g > 256 * 4) g = 256 * 4;
+    if (g < 1) g = 1;
+    return g;
+}
+inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
+
+#define CX_LN_DISPATCH(d, CALL)                     \
+    switch (d) {                                    \
+        case 256: { constexpr int NCH = 1; CALL; break; }  \
+        case 512: { constexpr int NCH = 2; CALL; break; }  \
+        case 768: { constexpr int NCH = 3; CALL; break; }  \
+        case 1024: { constexpr int NCH = 4; CALL; break; } \
+        default: return CX_ERR_SHAPE;               \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int cx_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* gamma, const float* beta,
+                     uint16_t* out, uint16_t* z_out, float* mean, float* rstd, int rows, int d, float eps,
+                     void* stream) {
+    if (rows <= 0) return CX_OK;
+    if (!x0 || !gamma || !beta || !out || !mean || !rstd) return CX_ERR_ARG;
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(ln_grid(rows)), dim3(256), 0,
+                                         (hipStream_t)stream, x0, residual, gamma, beta, out, z_out, mean, rstd,
+                                         rows, eps));
+    return done();
+}
+
+int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                     const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
+                     float* dbeta, int rows, int d, void* stream) {
+    if (rows <= 0) return CX_OK;
+    if (!dout_a || !z || !gamma || !mean || !rstd || !dz) return CX_ERR_ARG;
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(ln_grid(rows)), dim3(256), smem,
+                                         (hipStream_t)stream, dout_a, dout_b, z, gamma, mean, rstd, dz_extra, dz,
+                                         dgamma, dbeta, rows));
+    return done();
+}
+
+int cx_embed_ln_fwd(const int64_t* input_ids, const int32_t* indices, const float* word, const float* type0,
+                    const float* pos_emb, const float* gamma, const float* beta, uint16_t* out, float* mean,
+                    float* rstd, int T, int S, int d, float eps, void* stream) {
+    if (T <= 0) return CX_OK;
+    if (!input_ids || !indices || !word || !type0 || !gamma || !beta || !out) return CX_ERR_ARG;
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_fwd_kernel<NCH>), dim3(ln_grid(T)), dim3(256), 0,
+                                         (hipStream_t)stream, input_ids, indices, word, type0, pos_emb, gamma, beta,
+                                         out, mean, rstd, T, S, eps));
+    return done();
+}
+
+int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_t* input_ids,
+                    const int32_t* indices, const float* word, const float* type0, const float* pos_emb,
+                    const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
+                    float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, void* stream) {
+    if (T <= 0) return CX_OK;
+    if (!dout_a || !input_ids || !indices || !word || !type0 || !gamma || !mean || !rstd) return CX_ERR_ARG;
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_bwd_kernel<NCH>), dim3(ln_grid(T)), dim3(256), smem,
+                                         (hipStream_t)stream, dout_a, dout_b, input_ids, indices, word, type0,
+                                         pos_emb, gamma, mean, rstd, dword, dtype0, dpos, dgamma, dbeta, T, S,
+                                         padding_idx));
+    return done();
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// probe.hip -- hardware self-checks run by tests/test_probe_gpu.py: they pin, on the actual gfx950 silicon, the two
+// layout facts every MFMA kernel in this library relies on (accumulator row/column mapping of v_mfma_f32_32x32x16_bf16
+// and the cross-lane pattern of ds_read_b64_tr_b16).
+#include "cx_common.h"
+#include "../../include/contrastors_hip.h"
+
+namespace {
+
+// D[i][j] = (i+1) + 64*(j+1) from A[i][0]=i+1, A[i][1]=1, B[0][j]=1, B[1][j]=64*(j+1)  (all exact in bf16).
+__global__ void probe_mfma_kernel(float* out) {
+    const int lane = threadIdx.x & 63, hi = lane >> 5, l31 = lane & 31;
+    union { bf16_t h[8]; bf16x8_t v; } a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a.h[e] = b.h[e] = 0;
+    if (hi == 0) {
+        a.h[0] = f32_to_bf16((float)(l31 + 1));
+        a.h[1] = f32_to_bf16(1.f);
+        b.h[0] = f32_to_bf16(1.f);
+        b.h[1] = f32_to_bf16(64.f * (l31 + 1));
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma_bf16_32x32x16(a.v, b.v, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[acc_row(r, hi) * 32 + l31] = acc[r];
+}
+
+__global__ void probe_tr16_kernel(const uint16_t* in, uint16_t* out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[256];
+    const int lane = threadIdx.x;
+    for (int e = 0; e < 4; ++e) lds[lane * 4 + e] = in[lane * 4 + e];
+    __syncthreads();
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+    const bf16x4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(lds + lane * 4));
+    union { bf16x4_t v; uint16_t h[4]; } u;
+    u.v = t;
+    for (int e = 0; e < 4; ++e) out[lane * 4 + e] = u.h[e];
+}
+
+}  // namespace
+
+extern "C" {
+int cx_probe_mfma_layout(float* out_32x32, void* stream) {
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_32x32);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in_64x4, out_64x4);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+}

@@ -1,0 +1,198 @@
+"""InfoNCE loss + GradCache on the fused HIP path (host-side mirror of sc/loss.py:76-213).
+
+Public signatures are the reference's: `clip_loss(query, document, logit_scale, step, gather_enabled, tracker,
+dataset, bidirectional)` and `grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scale,
+bidirectional, router_aux_coeff)`.  What changes is underneath:
+  * the (N x G) similarity + cross-entropy is one exact-fp32 MFMA kernel that never writes the logits
+    (cx_infonce_fwd / cx_infonce_bwd), instead of matmul -> scale -> F.cross_entropy;
+  * GradCache chunks run as single native calls over a pre-allocated arena; chunk boundaries / lengths are resolved
+    on the host once per step (one sync per tower instead of one per model call);
+  * the data-parallel gradient all-reduce is ONE flat collective per step issued here (the reference's DDP fires
+    twice) -- towers expose `sync_gradients()`.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _C
+from .distributed import gather_with_grad
+
+
+def _scale_of(logit_scale) -> tuple:
+    """(python float scale, parameter tensor or None).  LogitScale.forward(x) = x * exp(param)
+    (sc/models/biencoder/modeling_biencoder.py:30-38)."""
+    if isinstance(logit_scale, (int, float)):
+        return float(logit_scale), None
+    p = getattr(logit_scale, "logit_scale", None)
+    if p is None:
+        raise TypeError("logit_scale must be a LogitScale module or a number")
+    const = getattr(logit_scale, "_const_scale", None)
+    if const is not None and not p.requires_grad:
+        return float(const), None
+    return float(p.detach().exp().item()), (p if p.requires_grad else None)
+
+
+class _FusedInfoNCE(torch.autograd.Function):
+    """sum_i (lse_i - logit_{i,label_i}) * coef  for logits = scale * Q D^T, without materialising the logits."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor, labels: torch.Tensor, scale: float, coef: float,
+                scale_param: Optional[torch.Tensor]):
+        if not q.is_cuda:
+            raise RuntimeError("fused InfoNCE needs the HIP device path (no CPU fallback)")
+        lib = _C.lib()
+        if q.dtype != torch.float32:
+            q = q.float()
+        if d.dtype != torch.float32:
+            d = d.float()
+        if q.stride(-1) != 1:
+            q = q.contiguous()
+        if d.stride(-1) != 1:
+            d = d.contiguous()
+        N, dim = q.shape
+        G = d.shape[0]
+        ws = torch.empty(lib.cx_infonce_ws_floats(N, G), dtype=torch.float32, device=q.device)
+        lse = torch.empty(N, dtype=torch.float32, device=q.device)
+        rows = torch.empty(N, dtype=torch.float32, device=q.device)
+        _C.check(lib.cx_infonce_fwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), scale, ws.data_ptr(),
+                                    lse.data_ptr(), rows.data_ptr(), N, G, dim, q.stride(0), d.stride(0),
+                                    _C.cur_stream()), "cx_infonce_fwd")
+        ctx.save_for_backward(q, d, labels, lse)
+        ctx.scale, ctx.coef, ctx.has_scale_param = scale, coef, scale_param is not None
+        ctx.loss_rows = rows
+        return rows.sum() * coef
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, d, labels, lse = ctx.saved_tensors
+        lib = _C.lib()
+        N, dim = q.shape
+        G = d.shape[0]
+        dev = q.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gm = torch.empty(N, G, **f32)
+        gmt = torch.empty(G, N, **f32)
+        qt = torch.empty(dim, N, **f32)
+        dt = torch.empty(dim, G, **f32)
+        dq = torch.empty(N, dim, **f32)
+        dd = torch.empty(G, dim, **f32)
+        dscale = torch.zeros(1, **f32) if ctx.has_scale_param else None
+        _C.check(lib.cx_infonce_bwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), lse.data_ptr(), ctx.scale,
+                                    ctx.coef, gm.data_ptr(), gmt.data_ptr(), qt.data_ptr(), dt.data_ptr(),
+                                    dq.data_ptr(), dd.data_ptr(), _C.ptr(dscale), N, G, dim, q.stride(0),
+                                    d.stride(0), _C.cur_stream()), "cx_infonce_bwd")
+        dq = dq * gout
+        dd = dd * gout
+        # d loss / d log_scale = (d loss / d scale) * scale   (scale = exp(param))
+        gparam = (dscale[0] * ctx.scale * gout).reshape(()) if ctx.has_scale_param else None
+        return dq, dd, None, None, None, gparam
+
+
+def make_labels(n_query: int, n_docs_all: int, rank: int, world: int, device) -> torch.Tensor:
+    """int64 labels exactly as sc/loss.py:108-117: (arange(N) + rank*N) * (M_all // (N*world))."""
+    labels = torch.arange(n_query, device=device)
+    labels = labels + rank * n_query
+    return labels * (n_docs_all // (n_query * world))
+
+
+def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tracker=None, dataset="",
+              bidirectional=False):
+    """InfoNCE over (local queries) x (all gathered documents); see sc/loss.py:76-132 for the contract."""
+    if gather_enabled:
+        document = gather_with_grad(document)
+    if query.dtype != document.dtype:
+        document = document.to(query.dtype)
+    inited = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if inited else 0
+    world = dist.get_world_size() if inited else 1  # the reference requires an initialised group (quirk 3)
+    n = query.shape[0]
+    labels = make_labels(n, document.shape[0], rank, world, query.device)
+    scale, scale_param = _scale_of(logit_scale)
+    if bidirectional:
+        # sc/loss.py:119-123: CE(q->d) + CE(d->q) with the same labels, no world-size factor
+        l_qd = _FusedInfoNCE.apply(query, document, labels, scale, 1.0 / n, scale_param)
+        l_dq = _FusedInfoNCE.apply(document, query, labels, scale, 1.0 / document.shape[0], scale_param)
+        loss = l_qd + l_dq
+    else:
+        loss = _FusedInfoNCE.apply(query, document, labels, scale, float(world) / n, scale_param)
+    if tracker is not None:
+        with torch.no_grad():
+            sim = (query.float() @ document.float().T) * scale
+            acc = (sim.argmax(dim=1) == labels).float().mean()
+        tracker.log({f"accuracy/accuracy_{dataset}": acc.detach().cpu().item()}, step=step)
+    return loss
+
+
+# ----------------------------------------------------------------------------------------------------- GradCache
+def _split_inputs(inputs: Dict[str, torch.Tensor], chunk_size: int) -> List[Dict]:
+    """Chunk a tower's input dict along the batch axis and attach host-side sequence lengths (one sync per tower)."""
+    total = inputs["input_ids"].shape[0]
+    lens = None
+    mask = inputs.get("attention_mask")
+    if "seqlens" in inputs:
+        lens = inputs["seqlens"]
+    elif mask is not None and mask.is_cuda:
+        # right-padding check + lengths in one transfer
+        lens_t = mask.sum(-1)
+        right_padded = (mask[:, 1:] <= mask[:, :-1]).all()
+        host = torch.stack([lens_t.max(), right_padded.to(lens_t.dtype)]).cpu()  # the one sync
+        lens = lens_t.cpu().numpy() if bool(host[1]) else None
+    chunks = []
+    for s in range(0, total, chunk_size):
+        c = {k: v[s: s + chunk_size] for k, v in inputs.items() if torch.is_tensor(v) and v.shape[0] == total}
+        if lens is not None:
+            c["seqlens"] = lens[s: s + chunk_size]
+        chunks.append(c)
+    return chunks
+
+
+def get_chunked_embeddings(model, chunks):
+    """Pass 1 (sc/loss.py:135-146): no-grad chunk forwards; returns (N,d) embeddings."""
+    embs = []
+    with torch.no_grad():
+        for c in chunks:
+            embs.append(model(**c)["embedding"])
+    return torch.cat(embs, dim=0)
+
+
+def accumulate_gradients(model, chunks, cache):
+    """Pass 2 (sc/loss.py:149-161): re-forward with grad and back-propagate the cached embedding gradient."""
+    for c, g in zip(chunks, cache):
+        out = model(**c)["embedding"]
+        surrogate = torch.dot(out.flatten(), g.flatten().to(out.dtype))
+        surrogate.backward()
+
+
+def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional=False):
+    """sc/loss.py:164-184: loss on detached embeddings, gradients w.r.t. the embeddings only."""
+    q = query_embeddings.detach().requires_grad_()
+    d = document_embeddings.detach().requires_grad_()
+    loss = clip_loss(q, d, logit_scale, gather_enabled=True, bidirectional=bidirectional)
+    loss.backward()
+    return q.grad, d.grad, loss.detach()
+
+
+def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scale, bidirectional=False,
+                    router_aux_coeff=False):
+    """GradCache step (sc/loss.py:187-213).  Leaves parameter gradients in the towers and returns the loss."""
+    q_chunks = _split_inputs(t1_inputs, chunk_size)
+    d_chunks = _split_inputs(t2_inputs, chunk_size)
+    was_training1, was_training2 = tower1.training, tower2.training
+    q_embs = get_chunked_embeddings(tower1, q_chunks)
+    d_embs = get_chunked_embeddings(tower2, d_chunks)
+    q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional)
+    sizes_q = [c["input_ids"].shape[0] for c in q_chunks]
+    sizes_d = [c["input_ids"].shape[0] for c in d_chunks]
+    accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q))
+    if was_training2:
+        accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d))
+    # data-parallel reduction of the accumulated gradients: once per step, one flat buffer per distinct tower
+    seen = set()
+    for tw, active in ((tower1, was_training1), (tower2, was_training2)):
+        if active and id(tw) not in seen and hasattr(tw, "sync_gradients"):
+            seen.add(id(tw))
+            tw.sync_gradients()
+    return loss

@@ -1,0 +1,479 @@
+"""NomicBert / BERT encoder on the native MI355X engine.
+
+Host-side mirror of the reference's flash model (sc/models/encoder/modeling_nomic_bert.py:488-587 `NomicBertModel`,
+configuration_nomic_bert.py, and the Block/FlashAttention/MLP python it drives): same config field names, same
+state-dict keys, but the whole forward / backward of a chunk is ONE call into
+libcontrastors_hip.so (cx_encoder_forward / cx_encoder_backward) over a caller-owned activation arena.
+
+Memory layout (sized for 288 GB HBM3E):
+  * fp32 master parameters live in ONE flat buffer `[decay segment | no-decay segment]` (optimizer.py:16-25 grouping),
+    gradients in a second flat buffer of the same layout -> the optimizer, grad-clip and the DP all-reduce each touch
+    two big tensors instead of ~150 small ones;
+  * bf16 shadows of every Linear weight (row-major for fwd, transposed for dgrad) are refreshed once per optimizer
+    step (`sync_shadows`), replacing the reference's per-chunk autocast re-cast;
+  * activations of a chunk live in per-layer slots of a pre-allocated arena (`_ChunkArena`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _C
+
+
+@dataclass
+class NomicBertConfig:
+    """Field names follow sc/models/encoder/configuration_nomic_bert.py:4-56 (GPT2Config naming)."""
+
+    vocab_size: int = 30528
+    n_positions: int = 2048
+    n_embd: int = 768
+    n_layer: int = 12
+    n_head: int = 12
+    n_inner: int = 3072
+    activation_function: str = "swiglu"
+    rotary_emb_fraction: float = 1.0
+    rotary_emb_base: float = 1000.0
+    rotary_emb_interleaved: bool = False
+    qkv_proj_bias: bool = False
+    mlp_fc1_bias: bool = False
+    mlp_fc2_bias: bool = False
+    prenorm: bool = False
+    layer_norm_epsilon: float = 1e-12
+    type_vocab_size: int = 2
+    pad_token_id: int = 0
+    initializer_range: float = 0.02
+    resid_pdrop: float = 0.0
+    embd_pdrop: float = 0.0
+    attn_pdrop: float = 0.0
+    causal: bool = False
+    use_rms_norm: bool = False
+    max_position_embeddings: int = 512  # learned absolute positions when rotary_emb_fraction == 0
+
+    def __post_init__(self):
+        if self.prenorm or self.causal or self.use_rms_norm or self.rotary_emb_interleaved:
+            raise NotImplementedError("engine covers the post-norm, non-causal, LayerNorm encoder (cfg 1-3)")
+        if self.resid_pdrop or self.embd_pdrop or self.attn_pdrop:
+            raise NotImplementedError("dropout > 0 is not implemented in the fused kernels (all BASELINE configs use 0)")
+        if self.n_embd != self.n_head * 64:
+            raise NotImplementedError("head_dim must be 64")
+        if self.rotary_emb_fraction not in (0.0, 1.0):
+            raise NotImplementedError("rotary_emb_fraction must be 0 or 1")
+        if self.activation_function not in ("swiglu", "gelu", "gelu_new"):
+            raise NotImplementedError(self.activation_function)
+
+    @property
+    def gated(self) -> bool:
+        return self.activation_function == "swiglu"
+
+    @property
+    def hidden_size(self) -> int:
+        return self.n_embd
+
+    @classmethod
+    def nomic_bert_2048(cls, **kw) -> "NomicBertConfig":
+        """cfg 2/3 constants: SURVEY.md §8(d) / Appendix D (mlm.yaml:33-46, bert.py:11-50)."""
+        return cls(**kw)
+
+    @classmethod
+    def bert_base_uncased(cls, **kw) -> "NomicBertConfig":
+        """cfg 1: bert_config_to_nomic_config of the standard HF BertConfig (sc/models/encoder/bert.py:11-50)."""
+        base = dict(vocab_size=30522, n_positions=512, max_position_embeddings=512, activation_function="gelu",
+                    rotary_emb_fraction=0.0, qkv_proj_bias=True, mlp_fc1_bias=True, mlp_fc2_bias=True)
+        base.update(kw)
+        return cls(**base)
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class _ChunkArena:
+    """Device memory for one in-flight chunk (CxChunkBuffers).  `n_slots` = 1 for no-grad forwards, n_layer else."""
+
+    def __init__(self, cfg: NomicBertConfig, T_cap: int, n_slots: int, with_backward: bool, B_cap: int,
+                 device: torch.device):
+        d, I, H = cfg.n_embd, cfg.n_inner, cfg.n_head
+        wfc1 = 2 * I if cfg.gated else I
+        bf = dict(dtype=torch.bfloat16, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.T_cap, self.n_slots, self.with_backward, self.B_cap = T_cap, n_slots, with_backward, B_cap
+        t: Dict[str, torch.Tensor] = {}
+        t["h0"] = torch.empty(T_cap, d, **bf)
+        t["emb_mean"] = torch.empty(T_cap, **f32)
+        t["emb_rstd"] = torch.empty(T_cap, **f32)
+        t["qkv"] = torch.empty(n_slots, T_cap, 3 * d, **bf)
+        t["ctx"] = torch.empty(n_slots, T_cap, d, **bf)
+        t["lse"] = torch.empty(n_slots, T_cap * H, **f32)
+        for n in ("z1", "h1", "z2", "h2"):
+            t[n] = torch.empty(n_slots, T_cap, d, **bf)
+        for n in ("mean1", "rstd1", "mean2", "rstd2"):
+            t[n] = torch.empty(n_slots, T_cap, **f32)
+        t["yg"] = torch.empty(n_slots, T_cap, wfc1, **bf)
+        t["act"] = torch.empty(n_slots, T_cap, I, **bf)
+        t["pool_norm"] = torch.empty(B_cap, **f32)
+        if with_backward:
+            wide = max(3 * d, wfc1)
+            for n in ("g_a", "g_b", "g_c"):
+                t[n] = torch.empty(T_cap, d, **bf)
+            t["g_wide"] = torch.empty(T_cap, wide, **bf)
+            t["g_act"] = torch.empty(T_cap, I, **bf)
+            t["tr_a"] = torch.empty(wide, T_cap, **bf)
+            t["tr_b"] = torch.empty(wide, T_cap, **bf)
+            t["delta"] = torch.empty(T_cap * H, **f32)
+        self.tensors = t
+        self.desc = _C.CxChunkBuffers()
+        self.desc.T_cap = T_cap
+        for name, _ in _C.CxChunkBuffers._fields_[1:]:
+            setattr(self.desc, name, t[name].data_ptr() if name in t else None)
+        self.emb_out: Optional[torch.Tensor] = None  # set by a saving forward, consumed by backward
+
+    def nbytes(self) -> int:
+        return sum(x.numel() * x.element_size() for x in self.tensors.values())
+
+
+@dataclass
+class VarlenBatch:
+    """Token-stream view of a right- or arbitrarily-padded (B,S) batch (flash_attn.bert_padding.unpad_input)."""
+
+    input_ids: torch.Tensor   # (B,S) int64, device
+    indices: torch.Tensor     # (T,) int32, device: flat positions b*S+s of the kept tokens
+    cu_seqlens: torch.Tensor  # (B+1,) int32, device
+    B: int
+    S: int
+    T: int
+    max_seqlen: int
+
+    @staticmethod
+    def from_lengths(input_ids: torch.Tensor, seqlens) -> "VarlenBatch":
+        """Right-padded batch with host-known lengths: no device->host sync (the dataloader knows the lengths)."""
+        B, S = input_ids.shape
+        lens = np.asarray(seqlens, dtype=np.int64).reshape(B)
+        cu = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        T = int(cu[-1])
+        if (lens == S).all():
+            idx = np.arange(B * S, dtype=np.int32)
+        else:
+            idx = np.concatenate([b * S + np.arange(l, dtype=np.int32) for b, l in enumerate(lens)]).astype(np.int32)
+        dev = input_ids.device
+        return VarlenBatch(input_ids, torch.from_numpy(idx).to(dev, non_blocking=True),
+                           torch.from_numpy(cu).to(dev, non_blocking=True), B, S, T, int(lens.max()) if B else 0)
+
+    @staticmethod
+    def from_mask(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> "VarlenBatch":
+        """Arbitrary mask, semantics of unpad_input.  Costs one host sync like the reference."""
+        B, S = input_ids.shape
+        if attention_mask is None:
+            return VarlenBatch.from_lengths(input_ids, [S] * B)
+        mask = attention_mask.to(torch.bool)
+        lens = mask.sum(-1, dtype=torch.int32)
+        idx = torch.nonzero(mask.flatten(), as_tuple=False).flatten().to(torch.int32)
+        cu = torch.zeros(B + 1, dtype=torch.int32, device=input_ids.device)
+        cu[1:] = torch.cumsum(lens, 0)
+        return VarlenBatch(input_ids, idx, cu, B, S, int(idx.numel()), int(lens.max().item()) if B else 0)
+
+
+class NomicBertEngine(torch.nn.Module):
+    """Encoder trunk + pooling on libcontrastors_hip.so.  Parameters are views into flat fp32 buffers."""
+
+    def __init__(self, config: NomicBertConfig, device="cuda", pooling: str = "mean", normalize: bool = True,
+                 seed: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.device_ = torch.device(device)
+        if self.device_.type != "cuda":
+            raise RuntimeError("NomicBertEngine needs an MI355X (cuda/hip device); there is no CPU path")
+        self.lib = _C.lib()
+        if pooling not in ("mean", "cls"):
+            raise NotImplementedError(f"pooling={pooling}")
+        self.pool_mode = 0 if pooling == "mean" else 1
+        self.normalize_default = bool(normalize)
+        cfg = config
+        d, I, L = cfg.n_embd, cfg.n_inner, cfg.n_layer
+        wfc1 = 2 * I if cfg.gated else I
+
+        # ---- parameter registry: (storage name, shape) --------------------------------------------------------
+        decay: List[Tuple[str, Tuple[int, ...]]] = [("embeddings.word_embeddings.weight", (cfg.vocab_size, d))]
+        if cfg.rotary_emb_fraction == 0.0:
+            decay.append(("embeddings.position_embeddings.weight", (cfg.max_position_embeddings, d)))
+        decay.append(("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, d)))
+        nodecay: List[Tuple[str, Tuple[int, ...]]] = [("emb_ln.weight", (d,)), ("emb_ln.bias", (d,))]
+        for l in range(L):
+            p = f"encoder.layers.{l}."
+            decay += [(p + "attn.Wqkv.weight", (3 * d, d)), (p + "attn.out_proj.weight", (d, d)),
+                      (p + "mlp.fc1_fused.weight", (wfc1, d)), (p + "mlp.fc2.weight", (d, I))]
+            if cfg.qkv_proj_bias:
+                nodecay += [(p + "attn.Wqkv.bias", (3 * d,)), (p + "attn.out_proj.bias", (d,))]
+            if cfg.mlp_fc1_bias:
+                nodecay.append((p + "mlp.fc1_fused.bias", (wfc1,)))
+            if cfg.mlp_fc2_bias:
+                nodecay.append((p + "mlp.fc2.bias", (d,)))
+            nodecay += [(p + "norm1.weight", (d,)), (p + "norm1.bias", (d,)),
+                        (p + "norm2.weight", (d,)), (p + "norm2.bias", (d,))]
+        self._layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, shape in decay:
+            self._layout[name] = (off, shape)
+            off += _round_up(int(np.prod(shape)), 64)
+        self.n_decay = off
+        for name, shape in nodecay:
+            self._layout[name] = (off, shape)
+            off += _round_up(int(np.prod(shape)), 64)
+        self.n_total = off
+        self._linear_names = [n for n, s in decay if ".layers." in n]
+        self._lin_begin = self._layout[self._linear_names[0]][0]
+        self._lin_end = self.n_decay
+
+        dev = self.device_
+        self.flat_param = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        # what torch.optim sees: two parameters (decay / no-decay) whose .grad alias the flat gradient buffer
+        self.flat_decay = torch.nn.Parameter(self.flat_param[: self.n_decay])
+        self.flat_nodecay = torch.nn.Parameter(self.flat_param[self.n_decay:])
+        self.flat_decay.grad = self.flat_grad[: self.n_decay]
+        self.flat_nodecay.grad = self.flat_grad[self.n_decay:]
+        # bf16 shadows of the Linear weights (same relative layout) + transposed copies
+        n_lin = self._lin_end - self._lin_begin
+        self.w16 = torch.zeros(n_lin, dtype=torch.bfloat16, device=dev)
+        self.w16_t = torch.zeros(n_lin, dtype=torch.bfloat16, device=dev)
+
+        self._init_weights(seed)
+        self._build_rotary()
+        self._build_desc()
+        self._arena_nograd: Optional[_ChunkArena] = None
+        self._arena_free: List[_ChunkArena] = []
+        self.sync_shadows()
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def p(self, name: str) -> torch.Tensor:
+        off, shape = self._layout[name]
+        return self.flat_param[off: off + int(np.prod(shape))].view(shape)
+
+    def g(self, name: str) -> torch.Tensor:
+        off, shape = self._layout[name]
+        return self.flat_grad[off: off + int(np.prod(shape))].view(shape)
+
+    def _w16(self, name: str, transposed: bool = False) -> torch.Tensor:
+        off, shape = self._layout[name]
+        buf = self.w16_t if transposed else self.w16
+        o = off - self._lin_begin
+        shp = (shape[1], shape[0]) if transposed else shape
+        return buf[o: o + int(np.prod(shape))].view(shp)
+
+    def _init_weights(self, seed: Optional[int]):
+        """normal(0, initializer_range) for Linear/Embedding weights, zero biases, LN = (1, 0), padding row zero
+        (sc/models/encoder/modeling_nomic_bert.py:284-292)."""
+        cfg = self.config
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(0 if seed is None else seed)
+        with torch.no_grad():
+            for name, (off, shape) in self._layout.items():
+                n = int(np.prod(shape))
+                view = self.flat_param[off: off + n]
+                if name.endswith(".bias"):
+                    view.zero_()
+                elif len(shape) == 1:
+                    view.fill_(1.0)
+                else:
+                    w = torch.empty(shape, dtype=torch.float32).normal_(0.0, cfg.initializer_range, generator=gen)
+                    if name == "embeddings.word_embeddings.weight":
+                        w[cfg.pad_token_id].zero_()
+                    view.copy_(w.flatten())
+
+    def reference_state_dict(self) -> Dict[str, torch.Tensor]:
+        """State dict with the reference's keys (Appendix E): fc1_fused is split into fc11/fc12 (or fc1)."""
+        out: Dict[str, torch.Tensor] = {}
+        I = self.config.n_inner
+        for name in self._layout:
+            t = self.p(name)
+            if ".mlp.fc1_fused." in name:
+                if self.config.gated:
+                    out[name.replace("fc1_fused", "fc11")] = t[:I]
+                    out[name.replace("fc1_fused", "fc12")] = t[I:]
+                else:
+                    out[name.replace("fc1_fused", "fc1")] = t
+            else:
+                out[name] = t
+        return out
+
+    def reference_grad_dict(self) -> Dict[str, torch.Tensor]:
+        out: Dict[str, torch.Tensor] = {}
+        I = self.config.n_inner
+        for name in self._layout:
+            t = self.g(name)
+            if ".mlp.fc1_fused." in name:
+                if self.config.gated:
+                    out[name.replace("fc1_fused", "fc11")] = t[:I]
+                    out[name.replace("fc1_fused", "fc12")] = t[I:]
+                else:
+                    out[name.replace("fc1_fused", "fc1")] = t
+            else:
+                out[name] = t
+        return out
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Copy weights keyed like the reference flash model / its eager twin (tests/test_huggingface.py:30-34)."""
+        mine = self.reference_state_dict()
+        missing = [k for k in mine if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}...")
+        for k, dst in mine.items():
+            if k in sd:
+                src = sd[k]
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"{k}: shape {tuple(src.shape)} != {tuple(dst.shape)}")
+                dst.copy_(src.to(device=dst.device, dtype=torch.float32))
+        self.sync_shadows()
+
+    @torch.no_grad()
+    def sync_shadows(self):
+        """Refresh the bf16 (and transposed bf16) copies of every Linear weight from the fp32 masters."""
+        s = _C.cur_stream()
+        n = self._lin_end - self._lin_begin
+        _C.check(self.lib.cx_cast_f32_to_bf16(self.flat_param.data_ptr() + 4 * self._lin_begin, self.w16.data_ptr(),
+                                               n, s), "cast")
+        for name in self._linear_names:
+            off, shape = self._layout[name]
+            _C.check(self.lib.cx_cast_transpose_f32_to_bf16(self.flat_param.data_ptr() + 4 * off,
+                                                             self._w16(name, True).data_ptr(), shape[0], shape[1],
+                                                             s), "cast_transpose")
+
+    def zero_grad(self, set_to_none: bool = False):  # noqa: D401 - torch signature
+        self.flat_grad.zero_()
+
+    # ------------------------------------------------------------------------------------------------ descriptors
+    def _build_rotary(self):
+        cfg = self.config
+        self.rot_cos = self.rot_sin = None
+        if cfg.rotary_emb_fraction > 0:
+            dim = 64
+            # flash_attn RotaryEmbedding: inv_freq = 1/base^(arange(0,dim,2)/dim), fp32
+            inv_freq = 1.0 / (cfg.rotary_emb_base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+            t = torch.arange(cfg.n_positions, dtype=torch.float32)
+            freqs = torch.outer(t, inv_freq)
+            self.rot_cos = torch.cos(freqs).contiguous().to(self.device_)
+            self.rot_sin = torch.sin(freqs).contiguous().to(self.device_)
+
+    def _build_desc(self):
+        cfg = self.config
+        L = cfg.n_layer
+        self._layers_arr = (_C.CxLayerWeights * L)()
+        P = lambda n: self.p(n).data_ptr() if n in self._layout else None  # noqa: E731
+        G = lambda n: self.g(n).data_ptr() if n in self._layout else None  # noqa: E731
+        for l in range(L):
+            pre = f"encoder.layers.{l}."
+            lw = self._layers_arr[l]
+            for fld, nm in (("Wqkv", "attn.Wqkv.weight"), ("Wout", "attn.out_proj.weight"),
+                            ("Wfc1", "mlp.fc1_fused.weight"), ("Wfc2", "mlp.fc2.weight")):
+                setattr(lw, fld, self._w16(pre + nm).data_ptr())
+                setattr(lw, fld + "T", self._w16(pre + nm, True).data_ptr())
+                setattr(lw, "g" + fld, G(pre + nm))
+            for fld, nm in (("bqkv", "attn.Wqkv.bias"), ("bout", "attn.out_proj.bias"),
+                            ("bfc1", "mlp.fc1_fused.bias"), ("bfc2", "mlp.fc2.bias")):
+                setattr(lw, fld, P(pre + nm))
+                setattr(lw, "g" + fld, G(pre + nm))
+            for fld, nm in (("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"), ("ln2_g", "norm2.weight"),
+                            ("ln2_b", "norm2.bias")):
+                setattr(lw, fld, P(pre + nm))
+                setattr(lw, "g" + fld, G(pre + nm))
+        e = _C.CxEncoderDesc()
+        e.n_layer, e.d, e.n_head, e.d_inner, e.gated = L, cfg.n_embd, cfg.n_head, cfg.n_inner, int(cfg.gated)
+        e.vocab, e.padding_idx = cfg.vocab_size, cfg.pad_token_id
+        e.max_pos = cfg.max_position_embeddings if cfg.rotary_emb_fraction == 0 else cfg.n_positions
+        e.ln_eps = cfg.layer_norm_epsilon
+        e.softmax_scale = 1.0 / math.sqrt(64.0)  # 1/norm_factor, sc/layers/attention.py:44-48,163
+        e.word_emb = P("embeddings.word_embeddings.weight")
+        e.type_emb = P("embeddings.token_type_embeddings.weight")
+        e.pos_emb = P("embeddings.position_embeddings.weight")
+        e.emb_ln_g, e.emb_ln_b = P("emb_ln.weight"), P("emb_ln.bias")
+        e.gword_emb = G("embeddings.word_embeddings.weight")
+        e.gtype_emb = G("embeddings.token_type_embeddings.weight")
+        e.gpos_emb = G("embeddings.position_embeddings.weight")
+        e.gemb_ln_g, e.gemb_ln_b = G("emb_ln.weight"), G("emb_ln.bias")
+        e.rot_cos = None if self.rot_cos is None else self.rot_cos.data_ptr()
+        e.rot_sin = None if self.rot_sin is None else self.rot_sin.data_ptr()
+        e.layers = C.cast(self._layers_arr, C.POINTER(_C.CxLayerWeights))
+        e.pool_mode, e.normalize = self.pool_mode, 1
+        self._desc = e
+
+    # ------------------------------------------------------------------------------------------------ arenas
+    def _get_arena(self, T: int, B: int, save: bool) -> _ChunkArena:
+        T_cap = _round_up(max(T, 1), 128)
+        if not save:
+            a = self._arena_nograd
+            if a is None or a.T_cap < T_cap or a.B_cap < B:
+                a = _ChunkArena(self.config, T_cap, 1, False, max(B, 1), self.device_)
+                self._arena_nograd = a
+            return a
+        for i, a in enumerate(self._arena_free):
+            if a.T_cap >= T_cap and a.B_cap >= B:
+                return self._arena_free.pop(i)
+        return _ChunkArena(self.config, T_cap, self.config.n_layer, True, max(B, 1), self.device_)
+
+    def release_arena(self, arena: _ChunkArena):
+        arena.emb_out = None
+        self._arena_free.append(arena)
+
+    # ------------------------------------------------------------------------------------------------ compute
+    def forward_chunk(self, vb: VarlenBatch, save_for_backward: bool, normalize: Optional[bool] = None,
+                      out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[_ChunkArena]]:
+        """Enqueue one chunk forward.  Returns (embeddings (B,d) fp32, arena holding the saved activations)."""
+        d = self.config.n_embd
+        if vb.S > (self.config.n_positions if self.rot_cos is not None else self.config.max_position_embeddings):
+            raise ValueError("sequence longer than the position table")
+        if out is None:
+            out = torch.empty(vb.B, d, dtype=torch.float32, device=self.device_)
+        arena = self._get_arena(vb.T, vb.B, save_for_backward)
+        self._desc.normalize = int(self.normalize_default if normalize is None else normalize)
+        rc = self.lib.cx_encoder_forward(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
+                                         vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
+                                         vb.max_seqlen, int(save_for_backward), out.data_ptr(), _C.cur_stream())
+        _C.check(rc, "cx_encoder_forward")
+        if save_for_backward:
+            arena.emb_out = out
+            arena.normalize = self._desc.normalize
+            return out, arena
+        return out, None
+
+    def backward_chunk(self, vb: VarlenBatch, arena: _ChunkArena, demb: torch.Tensor):
+        """Accumulate every parameter gradient for the chunk whose activations are in `arena`."""
+        assert arena.emb_out is not None, "backward_chunk needs a forward with save_for_backward=True"
+        demb = demb.to(torch.float32).contiguous()
+        self._desc.normalize = arena.normalize
+        rc = self.lib.cx_encoder_backward(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
+                                          vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
+                                          vb.max_seqlen, demb.data_ptr(), arena.emb_out.data_ptr(), _C.cur_stream())
+        _C.check(rc, "cx_encoder_backward")
+        self.release_arena(arena)
+
+    # nn.Module-style call used by BiEncoder: differentiable w.r.t. the engine's own parameters
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                normalize: Optional[bool] = None) -> torch.Tensor:
+        vb = VarlenBatch.from_mask(input_ids, attention_mask)
+        if torch.is_grad_enabled() and self.training:
+            return _EncodeFn.apply(self.flat_decay, self, vb, normalize)
+        emb, _ = self.forward_chunk(vb, False, normalize)
+        return emb
+
+
+class _EncodeFn(torch.autograd.Function):
+    """autograd bridge: backward accumulates straight into the engine's flat gradient buffer (as the reference's
+    `surrogate.backward()` accumulates into .grad, sc/loss.py:158-161) and reports no gradient for its inputs."""
+
+    @staticmethod
+    def forward(ctx, _anchor, engine: NomicBertEngine, vb: VarlenBatch, normalize):
+        emb, arena = engine.forward_chunk(vb, True, normalize)
+        ctx.engine, ctx.vb, ctx.arena = engine, vb, arena
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        ctx.engine.backward_chunk(ctx.vb, ctx.arena, demb)
+        return None, None, None, None

@@ -1,0 +1,218 @@
+/* contrastors_hip.h -- C-ABI of libcontrastors_hip.so (gfx950 / MI355X only).
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b): the reference (nomic-ai/contrastors) reaches its native
+ * hot path through the python symbol surface of the third-party `flash_attn` package; every entry point
+ * below is what that surface binds for ONE op, with the reference call site it replaces.  Rules:
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - bf16 tensors are `uint16_t*` (raw bfloat16 bits), row-major, leading dimension in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only enqueues work;
+ *   - nothing allocates or frees: outputs and scratch are caller-owned (torch caching allocator upstream);
+ *   - return value: CX_OK (0) or a negative CX_ERR_* code; the library never throws and never exits.
+ * Reference paths are relative to /root/reference/src/contrastors (abbreviated sc/).
+ */
+#ifndef CONTRASTORS_HIP_H
+#define CONTRASTORS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CX_OK 0
+#define CX_ERR_SHAPE (-1)  /* unsupported shape (e.g. K % 64 != 0, head_dim != 64) */
+#define CX_ERR_ALIGN (-2)  /* pointer / leading dimension not aligned as required */
+#define CX_ERR_ARG (-3)    /* invalid enum / null pointer */
+#define CX_ERR_LAUNCH (-4) /* hipGetLastError() != hipSuccess after the launch */
+
+/* ---- library info -------------------------------------------------------------------------------- */
+int cx_abi_version(void);          /* bumped on any signature change */
+const char* cx_build_info(void);   /* "gfx950 <date> <compiler>" */
+const char* cx_error_string(int code);
+
+/* ---- K9  FusedDense  (flash_attn.ops.fused_dense.FusedDense; sc/layers/attention.py:82-85,112-114,243,
+ *          sc/layers/mlp.py:24-28,61-83) ----------------------------------------------------------------
+ * Out[m][n] = alpha * sum_k X[m][k] * W[n][k] (+ bias[n])          X:(M,K) ldx   W:(N,K) ldw   Out:(M,N) ldo
+ * out_mode 0: Out is bf16;  1: Out is fp32 (overwrite);  2: Out is fp32, atomically ACCUMULATED (wgrad; the
+ * only mode that honours split_k > 1).  Requirements: K % 64 == 0, N % 4 == 0, ldx/ldw % 8 == 0, ldo % 4 == 0.
+ * forward: X=act, W=weight.  dgrad: X=dY, W=W^T.  wgrad: X=dY^T, W=act^T (both via cx_transpose_bf16). */
+int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float* bias, int M, int N, int K, int ldx,
+                    int ldw, int ldo, int out_mode, int split_k, float alpha, void* stream);
+void cx_gemm_set_glds(int enable); /* 1 (default): operand tiles via global_load_lds DMA; 0: register staging */
+int cx_gemm_get_glds(void);
+
+/* Out[c][r] = In[r][c] for r < rows, zero for rows <= r < rows_pad (token padding for the wgrad reduction).
+ * In:(rows,cols) ld_in, Out:(cols,rows_pad) ld_out.  cols % 8 == 0. */
+int cx_transpose_bf16(const uint16_t* In, uint16_t* Out, int rows, int cols, int ld_in, int ld_out, int rows_pad,
+                      void* stream);
+/* fp32 master weights -> bf16 shadow (row-major copy) and optional transposed bf16 shadow (for dgrad). */
+int cx_cast_f32_to_bf16(const float* In, uint16_t* Out, long n, void* stream);
+int cx_cast_transpose_f32_to_bf16(const float* In, uint16_t* OutT, int rows, int cols, void* stream);
+int cx_cast_bf16_to_f32(const uint16_t* In, float* Out, long n, void* stream);
+
+/* ---- K5/K6  dropout_add_layer_norm / layer_norm  (flash_attn.ops.layer_norm; sc/layers/block.py:309-319,
+ *             422-431,453-462; sc/models/encoder/modeling_nomic_bert.py:534; sc/models/vit/vit.py:253-263) ---
+ * z = x0 + residual (residual may be NULL); out = (z-mean)*rstd*gamma + beta.  Statistics in fp32.
+ * z_out (may be NULL, may alias x0) receives z in bf16 (kept for backward / the pre-norm residual stream).
+ * dropout p == 0 only (all five BASELINE configs train with resid_pdrop = 0).  d in {256,512,768,1024}. */
+int cx_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* gamma, const float* beta,
+                     uint16_t* out, uint16_t* z_out, float* mean, float* rstd, int rows, int d, float eps,
+                     void* stream);
+/* dout = dout_a + dout_b (dout_b may be NULL); dz_extra (may be NULL) is added to dz (pre-norm residual grad).
+ * dz: bf16 (rows,d) (grad of x0 and of residual); dgamma/dbeta: fp32[d], atomically accumulated. */
+int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                     const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
+                     float* dbeta, int rows, int d, void* stream);
+
+/* ---- a11 BertEmbeddings + K6 embedding LayerNorm, on the unpadded token stream
+ *          (sc/layers/embedding.py:594-615, sc/models/encoder/modeling_nomic_bert.py:531-535, K4 unpad_input
+ *          sc/models/encoder/modeling_nomic_bert.py:332-333) -------------------------------------------------
+ * token t: flat = indices[t] (= b*S + s of the padded batch); id = input_ids[flat]; pos = flat % S.
+ * z = word[id] + type[0] (+ pos_emb[pos] if pos_emb != NULL); out = LN(z) in bf16; mean/rstd saved. */
+int cx_embed_ln_fwd(const int64_t* input_ids, const int32_t* indices, const float* word, const float* type0,
+                    const float* pos_emb, const float* gamma, const float* beta, uint16_t* out, float* mean,
+                    float* rstd, int T, int S, int d, float eps, void* stream);
+/* backward: scatter-adds into fp32 grads (word rows except padding_idx, type row 0, pos rows), dgamma/dbeta. */
+int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_t* input_ids,
+                    const int32_t* indices, const float* word, const float* type0, const float* pos_emb,
+                    const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
+                    float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, void* stream);
+
+/* ---- K10 swiglu (flash_attn.ops.activations.swiglu; sc/layers/mlp.py:75) and GELU(erf) (mlp.py:30-34) ----
+ * yg:(T, 2*I) = [ y = fc11(x) | gate = fc12(x) ];  act = silu(gate) * y, fp32 math, one rounding. */
+int cx_swiglu_fwd(const uint16_t* yg, uint16_t* act, int T, int I, void* stream);
+int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T, int I, void* stream);
+/* act = gelu_erf(pre + bias); bias fp32[I] may be NULL.  backward: dpre = dact * gelu'(pre + bias). */
+int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream);
+int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, int T, int I,
+                     void* stream);
+/* dbias[n] += sum_t dY[t][n]  (fp32 atomic accumulate; bgrad half of FusedDense backward). */
+int cx_bias_grad(const uint16_t* dY, float* dbias, int T, int N, int ld, void* stream);
+
+/* ---- K1/K2 + K11  flash_attn_varlen_qkvpacked_func with rotary fused into the Q/K tile load
+ *          (sc/layers/attention.py:122-135,172-182; sc/layers/embedding.py:685-706) -------------------------
+ * qkv:(T,3,H,64) bf16 packed, cu_seqlens:(B+1) int32, non-causal, softmax in fp32, dropout 0.
+ * rot_cos/rot_sin: fp32 (>= max_seqlen, 32) tables for full non-interleaved rotary, or NULL for no rotary
+ * (bert-base / ViT).  out:(T,H,64) bf16.  lse:(H,T) fp32 (natural log of the scaled-score softmax denominator). */
+int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
+                       uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
+                       void* stream);
+/* delta:(H,T) fp32 scratch (rowsum(dO*O)); dqkv:(T,3,H,64) bf16 fully overwritten (dq,dk un-rotated). */
+int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
+                       const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
+                       uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
+/* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
+int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
+                          int B, int H, int T, int max_seqlen, int sign, void* stream);
+
+/* ---- a9 BiEncoder pooling + normalize (sc/models/biencoder/modeling_biencoder.py:79-90,44-49,314-319) -----
+ * mode 0 = mean over the sequence's tokens, 1 = cls (first token).  emb:(B,d) fp32 = x / max(||x||, 1e-12);
+ * if normalize == 0 the raw pooled vector is written.  norm:(B) fp32 saved for backward. */
+int cx_pool_normalize_fwd(const uint16_t* h, const int32_t* cu_seqlens, float* emb, float* norm, int B, int d,
+                          int mode, int normalize, void* stream);
+int cx_pool_normalize_bwd(const float* demb, const float* emb, const float* norm, const int32_t* cu_seqlens,
+                          uint16_t* dh, int B, int d, int mode, int normalize, void* stream);
+
+/* ---- K13 fused InfoNCE (sc/loss.py:76-132 clip_loss; LogitScale sc/models/biencoder/modeling_biencoder.py:30-41)
+ * Q:(N,dim) ldq, D:(G,dim) ldd fp32 (D = rank-ordered all-gather of the document embeddings),
+ * labels:(N) int64 = (arange(N)+rank*N)*(G/(N*world)) computed by the host exactly as loss.py:108-117.
+ * logits = scale * Q D^T are never written: exact-fp32 MFMA tiles feed an online row log-sum-exp.
+ * ws: fp32 scratch of cx_infonce_ws_floats(N,G) floats.  Outputs: lse:(N) fp32, loss_rows:(N) fp32
+ * (= lse_i - logit_{i,label_i}); the host takes mean * world_size (loss.py:125). */
+long cx_infonce_ws_floats(int N, int G);
+int cx_infonce_fwd(const float* Q, const float* D, const int64_t* labels, float scale, float* ws, float* lse,
+                   float* loss_rows, int N, int G, int dim, int ldq, int ldd, void* stream);
+/* backward of  coef * sum_i loss_rows[i]:  Gm[i][j] = coef*scale*(softmax_ij - [j==label_i]) is written to
+ * Gmat:(N,G) and GmatT:(G,N) fp32 scratch; dQ:(N,dim) = Gm D, dD:(G,dim) = Gm^T Q (overwritten);
+ * dscale_accum (may be NULL): += coef * sum_ij (softmax_ij - y_ij) * (Q D^T)_ij   (d loss / d scale).
+ * QT:(dim,N) and DT:(dim,G) fp32 scratch for the K-contiguous operands of the two output GEMMs. */
+int cx_infonce_bwd(const float* Q, const float* D, const int64_t* labels, const float* lse, float scale, float coef,
+                   float* Gmat, float* GmatT, float* QT, float* DT, float* dQ, float* dD, float* dscale_accum,
+                   int N, int G, int dim, int ldq, int ldd, void* stream);
+/* plain exact-fp32 MFMA GEMM  C[m][n] = sum_k A[m][k] B[n][k]  (K % 16 == 0). */
+int cx_sgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                void* stream);
+int cx_transpose_f32(const float* In, float* Out, int rows, int cols, int ld_in, int ld_out, void* stream);
+
+/* ---- native encoder engine (a10-a17: NomicBertModel / NomicBertEncoder / Block / FlashAttention / (Gated)MLP,
+ *      sc/models/encoder/modeling_nomic_bert.py:307-395,515-587; sc/layers/block.py:389-463) -----------------
+ * One call enqueues a whole chunk forward (embeddings -> L post-norm blocks -> pool -> normalize) or backward on
+ * `stream`.  All memory is described by the caller in CxEncoderDesc / CxChunkBuffers. */
+typedef struct CxLayerWeights {
+    const uint16_t* Wqkv;   /* (3d, d) bf16 */
+    const uint16_t* Wout;   /* (d, d) */
+    const uint16_t* Wfc1;   /* gated: (2I, d) = [fc11; fc12];  plain MLP: (I, d) */
+    const uint16_t* Wfc2;   /* (d, I) */
+    const uint16_t* WqkvT;  /* transposed bf16 shadows for dgrad: (d, 3d) */
+    const uint16_t* WoutT;  /* (d, d) */
+    const uint16_t* Wfc1T;  /* (d, 2I) or (d, I) */
+    const uint16_t* Wfc2T;  /* (I, d) */
+    const float* bqkv;      /* fp32 biases or NULL (nomic-bert has none) */
+    const float* bout;
+    const float* bfc1;
+    const float* bfc2;
+    const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+    /* fp32 gradient accumulators (same shapes as the fp32 master parameters) */
+    float* gWqkv; float* gWout; float* gWfc1; float* gWfc2;
+    float* gbqkv; float* gbout; float* gbfc1; float* gbfc2;
+    float* gln1_g; float* gln1_b; float* gln2_g; float* gln2_b;
+} CxLayerWeights;
+
+typedef struct CxEncoderDesc {
+    int n_layer, d, n_head, d_inner, gated; /* gated=1: SwiGLU GatedMLP; 0: GELU(erf) MLP */
+    int vocab, max_pos, padding_idx;
+    float ln_eps, softmax_scale;
+    const float* word_emb; const float* type_emb; const float* pos_emb; /* fp32 masters; pos_emb NULL for rotary */
+    const float* emb_ln_g; const float* emb_ln_b;
+    float* gword_emb; float* gtype_emb; float* gpos_emb; float* gemb_ln_g; float* gemb_ln_b;
+    const float* rot_cos; const float* rot_sin; /* NULL when rotary_emb_fraction == 0 */
+    const CxLayerWeights* layers;              /* HOST array of n_layer entries (device pointers inside) */
+    int pool_mode, normalize;
+} CxEncoderDesc;
+
+/* Per-chunk activation arena (device memory owned by the caller).  save_for_backward = 0 lets every layer reuse
+ * the layer-0 slots (GradCache pass 1, sc/loss.py:135-146); = 1 keeps per-layer slots (pass 2, loss.py:149-161). */
+typedef struct CxChunkBuffers {
+    long T_cap;                 /* capacity in tokens of every per-token buffer (>= round_up(T,128)) */
+    uint16_t* h0;               /* (T,d) embedding-LN output */
+    float* emb_mean; float* emb_rstd;
+    /* per layer, n_layer slots each (slot stride = T_cap * width elements): */
+    uint16_t* qkv;              /* (T,3d) */
+    uint16_t* ctx;              /* (T,d) attention output (pre out_proj) */
+    float* lse;                 /* (H,T) */
+    uint16_t* z1;               /* (T,d) attn_out + residual (LN1 input) */
+    uint16_t* h1;               /* (T,d) LN1 output */
+    float* mean1; float* rstd1;
+    uint16_t* yg;               /* (T,2I) or (T,I) fc1 output */
+    uint16_t* act;              /* (T,I) */
+    uint16_t* z2;               /* (T,d) */
+    uint16_t* h2;               /* (T,d) LN2 output = layer output */
+    float* mean2; float* rstd2;
+    float* pool_norm;           /* (B) */
+    /* backward scratch (single slot each): */
+    uint16_t* g_a; uint16_t* g_b; uint16_t* g_c;   /* (T,d) gradient ping-pong buffers */
+    uint16_t* g_wide;           /* (T, max(3d, 2I)) */
+    uint16_t* g_act;            /* (T, I) */
+    uint16_t* tr_a; uint16_t* tr_b; /* transposed operands for wgrad: (max(3d,2I), T_cap) each */
+    float* delta;               /* (H,T) */
+} CxChunkBuffers;
+
+/* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.
+ * emb_out:(Bc,d) fp32. */
+int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
+                       const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
+                       int save_for_backward, float* emb_out, void* stream);
+/* demb:(Bc,d) fp32 cached embedding gradient (GradCache surrogate, sc/loss.py:158-161). Accumulates every
+ * parameter gradient in enc->g* / layers[i].g*.  Must follow a forward with save_for_backward = 1 on `buf`. */
+int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
+                        const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
+                        const float* demb, const float* emb_out, void* stream);
+
+/* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
+int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
+int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTRASTORS_HIP_H */

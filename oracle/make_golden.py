@@ -1,0 +1,206 @@
+"""Generate tests/golden/*.npz by running the reference's own code on CPU (fp32).  TEST INFRASTRUCTURE.
+
+Run in the build container:  python -m oracle.make_golden
+Fixtures are small (inputs + outputs only); model weights are re-created from a seed by
+oracle.encoder_ref.random_state_dict and pinned by a checksum stored in the fixture.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import encoder_ref, ref_import  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+TINY_NOMIC = dict(vocab_size=512, n_positions=64, n_embd=256, n_layer=2, n_head=4, n_inner=512,
+                  activation_function="swiglu", rotary_emb_fraction=1.0, rotary_emb_base=1000.0,
+                  qkv_proj_bias=False, mlp_fc1_bias=False, mlp_fc2_bias=False, layer_norm_epsilon=1e-12,
+                  type_vocab_size=2, pad_token_id=0, max_position_embeddings=64)
+TINY_BERT = dict(TINY_NOMIC, activation_function="gelu", rotary_emb_fraction=0.0, qkv_proj_bias=True,
+                 mlp_fc1_bias=True, mlp_fc2_bias=True)
+
+
+def cfg_ns(d):
+    return SimpleNamespace(**d)
+
+
+def ref_model(cfgd, sd):
+    _, rcfg, rmod = ref_import.load()
+    c = rcfg.NomicBertConfig(
+        vocab_size=cfgd["vocab_size"], n_positions=cfgd["n_positions"], n_embd=cfgd["n_embd"],
+        n_layer=cfgd["n_layer"], n_head=cfgd["n_head"], n_inner=cfgd["n_inner"],
+        activation_function=cfgd["activation_function"], rotary_emb_fraction=cfgd["rotary_emb_fraction"],
+        rotary_emb_base=cfgd["rotary_emb_base"], qkv_proj_bias=cfgd["qkv_proj_bias"],
+        mlp_fc1_bias=cfgd["mlp_fc1_bias"], mlp_fc2_bias=cfgd["mlp_fc2_bias"],
+        layer_norm_epsilon=cfgd["layer_norm_epsilon"], type_vocab_size=cfgd["type_vocab_size"],
+        pad_token_id=cfgd["pad_token_id"], resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+        max_position_embeddings=cfgd["max_position_embeddings"], prenorm=False, use_flash_attn=False,
+    )
+    m = rmod.NomicBertModel(c, add_pooling_layer=False)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("inv_freq" in k or "norm_factor" in k for k in missing), missing
+    return m.eval()
+
+
+def checksum(sd):
+    return np.array([float(sum(v.double().sum() for v in sd.values())),
+                     float(sum((v.double() ** 2).sum() for v in sd.values()))])
+
+
+def make_inputs(cfgd, B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, cfgd["vocab_size"], (B, S), generator=g)
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ids = ids * mask  # pad id 0
+    return ids, mask, lens
+
+
+def gen_encoder(name, cfgd, seed):
+    cfg = cfg_ns(cfgd)
+    sd = encoder_ref.random_state_dict(cfg, seed)
+    m = ref_model(cfgd, sd)
+    ids, mask, lens = make_inputs(cfgd, 6, 32, seed + 1)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    hid = m(ids, attention_mask=mask).last_hidden_state
+    hid0 = hid * mask.unsqueeze(-1)  # reference tests zero the padded rows (tests/test_flash_bert.py:65,71)
+    # BiEncoder pooling restated (modeling_biencoder.py:79-90, :317) on top of the REFERENCE hidden states
+    s = (hid * mask.unsqueeze(-1).float()).sum(1) / mask.sum(1, keepdim=True).float()
+    emb = torch.nn.functional.normalize(s, dim=-1)
+    g = torch.Generator().manual_seed(seed + 2)
+    probe = torch.randn(emb.shape, generator=g)
+    (emb * probe).sum().backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    keep = {}
+    for k, gten in grads.items():
+        keep["gnorm/" + k] = np.array(float(gten.norm()))
+    keep["g/emb_ln.weight"] = grads["emb_ln.weight"].numpy()
+    keep["g/encoder.layers.0.attn.Wqkv.weight[:16,:16]"] = grads["encoder.layers.0.attn.Wqkv.weight"][:16, :16].numpy()
+    keep["g/encoder.layers.1.mlp.fc2.weight[:16,:16]"] = grads["encoder.layers.1.mlp.fc2.weight"][:16, :16].numpy()
+    keep["g/embeddings.word_embeddings.weight[rows]"] = grads["embeddings.word_embeddings.weight"][ids[0, :8]].numpy()
+    np.savez_compressed(GOLD / f"{name}.npz", seed=seed, input_ids=ids.numpy(), attention_mask=mask.numpy(),
+                        lens=lens.numpy(), hidden=hid0.detach().numpy(), embedding=emb.detach().numpy(),
+                        probe=probe.numpy(), weight_checksum=checksum(sd), **keep,
+                        **{"cfg/" + k: np.array(v) for k, v in cfgd.items()})
+    print(name, "hidden", tuple(hid.shape), "emb norm", float(emb.norm()))
+
+
+class _Scale(torch.nn.Module):
+    """Stand-in for LogitScale with a fixed scale (reference passes a module: sc/loss.py:109)."""
+
+    def __init__(self, s):
+        super().__init__()
+        self.s = s
+
+    def forward(self, x):
+        return x * self.s
+
+
+def gen_clip_loss_single():
+    ref_loss, _, _ = ref_import.load()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    for tag, N, M, bid in (("sq", 8, 8, False), ("neg", 8, 24, False), ("bi", 8, 8, True), ("big", 96, 288, False)):
+        q = torch.nn.functional.normalize(torch.randn(N, 64, generator=g), dim=-1).requires_grad_()
+        d = torch.nn.functional.normalize(torch.randn(M, 64, generator=g), dim=-1).requires_grad_()
+        loss = ref_loss.clip_loss(q, d, _Scale(50.0), bidirectional=bid)
+        loss.backward()
+        out.update({f"{tag}/q": q.detach().numpy(), f"{tag}/d": d.detach().numpy(), f"{tag}/loss": loss.detach().numpy(),
+                    f"{tag}/dq": q.grad.numpy(), f"{tag}/dd": d.grad.numpy()})
+    # KAT of the reference's own unit test (tests/test_loss.py:5-17)
+    q = torch.tensor([[1.0, 2], [2, 3], [3, 4]])
+    d = torch.tensor([[1.0, 2], [3, 4], [2, 3]])
+    qn, dn = torch.nn.functional.normalize(q, dim=-1), torch.nn.functional.normalize(d, dim=-1)
+    out["kat/q"], out["kat/d"] = qn.numpy(), dn.numpy()
+    out["kat/loss"] = ref_loss.clip_loss(qn, dn, _Scale(1.0)).numpy()
+    np.savez_compressed(GOLD / "clip_loss_w1.npz", **out)
+    dist.destroy_process_group()
+    print("clip_loss_w1 done")
+
+
+def _rank_clip(rank, world, tmp):
+    ref_loss, _, _ = ref_import.load()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29612", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    q = torch.nn.functional.normalize(torch.randn(4, 64, generator=g), dim=-1).requires_grad_()
+    d = torch.nn.functional.normalize(torch.randn(12, 64, generator=g), dim=-1).requires_grad_()  # 1 pos + 2 neg
+    loss = ref_loss.clip_loss(q, d, _Scale(50.0), gather_enabled=True)
+    loss.backward()
+    np.savez(f"{tmp}/r{rank}.npz", q=q.detach().numpy(), d=d.detach().numpy(), loss=loss.detach().numpy(),
+             dq=q.grad.numpy(), dd=d.grad.numpy())
+    dist.destroy_process_group()
+
+
+class _Tower(torch.nn.Module):
+    """Reference eager trunk + BiEncoder mean-pool/normalise restatement, shaped like BiEncoder's output dict."""
+
+    def __init__(self, trunk):
+        super().__init__()
+        self.trunk = trunk
+
+    def forward(self, input_ids, attention_mask=None, **kw):
+        h = self.trunk(input_ids, attention_mask=attention_mask).last_hidden_state
+        s = (h * attention_mask.unsqueeze(-1).float()).sum(1) / attention_mask.sum(1, keepdim=True).float()
+        return {"embedding": torch.nn.functional.normalize(s, dim=-1)}
+
+
+def _rank_gradcache(rank, world, tmp):
+    warnings.filterwarnings("ignore")
+    ref_loss, _, _ = ref_import.load()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29613", rank=rank, world_size=world)
+    cfg = cfg_ns(TINY_NOMIC)
+    sd = encoder_ref.random_state_dict(cfg, 11)
+    tower = _Tower(ref_model(TINY_NOMIC, sd)).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(tower, broadcast_buffers=False)
+    ddp.device = torch.device("cpu")
+    qi, qm, _ = make_inputs(TINY_NOMIC, 4, 16, 300 + rank)
+    di, dm, _ = make_inputs(TINY_NOMIC, 4, 32, 400 + rank)
+    loss = ref_loss.grad_cache_loss(ddp, {"input_ids": qi, "attention_mask": qm}, ddp,
+                                    {"input_ids": di, "attention_mask": dm}, chunk_size=2,
+                                    logit_scale=_Scale(20.0))
+    grads = {k: p.grad.detach().clone() for k, p in tower.trunk.named_parameters() if p.grad is not None}
+    keep = {"gnorm/" + k: np.array(float(v.norm())) for k, v in grads.items()}
+    keep["g/emb_ln.weight"] = grads["emb_ln.weight"].numpy()
+    keep["g/encoder.layers.1.attn.out_proj.weight[:16,:16]"] = grads["encoder.layers.1.attn.out_proj.weight"][:16, :16].numpy()
+    np.savez(f"{tmp}/gc{rank}.npz", q_ids=qi.numpy(), q_mask=qm.numpy(), d_ids=di.numpy(), d_mask=dm.numpy(),
+             loss=loss.detach().numpy(), **keep)
+    dist.destroy_process_group()
+
+
+def gen_multirank():
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_rank_clip, args=(2, tmp), nprocs=2, join=True)
+        r = [np.load(f"{tmp}/r{i}.npz") for i in range(2)]
+        np.savez_compressed(GOLD / "clip_loss_w2.npz", **{f"r{i}/{k}": r[i][k] for i in range(2) for k in r[i].files})
+        mp.spawn(_rank_gradcache, args=(2, tmp), nprocs=2, join=True)
+        r = [np.load(f"{tmp}/gc{i}.npz") for i in range(2)]
+        np.savez_compressed(GOLD / "grad_cache_w2.npz", seed=11,
+                            **{f"r{i}/{k}": r[i][k] for i in range(2) for k in r[i].files})
+    print("multi-rank fixtures done")
+
+
+if __name__ == "__main__":
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    GOLD.mkdir(parents=True, exist_ok=True)
+    gen_encoder("encoder_nomic_tiny", TINY_NOMIC, 1)
+    gen_encoder("encoder_bert_tiny", TINY_BERT, 2)
+    gen_clip_loss_single()
+    gen_multirank()

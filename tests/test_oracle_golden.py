@@ -1,0 +1,115 @@
+"""The oracle (oracle/*.py, a CPU restatement) is pinned against fixtures produced by the REFERENCE's own code
+(oracle/make_golden.py imports /root/reference ... loss.py and modeling_hf_nomic_bert.py).  CPU only."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_ref, infonce_ref
+
+
+def _cfg(g):
+    d = {}
+    for k in g.files:
+        if k.startswith("cfg/"):
+            v = g[k]
+            d[k[4:]] = v.item() if v.shape == () else v
+    return SimpleNamespace(**{k: (str(v) if isinstance(v, (str, np.str_)) else v) for k, v in d.items()})
+
+
+@pytest.mark.parametrize("name", ["encoder_nomic_tiny", "encoder_bert_tiny"])
+def test_encoder_restatement_matches_reference(gold, name):
+    g = gold(name)
+    cfg = _cfg(g)
+    sd = encoder_ref.random_state_dict(cfg, int(g["seed"]))
+    cs = np.array([float(sum(v.double().sum() for v in sd.values())),
+                   float(sum((v.double() ** 2).sum() for v in sd.values()))])
+    np.testing.assert_allclose(cs, g["weight_checksum"], rtol=1e-12)
+    for v in sd.values():
+        v.requires_grad_(True)
+    ids = torch.from_numpy(g["input_ids"])
+    mask = torch.from_numpy(g["attention_mask"])
+    hid = encoder_ref.encoder_hidden_states(sd, cfg, ids, mask)
+    np.testing.assert_allclose((hid * mask.unsqueeze(-1)).detach().numpy(), g["hidden"], atol=2e-5, rtol=1e-4)
+    emb = encoder_ref.biencoder_embedding(sd, cfg, ids, mask)
+    np.testing.assert_allclose(emb.detach().numpy(), g["embedding"], atol=2e-6)
+    (emb * torch.from_numpy(g["probe"])).sum().backward()
+    for k in g.files:
+        if k.startswith("gnorm/"):
+            name_ = k[6:]
+            assert abs(float(sd[name_].grad.norm()) - float(g[k])) <= 1e-4 * max(1.0, float(g[k])), name_
+    np.testing.assert_allclose(sd["emb_ln.weight"].grad.numpy(), g["g/emb_ln.weight"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(sd["encoder.layers.0.attn.Wqkv.weight"].grad[:16, :16].numpy(),
+                               g["g/encoder.layers.0.attn.Wqkv.weight[:16,:16]"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(sd["embeddings.word_embeddings.weight"].grad[ids[0, :8]].numpy(),
+                               g["g/embeddings.word_embeddings.weight[rows]"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,bid", [("sq", False), ("neg", False), ("bi", True), ("big", False)])
+def test_clip_loss_restatement_w1(gold, tag, bid):
+    g = gold("clip_loss_w1")
+    q = torch.from_numpy(g[f"{tag}/q"]).requires_grad_()
+    d = torch.from_numpy(g[f"{tag}/d"]).requires_grad_()
+    loss = infonce_ref.clip_loss_ref(q, d, 50.0, bidirectional=bid)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"{tag}/loss"], rtol=1e-5)
+    np.testing.assert_allclose(q.grad.numpy(), g[f"{tag}/dq"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(d.grad.numpy(), g[f"{tag}/dd"], atol=1e-6, rtol=1e-4)
+
+
+def test_reference_kat_toy_infonce(gold):
+    """tests/test_loss.py:5-17 of the reference: clip_loss == -mean log softmax on the diagonal labels."""
+    g = gold("clip_loss_w1")
+    q, d = torch.from_numpy(g["kat/q"]), torch.from_numpy(g["kat/d"])
+    naive = -torch.log_softmax(q @ d.T, dim=1)[torch.arange(3), torch.arange(3)].mean()
+    np.testing.assert_allclose(naive.item(), g["kat/loss"], rtol=1e-6)
+    np.testing.assert_allclose(infonce_ref.clip_loss_ref(q, d, 1.0).item(), g["kat/loss"], rtol=1e-6)
+    lse, rows = infonce_ref.infonce_rows_np(g["kat/q"], g["kat/d"], np.arange(3), 1.0)
+    np.testing.assert_allclose(rows.mean(), g["kat/loss"], rtol=1e-6)
+
+
+def test_labels_bit_exact():
+    # sc/loss.py:108-117 with hard negatives: stride 1+N_neg, rank offset
+    np.testing.assert_array_equal(infonce_ref.labels_for(4, 24, 1, 2), np.array([12, 15, 18, 21], dtype=np.int64))
+    np.testing.assert_array_equal(infonce_ref.labels_for(3, 3, 0, 1), np.arange(3))
+
+
+def test_clip_loss_restatement_two_ranks(gold):
+    g = gold("clip_loss_w2")
+    qs = [torch.from_numpy(g[f"r{r}/q"]).requires_grad_() for r in range(2)]
+    ds = [torch.from_numpy(g[f"r{r}/d"]).requires_grad_() for r in range(2)]
+    losses = infonce_ref.multi_rank_clip_loss_ref(qs, ds, 50.0)
+    sum(losses).backward()
+    for r in range(2):
+        np.testing.assert_allclose(losses[r].item(), g[f"r{r}/loss"], rtol=1e-5)
+        np.testing.assert_allclose(qs[r].grad.numpy(), g[f"r{r}/dq"], atol=1e-6, rtol=1e-4)
+        np.testing.assert_allclose(ds[r].grad.numpy(), g[f"r{r}/dd"], atol=1e-6, rtol=1e-4)
+
+
+def test_gradcache_ddp_two_ranks(gold):
+    """Reference grad_cache_loss under 2-rank gloo DDP == full-batch loss, gradients averaged over ranks."""
+    from oracle.make_golden import TINY_NOMIC
+
+    g = gold("grad_cache_w2")
+    cfg = SimpleNamespace(**TINY_NOMIC)
+    sd = encoder_ref.random_state_dict(cfg, int(g["seed"]))
+    for v in sd.values():
+        v.requires_grad_(True)
+    qs, ds = [], []
+    for r in range(2):
+        qs.append(encoder_ref.biencoder_embedding(sd, cfg, torch.from_numpy(g[f"r{r}/q_ids"]),
+                                                  torch.from_numpy(g[f"r{r}/q_mask"])))
+        ds.append(encoder_ref.biencoder_embedding(sd, cfg, torch.from_numpy(g[f"r{r}/d_ids"]),
+                                                  torch.from_numpy(g[f"r{r}/d_mask"])))
+    losses = infonce_ref.multi_rank_clip_loss_ref(qs, ds, 20.0)
+    (sum(losses) / 2).backward()  # DDP averages parameter gradients over the 2 ranks
+    for r in range(2):
+        np.testing.assert_allclose(losses[r].item(), g[f"r{r}/loss"], rtol=2e-5)
+    np.testing.assert_allclose(sd["emb_ln.weight"].grad.numpy(), g["r0/g/emb_ln.weight"], atol=3e-5, rtol=1e-3)
+    np.testing.assert_allclose(sd["encoder.layers.1.attn.out_proj.weight"].grad[:16, :16].numpy(),
+                               g["r0/g/encoder.layers.1.attn.out_proj.weight[:16,:16]"], atol=3e-5, rtol=1e-3)
+    for k in g.files:
+        if k.startswith("r0/gnorm/"):
+            n = k[len("r0/gnorm/"):]
+            assert abs(float(sd[n].grad.norm()) - float(g[k])) <= 2e-3 * max(1e-3, float(g[k])), n
