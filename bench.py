@@ -1,0 +1,192 @@
+"""bench.py -- query-doc pairs/sec of the contrastive GradCache training step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): nomic-bert-2048 architecture (random init, no hub), bi-encoder with mean pooling,
+paired InfoNCE at logit scale 50, seq_len 128, GLOBAL batch 16384 (fixed; each of the N ranks owns 16384/N pairs ->
+"strong" scaling), GradCache chunked re-forward, bf16 MFMA compute with fp32 master weights, grad-clip 1.0, AdamW,
+cosine schedule.  A step = everything in the reference's training_step (sc/trainers/base.py:366-393): GradCache pass 1,
+embedding all-gather, fused loss fwd/bwd, pass 2 (re-forward + backward), gradient all-reduce, clip, AdamW, scheduler,
+bf16 shadow refresh.  Synthetic token ids are staged in HBM before the timed region.
+
+One JSON line on rank 0 with `roofline` (dominant kernel = bf16 MFMA GEMM, timed live with HIP events on its own
+stream, sampled every 8th launch) and `cpu_baseline` (oracle = CPU restatement of the reference, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+from types import SimpleNamespace
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+GFLOP_PER_PAIR = 236.84       # 2 seqs x 4 fwd-equivalents x 29.595 GFLOP + loss
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--global-batch", type=int, default=16384)
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--chunk-size", type=int, default=int(os.environ.get("CX_BENCH_CHUNK", 64)),
+                    help="GradCache chunk (reference recipe: 64, contrastive_pretrain.yaml:15)")
+    ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the metric
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-stride", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(seq_len: int) -> dict:
+    """Reference algorithm (oracle restatement, fp32, torch CPU kernels) on a bounded sample of the same workload:
+    direct forward+backward of 8 query-document pairs through the 12-layer encoder + InfoNCE."""
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from oracle import encoder_ref, infonce_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = NomicBertConfig.nomic_bert_2048()
+    ns = SimpleNamespace(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    sd = encoder_ref.random_state_dict(ns, 0)
+    for v in sd.values():
+        v.requires_grad_(True)
+    pairs = 8
+    g = torch.Generator().manual_seed(1234)
+    q = torch.randint(1000, 30522, (pairs, seq_len), generator=g)
+    d = torch.randint(1000, 30522, (pairs, seq_len), generator=g)
+    mask = torch.ones(pairs, seq_len, dtype=torch.long)
+
+    def step():
+        loss = infonce_ref.clip_loss_ref(encoder_ref.biencoder_embedding(sd, ns, q, mask),
+                                         encoder_ref.biencoder_embedding(sd, ns, d, mask), 50.0)
+        loss.backward()
+
+    step()  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        step()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{pairs} pairs x seq {seq_len}, direct fwd+bwd+InfoNCE (3x fwd FLOPs, no GradCache re-forward), "
+                      f"fp32 torch-CPU, {reps} reps, {dt:.2f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from contrastors_amd import _C
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
+    from contrastors_amd.loss import grad_cache_loss
+    from contrastors_amd.nomic_bert import NomicBertConfig
+
+    lib = _C.lib()
+    G, S = args.global_batch, args.seq_len
+    assert G % world == 0
+    b = G // world
+    cfg = NomicBertConfig.nomic_bert_2048(n_layer=args.layers)
+    tower = BiEncoder(BiEncoderConfig(model_name="nomic-ai/nomic-bert-2048", pooling="mean", logit_scale=50.0,
+                                      trunk_config=cfg), device=dev, seed=0).train()
+    tower.broadcast_parameters(0)
+    scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(dev)
+    opt = torch.optim.AdamW(tower.param_groups(0.01), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    total_steps, warm = 12000, 700  # contrastive_pretrain.yaml: cosine, warmup 700
+    sched = torch.optim.lr_scheduler.LambdaLR(
+        opt, lambda s: (s + 1) / warm if s < warm else 0.5 * (1 + math.cos(math.pi * (s - warm) / (total_steps - warm))))
+
+    # synthetic (query, document) token ids, SURVEY.md §8(d): staged on the device before timing
+    g = torch.Generator().manual_seed(1234 + rank)
+    q_ids = torch.randint(1000, 30522, (b, S), generator=g)
+    d_ids = torch.randint(1000, 30522, (b, S), generator=g)
+    q_ids[:, 0] = 101
+    d_ids[:, 0] = 101
+    lens = [S] * b
+    q_in = {"input_ids": q_ids.to(dev), "seqlens": lens}
+    d_in = {"input_ids": d_ids.to(dev), "seqlens": lens}
+    params = [p for grp in opt.param_groups for p in grp["params"]]
+
+    def step():
+        tower.trunk.zero_grad()
+        loss = grad_cache_loss(tower, q_in, tower, d_in, args.chunk_size, scale)
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        sched.step()
+        tower.trunk.sync_shadows()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.cx_prof_gemm_config(1, args.prof_stride)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    ms, fl = C.c_double(), C.c_double()
+    n_t, n_all = C.c_long(), C.c_long()
+    lib.cx_prof_gemm_collect(C.byref(ms), C.byref(fl), C.byref(n_t), C.byref(n_all))
+    lib.cx_prof_gemm_config(0, 1)
+    if rank == 0:
+        pairs_per_s = G * args.steps / dt
+        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        out = {
+            "metric": "query-doc pairs/sec (whole node), nomic-bert-2048 seq128 global-batch 16384",
+            "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: nomic-bert-2048 bi-encoder contrastive pretrain step (GradCache, "
+                                   "paired InfoNCE scale 50, AdamW, clip 1.0)",
+                       "global_batch": G, "pairs_per_gpu": b, "seq_len": S, "grad_cache_chunk": args.chunk_size,
+                       "n_layer": cfg.n_layer, "parallelism": f"dp{world}", "loss_last_step": float(loss.item())},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "gemm_bf16_nt_kernel (cx_gemm_bf16_nt: fwd, dgrad and wgrad launches)",
+                         "launches_timed": n_t.value, "launches_total": n_all.value,
+                         "avg_launch_us": 1e3 * ms.value / max(1, n_t.value),
+                         "algorithmic_flop_per_launch": fl.value / max(1, n_t.value),
+                         "whole_step_frac_of_mfma_peak": pairs_per_s / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

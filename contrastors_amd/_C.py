@@ -62,6 +62,8 @@ _SIGS = {
     "cx_build_info": (C.c_char_p, []),
     "cx_error_string": (C.c_char_p, [i32]),
     "cx_gemm_bf16_nt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "cx_prof_gemm_config": (i32, [i32, i32]),
+    "cx_prof_gemm_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "cx_gemm_set_glds": (None, [i32]),
     "cx_gemm_get_glds": (i32, []),
     "cx_transpose_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -192,6 +192,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
 
 int g_use_glds = 1;
 
+// ---- sampled per-launch timing (bench.py's live roofline measurement) --------------------------------------
+// Every `stride`-th launch is bracketed by two HIP events recorded on the launch stream; cx_prof_gemm_collect()
+// turns them into (sum of durations, sum of algorithmic FLOPs) for exactly the sampled launches.
+struct GemmProf {
+    bool enabled = false;
+    int stride = 1;
+    long launches = 0;
+    static constexpr int CAP = 8192;
+    hipEvent_t ev0[CAP], ev1[CAP];
+    double flop[CAP];
+    int created = 0, used = 0;
+} g_prof;
+
 template <bool GLDS>
 hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
@@ -230,9 +243,48 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     if (out_mode != OUT_F32_ATOMIC) split_k = 1;  // only the accumulating epilogue can combine K slices
     p.split_k = split_k;
     p.alpha = alpha;
+    int slot = -1;
+    if (g_prof.enabled) {
+        if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
+            slot = g_prof.used++;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev0[slot]) != hipSuccess || hipEventCreate(&g_prof.ev1[slot]) != hipSuccess)
+                    return CX_ERR_LAUNCH;
+                g_prof.created = slot + 1;
+            }
+            g_prof.flop[slot] = 2.0 * (double)M * (double)N * (double)K;
+            (void)hipEventRecord(g_prof.ev0[slot], (hipStream_t)stream);
+        }
+        ++g_prof.launches;
+    }
     hipError_t e = g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
                               : launch_mode<false>(p, out_mode, (hipStream_t)stream);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+int cx_prof_gemm_config(int enable, int stride) {
+    g_prof.enabled = enable != 0;
+    g_prof.stride = stride > 0 ? stride : 1;
+    g_prof.launches = 0;
+    g_prof.used = 0;
+    return CX_OK;
+}
+
+int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_timed, long* launches_total) {
+    double ms = 0.0, fl = 0.0;
+    for (int i = 0; i < g_prof.used; ++i) {
+        if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) return CX_ERR_LAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) return CX_ERR_LAUNCH;
+        ms += t;
+        fl += g_prof.flop[i];
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flop) *total_flop = fl;
+    if (launches_timed) *launches_timed = g_prof.used;
+    if (launches_total) *launches_total = g_prof.launches;
+    return CX_OK;
 }
 
 }  // extern "C"

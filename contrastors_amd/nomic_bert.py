@@ -137,6 +137,9 @@ class _ChunkArena:
         return sum(x.numel() * x.element_size() for x in self.tensors.values())
 
 
+_FULL_CACHE: Dict[tuple, tuple] = {}
+
+
 @dataclass
 class VarlenBatch:
     """Token-stream view of a right- or arbitrarily-padded (B,S) batch (flash_attn.bert_padding.unpad_input)."""
@@ -154,16 +157,24 @@ class VarlenBatch:
         """Right-padded batch with host-known lengths: no device->host sync (the dataloader knows the lengths)."""
         B, S = input_ids.shape
         lens = np.asarray(seqlens, dtype=np.int64).reshape(B)
+        dev = input_ids.device
+        full = bool((lens == S).all())
+        if full:  # throughput case: every chunk shares the same index tensors, build them once per (B,S,device)
+            hit = _FULL_CACHE.get((B, S, str(dev)))
+            if hit is not None:
+                return VarlenBatch(input_ids, hit[0], hit[1], B, S, B * S, S)
         cu = np.zeros(B + 1, dtype=np.int32)
         np.cumsum(lens, out=cu[1:])
         T = int(cu[-1])
-        if (lens == S).all():
+        if full:
             idx = np.arange(B * S, dtype=np.int32)
         else:
             idx = np.concatenate([b * S + np.arange(l, dtype=np.int32) for b, l in enumerate(lens)]).astype(np.int32)
-        dev = input_ids.device
-        return VarlenBatch(input_ids, torch.from_numpy(idx).to(dev, non_blocking=True),
-                           torch.from_numpy(cu).to(dev, non_blocking=True), B, S, T, int(lens.max()) if B else 0)
+        idx_t = torch.from_numpy(idx).to(dev, non_blocking=True)
+        cu_t = torch.from_numpy(cu).to(dev, non_blocking=True)
+        if full:
+            _FULL_CACHE[(B, S, str(dev))] = (idx_t, cu_t)
+        return VarlenBatch(input_ids, idx_t, cu_t, B, S, T, int(lens.max()) if B else 0)
 
     @staticmethod
     def from_mask(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> "VarlenBatch":

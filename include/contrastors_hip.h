@@ -38,6 +38,11 @@ const char* cx_error_string(int code);
  * forward: X=act, W=weight.  dgrad: X=dY, W=W^T.  wgrad: X=dY^T, W=act^T (both via cx_transpose_bf16). */
 int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float* bias, int M, int N, int K, int ldx,
                     int ldw, int ldo, int out_mode, int split_k, float alpha, void* stream);
+/* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
+ * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
+ * (2*M*N*K) of exactly the sampled launches. */
+int cx_prof_gemm_config(int enable, int stride);
+int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_timed, long* launches_total);
 void cx_gemm_set_glds(int enable); /* 1 (default): operand tiles via global_load_lds DMA; 0: register staging */
 int cx_gemm_get_glds(void);
 

@@ -49,12 +49,13 @@ def encoder_hidden_states(sd: Dict[str, torch.Tensor], cfg, input_ids: torch.Ten
         x = x + sd["embeddings.position_embeddings.weight"][:S].unsqueeze(0)
     x = F.layer_norm(x, (d,), sd["emb_ln.weight"], sd["emb_ln.bias"], cfg.layer_norm_epsilon)
     if attention_mask is None:
-        attention_mask = torch.ones(B, S, dtype=torch.long)
-    key_bias = torch.zeros(B, 1, 1, S, dtype=x.dtype)
+        attention_mask = torch.ones(B, S, dtype=torch.long, device=x.device)
+    key_bias = torch.zeros(B, 1, 1, S, dtype=x.dtype, device=x.device)
     key_bias = key_bias.masked_fill(attention_mask.view(B, 1, 1, S) == 0, torch.finfo(x.dtype).min)
     cos = sin = None
     if cfg.rotary_emb_fraction > 0:
         cos, sin = rotary_tables(S, int(dh * cfg.rotary_emb_fraction), cfg.rotary_emb_base, x.dtype)
+        cos, sin = cos.to(x.device), sin.to(x.device)
     for l in range(cfg.n_layer):
         p = f"encoder.layers.{l}."
         qkv = F.linear(x, sd[p + "attn.Wqkv.weight"], sd.get(p + "attn.Wqkv.bias"))

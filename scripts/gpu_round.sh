@@ -1,0 +1,34 @@
+#!/bin/bash
+# One gpurun call: parity tests, smoke, a bench line and (optionally) a rocprofv3 kernel-trace of the bench.
+# usage: scripts/gpu_round.sh [tests|bench|prof|all]  (everything lands in gpurun_out/)
+set -u
+mode=${1:-all}
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd "${GRAFT_REPO_ROOT:-.}"
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 > gpurun_out/rocminfo.txt
+lscpu | grep -E "Model name|^CPU\(s\)" >> gpurun_out/rocminfo.txt
+if [[ $mode == tests || $mode == all ]]; then
+  rm -f gpurun_out/kernel_report.jsonl
+  timeout 1500 python -m pytest tests -m gpu -q -x --timeout=600 ${PYTEST_ARGS:-} > gpurun_out/pytest.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest.log
+  tail -30 gpurun_out/pytest.log
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
+  tail -3 gpurun_out/smoke.log
+fi
+if [[ $mode == bench || $mode == all ]]; then
+  timeout 900 python bench.py ${BENCH_ARGS:---steps 2 --warmup 1} > gpurun_out/bench.log 2>&1; echo "bench exit $?" >> gpurun_out/bench.log
+  tail -5 gpurun_out/bench.log
+fi
+if [[ $mode == prof || $mode == all ]]; then
+  export TMPDIR=/tmp
+  out=$PWD/gpurun_out/prof
+  rm -rf $out; mkdir -p $out
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $out -o bench -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --global-batch 2048 --no-cpu-baseline} > $out/run.log 2>&1; echo "prof exit $?" >> $out/run.log)
+  tail -3 $out/run.log
+  find $out -name "*kernel_stats*" | head
+  f=$(find $out -name "*kernel_stats*.csv" | head -1)
+  [[ -n "$f" ]] && head -25 "$f"
+  # keep the merge-back small: drop the raw per-dispatch trace if it is large
+  find $out -name "*kernel_trace*.csv" -size +20M -delete
+fi

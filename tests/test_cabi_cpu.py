@@ -1,0 +1,73 @@
+"""CPU-side checks of the boundary: the shared object loads, exports every symbol include/contrastors_hip.h declares,
+and the ctypes struct mirrors have the C compiler's layout.  No compute call is made (no GPU here)."""
+import ctypes as C
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HDR = ROOT / "include" / "contrastors_hip.h"
+
+
+@pytest.fixture(scope="module")
+def built():
+    from contrastors_amd import build
+
+    return build.build()
+
+
+def test_header_symbols_exported(built):
+    from contrastors_amd import _C
+
+    text = HDR.read_text()
+    declared = set(re.findall(r"\b(cx_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    lib = _C.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_C.EXPORTED_SYMBOLS), declared ^ set(_C.EXPORTED_SYMBOLS)
+    assert lib.cx_abi_version() == 1
+    assert b"gfx950" in lib.cx_build_info()
+    assert lib.cx_error_string(-1) == b"unsupported shape"
+    assert lib.cx_infonce_ws_floats(2048, 16384) == 2048 * (2 * 2 * 128 + 1)
+
+
+def test_ctypes_struct_layout_matches_c(tmp_path, built):
+    from contrastors_amd import _C
+
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "contrastors_hip.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu\\n\", sizeof(CxLayerWeights), sizeof(CxEncoderDesc),"
+        " sizeof(CxChunkBuffers), offsetof(CxEncoderDesc, layers), offsetof(CxEncoderDesc, word_emb),"
+        " offsetof(CxChunkBuffers, delta)); return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
+    got = list(map(int, subprocess.check_output([str(exe)]).split()))
+    want = [C.sizeof(_C.CxLayerWeights), C.sizeof(_C.CxEncoderDesc), C.sizeof(_C.CxChunkBuffers),
+            _C.CxEncoderDesc.layers.offset, _C.CxEncoderDesc.word_emb.offset, _C.CxChunkBuffers.delta.offset]
+    assert got == want
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from contrastors_amd import _C
+
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(ImportError):
+        _C.lib()
+
+
+def test_engine_refuses_cpu():
+    from contrastors_amd.nomic_bert import NomicBertConfig, NomicBertEngine
+
+    with pytest.raises(RuntimeError):
+        NomicBertEngine(NomicBertConfig(n_layer=1), device="cpu")
+
+
+def test_product_never_imports_oracle():
+    for p in (ROOT / "contrastors_amd").rglob("*.py"):
+        assert "oracle" not in re.sub(r'""".*?"""', "", p.read_text(), flags=re.S).replace("# oracle", ""), p

@@ -1,0 +1,127 @@
+"""Encoder engine (one native call per chunk) vs the reference: (1) golden fixtures produced by the reference's own
+eager model, (2) the fp32 oracle at the BASELINE architecture, judged with the reference's own tolerance rule
+  err(new) <= 3 * err(bf16 eager)   (tests/test_flash_bert.py:77-82, tests/test_huggingface.py:57-62)
+plus the absolute BiEncoder-embedding tolerance atol=5e-3 (tests/test_flash_bert.py:258)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from contrastors_amd.nomic_bert import NomicBertConfig, NomicBertEngine, VarlenBatch
+from oracle import encoder_ref
+from tests.gpu_util import max_err, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cfg_from_gold(g):
+    d = {k[4:]: (g[k].item() if g[k].shape == () else g[k]) for k in g.files if k.startswith("cfg/")}
+    d = {k: (str(v) if isinstance(v, (str, np.str_)) else v) for k, v in d.items()}
+    return NomicBertConfig(**{k: v for k, v in d.items() if k in NomicBertConfig.__dataclass_fields__}), SimpleNamespace(**d)
+
+
+def _oracle(sd, cfg, ids, mask, bf16: bool):
+    sdd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        emb = encoder_ref_on_device(sdd, cfg, ids, mask)
+    return emb.float(), sdd
+
+
+def encoder_ref_on_device(sd, cfg, ids, mask):
+    return encoder_ref.biencoder_embedding(sd, cfg, ids, mask)
+
+
+@pytest.mark.parametrize("name", ["encoder_nomic_tiny", "encoder_bert_tiny"])
+def test_engine_matches_reference_golden(gold, name):
+    g = gold(name)
+    cfg, ns = _cfg_from_gold(g)
+    sd = encoder_ref.random_state_dict(ns, int(g["seed"]))
+    eng = NomicBertEngine(cfg, device=DEV)
+    eng.load_reference_state_dict(sd)
+    eng.train()
+    ids = torch.from_numpy(g["input_ids"]).to(DEV)
+    mask = torch.from_numpy(g["attention_mask"]).to(DEV)
+    vb = VarlenBatch.from_lengths(ids, g["lens"])
+    assert torch.equal(vb.indices.cpu(), VarlenBatch.from_mask(ids, mask).indices.cpu())
+    emb, arena = eng.forward_chunk(vb, True)
+    gold_emb = torch.from_numpy(g["embedding"]).to(DEV)
+    e_hip = max_err(emb, gold_emb)
+    emb_bf16, sd_bf = _oracle(sd, ns, ids, mask, True)
+    e_bf16 = max_err(emb_bf16, gold_emb)
+    # no-grad (single slot) forward must give the same numbers as the saving forward
+    emb2, _ = eng.forward_chunk(vb, False)
+    assert torch.equal(emb, emb2)
+    probe = torch.from_numpy(g["probe"]).to(DEV)
+    eng.zero_grad()
+    eng.backward_chunk(vb, arena, probe)
+    (emb_bf16 * probe).sum().backward()
+    grads = eng.reference_grad_dict()
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("gnorm/"):
+            continue
+        n = k[6:]
+        want = float(g[k])
+        got = float(grads[n].norm())
+        bf = float(sd_bf[n].grad.norm())
+        e_h, e_b = abs(got - want), abs(bf - want)
+        worst = max(worst, e_h / max(want, 1e-6))
+        assert e_h <= 3 * e_b + 2e-2 * want + 1e-5, f"{n}: |grad| {got} vs reference {want} (bf16 eager {bf})"
+    sl = grads["encoder.layers.0.attn.Wqkv.weight"][:16, :16]
+    e_sl = rel_err(sl, torch.from_numpy(g["g/encoder.layers.0.attn.Wqkv.weight[:16,:16]"]).to(DEV))
+    e_ln = rel_err(grads["emb_ln.weight"], torch.from_numpy(g["g/emb_ln.weight"]).to(DEV))
+    rows = grads["embeddings.word_embeddings.weight"][ids[0, :8]]
+    e_we = rel_err(rows, torch.from_numpy(g["g/embeddings.word_embeddings.weight[rows]"]).to(DEV))
+    report("engine_golden", name=name, e_emb_hip=e_hip, e_emb_bf16=e_bf16, worst_gnorm_rel=worst, e_wqkv_slice=e_sl,
+           e_embln=e_ln, e_wordrows=e_we)
+    assert e_hip <= 5e-3, "BiEncoder embedding tolerance of tests/test_flash_bert.py:258"
+    assert e_hip <= 3 * e_bf16 + 1e-4, "reference rule: err <= 3 x err(bf16 eager)"
+    assert e_sl < 5e-2 and e_ln < 5e-2 and e_we < 5e-2
+
+
+@pytest.mark.parametrize("arch", ["nomic", "bert"])
+def test_engine_full_architecture_vs_oracle(arch):
+    """12-layer d=768 BASELINE architectures (cfg 2 / cfg 1), B=6 ragged S<=128, fp32 oracle as judge."""
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=4096) if arch == "nomic" else NomicBertConfig.bert_base_uncased(vocab_size=4096)
+    ns = SimpleNamespace(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    sd = encoder_ref.random_state_dict(ns, 5)
+    eng = NomicBertEngine(cfg, device=DEV)
+    eng.load_reference_state_dict(sd)
+    eng.train()
+    g = torch.Generator().manual_seed(6)
+    B, S = 6, 128
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    lens[0] = S
+    ids = torch.randint(3, 4096, (B, S), generator=g)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    ids = (ids * mask).to(DEV)
+    mask = mask.to(DEV)
+    vb = VarlenBatch.from_lengths(ids, lens.numpy())
+    emb, arena = eng.forward_chunk(vb, True)
+    ref, sd32 = _oracle(sd, ns, ids, mask, False)
+    ref16, sd16 = _oracle(sd, ns, ids, mask, True)
+    e_hip, e_b = max_err(emb, ref), max_err(ref16, ref)
+    m_hip, m_b = float((emb - ref).abs().mean()), float((ref16 - ref).abs().mean())
+    probe = torch.randn(B, cfg.n_embd, generator=g).to(DEV)
+    eng.zero_grad()
+    eng.backward_chunk(vb, arena, probe)
+    (ref * probe).sum().backward()
+    (ref16 * probe).sum().backward()
+    grads = eng.reference_grad_dict()
+    worst_ratio, worst_name = 0.0, ""
+    for n, gh in grads.items():
+        if n == "embeddings.position_embeddings.weight":
+            gh = gh[:S]
+            r32, r16 = sd32[n].grad[:S], sd16[n].grad[:S]
+        else:
+            r32, r16 = sd32[n].grad, sd16[n].grad
+        eh, eb = rel_err(gh, r32), rel_err(r16.float(), r32)
+        if eh / (eb + 1e-4) > worst_ratio:
+            worst_ratio, worst_name = eh / (eb + 1e-4), n
+        assert eh <= 3 * eb + 2e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    report("engine_full", arch=arch, e_emb_hip=e_hip, e_emb_bf16=e_b, mean_hip=m_hip, mean_bf16=m_b,
+           worst_grad_ratio=worst_ratio, worst_grad_name=worst_name)
+    assert e_hip <= 3 * e_b + 1e-4 and m_hip <= 3 * m_b + 1e-5
+    assert e_hip <= 5e-3

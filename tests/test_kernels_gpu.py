@@ -1,0 +1,368 @@
+"""Per-kernel parity: every C-ABI entry point vs a plain torch fp32 reference of the same op, on seeded inputs.
+Tolerances are written at each assert.  Runs on the MI355X box only (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from contrastors_amd import _C
+from tests.gpu_util import L, S, bf, gemm, max_err, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _randn(*s, seed=0, std=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*s, generator=g) * std).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------- hardware probes
+def test_probe_mfma_accumulator_layout():
+    out = torch.zeros(32, 32, device=DEV)
+    _C.check(L().cx_probe_mfma_layout(out.data_ptr(), S()))
+    i = torch.arange(32, device=DEV).float()
+    want = (i[:, None] + 1) + 64 * (i[None, :] + 1)  # asymmetric: catches a transposed C mapping
+    assert torch.equal(out, want)
+
+
+def test_probe_ds_read_tr16_pattern():
+    src = torch.arange(256, dtype=torch.int16, device=DEV)
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    _C.check(L().cx_probe_ds_read_tr16(src.data_ptr(), out.data_ptr(), S()))
+    got = out.cpu().numpy().reshape(64, 4)
+    want = np.zeros((64, 4), dtype=np.int16)
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        for j in range(4):
+            want[lane, j] = (g * 16 + 4 * j + i // 4) * 4 + (i % 4)
+    report("probe_tr16", match=bool((got == want).all()), got_lane0=got[0].tolist(), got_lane1=got[1].tolist(),
+           got_lane5=got[5].tolist(), got_lane17=got[17].tolist())
+    if not (got == want).all():
+        pytest.xfail("ds_read_b64_tr_b16 lane pattern differs from the documented one (not used by shipped kernels)")
+
+
+# ------------------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
+                                   (257, 6144, 768)])
+def test_gemm_bf16_nt(glds, M, N, K):
+    L().cx_gemm_set_glds(glds)
+    try:
+        x, w = bf(_randn(M, K, seed=1)), bf(_randn(N, K, seed=2, std=0.05))
+        bias = _randn(N, seed=3)
+        ref = x.float() @ w.float().T
+        out32 = gemm(x, w, out_mode=1)
+        e32 = rel_err(out32, ref)
+        out16 = gemm(x, w, bias=bias, out_mode=0)
+        e16 = rel_err(out16.float(), ref + bias)
+        acc = torch.ones(M, N, device=DEV)
+        gemm(x, w, out_mode=2, split_k=min(4, K // 64), out=acc)
+        eacc = rel_err(acc - 1.0, ref)
+        report("gemm", glds=glds, M=M, N=N, K=K, e32=e32, e16=e16, eacc=eacc)
+        assert e32 < 1e-5, "fp32-out GEMM: only accumulation-order error allowed"
+        assert e16 < 4e-3, "bf16-out GEMM: one bf16 rounding (2^-9 rel) of the fp32 result"
+        assert eacc < 1e-5
+    finally:
+        L().cx_gemm_set_glds(1)
+
+
+def test_gemm_linearity_full_size():
+    """Size-independent property at the BASELINE chunk shape: gemm(x1 + x2) == gemm(x1) + gemm(x2) in fp32 out."""
+    M, N, K = 8192, 6144, 768
+    x1, x2 = bf(_randn(M, K, seed=4)), bf(_randn(M, K, seed=5))
+    x1 = (x1.float() * 0.5).to(torch.bfloat16)  # keep x1+x2 exactly representable: halves and sums of bf16
+    x2 = (x2.float() * 0.5).to(torch.bfloat16)
+    xs = (x1.float() + x2.float())
+    exact = xs.to(torch.bfloat16).float().equal(xs)
+    w = bf(_randn(N, K, seed=6, std=0.05))
+    a = gemm(x1, w, out_mode=1) + gemm(x2, w, out_mode=1)
+    if exact:
+        b = gemm(xs.to(torch.bfloat16), w, out_mode=1)
+        assert rel_err(a, b) < 1e-5
+    assert torch.isfinite(a).all()
+
+
+def test_transpose_and_casts():
+    x = bf(_randn(1000, 768, seed=7))
+    out = torch.full((768, 1024), 7.0, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_transpose_bf16(x.data_ptr(), out.data_ptr(), 1000, 768, 768, 1024, 1024, S()))
+    assert torch.equal(out[:, :1000], x.T)
+    assert torch.count_nonzero(out[:, 1000:]) == 0, "token padding must be zero-filled"
+    w = _randn(300, 200, seed=8)
+    o16 = torch.empty(300 * 200, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_cast_f32_to_bf16(w.data_ptr(), o16.data_ptr(), w.numel(), S()))
+    assert torch.equal(o16.view(300, 200), w.to(torch.bfloat16)), "RNE cast must match torch bit-for-bit"
+    ot = torch.empty(200, 300, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_cast_transpose_f32_to_bf16(w.data_ptr(), ot.data_ptr(), 300, 200, S()))
+    assert torch.equal(ot, w.T.to(torch.bfloat16))
+    back = torch.empty(300 * 200, dtype=torch.float32, device=DEV)
+    _C.check(L().cx_cast_bf16_to_f32(o16.data_ptr(), back.data_ptr(), w.numel(), S()))
+    assert torch.equal(back, o16.float())
+    f = _randn(130, 70, seed=9)
+    ft = torch.empty(70, 130, device=DEV)
+    _C.check(L().cx_transpose_f32(f.data_ptr(), ft.data_ptr(), 130, 70, 70, 130, S()))
+    assert torch.equal(ft, f.T)
+
+
+# ------------------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("d", [256, 768, 1024])
+@pytest.mark.parametrize("rows", [1, 1003])
+def test_layernorm_fwd_bwd(d, rows):
+    x0, res = bf(_randn(rows, d, seed=10)), bf(_randn(rows, d, seed=11))
+    g, b = 1 + _randn(d, seed=12, std=0.1), _randn(d, seed=13, std=0.1)
+    out = torch.empty_like(x0)
+    z = torch.empty_like(x0)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    _C.check(L().cx_layernorm_fwd(x0.data_ptr(), res.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                  z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, d, 1e-12, S()))
+    zr = (x0.float() + res.float()).requires_grad_()
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(zr, (d,), gr, br, 1e-12)
+    assert max_err(out.float(), ref) < 0.04, "bf16 output of O(1..4) values: 1 ulp = 2^-7"
+    assert rel_err(out.float(), ref) < 4e-3
+    assert torch.equal(z, zr.detach().to(torch.bfloat16))
+    assert max_err(mean, zr.mean(-1)) < 1e-5
+    da, db_ = bf(_randn(rows, d, seed=14)), bf(_randn(rows, d, seed=15))
+    ref.backward(da.float() + db_.float())
+    dz = torch.empty_like(x0)
+    dg, dbeta = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    _C.check(L().cx_layernorm_bwd(da.data_ptr(), db_.data_ptr(), z.data_ptr(), g.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), None, dz.data_ptr(), dg.data_ptr(), dbeta.data_ptr(), rows, d,
+                                  S()))
+    e_dz, e_dg, e_db = rel_err(dz.float(), zr.grad), rel_err(dg, gr.grad), rel_err(dbeta, br.grad)
+    report("layernorm", d=d, rows=rows, e_dz=e_dz, e_dg=e_dg, e_db=e_db)
+    assert e_dz < 8e-3, "dz is stored in bf16 and xhat is rebuilt from bf16 z"
+    assert e_dg < 5e-3 and e_db < 1e-4
+
+
+def test_embed_ln_fwd_bwd():
+    V, d, B, Sq = 500, 768, 5, 24
+    for use_pos in (False, True):
+        word, type_e, pos_e = _randn(V, d, seed=20, std=0.5), _randn(2, d, seed=21, std=0.5), _randn(64, d, seed=22, std=0.5)
+        g, b = 1 + _randn(d, seed=23, std=0.1), _randn(d, seed=24, std=0.1)
+        gen = torch.Generator().manual_seed(25)
+        ids = torch.randint(0, V, (B, Sq), generator=gen).to(DEV)
+        lens = [24, 3, 17, 24, 9]
+        idx = torch.cat([torch.arange(l) + bb * Sq for bb, l in enumerate(lens)]).to(torch.int32).to(DEV)
+        T = idx.numel()
+        out = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+        mean, rstd = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+        pe = pos_e if use_pos else None
+        _C.check(L().cx_embed_ln_fwd(ids.data_ptr(), idx.data_ptr(), word.data_ptr(), type_e.data_ptr(), _C.ptr(pe),
+                                     g.data_ptr(), b.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), T,
+                                     Sq, d, 1e-12, S()))
+        wr, tr, pr = word.clone().requires_grad_(), type_e.clone().requires_grad_(), pos_e.clone().requires_grad_()
+        gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+        flat = ids.flatten()[idx.long()]
+        z = wr[flat] + tr[0] + (pr[(idx.long() % Sq)] if use_pos else 0)
+        ref = torch.nn.functional.layer_norm(z, (d,), gr, br, 1e-12)
+        assert rel_err(out.float(), ref) < 4e-3
+        da = bf(_randn(T, d, seed=26))
+        ref.backward(da.float())
+        dw, dt, dp = torch.zeros_like(word), torch.zeros(d, device=DEV), torch.zeros_like(pos_e)
+        dg, dbt = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        pad = int(flat[0])  # pretend the first token's id is the padding index: its row must get no gradient
+        _C.check(L().cx_embed_ln_bwd(da.data_ptr(), None, ids.data_ptr(), idx.data_ptr(), word.data_ptr(),
+                                     type_e.data_ptr(), _C.ptr(pe), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     dw.data_ptr(), dt.data_ptr(), dp.data_ptr() if use_pos else None, dg.data_ptr(),
+                                     dbt.data_ptr(), T, Sq, d, pad, S()))
+        want_dw = wr.grad.clone()
+        want_dw[pad] = 0
+        assert rel_err(dw, want_dw) < 1e-4 and torch.count_nonzero(dw[pad]) == 0
+        assert rel_err(dt, tr.grad[0]) < 1e-4
+        assert rel_err(dg, gr.grad) < 1e-4 and rel_err(dbt, br.grad) < 1e-4
+        if use_pos:
+            assert rel_err(dp, pr.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- activations and bias
+def test_swiglu_gelu_biasgrad():
+    T, I = 777, 3072
+    yg = bf(_randn(T, 2 * I, seed=30))
+    act = torch.empty(T, I, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_swiglu_fwd(yg.data_ptr(), act.data_ptr(), T, I, S()))
+    ygr = yg.float().requires_grad_()
+    ref = torch.nn.functional.silu(ygr[:, I:]) * ygr[:, :I]
+    assert torch.equal(act, ref.to(torch.bfloat16)) or rel_err(act.float(), ref) < 3e-3
+    d = bf(_randn(T, I, seed=31))
+    ref.backward(d.float())
+    dyg = torch.empty_like(yg)
+    _C.check(L().cx_swiglu_bwd(d.data_ptr(), yg.data_ptr(), dyg.data_ptr(), T, I, S()))
+    assert rel_err(dyg.float(), ygr.grad) < 4e-3
+    pre, bias = bf(_randn(T, I, seed=32)), _randn(I, seed=33, std=0.2)
+    _C.check(L().cx_bias_gelu_fwd(pre.data_ptr(), bias.data_ptr(), act.data_ptr(), T, I, S()))
+    pr = pre.float().requires_grad_()
+    ref = torch.nn.functional.gelu(pr + bias)
+    assert rel_err(act.float(), ref) < 3e-3
+    ref.backward(d.float())
+    dpre = torch.empty_like(pre)
+    _C.check(L().cx_bias_gelu_bwd(d.data_ptr(), pre.data_ptr(), bias.data_ptr(), dpre.data_ptr(), T, I, S()))
+    assert rel_err(dpre.float(), pr.grad) < 4e-3
+    db = torch.zeros(I, device=DEV)
+    _C.check(L().cx_bias_grad(d.data_ptr(), db.data_ptr(), T, I, I, S()))
+    assert rel_err(db, d.float().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, lens, cos, sin, scale):
+    """fp32 torch reference on the packed varlen tensor; returns out (T,H,64) and autograd handles."""
+    T, _, H, D = qkv.shape
+    outs, t0 = [], 0
+    for l in lens:
+        x = qkv[t0:t0 + l]
+        q, k, v = x[:, 0], x[:, 1], x[:, 2]
+        if cos is not None:
+            c, s = cos[:l, None, :], sin[:l, None, :]
+
+            def rot(u):
+                u1, u2 = u[..., :32], u[..., 32:]
+                return torch.cat([u1 * c - u2 * s, u2 * c + u1 * s], -1)
+
+            # the fused kernel rounds the rotated q/k to bf16 before the MFMA, exactly like the reference's rotary op
+            q, k = rot(q), rot(k)
+        sc = torch.einsum("qhd,khd->hqk", q, k) * scale
+        outs.append(torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), v))
+        t0 += l
+    return torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("rotary", [True, False])
+@pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8])
+def test_attention_fwd_bwd(rotary, lens):
+    H, D = 3, 64
+    T, B, mx = sum(lens), len(lens), max(lens)
+    qkv = bf(_randn(T, 3, H, D, seed=40))
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    cos = sin = None
+    if rotary:
+        inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2).float() / D))
+        fr = torch.outer(torch.arange(512).float(), inv)
+        cos, sin = torch.cos(fr).to(DEV).contiguous(), torch.sin(fr).to(DEV).contiguous()
+    scale = 1 / math.sqrt(D)
+    out = torch.empty(T, H, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(H, T, device=DEV)
+    _C.check(L().cx_attn_varlen_fwd(qkv.data_ptr(), cu.data_ptr(), _C.ptr(cos), _C.ptr(sin), out.data_ptr(),
+                                    lse.data_ptr(), B, H, T, mx, scale, S()))
+    qr = qkv.float().requires_grad_()
+    ref = _attn_ref(qr, lens, cos, sin, scale)
+    e_out = rel_err(out.float(), ref)
+    do = bf(_randn(T, H, D, seed=41))
+    ref.backward(do.float())
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(H, T, device=DEV)
+    _C.check(L().cx_attn_varlen_bwd(do.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(),
+                                    _C.ptr(cos), _C.ptr(sin), delta.data_ptr(), dqkv.data_ptr(), B, H, T, mx, scale,
+                                    S()))
+    e_dq = rel_err(dqkv[:, 0].float(), qr.grad[:, 0])
+    e_dk = rel_err(dqkv[:, 1].float(), qr.grad[:, 1])
+    e_dv = rel_err(dqkv[:, 2].float(), qr.grad[:, 2])
+    report("attention", rotary=rotary, lens=str(lens), e_out=e_out, e_dq=e_dq, e_dk=e_dk, e_dv=e_dv)
+    assert torch.isfinite(dqkv.float()).all(), "every dqkv element must be written"
+    # bf16 P/dS operands (2^-9) + bf16 rotated q/k: a few 1e-3 relative in the Frobenius norm
+    assert e_out < 6e-3
+    assert e_dq < 1.5e-2 and e_dk < 1.5e-2 and e_dv < 1.0e-2
+
+
+def test_rotary_standalone_roundtrip():
+    lens, H = [33, 128, 7], 2
+    T = sum(lens)
+    qkv = bf(_randn(T, 3, H, 64, seed=42))
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    inv = 1.0 / (1000.0 ** (torch.arange(0, 64, 2).float() / 64))
+    fr = torch.outer(torch.arange(128).float(), inv)
+    cos, sin = torch.cos(fr).to(DEV).contiguous(), torch.sin(fr).to(DEV).contiguous()
+    work = qkv.clone()
+    _C.check(L().cx_rotary_qkv_inplace(work.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), 3, H, T, 128,
+                                       1, S()))
+    assert torch.equal(work[:, 2], qkv[:, 2]), "v must be untouched"
+    pos = torch.cat([torch.arange(l) for l in lens]).to(DEV)
+    c, s = cos[pos][:, None, :], sin[pos][:, None, :]
+    q = qkv[:, 0].float()
+    want = torch.cat([q[..., :32] * c - q[..., 32:] * s, q[..., 32:] * c + q[..., :32] * s], -1)
+    assert torch.equal(work[:, 0], want.to(torch.bfloat16))
+    _C.check(L().cx_rotary_qkv_inplace(work.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), 3, H, T, 128,
+                                       -1, S()))
+    assert rel_err(work.float(), qkv.float()) < 6e-3  # rotate then un-rotate, two bf16 roundings
+
+
+# --------------------------------------------------------------------------------------------------------- pooling
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("normalize", [1, 0])
+def test_pool_normalize(mode, normalize):
+    lens, d = [128, 5, 77, 1], 768
+    T, B = sum(lens), len(lens)
+    h = bf(_randn(T, d, seed=50))
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    emb, nrm = torch.empty(B, d, device=DEV), torch.empty(B, device=DEV)
+    _C.check(L().cx_pool_normalize_fwd(h.data_ptr(), cu.data_ptr(), emb.data_ptr(), nrm.data_ptr(), B, d, mode,
+                                       normalize, S()))
+    hr = h.float().requires_grad_()
+    parts, t0 = [], 0
+    for l in lens:
+        parts.append(hr[t0] if mode == 1 else hr[t0:t0 + l].mean(0))
+        t0 += l
+    pooled = torch.stack(parts)
+    ref = torch.nn.functional.normalize(pooled, dim=-1) if normalize else pooled
+    assert max_err(emb, ref) < 2e-6 * (1 if normalize else 50)
+    gup = _randn(B, d, seed=51)
+    ref.backward(gup)
+    dh = torch.full_like(h, float("nan"))
+    _C.check(L().cx_pool_normalize_bwd(gup.data_ptr(), emb.data_ptr(), nrm.data_ptr(), cu.data_ptr(), dh.data_ptr(), B,
+                                       d, mode, normalize, S()))
+    assert torch.isfinite(dh.float()).all()
+    assert rel_err(dh.float(), hr.grad) < 4e-3
+
+
+# --------------------------------------------------------------------------------------------------------- InfoNCE
+def _infonce(q, d, labels, scale, coef, want_dscale=False):
+    N, dim = q.shape
+    G = d.shape[0]
+    lib = L()
+    ws = torch.empty(lib.cx_infonce_ws_floats(N, G), device=DEV)
+    lse, rows = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    _C.check(lib.cx_infonce_fwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), scale, ws.data_ptr(), lse.data_ptr(),
+                                rows.data_ptr(), N, G, dim, q.stride(0), d.stride(0), S()))
+    gm, gmt = torch.empty(N, G, device=DEV), torch.empty(G, N, device=DEV)
+    qt, dt = torch.empty(dim, N, device=DEV), torch.empty(dim, G, device=DEV)
+    dq, dd = torch.empty(N, dim, device=DEV), torch.empty(G, dim, device=DEV)
+    dsc = torch.zeros(1, device=DEV)
+    _C.check(lib.cx_infonce_bwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), lse.data_ptr(), scale, coef,
+                                gm.data_ptr(), gmt.data_ptr(), qt.data_ptr(), dt.data_ptr(), dq.data_ptr(),
+                                dd.data_ptr(), dsc.data_ptr(), N, G, dim, q.stride(0), d.stride(0), S()))
+    return lse, rows, dq, dd, gm, dsc
+
+
+@pytest.mark.parametrize("N,G,dim,neg", [(96, 288, 64, 3), (128, 128, 768, 1), (2048, 16384, 768, 1), (48, 144, 128, 3)])
+def test_infonce_vs_torch(N, G, dim, neg):
+    q = torch.nn.functional.normalize(_randn(N, dim, seed=60), dim=-1)
+    d = torch.nn.functional.normalize(_randn(G, dim, seed=61), dim=-1)
+    W = G // (N * neg)
+    labels = ((torch.arange(N) + 0 * N) * (G // (N * W))).to(DEV) if W >= 1 else torch.arange(N, device=DEV)
+    scale, coef = 50.0, float(W) / N
+    lse, rows, dq, dd, gm, dsc = _infonce(q, d, labels, scale, coef)
+    qr, dr = q.double().requires_grad_(), d.double().requires_grad_()
+    sp = torch.tensor(scale, dtype=torch.float64, device=DEV, requires_grad=True)
+    logits = (qr @ dr.T) * sp
+    loss = torch.nn.functional.cross_entropy(logits, labels, reduction="sum") * coef
+    loss.backward()
+    e_loss = abs(float(rows.double().sum() * coef - loss)) / abs(float(loss))
+    e_dq, e_dd = rel_err(dq, qr.grad), rel_err(dd, dr.grad)
+    e_ds = abs(float(dsc[0]) - float(sp.grad)) / (abs(float(sp.grad)) + 1e-12)
+    rowsum = float(gm.sum(1).abs().max())
+    report("infonce", N=N, G=G, dim=dim, e_loss=e_loss, e_dq=e_dq, e_dd=e_dd, e_dscale=e_ds, rowsum=rowsum)
+    # exact-fp32 MFMA: fp32 round-off only (logits up to 50 -> abs err ~1e-5)
+    assert e_loss < 2e-6
+    assert max_err(lse, torch.logsumexp(logits, 1)) < 5e-5
+    assert e_dq < 2e-5 and e_dd < 2e-5
+    assert e_ds < 1e-3
+    # size-independent property: every row of (softmax - onehot) sums to zero
+    assert rowsum < 1e-5 * coef * scale * 10 + 1e-6
+
+
+def test_sgemm_nt():
+    a, b = _randn(300, 160, seed=70), _randn(200, 160, seed=71)
+    c = torch.empty(300, 200, device=DEV)
+    _C.check(L().cx_sgemm_nt(a.data_ptr(), b.data_ptr(), c.data_ptr(), 300, 200, 160, 160, 160, 200, S()))
+    assert rel_err(c, a.double() @ b.double().T) < 2e-6
