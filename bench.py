@@ -46,8 +46,39 @@ def parse():
                     help="GradCache chunk (reference recipe: 64, contrastive_pretrain.yaml:15)")
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the metric
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--prof-stride", type=int, default=8)
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a 256-thread OpenMP pool on
+    an 8-core quota would spin for minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_subprocess(seq_len: int, timeout_s: int = 240) -> dict:
+    """Run the CPU leg in a child process with a hard time bound so the GPU line is never lost to a slow host."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-only", "--seq-len",
+                            str(seq_len)], capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "pairs/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"cpu leg failed: {r.stderr.strip()[-200:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "pairs/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"cpu leg exceeded {timeout_s} s"}
 
 
 def cpu_baseline(seq_len: int) -> dict:
@@ -56,7 +87,7 @@ def cpu_baseline(seq_len: int) -> dict:
     from contrastors_amd.nomic_bert import NomicBertConfig
     from oracle import encoder_ref, infonce_ref
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = NomicBertConfig.nomic_bert_2048()
     ns = SimpleNamespace(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
@@ -87,6 +118,9 @@ def cpu_baseline(seq_len: int) -> dict:
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.seq_len)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,7 +215,7 @@ def main():
                          "whole_step_frac_of_mfma_peak": pairs_per_s / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S)
+            out["cpu_baseline"] = cpu_baseline_subprocess(S)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -111,6 +111,10 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m contrastors_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        # libcontrastors_hip.so needs libamdhip64.so.7; torch bundles its own copy with the same SONAME.  Import torch
+        # FIRST so that copy is the single HIP runtime of the process (two runtimes = launches on foreign streams fail).
+        import torch  # noqa: F401
+
         h = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGS.items():
             fn = getattr(h, name)  # AttributeError if the symbol is missing: fail loudly

@@ -80,6 +80,7 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
                        int save_for_backward, float* emb_out, void* stream) {
     if (Bc <= 0 || T <= 0) return CX_OK;
     CX_TRY(check_desc(enc, buf, T));
+    (void)hipGetLastError();  // a stale error of some earlier, unrelated runtime call must not fail this launch train
     const int d = enc->d, I = enc->d_inner, H = enc->n_head;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
 
@@ -118,6 +119,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     if (!demb || !emb_out || !buf->g_a || !buf->g_b || !buf->g_c || !buf->g_wide || !buf->g_act || !buf->tr_a ||
         !buf->tr_b || !buf->delta)
         return CX_ERR_ARG;
+    (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
 

@@ -38,15 +38,18 @@ struct SgemmParams {
 
 struct SRegs { float4 r0, r1; };  // named members, not an array (keeps them in VGPRs)
 
-CX_DEVICE float4 sload(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int item) {
+CX_DEVICE float4 sload(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int K, int item) {
     const int r = item >> 2, c = item & 3;
     int gr = row0 + r;
     gr = gr < nrows ? gr : nrows - 1;
-    return *reinterpret_cast<const float4*>(base + (size_t)gr * ld + k0 + c * 4);
+    const int k = k0 + c * 4;
+    if (k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);  // K % 4 == 0: a chunk is all-in or all-out
+    return *reinterpret_cast<const float4*>(base + (size_t)gr * ld + k);
 }
-CX_DEVICE void sstage(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int tid, SRegs& regs) {
-    regs.r0 = sload(base, ld, row0, nrows, k0, tid);
-    regs.r1 = sload(base, ld, row0, nrows, k0, 256 + tid);
+CX_DEVICE void sstage(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int K, int tid,
+                      SRegs& regs) {
+    regs.r0 = sload(base, ld, row0, nrows, k0, K, tid);
+    regs.r1 = sload(base, ld, row0, nrows, k0, K, 256 + tid);
 }
 CX_DEVICE void scommit(char* tile, int tid, const SRegs& regs) {
     *reinterpret_cast<float4*>(tile + stile_off(tid >> 2, tid & 3)) = regs.r0;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
     const int lid = xcd_remap(blockIdx.x, nwg);
     const int tn = lid % p.tiles_n, tm = lid / p.tiles_n;
     const int m0 = tm * SBM, n0 = tn * SBN;
-    const int nk = p.K / SBK;
+    const int nk = (p.K + SBK - 1) / SBK;
 
     f32x16_t acc[2][2];  // [n-block a][m-block b]
 #pragma unroll
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     SRegs ar = {}, br = {};
-    sstage(p.A, p.lda, m0, p.M, 0, tid, ar);
-    sstage(p.B, p.ldb, n0, p.N, 0, tid, br);
+    sstage(p.A, p.lda, m0, p.M, 0, p.K, tid, ar);
+    sstage(p.B, p.ldb, n0, p.N, 0, p.K, tid, br);
     scommit(smem, tid, ar);
     scommit(smem + STILE, tid, br);
     __syncthreads();
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
         char* nxt = smem + ((it + 1) & 1) * 2 * STILE;
         const bool more = (it + 1) < nk;
         if (more) {
-            sstage(p.A, p.lda, m0, p.M, (it + 1) * SBK, tid, ar);
-            sstage(p.B, p.ldb, n0, p.N, (it + 1) * SBK, tid, br);
+            sstage(p.A, p.lda, m0, p.M, (it + 1) * SBK, p.K, tid, ar);
+            sstage(p.B, p.ldb, n0, p.N, (it + 1) * SBK, p.K, tid, br);
         }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -237,7 +240,7 @@ int launch(const SgemmParams& p, hipStream_t s) {
 }
 
 int check_common(int M, int N, int K, int lda, int ldb) {
-    if (K <= 0 || (K % SBK) != 0) return CX_ERR_SHAPE;
+    if (K <= 0 || (K % 4) != 0) return CX_ERR_SHAPE;
     if ((lda % 4) != 0 || (ldb % 4) != 0) return CX_ERR_ALIGN;
     (void)M; (void)N;
     return CX_OK;
@@ -292,7 +295,7 @@ int cx_infonce_bwd(const float* Q, const float* D, const int64_t* labels, const 
     if (!Q || !D || !labels || !lse || !Gmat || !GmatT || !QT || !DT || !dQ || !dD) return CX_ERR_ARG;
     int rc = check_common(N, G, dim, ldq, ldd);
     if (rc != CX_OK) return rc;
-    if ((N % SBK) != 0 || (G % SBK) != 0) return CX_ERR_SHAPE;  // they are the K of the two output GEMMs
+    if ((N % 4) != 0 || (G % 4) != 0) return CX_ERR_SHAPE;  // they are the K (and ld) of the two output GEMMs
     SgemmParams p = {};
     p.A = Q; p.B = D; p.M = N; p.N = G; p.K = dim; p.lda = ldq; p.ldb = ldd;
     p.tiles_m = (N + SBM - 1) / SBM; p.tiles_n = (G + SBN - 1) / SBN;

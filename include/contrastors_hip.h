@@ -130,11 +130,12 @@ int cx_infonce_fwd(const float* Q, const float* D, const int64_t* labels, float 
 /* backward of  coef * sum_i loss_rows[i]:  Gm[i][j] = coef*scale*(softmax_ij - [j==label_i]) is written to
  * Gmat:(N,G) and GmatT:(G,N) fp32 scratch; dQ:(N,dim) = Gm D, dD:(G,dim) = Gm^T Q (overwritten);
  * dscale_accum (may be NULL): += coef * sum_ij (softmax_ij - y_ij) * (Q D^T)_ij   (d loss / d scale).
- * QT:(dim,N) and DT:(dim,G) fp32 scratch for the K-contiguous operands of the two output GEMMs. */
+ * QT:(dim,N) and DT:(dim,G) fp32 scratch for the K-contiguous operands of the two output GEMMs.
+ * Requirements: dim % 4 == 0, N % 4 == 0, G % 4 == 0, ldq/ldd % 4 == 0. */
 int cx_infonce_bwd(const float* Q, const float* D, const int64_t* labels, const float* lse, float scale, float coef,
                    float* Gmat, float* GmatT, float* QT, float* DT, float* dQ, float* dD, float* dscale_accum,
                    int N, int G, int dim, int ldq, int ldd, void* stream);
-/* plain exact-fp32 MFMA GEMM  C[m][n] = sum_k A[m][k] B[n][k]  (K % 16 == 0). */
+/* plain exact-fp32 MFMA GEMM  C[m][n] = sum_k A[m][k] B[n][k]  (K % 4 == 0; lda, ldb % 4 == 0). */
 int cx_sgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 void* stream);
 int cx_transpose_f32(const float* In, float* Out, int rows, int cols, int ld_in, int ld_out, void* stream);

@@ -10,9 +10,18 @@ rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6
 lscpu | grep -E "Model name|^CPU\(s\)" >> gpurun_out/rocminfo.txt
 if [[ $mode == tests || $mode == all ]]; then
   rm -f gpurun_out/kernel_report.jsonl
-  timeout 1500 python -m pytest tests -m gpu -q -x --timeout=600 ${PYTEST_ARGS:-} > gpurun_out/pytest.log 2>&1
-  echo "pytest exit $?" >> gpurun_out/pytest.log
-  tail -30 gpurun_out/pytest.log
+  : > gpurun_out/pytest.log
+  if [[ -n "${PYTEST_SPLIT:-}" ]]; then
+    # one process per test function: a memory fault in one kernel does not hide the verdicts of the others
+    for t in $(python -m pytest tests -m gpu --collect-only -q 2>/dev/null | grep "::" | sed 's/\[.*//' | sort -u); do
+      echo "=== $t" >> gpurun_out/pytest.log
+      timeout 600 python -m pytest "$t" -m gpu -q --timeout=300 2>&1 | tail -25 >> gpurun_out/pytest.log
+    done
+  else
+    timeout 1500 python -m pytest tests -m gpu -q --timeout=600 ${PYTEST_ARGS:-} >> gpurun_out/pytest.log 2>&1
+    echo "pytest exit $?" >> gpurun_out/pytest.log
+  fi
+  grep -E "^===|passed|failed|error|Error|assert|xfail" gpurun_out/pytest.log | tail -60
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
   tail -3 gpurun_out/smoke.log
 fi

@@ -281,7 +281,8 @@ def test_rotary_standalone_roundtrip():
     c, s = cos[pos][:, None, :], sin[pos][:, None, :]
     q = qkv[:, 0].float()
     want = torch.cat([q[..., :32] * c - q[..., 32:] * s, q[..., 32:] * c + q[..., :32] * s], -1)
-    assert torch.equal(work[:, 0], want.to(torch.bfloat16))
+    # fp32 rotation (the compiler may contract mul+sub into fma) then one bf16 rounding: at most 1 bf16 ulp apart
+    assert rel_err(work[:, 0].float(), want) < 3e-3 and max_err(work[:, 0].float(), want) < 0.04
     _C.check(L().cx_rotary_qkv_inplace(work.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), 3, H, T, 128,
                                        -1, S()))
     assert rel_err(work.float(), qkv.float()) < 6e-3  # rotate then un-rotate, two bf16 roundings

@@ -35,7 +35,7 @@ def test_clip_loss_matches_reference_golden(gold, tag, bid):
 def test_reference_kat_and_labels(gold):
     g = gold("clip_loss_w1")
     q, d = torch.from_numpy(g["kat/q"]).to(DEV), torch.from_numpy(g["kat/d"]).to(DEV)
-    # dim 2 is below the kernel's K granularity (16): zero-pad the feature axis (dot products unchanged)
+    # dim 2 is below the kernel's K granularity (4): zero-pad the feature axis (dot products unchanged)
     qp, dp = torch.zeros(3, 16, device=DEV), torch.zeros(3, 16, device=DEV)
     qp[:, :2], dp[:, :2] = q, d
     loss = clip_loss(qp, dp, 1.0)
