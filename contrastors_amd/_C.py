@@ -52,8 +52,9 @@ class CxChunkBuffers(C.Structure):
         for n in (
             "h0", "emb_mean", "emb_rstd", "qkv", "ctx", "lse", "z1", "h1", "mean1", "rstd1", "yg", "act", "z2",
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
+            "ws_f32",
         )
-    ]
+    ] + [("ws_floats", i64)]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.
@@ -62,6 +63,9 @@ _SIGS = {
     "cx_build_info": (C.c_char_p, []),
     "cx_error_string": (C.c_char_p, [i32]),
     "cx_gemm_bf16_nt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "cx_gemm_bf16_nt_accum": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "cx_gemm_set_variant": (None, [i32]),
+    "cx_gemm_get_variant": (i32, []),
     "cx_prof_gemm_config": (i32, [i32, i32]),
     "cx_prof_gemm_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "cx_gemm_set_glds": (None, [i32]),

@@ -67,8 +67,7 @@ int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW,
     const int Tp = (int)round_up(T, 64);
     CX_TRY(cx_transpose_bf16(dY, b->tr_a, T, out_f, out_f, Tp, Tp, stream));
     CX_TRY(cx_transpose_bf16(X, b->tr_b, T, in_f, in_f, Tp, Tp, stream));
-    return cx_gemm_bf16_nt(b->tr_a, b->tr_b, gW, nullptr, out_f, in_f, Tp, Tp, Tp, in_f, /*atomic f32*/ 2,
-                           wgrad_split(out_f, in_f, Tp), 1.f, stream);
+    return cx_gemm_bf16_nt_accum(b->tr_a, b->tr_b, gW, b->ws_f32, b->ws_floats, out_f, in_f, Tp, Tp, Tp, stream);
 }
 
 }  // namespace
@@ -117,7 +116,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     if (Bc <= 0 || T <= 0) return CX_OK;
     CX_TRY(check_desc(enc, buf, T));
     if (!demb || !emb_out || !buf->g_a || !buf->g_b || !buf->g_c || !buf->g_wide || !buf->g_act || !buf->tr_a ||
-        !buf->tr_b || !buf->delta)
+        !buf->tr_b || !buf->delta || !buf->ws_f32)
         return CX_ERR_ARG;
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;

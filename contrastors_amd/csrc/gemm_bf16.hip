@@ -190,6 +190,193 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
     }
 }
 
+
+// =====================================================================================================================
+// v2: 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 per wave), 3-stage LDS ring filled by LDS-DMA.
+// One raw s_barrier per K-tile; the DMA of tile t+2 is issued right after the barrier of iteration t and only has to
+// land two iterations later (counted vmcnt keeps tile t+1's six DMA instructions in flight ACROSS the barrier -- guide
+// §5 "Pipelining across barriers").  All LDS lives in ONE dynamic array (a second __shared__ object makes hipcc drain
+// vmcnt(0) in front of every ds_read).
+// =====================================================================================================================
+constexpr int V2_BM = 256, V2_BN = 128;
+constexpr int V2_STAGE = (V2_BM + V2_BN) * BK * 2;  // 48 KiB
+constexpr int V2_NSTAGE = 3;
+enum { OUT_F32_PARTIAL = 3 };
+
+template <int OUT_MODE>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tn = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tm = lid % p.tiles_m;
+    const int sk = lid / p.tiles_m;
+    const int m0 = tm * V2_BM, n0 = tn * V2_BN;
+    const int nk_total = p.K / BK;
+    const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
+    const int kt_end = (int)(((long)nk_total * (sk + 1)) / p.split_k);
+    const int nk = kt_end - kt_begin;
+
+    // per-lane DMA source pointers (advance by one K-tile = 128 B per issue) and wave-uniform LDS slots
+    const bf16_t* xsrc[4];
+    const bf16_t* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        xsrc[j] = p.X + (size_t)gr * p.ldx + (size_t)kt_begin * BK + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = n0 + r;
+        gr = gr < p.N ? gr : p.N - 1;
+        wsrc[j] = p.W + (size_t)gr * p.ldw + (size_t)kt_begin * BK + c * 8;
+    }
+    auto issue = [&](int stage) {
+        char* base = dsm + stage * V2_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            xsrc[j] += BK;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j],
+                                             (lds_void_ptr)(base + V2_BM * BK * 2 + (j * 8 + wave) * 1024), 16, 0, 0);
+            wsrc[j] += BK;
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    int st_cur = 0, st_fill = 2;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile t landed; tile t+1 (6 DMA ops) may still fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // everyone's share of tile t is in LDS; everyone is done reading stage st_fill
+        if (t + 2 < nk) issue(st_fill);
+        const char* xs = dsm + st_cur * V2_STAGE;
+        const char* ws = xs + V2_BM * BK * 2;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t wf[2], xf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                wf[b] = lds_read_frag(ws, tile64_off(wn * 64 + b * 32 + l31, ks * 2 + hi));
+                xf[b] = lds_read_frag(xs, tile64_off(wm * 64 + b * 32 + l31, ks * 2 + hi));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        st_cur = (st_cur == V2_NSTAGE - 1) ? 0 : st_cur + 1;
+        st_fill = (st_fill == V2_NSTAGE - 1) ? 0 : st_fill + 1;
+    }
+
+    const bool add_bias = (p.bias != nullptr) && (sk == 0);
+    float* part = nullptr;
+    if constexpr (OUT_MODE == OUT_F32_PARTIAL) part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = m0 + wm * 64 + b * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e] * p.alpha;
+                if (add_bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if constexpr (OUT_MODE == OUT_BF16) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = pk;
+                } else if constexpr (OUT_MODE == OUT_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.Out) + (size_t)m * p.ldo + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else if constexpr (OUT_MODE == OUT_F32_PARTIAL) {
+                    *reinterpret_cast<float4*>(part + (size_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    float* o = reinterpret_cast<float*>(p.Out) + (size_t)m * p.ldo + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
+                }
+            }
+        }
+    }
+}
+
+// out[i] += sum_s part[s][i]   (float4 per thread; fixed summation order -> deterministic wgrad)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            long n4, long slab, int splits) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4*>(out)[i];
+        for (int s = 0; s < splits; ++s) {
+            const float4 v = reinterpret_cast<const float4*>(part + s * slab)[i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+
+template <int OUT_MODE>
+hipError_t launch_v2_mode(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_v2_kernel<OUT_MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, V2_NSTAGE * V2_STAGE);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    hipLaunchKernelGGL((gemm_bf16_nt_v2_kernel<OUT_MODE>), dim3(nwg), dim3(512), V2_NSTAGE * V2_STAGE, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_v2(const GemmParams& p, int out_mode, hipStream_t stream) {
+    switch (out_mode) {
+        case OUT_BF16: return launch_v2_mode<OUT_BF16>(p, stream);
+        case OUT_F32: return launch_v2_mode<OUT_F32>(p, stream);
+        case OUT_F32_PARTIAL: return launch_v2_mode<OUT_F32_PARTIAL>(p, stream);
+        default: return launch_v2_mode<OUT_F32_ATOMIC>(p, stream);
+    }
+}
+
+int g_variant = 2;  // 2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
+
 int g_use_glds = 1;
 
 // ---- sampled per-launch timing (bench.py's live roofline measurement) --------------------------------------
@@ -221,6 +408,8 @@ hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
 
 extern "C" {
 
+void cx_gemm_set_variant(int v) { g_variant = (v == 1) ? 1 : 2; }
+int cx_gemm_get_variant(void) { return g_variant; }
 void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }
 int cx_gemm_get_glds(void) { return g_use_glds; }
 
@@ -235,8 +424,9 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     GemmParams p;
     p.X = X; p.W = W; p.Out = Out; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
-    p.tiles_m = (M + BM - 1) / BM;
-    p.tiles_n = (N + BN - 1) / BN;
+    const bool v2 = (g_variant == 2) && g_use_glds;
+    p.tiles_m = v2 ? (M + V2_BM - 1) / V2_BM : (M + BM - 1) / BM;
+    p.tiles_n = v2 ? (N + V2_BN - 1) / V2_BN : (N + BN - 1) / BN;
     const int nk = K / BK;
     if (split_k < 1) split_k = 1;
     if (split_k > nk) split_k = nk;
@@ -257,10 +447,55 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
         }
         ++g_prof.launches;
     }
-    hipError_t e = g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
-                              : launch_mode<false>(p, out_mode, (hipStream_t)stream);
+    hipError_t e = v2 ? launch_v2(p, out_mode, (hipStream_t)stream)
+                      : (g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
+                                    : launch_mode<false>(p, out_mode, (hipStream_t)stream));
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+// Out(M,N) fp32 += X W^T with the K range split over `split_k` workgroup groups whose fp32 partial tiles go to `ws`
+// with plain stores, followed by one fixed-order reduction pass (no device-scope atomics: those serialise at the
+// memory fabric because the XCD L2s are not coherent -- 235 us floor per launch measured in round 1).
+int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, float* ws, long ws_floats, int M, int N,
+                          int K, int ldx, int ldw, void* stream) {
+    if (M <= 0 || N <= 0) return CX_OK;
+    if (K <= 0 || (K % BK) != 0 || (N % 4) != 0) return CX_ERR_SHAPE;
+    if (!ws || !Out) return CX_ERR_ARG;
+    const long slab = (long)M * N;
+    if (ws_floats < slab) return CX_ERR_SHAPE;
+    const bool v2 = (g_variant == 2) && g_use_glds;
+    const long tiles = v2 ? (long)((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN)
+                          : (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const long nk = K / BK;
+    long split = ((v2 ? 256 : 512) + tiles - 1) / tiles;  // fill every CU once (v2: 1 block/CU, v1: 2 blocks/CU)
+    if (split > nk / 4) split = nk / 4;                    // keep >= 4 K-tiles per slice (pipeline depth)
+    if (split > ws_floats / slab) split = ws_floats / slab;
+    if (split < 1) split = 1;
+    int rc;
+    if (v2) {
+        GemmParams p;
+        p.X = X; p.W = W; p.Out = ws; p.bias = nullptr;
+        p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = N;
+        p.tiles_m = (M + V2_BM - 1) / V2_BM; p.tiles_n = (N + V2_BN - 1) / V2_BN;
+        p.split_k = (int)split; p.alpha = 1.f;
+        rc = launch_v2(p, OUT_F32_PARTIAL, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+    } else {
+        // v1 has no partial epilogue: one slice at a time into its slab via the overwrite mode
+        rc = CX_OK;
+        for (long s = 0; s < split && rc == CX_OK; ++s) {
+            const long k0 = nk * s / split * BK, k1 = nk * (s + 1) / split * BK;
+            rc = cx_gemm_bf16_nt(X + k0, W + k0, ws + s * slab, nullptr, M, N, (int)(k1 - k0), ldx, ldw, N, OUT_F32, 1,
+                                 1.f, stream);
+        }
+    }
+    if (rc != CX_OK) return rc;
+    const long n4 = slab / 4;
+    long g = (n4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, ws, Out, n4, slab,
+                       (int)split);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
 int cx_prof_gemm_config(int enable, int stride) {

@@ -126,11 +126,16 @@ class _ChunkArena:
             t["tr_a"] = torch.empty(wide, T_cap, **bf)
             t["tr_b"] = torch.empty(wide, T_cap, **bf)
             t["delta"] = torch.empty(T_cap * H, **f32)
+            # split-K workspace of the wgrad GEMMs: room for >= 2 slabs of the largest weight, 16 of the smallest
+            t["ws_f32"] = torch.empty(max(2 * wide * d, 16 * d * d), **f32)
         self.tensors = t
         self.desc = _C.CxChunkBuffers()
         self.desc.T_cap = T_cap
         for name, _ in _C.CxChunkBuffers._fields_[1:]:
-            setattr(self.desc, name, t[name].data_ptr() if name in t else None)
+            if name == "ws_floats":
+                self.desc.ws_floats = t["ws_f32"].numel() if "ws_f32" in t else 0
+            else:
+                setattr(self.desc, name, t[name].data_ptr() if name in t else None)
         self.emb_out: Optional[torch.Tensor] = None  # set by a saving forward, consumed by backward
 
     def nbytes(self) -> int:

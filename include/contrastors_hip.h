@@ -38,6 +38,13 @@ const char* cx_error_string(int code);
  * forward: X=act, W=weight.  dgrad: X=dY, W=W^T.  wgrad: X=dY^T, W=act^T (both via cx_transpose_bf16). */
 int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float* bias, int M, int N, int K, int ldx,
                     int ldw, int ldo, int out_mode, int split_k, float alpha, void* stream);
+/* Out:(M,N) fp32 (ld = N) += X W^T with split-K through a caller-owned fp32 workspace `ws` (>= M*N floats; more lets
+ * more K slices run concurrently) and a fixed-order reduction: the wgrad form (X = dY^T, W = act^T, K = tokens).
+ * Deterministic; no atomics. */
+int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, float* ws, long ws_floats, int M, int N,
+                          int K, int ldx, int ldw, void* stream);
+void cx_gemm_set_variant(int v); /* 2 (default): 256x128 tile, 3-stage LDS-DMA ring; 1: 128x128 2-stage kernel */
+int cx_gemm_get_variant(void);
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
  * (2*M*N*K) of exactly the sampled launches. */
@@ -201,6 +208,8 @@ typedef struct CxChunkBuffers {
     uint16_t* g_act;            /* (T, I) */
     uint16_t* tr_a; uint16_t* tr_b; /* transposed operands for wgrad: (max(3d,2I), T_cap) each */
     float* delta;               /* (H,T) */
+    float* ws_f32;              /* split-K workspace for the wgrad GEMMs */
+    long ws_floats;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.

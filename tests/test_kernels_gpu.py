@@ -44,11 +44,12 @@ def test_probe_ds_read_tr16_pattern():
 
 
 # ------------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("variant", ["v2", "v1_glds", "v1_reg"])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
-                                   (257, 6144, 768)])
-def test_gemm_bf16_nt(glds, M, N, K):
-    L().cx_gemm_set_glds(glds)
+                                   (257, 6144, 768), (300, 768, 128)])
+def test_gemm_bf16_nt(variant, M, N, K):
+    L().cx_gemm_set_variant(2 if variant == "v2" else 1)
+    L().cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
     try:
         x, w = bf(_randn(M, K, seed=1)), bf(_randn(N, K, seed=2, std=0.05))
         bias = _randn(N, seed=3)
@@ -60,12 +61,35 @@ def test_gemm_bf16_nt(glds, M, N, K):
         acc = torch.ones(M, N, device=DEV)
         gemm(x, w, out_mode=2, split_k=min(4, K // 64), out=acc)
         eacc = rel_err(acc - 1.0, ref)
-        report("gemm", glds=glds, M=M, N=N, K=K, e32=e32, e16=e16, eacc=eacc)
+        # workspace split-K accumulate (the wgrad form): Out += X W^T, twice, deterministic
+        acc2 = torch.ones(M, N, device=DEV)
+        ws = torch.empty(3 * M * N + 5, device=DEV)
+        for _ in range(2):
+            _C.check(L().cx_gemm_bf16_nt_accum(x.data_ptr(), w.data_ptr(), acc2.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               M, N, K, K, K, S()))
+        eacc2 = rel_err(acc2 - 1.0, 2 * ref)
+        report("gemm", variant=variant, M=M, N=N, K=K, e32=e32, e16=e16, eacc=eacc, eacc2=eacc2)
         assert e32 < 1e-5, "fp32-out GEMM: only accumulation-order error allowed"
         assert e16 < 4e-3, "bf16-out GEMM: one bf16 rounding (2^-9 rel) of the fp32 result"
-        assert eacc < 1e-5
+        assert eacc < 1e-5 and eacc2 < 1e-5
     finally:
+        L().cx_gemm_set_variant(2)
         L().cx_gemm_set_glds(1)
+
+
+def test_wgrad_shape_accum_deterministic():
+    """wgrad form at the BASELINE chunk: dW(768,3072) += dY^T act over 8192 tokens; bit-identical across runs."""
+    T, O, I = 8192, 768, 3072
+    dyT, actT = bf(_randn(O, T, seed=80, std=0.1)), bf(_randn(I, T, seed=81))
+    ws = torch.empty(16 * O * O, device=DEV)
+    outs = []
+    for _ in range(2):
+        g = torch.zeros(O, I, device=DEV)
+        _C.check(L().cx_gemm_bf16_nt_accum(dyT.data_ptr(), actT.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), O,
+                                           I, T, T, T, S()))
+        outs.append(g)
+    assert torch.equal(outs[0], outs[1]), "fixed-order split-K reduction must be deterministic"
+    assert rel_err(outs[0], dyT.float() @ actT.float().T) < 1e-5
 
 
 def test_gemm_linearity_full_size():
