@@ -66,6 +66,7 @@ _SIGS = {
     "cx_gemm_bf16_nt_accum": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_set_variant": (None, [i32]),
     "cx_gemm_get_variant": (i32, []),
+    "cx_gemm_set_debug": (None, [i32]),
     "cx_prof_gemm_config": (i32, [i32, i32]),
     "cx_prof_gemm_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "cx_gemm_set_glds": (None, [i32]),
@@ -78,8 +79,9 @@ _SIGS = {
     "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "cx_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cx_embed_ln_bwd": (i32, [vp] * 15 + [i32, i32, i32, i32, vp]),
-    "cx_swiglu_fwd": (i32, [vp, vp, i32, i32, vp]),
-    "cx_swiglu_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cx_swiglu_fwd": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cx_swiglu_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cx_gemm_bf16_swiglu": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_bias_gelu_fwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "cx_bias_gelu_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),

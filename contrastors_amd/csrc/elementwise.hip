@@ -113,8 +113,13 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------------------------------ activations
 CX_DEVICE float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// column of y / gate for activation column c: concatenated [y | gate] (layout 0) or interleaved in groups of 32
+// ([y 0..31 | gate 0..31 | y 32..63 | ...], layout 1 = what the fused GEMM epilogue and its weight use)
+CX_DEVICE int ycol(int c, int I, int layout) { return layout ? ((c >> 5) << 6) + (c & 31) : c; }
+CX_DEVICE int gcol(int c, int I, int layout) { return layout ? ((c >> 5) << 6) + 32 + (c & 31) : I + c; }
+
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ yg, bf16_t* __restrict__ act,
-                                                         long T, int I) {
+                                                         long T, int I, int layout) {
     const int chunks = I >> 3;
     const long total = T * chunks;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
         const int c = (int)(i - t * chunks) * 8;
         const bf16_t* row = yg + t * (2L * I);
         float y[8], g[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(row + c), y);
-        unpack8(*reinterpret_cast<const uint4*>(row + I + c), g);
+        unpack8(*reinterpret_cast<const uint4*>(row + ycol(c, I, layout)), y);
+        unpack8(*reinterpret_cast<const uint4*>(row + gcol(c, I, layout)), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = g[e] * sigmoidf_(g[e]) * y[e];
         *reinterpret_cast<uint4*>(act + t * (long)I + c) = pack8(o);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
 
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dact,
                                                          const bf16_t* __restrict__ yg, bf16_t* __restrict__ dyg,
-                                                         long T, int I) {
+                                                         long T, int I, int layout) {
     const int chunks = I >> 3;
     const long total = T * chunks;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -142,8 +147,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
         const int c = (int)(i - t * chunks) * 8;
         const bf16_t* row = yg + t * (2L * I);
         float y[8], g[8], d[8], dy[8], dg[8];
-        unpack8(*reinterpret_cast<const uint4*>(row + c), y);
-        unpack8(*reinterpret_cast<const uint4*>(row + I + c), g);
+        unpack8(*reinterpret_cast<const uint4*>(row + ycol(c, I, layout)), y);
+        unpack8(*reinterpret_cast<const uint4*>(row + gcol(c, I, layout)), g);
         unpack8(*reinterpret_cast<const uint4*>(dact + t * (long)I + c), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -152,8 +157,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
             dg[e] = s * (1.f + g[e] * (1.f - s)) * d[e] * y[e];
         }
         bf16_t* orow = dyg + t * (2L * I);
-        *reinterpret_cast<uint4*>(orow + c) = pack8(dy);
-        *reinterpret_cast<uint4*>(orow + I + c) = pack8(dg);
+        *reinterpret_cast<uint4*>(orow + ycol(c, I, layout)) = pack8(dy);
+        *reinterpret_cast<uint4*>(orow + gcol(c, I, layout)) = pack8(dg);
     }
 }
 
@@ -393,19 +398,19 @@ int cx_transpose_f32(const float* In, float* Out, int rows, int cols, int ld_in,
     return done();
 }
 
-int cx_swiglu_fwd(const uint16_t* yg, uint16_t* act, int T, int I, void* stream) {
+int cx_swiglu_fwd(const uint16_t* yg, uint16_t* act, int T, int I, int layout, void* stream) {
     if (T <= 0) return CX_OK;
-    if (I % 8) return CX_ERR_SHAPE;
+    if ((I % 8) || (layout && (I % 32))) return CX_ERR_SHAPE;
     hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       yg, act, (long)T, I);
+                       yg, act, (long)T, I, layout);
     return done();
 }
 
-int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T, int I, void* stream) {
+int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T, int I, int layout, void* stream) {
     if (T <= 0) return CX_OK;
-    if (I % 8) return CX_ERR_SHAPE;
+    if ((I % 8) || (layout && (I % 32))) return CX_ERR_SHAPE;
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
-                       dact, yg, dyg, (long)T, I);
+                       dact, yg, dyg, (long)T, I, layout);
     return done();
 }
 

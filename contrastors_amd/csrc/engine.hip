@@ -95,10 +95,12 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
         CX_TRY(cx_gemm_bf16_nt(s.ctx(sl), w.Wout, s.z1(sl), w.bout, T, d, d, d, d, d, 0, 1, 1.f, stream));
         CX_TRY(cx_layernorm_fwd(s.z1(sl), h_in, w.ln1_g, w.ln1_b, s.h1(sl), s.z1(sl), s.mean1(sl), s.rstd1(sl), T, d,
                                 enc->ln_eps, stream));
-        CX_TRY(cx_gemm_bf16_nt(s.h1(sl), w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
         if (enc->gated) {
-            CX_TRY(cx_swiglu_fwd(s.yg(sl), s.act(sl), T, I, stream));
+            // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
+            CX_TRY(cx_gemm_bf16_swiglu(s.h1(sl), w.Wfc1, save_for_backward ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d,
+                                       s.wfc1, I, stream));
         } else {
+            CX_TRY(cx_gemm_bf16_nt(s.h1(sl), w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
             CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
         }
         CX_TRY(cx_gemm_bf16_nt(s.act(sl), w.Wfc2, s.z2(sl), w.bfc2, T, d, I, I, I, d, 0, 1, 1.f, stream));
@@ -138,7 +140,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
         CX_TRY(cx_gemm_bf16_nt(buf->g_c, w.Wfc2T, buf->g_act, nullptr, T, I, d, d, d, I, 0, 1, 1.f, stream));
         // activation
         if (enc->gated) {
-            CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, stream));
+            CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
         } else {
             CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), w.bfc1, buf->g_wide, T, I, stream));
             if (w.gbfc1) CX_TRY(cx_bias_grad(buf->g_wide, w.gbfc1, T, I, I, stream));

@@ -13,6 +13,7 @@
 // lane ends up holding 4 consecutive n for one m -> 8/16-byte epilogue stores.
 #include "cx_common.h"
 #include "../../include/contrastors_hip.h"
+#include "gemm_params.h"
 
 namespace {
 
@@ -22,18 +23,7 @@ constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ATOMIC = 2 };
-
-struct GemmParams {
-    const bf16_t* X;
-    const bf16_t* W;
-    void* Out;
-    const float* bias;  // fp32[N] or nullptr
-    int M, N, K;
-    int ldx, ldw, ldo;
-    int tiles_m, tiles_n, split_k;
-    float alpha;
-};
+enum OutMode { OUT_BF16 = GEMM_OUT_BF16, OUT_F32 = GEMM_OUT_F32, OUT_F32_ATOMIC = GEMM_OUT_F32_ATOMIC };
 
 // Staging registers as a plain struct of named members: an indexed array here is not scalarised by the compiler
 // (it lands in scratch / promoted LDS).
@@ -201,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
 constexpr int V2_BM = 256, V2_BN = 128;
 constexpr int V2_STAGE = (V2_BM + V2_BN) * BK * 2;  // 48 KiB
 constexpr int V2_NSTAGE = 3;
-enum { OUT_F32_PARTIAL = 3 };
+enum { OUT_F32_PARTIAL = GEMM_OUT_F32_PARTIAL };
 
 template <int OUT_MODE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(GemmParams p) {
@@ -214,10 +204,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(GemmParams p) {
 
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
     int lid = xcd_remap(blockIdx.x, nwg);
-    const int tn = lid % p.tiles_n;
-    lid /= p.tiles_n;
-    const int tm = lid % p.tiles_m;
-    const int sk = lid / p.tiles_m;
+    const int per_k = p.tiles_m * p.tiles_n;
+    const int sk = lid / per_k;
+    lid -= sk * per_k;
+    int tm, tn;
+    if (p.sup_m > 0) {
+        // super-tile-major order: the ~32 workgroups an XCD runs concurrently cover sup_m x sup_n tiles that share
+        // sup_m X panels and sup_n W panels in that XCD's 4 MiB L2 (sup_* divide tiles_* exactly: a bijection)
+        const int per_sup = p.sup_m * p.sup_n;
+        const int nsup_n = p.tiles_n / p.sup_n;
+        const int sup = lid / per_sup, in = lid - sup * per_sup;
+        const int sm_i = sup / nsup_n, sn_i = sup - sm_i * nsup_n;
+        tm = sm_i * p.sup_m + in / p.sup_n;
+        tn = sn_i * p.sup_n + in % p.sup_n;
+    } else {
+        tn = lid % p.tiles_n;
+        tm = lid / p.tiles_n;
+    }
     const int m0 = tm * V2_BM, n0 = tn * V2_BN;
     const int nk_total = p.K / BK;
     const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
@@ -276,9 +279,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // everyone's share of tile t is in LDS; everyone is done reading stage st_fill
-        if (t + 2 < nk) issue(st_fill);
+        if (t + 2 < nk && !(p.dbg & 1)) issue(st_fill);
         const char* xs = dsm + st_cur * V2_STAGE;
         const char* ws = xs + V2_BM * BK * 2;
+        if (!(p.dbg & 2)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -294,10 +298,61 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(GemmParams p) {
                 for (int b = 0; b < 2; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
         }
         __builtin_amdgcn_s_setprio(0);
+        }
         st_cur = (st_cur == V2_NSTAGE - 1) ? 0 : st_cur + 1;
         st_fill = (st_fill == V2_NSTAGE - 1) ? 0 : st_fill + 1;
     }
 
+    if constexpr (OUT_MODE == OUT_BF16) {
+        if ((p.ldo & 7) == 0) {
+            // LDS-staged epilogue: every 128-B output line leaves the CU as ONE coalesced 8-lane x 16-B store instead of
+            // eight 16-B fragments issued by eight different instructions (partial-line writes cost an L2 request each:
+            // ~4 us per 256-tile round measured in round 1).  Each wave stages its own 64x64 tile; rows are padded to
+            // 144 B so the column-strided 8-B writes spread over the banks and the 16-B reads stay aligned.
+            constexpr int ROWB = 144;
+            const bool add_bias2 = (p.bias != nullptr) && (sk == 0);
+            __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages
+            char* my = dsm + wave * (64 * ROWB);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = a * 32 + 8 * q + 4 * hi;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e] * p.alpha;
+                        if (add_bias2) {
+                            const int n = n0 + wn * 64 + nl;
+                            if (n < p.N) {
+                                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                            }
+                        }
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(my + (b * 32 + l31) * ROWB + nl * 2) = pk;
+                    }
+            // LDS is in-order per wave: the reads below see this wave's own writes without a barrier
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ch * 8;
+                const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                if (m < p.M) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n;
+                    if (n + 8 <= p.N) {
+                        *reinterpret_cast<uint4*>(dst) = vv;
+                    } else if (n < p.N) {  // ragged N tail (N % 4 == 0): first half of the chunk only
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(vv.x, vv.y);
+                    }
+                }
+            }
+            return;
+        }
+    }
     const bool add_bias = (p.bias != nullptr) && (sk == 0);
     float* part = nullptr;
     if constexpr (OUT_MODE == OUT_F32_PARTIAL) part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
@@ -366,7 +421,17 @@ hipError_t launch_v2_mode(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_v2(const GemmParams& p, int out_mode, hipStream_t stream) {
+int largest_divisor_le(int n, int cap) {
+    for (int d = cap < n ? cap : n; d >= 1; --d)
+        if (n % d == 0) return d;
+    return 1;
+}
+
+hipError_t launch_v2(const GemmParams& p_in, int out_mode, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.sup_n = largest_divisor_le(p.tiles_n, 8);
+    p.sup_m = largest_divisor_le(p.tiles_m, 32 / p.sup_n);
+    if (p.sup_m * p.sup_n < 8) p.sup_m = p.sup_n = 0;  // awkward factorisation: keep the row-major order
     switch (out_mode) {
         case OUT_BF16: return launch_v2_mode<OUT_BF16>(p, stream);
         case OUT_F32: return launch_v2_mode<OUT_F32>(p, stream);
@@ -375,7 +440,8 @@ hipError_t launch_v2(const GemmParams& p, int out_mode, hipStream_t stream) {
     }
 }
 
-int g_variant = 2;  // 2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
+int g_dbg = 0;
+int g_variant = 2;  // 3: v3 persistent 256x256;  2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
 
 int g_use_glds = 1;
 
@@ -408,7 +474,8 @@ hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
 
 extern "C" {
 
-void cx_gemm_set_variant(int v) { g_variant = (v == 1) ? 1 : 2; }
+void cx_gemm_set_debug(int d) { g_dbg = d; }
+void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 3) ? v : 2; }
 int cx_gemm_get_variant(void) { return g_variant; }
 void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }
 int cx_gemm_get_glds(void) { return g_use_glds; }
@@ -424,7 +491,8 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     GemmParams p;
     p.X = X; p.W = W; p.Out = Out; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
-    const bool v2 = (g_variant == 2) && g_use_glds;
+    const bool v3 = (g_variant == 3) && g_use_glds && out_mode != OUT_F32_ATOMIC;
+    const bool v2 = ((g_variant == 2) || (g_variant == 3 && !v3)) && g_use_glds;
     p.tiles_m = v2 ? (M + V2_BM - 1) / V2_BM : (M + BM - 1) / BM;
     p.tiles_n = v2 ? (N + V2_BN - 1) / V2_BN : (N + BN - 1) / BN;
     const int nk = K / BK;
@@ -433,6 +501,10 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     if (out_mode != OUT_F32_ATOMIC) split_k = 1;  // only the accumulating epilogue can combine K slices
     p.split_k = split_k;
     p.alpha = alpha;
+    p.dbg = g_dbg;
+    p.Out2 = nullptr;
+    p.ldo2 = 0;
+    p.sup_m = p.sup_n = 0;
     int slot = -1;
     if (g_prof.enabled) {
         if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
@@ -447,7 +519,8 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
         }
         ++g_prof.launches;
     }
-    hipError_t e = v2 ? launch_v2(p, out_mode, (hipStream_t)stream)
+    hipError_t e = v3 ? cx_launch_gemm_v3(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
+                   : v2 ? launch_v2(p, out_mode, (hipStream_t)stream)
                       : (g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
                                     : launch_mode<false>(p, out_mode, (hipStream_t)stream));
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
@@ -464,21 +537,31 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
     if (!ws || !Out) return CX_ERR_ARG;
     const long slab = (long)M * N;
     if (ws_floats < slab) return CX_ERR_SHAPE;
+    const bool v3 = (g_variant == 3) && g_use_glds;
     const bool v2 = (g_variant == 2) && g_use_glds;
-    const long tiles = v2 ? (long)((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN)
+    const long tiles = v3 ? (long)((M + 255) / 256) * ((N + 255) / 256)
+                     : v2 ? (long)((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN)
                           : (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const long nk = K / BK;
-    long split = ((v2 ? 256 : 512) + tiles - 1) / tiles;  // fill every CU once (v2: 1 block/CU, v1: 2 blocks/CU)
+    long split = (((v2 || v3) ? 256 : 512) + tiles - 1) / tiles;  // fill every CU once (v2: 1 block/CU, v1: 2 blocks/CU)
     if (split > nk / 4) split = nk / 4;                    // keep >= 4 K-tiles per slice (pipeline depth)
     if (split > ws_floats / slab) split = ws_floats / slab;
     if (split < 1) split = 1;
     int rc;
-    if (v2) {
+    if (v3) {
+        GemmParams p;
+        p.X = X; p.W = W; p.Out = ws; p.bias = nullptr;
+        p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = N;
+        p.tiles_m = p.tiles_n = 0; p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
+        split = p.split_k;
+        rc = cx_launch_gemm_v3(p, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream) == hipSuccess ? CX_OK
+                                                                                                          : CX_ERR_LAUNCH;
+    } else if (v2) {
         GemmParams p;
         p.X = X; p.W = W; p.Out = ws; p.bias = nullptr;
         p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = N;
         p.tiles_m = (M + V2_BM - 1) / V2_BM; p.tiles_n = (N + V2_BN - 1) / V2_BN;
-        p.split_k = (int)split; p.alpha = 1.f;
+        p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
         rc = launch_v2(p, OUT_F32_PARTIAL, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
     } else {
         // v1 has no partial epilogue: one slice at a time into its slab via the overwrite mode
@@ -496,6 +579,39 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, ws, Out, n4, slab,
                        (int)split);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+// fc1 of the gated MLP with SwiGLU fused into the epilogue (K9 + K10).  W:(2I, K) holds fc11/fc12 rows interleaved
+// in groups of 32 ([y rows 0..31 | gate rows 0..31 | y rows 32..63 | ...]); YG (optional, may be NULL):(M, 2I) in the
+// same interleaved column layout; Act:(M, I) = silu(gate) * y.
+int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint16_t* Act, int M, int I, int K, int ldx,
+                        int ldw, int ld_yg, int ld_act, void* stream) {
+    if (M <= 0 || I <= 0) return CX_OK;
+    if (K <= 0 || (K % BK) != 0 || (I % 32) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0 || (ld_yg % 4) != 0 || (ld_act % 4) != 0) return CX_ERR_ALIGN;
+    if (!Act) return CX_ERR_ARG;
+    GemmParams p;
+    p.X = X; p.W = W; p.Out = YG; p.bias = nullptr;
+    p.M = M; p.N = 2 * I; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ld_yg;
+    p.tiles_m = p.tiles_n = 0; p.split_k = 1; p.alpha = 1.f; p.dbg = g_dbg;
+    p.Out2 = Act; p.ldo2 = ld_act; p.sup_m = p.sup_n = 0;
+    int slot = -1;
+    if (g_prof.enabled) {
+        if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
+            slot = g_prof.used++;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev0[slot]) != hipSuccess || hipEventCreate(&g_prof.ev1[slot]) != hipSuccess)
+                    return CX_ERR_LAUNCH;
+                g_prof.created = slot + 1;
+            }
+            g_prof.flop[slot] = 2.0 * (double)M * (double)(2 * I) * (double)K;
+            (void)hipEventRecord(g_prof.ev0[slot], (hipStream_t)stream);
+        }
+        ++g_prof.launches;
+    }
+    hipError_t e = cx_launch_gemm_v3(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
+    return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
 int cx_prof_gemm_config(int enable, int stride) {

@@ -1,0 +1,24 @@
+// gemm_params.h -- launch descriptor shared by the bf16 GEMM generations (gemm_bf16.hip, gemm_bf16_v3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_F32_ATOMIC = 2, GEMM_OUT_F32_PARTIAL = 3 };
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1 };
+
+struct GemmParams {
+    const uint16_t* X;
+    const uint16_t* W;
+    void* Out;
+    const float* bias;  // fp32[N] or nullptr
+    int M, N, K;
+    int ldx, ldw, ldo;
+    int tiles_m, tiles_n, split_k;
+    float alpha;
+    int dbg;    // experiments only: bit0 = no DMA in the main loop, bit1 = no LDS reads / MFMA
+    void* Out2; // SwiGLU epilogue: activation output (M, N/2) bf16
+    int ldo2;
+    int sup_m, sup_n;  // v2: L2 super-tile (sup_m x sup_n tiles walked together); 0 = plain row-major order
+};
+
+hipError_t cx_launch_gemm_v3(GemmParams p, int out_mode, int epi, hipStream_t stream);

@@ -311,6 +311,13 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     flush_param_grads<NCH>(dty, zero, dtype0, nullptr, smem);
 }
 
+// backward kernels end with 2*d device-scope atomics per block (they serialise at the memory fabric): one block per CU
+inline int ln_grid_bwd(int rows) {
+    int g = (rows + 3) / 4;
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    return g;
+}
 inline int ln_grid(int rows) {
     int g = (rows + 3) / 4;
     if (g > 256 * 4) g = 256 * 4;
@@ -349,7 +356,7 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
     if (rows <= 0) return CX_OK;
     if (!dout_a || !z || !gamma || !mean || !rstd || !dz) return CX_ERR_ARG;
     const size_t smem = (size_t)8 * d * sizeof(float);
-    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(ln_grid(rows)), dim3(256), smem,
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(ln_grid_bwd(rows)), dim3(256), smem,
                                          (hipStream_t)stream, dout_a, dout_b, z, gamma, mean, rstd, dz_extra, dz,
                                          dgamma, dbeta, rows));
     return done();
@@ -373,7 +380,7 @@ int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_
     if (T <= 0) return CX_OK;
     if (!dout_a || !input_ids || !indices || !word || !type0 || !gamma || !mean || !rstd) return CX_ERR_ARG;
     const size_t smem = (size_t)8 * d * sizeof(float);
-    CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_bwd_kernel<NCH>), dim3(ln_grid(T)), dim3(256), smem,
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_bwd_kernel<NCH>), dim3(ln_grid_bwd(T)), dim3(256), smem,
                                          (hipStream_t)stream, dout_a, dout_b, input_ids, indices, word, type0,
                                          pos_emb, gamma, mean, rstd, dword, dtype0, dpos, dgamma, dbeta, T, S,
                                          padding_idx));

@@ -66,6 +66,8 @@ class NomicBertConfig:
             raise NotImplementedError("rotary_emb_fraction must be 0 or 1")
         if self.activation_function not in ("swiglu", "gelu", "gelu_new"):
             raise NotImplementedError(self.activation_function)
+        if self.n_inner % 32:
+            raise NotImplementedError("n_inner must be a multiple of 32 (interleaved fc11/fc12 layout)")
 
     @property
     def gated(self) -> bool:
@@ -302,50 +304,62 @@ class NomicBertEngine(torch.nn.Module):
                         w[cfg.pad_token_id].zero_()
                     view.copy_(w.flatten())
 
-    def reference_state_dict(self) -> Dict[str, torch.Tensor]:
-        """State dict with the reference's keys (Appendix E): fc1_fused is split into fc11/fc12 (or fc1)."""
-        out: Dict[str, torch.Tensor] = {}
+    # The gated MLP stores fc11/fc12 as ONE (2I, d) matrix whose rows are interleaved in groups of 32
+    # ([fc11 0..31 | fc12 0..31 | fc11 32..63 | ...]) so that the fused GEMM epilogue finds y and gate of the same
+    # activation column in the same lane (cx_gemm_bf16_swiglu).  These helpers translate to the reference's keys.
+    def _split_fused(self, t: torch.Tensor):
         I = self.config.n_inner
+        v = t.view(I // 32, 2, 32, *t.shape[1:])
+        return v[:, 0].reshape(I, *t.shape[1:]), v[:, 1].reshape(I, *t.shape[1:])
+
+    def _export(self, getter) -> Dict[str, torch.Tensor]:
+        out: Dict[str, torch.Tensor] = {}
         for name in self._layout:
-            t = self.p(name)
+            t = getter(name)
             if ".mlp.fc1_fused." in name:
                 if self.config.gated:
-                    out[name.replace("fc1_fused", "fc11")] = t[:I]
-                    out[name.replace("fc1_fused", "fc12")] = t[I:]
+                    y, g = self._split_fused(t)
+                    out[name.replace("fc1_fused", "fc11")] = y
+                    out[name.replace("fc1_fused", "fc12")] = g
                 else:
                     out[name.replace("fc1_fused", "fc1")] = t
             else:
                 out[name] = t
         return out
 
+    def reference_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Parameters keyed like the reference (Appendix E).  fc11/fc12 entries are copies (de-interleaved)."""
+        return self._export(self.p)
+
     def reference_grad_dict(self) -> Dict[str, torch.Tensor]:
-        out: Dict[str, torch.Tensor] = {}
-        I = self.config.n_inner
-        for name in self._layout:
-            t = self.g(name)
-            if ".mlp.fc1_fused." in name:
-                if self.config.gated:
-                    out[name.replace("fc1_fused", "fc11")] = t[:I]
-                    out[name.replace("fc1_fused", "fc12")] = t[I:]
-                else:
-                    out[name.replace("fc1_fused", "fc1")] = t
-            else:
-                out[name] = t
-        return out
+        return self._export(self.g)
 
     @torch.no_grad()
     def load_reference_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         """Copy weights keyed like the reference flash model / its eager twin (tests/test_huggingface.py:30-34)."""
-        mine = self.reference_state_dict()
-        missing = [k for k in mine if k not in sd]
+        I = self.config.n_inner
+        missing = []
+        for name in self._layout:
+            dst = self.p(name)
+            if ".mlp.fc1_fused." in name and self.config.gated:
+                k1, k2 = name.replace("fc1_fused", "fc11"), name.replace("fc1_fused", "fc12")
+                if k1 not in sd or k2 not in sd:
+                    missing.append(k1)
+                    continue
+                v = dst.view(I // 32, 2, 32, *dst.shape[1:])
+                v[:, 0].copy_(sd[k1].to(device=dst.device, dtype=torch.float32).view(I // 32, 32, *dst.shape[1:]))
+                v[:, 1].copy_(sd[k2].to(device=dst.device, dtype=torch.float32).view(I // 32, 32, *dst.shape[1:]))
+                continue
+            key = name.replace("fc1_fused", "fc1")
+            if key not in sd:
+                missing.append(key)
+                continue
+            src = sd[key]
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"{key}: shape {tuple(src.shape)} != {tuple(dst.shape)}")
+            dst.copy_(src.to(device=dst.device, dtype=torch.float32))
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:5]}...")
-        for k, dst in mine.items():
-            if k in sd:
-                src = sd[k]
-                if tuple(src.shape) != tuple(dst.shape):
-                    raise ValueError(f"{k}: shape {tuple(src.shape)} != {tuple(dst.shape)}")
-                dst.copy_(src.to(device=dst.device, dtype=torch.float32))
         self.sync_shadows()
 
     @torch.no_grad()

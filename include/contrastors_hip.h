@@ -43,8 +43,9 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
  * Deterministic; no atomics. */
 int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, float* ws, long ws_floats, int M, int N,
                           int K, int ldx, int ldw, void* stream);
-void cx_gemm_set_variant(int v); /* 2 (default): 256x128 tile, 3-stage LDS-DMA ring; 1: 128x128 2-stage kernel */
+void cx_gemm_set_variant(int v); /* 2 (default): 256x128 3-stage LDS-DMA ring; 3: persistent 256x256; 1: 128x128 2-stage */
 int cx_gemm_get_variant(void);
+void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0 skip the main-loop DMA, bit1 skip LDS reads + MFMA */
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
  * (2*M*N*K) of exactly the sampled launches. */
@@ -91,9 +92,15 @@ int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_
                     float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, void* stream);
 
 /* ---- K10 swiglu (flash_attn.ops.activations.swiglu; sc/layers/mlp.py:75) and GELU(erf) (mlp.py:30-34) ----
- * yg:(T, 2*I) = [ y = fc11(x) | gate = fc12(x) ];  act = silu(gate) * y, fp32 math, one rounding. */
-int cx_swiglu_fwd(const uint16_t* yg, uint16_t* act, int T, int I, void* stream);
-int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T, int I, void* stream);
+ * yg:(T, 2*I) holds y = fc11(x) and gate = fc12(x);  act = silu(gate) * y, fp32 math, one rounding.
+ * layout 0: yg = [y | gate] concatenated; layout 1: interleaved in groups of 32 columns
+ * ([y 0..31 | gate 0..31 | y 32..63 | ...]) -- the layout of the fused fc1 weight and of cx_gemm_bf16_swiglu. */
+int cx_swiglu_fwd(const uint16_t* yg, uint16_t* act, int T, int I, int layout, void* stream);
+int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T, int I, int layout, void* stream);
+/* K9 + K10 fused: Act:(M,I) = silu(X Wg^T) * (X Wy^T) in one pass, W:(2I,K) rows interleaved by 32 as above; YG (may be
+ * NULL):(M,2I) receives the pre-activation pair in the interleaved layout (kept for backward). */
+int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint16_t* Act, int M, int I, int K, int ldx,
+                        int ldw, int ld_yg, int ld_act, void* stream);
 /* act = gelu_erf(pre + bias); bias fp32[I] may be NULL.  backward: dpre = dact * gelu'(pre + bias). */
 int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream);
 int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, int T, int I,
@@ -154,7 +161,7 @@ int cx_transpose_f32(const float* In, float* Out, int rows, int cols, int ld_in,
 typedef struct CxLayerWeights {
     const uint16_t* Wqkv;   /* (3d, d) bf16 */
     const uint16_t* Wout;   /* (d, d) */
-    const uint16_t* Wfc1;   /* gated: (2I, d) = [fc11; fc12];  plain MLP: (I, d) */
+    const uint16_t* Wfc1;   /* gated: (2I, d) fc11/fc12 rows interleaved by 32;  plain MLP: (I, d) */
     const uint16_t* Wfc2;   /* (d, I) */
     const uint16_t* WqkvT;  /* transposed bf16 shadows for dgrad: (d, 3d) */
     const uint16_t* WoutT;  /* (d, d) */

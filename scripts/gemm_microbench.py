@@ -1,0 +1,64 @@
+"""Time cx_gemm_bf16_nt on the encoder's GEMM shapes (HIP events, random bf16 data).  usage:
+   python scripts/gemm_microbench.py [--variant 2] [--chunk 64] [--reps 20] [--shapes fwd|all]"""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from contrastors_amd import _C  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variant", type=int, default=2)
+ap.add_argument("--glds", type=int, default=1)
+ap.add_argument("--chunk", type=int, default=64)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--only", type=str, default="")
+ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
+a = ap.parse_args()
+lib = _C.lib()
+lib.cx_gemm_set_variant(a.variant)
+lib.cx_gemm_set_glds(a.glds)
+lib.cx_gemm_set_debug(a.dbg)
+T = a.chunk * 128
+shapes = {  # name: (M, N, K)
+    "qkv_fwd": (T, 2304, 768), "out_fwd": (T, 768, 768), "fc1_fwd": (T, 6144, 768), "fc2_fwd": (T, 768, 3072),
+    "fc1_dgrad": (T, 768, 6144), "fc2_dgrad": (T, 3072, 768), "qkv_dgrad": (T, 768, 2304),
+    "qkv_wgrad": (2304, 768, T), "fc1_wgrad": (6144, 768, T), "fc2_wgrad": (768, 3072, T), "out_wgrad": (768, 768, T),
+}
+if a.shape:
+    shapes = {f"custom{i}": tuple(int(v) for v in sh.split(",")) for i, sh in enumerate(a.shape)}
+dev = "cuda"
+s = torch.cuda.current_stream().cuda_stream
+tot_f = tot_t = 0.0
+for name, (M, N, K) in shapes.items():
+    if a.only and a.only not in name:
+        continue
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    wg = name.endswith("wgrad")
+    out = torch.zeros(M, N, device=dev, dtype=torch.float32 if wg else torch.bfloat16)
+    ws = torch.empty(16 * 768 * 768 if wg else 1, device=dev)
+
+    def run():
+        if wg:
+            return lib.cx_gemm_bf16_nt_accum(x.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, N,
+                                             K, K, K, s)
+        return lib.cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, M, N, K, K, K, N, 0, 1, 1.0, s)
+
+    for _ in range(3):
+        assert run() == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / a.reps
+    fl = 2.0 * M * N * K
+    tot_f += fl
+    tot_t += us
+    print(f"{name:10s} M={M:6d} N={N:5d} K={K:6d}  {us:8.1f} us  {fl/us/1e6:7.1f} TF")
+print(f"sum: {tot_t:.1f} us  {tot_f/tot_t/1e6:.1f} TF  (variant {a.variant}, chunk {a.chunk})")

@@ -34,6 +34,13 @@ if [[ $mode == prof || $mode == all ]]; then
   out=$PWD/gpurun_out/prof
   rm -rf $out; mkdir -p $out
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $out -o bench -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --global-batch 2048 --no-cpu-baseline} > $out/run.log 2>&1; echo "prof exit $?" >> $out/run.log)
+  if [[ -n "${PMC:-}" ]]; then
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      (cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o b -- python $OLDPWD/bench.py --steps 1 --warmup 0 --global-batch 512 --no-cpu-baseline > $out/pmc_$ctr.log 2>&1)
+      python $OLDPWD/scripts/pmc_summary.py $out/pmc_$ctr/b_counter_collection.csv $ctr > $out/pmc_${ctr}_summary.txt 2>&1
+      rm -rf $out/pmc_$ctr
+    done
+  fi
   tail -3 $out/run.log
   find $out -name "*kernel_stats*" | head
   f=$(find $out -name "*kernel_stats*.csv" | head -1)

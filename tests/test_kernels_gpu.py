@@ -44,11 +44,11 @@ def test_probe_ds_read_tr16_pattern():
 
 
 # ------------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", ["v2", "v1_glds", "v1_reg"])
+@pytest.mark.parametrize("variant", ["v3", "v2", "v1_glds", "v1_reg"])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
                                    (257, 6144, 768), (300, 768, 128)])
 def test_gemm_bf16_nt(variant, M, N, K):
-    L().cx_gemm_set_variant(2 if variant == "v2" else 1)
+    L().cx_gemm_set_variant({"v3": 3, "v2": 2}.get(variant, 1))
     L().cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
     try:
         x, w = bf(_randn(M, K, seed=1)), bf(_randn(N, K, seed=2, std=0.05))
@@ -75,6 +75,34 @@ def test_gemm_bf16_nt(variant, M, N, K):
     finally:
         L().cx_gemm_set_variant(2)
         L().cx_gemm_set_glds(1)
+
+
+@pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
+def test_gemm_swiglu_fused(M, I, K):
+    """fc11 || fc12 GEMM with SwiGLU in the epilogue == standalone GEMM + swiglu (interleaved-by-32 weight rows)."""
+    x = bf(_randn(M, K, seed=90))
+    w11, w12 = bf(_randn(I, K, seed=91, std=0.05)), bf(_randn(I, K, seed=92, std=0.05))
+    wi = torch.stack([w11.view(I // 32, 32, K), w12.view(I // 32, 32, K)], 1).reshape(2 * I, K).contiguous()
+    yg = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV)
+    act = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), yg.data_ptr(), act.data_ptr(), M, I, K, K, K, 2 * I, I,
+                                     S()))
+    y_ref = (x.float() @ w11.float().T).to(torch.bfloat16)
+    g_ref = (x.float() @ w12.float().T).to(torch.bfloat16)
+    v = yg.view(M, I // 32, 2, 32)
+    assert rel_err(v[:, :, 0].reshape(M, I).float(), y_ref.float()) < 4e-3
+    assert rel_err(v[:, :, 1].reshape(M, I).float(), g_ref.float()) < 4e-3
+    # act must be exactly silu(gate)*y of the STORED bf16 pair (what backward will differentiate)
+    yy, gg = v[:, :, 0].reshape(M, I).float(), v[:, :, 1].reshape(M, I).float()
+    want = torch.nn.functional.silu(gg) * yy
+    assert rel_err(act.float(), want) < 3e-3
+    act2 = torch.empty_like(act)
+    _C.check(L().cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), None, act2.data_ptr(), M, I, K, K, K, 2 * I, I, S()))
+    assert torch.equal(act, act2), "no-grad variant (no pre-activation store) must give identical activations"
+    # interleaved-layout standalone ops agree with the fused epilogue
+    act3 = torch.empty_like(act)
+    _C.check(L().cx_swiglu_fwd(yg.data_ptr(), act3.data_ptr(), M, I, 1, S()))
+    assert rel_err(act3.float(), act.float()) < 2e-3
 
 
 def test_wgrad_shape_accum_deterministic():
@@ -206,14 +234,14 @@ def test_swiglu_gelu_biasgrad():
     T, I = 777, 3072
     yg = bf(_randn(T, 2 * I, seed=30))
     act = torch.empty(T, I, dtype=torch.bfloat16, device=DEV)
-    _C.check(L().cx_swiglu_fwd(yg.data_ptr(), act.data_ptr(), T, I, S()))
+    _C.check(L().cx_swiglu_fwd(yg.data_ptr(), act.data_ptr(), T, I, 0, S()))
     ygr = yg.float().requires_grad_()
     ref = torch.nn.functional.silu(ygr[:, I:]) * ygr[:, :I]
     assert torch.equal(act, ref.to(torch.bfloat16)) or rel_err(act.float(), ref) < 3e-3
     d = bf(_randn(T, I, seed=31))
     ref.backward(d.float())
     dyg = torch.empty_like(yg)
-    _C.check(L().cx_swiglu_bwd(d.data_ptr(), yg.data_ptr(), dyg.data_ptr(), T, I, S()))
+    _C.check(L().cx_swiglu_bwd(d.data_ptr(), yg.data_ptr(), dyg.data_ptr(), T, I, 0, S()))
     assert rel_err(dyg.float(), ygr.grad) < 4e-3
     pre, bias = bf(_randn(T, I, seed=32)), _randn(I, seed=33, std=0.2)
     _C.check(L().cx_bias_gelu_fwd(pre.data_ptr(), bias.data_ptr(), act.data_ptr(), T, I, S()))
