@@ -317,15 +317,16 @@ __global__ __launch_bounds__(256) void pool_normalize_bwd_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------ rotary
-// In-place non-interleaved rotary on the q and k slices of a packed (T,3,H,64) tensor.  One thread per
-// (token, q|k, head, chunk pair).  Position of token t = t - cu_seqlens[seq(t)] (sc/layers/embedding.py:685-706).
-__global__ __launch_bounds__(256) void rotary_qkv_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                         const float* __restrict__ cosv,
-                                                         const float* __restrict__ sinv, int B, int H, int T,
-                                                         float sign) {
+// In-place non-interleaved rotary on `nwhich` (T,H,64) slices of a token-major tensor (q and k of a packed qkv: nwhich=2,
+// which_stride=H*64, tok_stride=3*H*64; a standalone (T,H,64) tensor: nwhich=1).  One thread per (token, slice, head,
+// chunk pair).  Position of token t = t - cu_seqlens[seq(t)] (sc/layers/embedding.py:685-706).
+__global__ __launch_bounds__(256) void rotary_kernel(bf16_t* __restrict__ x, long tok_stride, long which_stride,
+                                                     int nwhich, const int32_t* __restrict__ cu,
+                                                     const float* __restrict__ cosv, const float* __restrict__ sinv,
+                                                     int H, float sign) {
     const int b = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
-    const long per_tok = 2L * H * 4;
+    const long per_tok = (long)nwhich * H * 4;
     const long total = (long)len * per_tok;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int pos = (int)(i / per_tok);
@@ -333,15 +334,15 @@ __global__ __launch_bounds__(256) void rotary_qkv_kernel(bf16_t* __restrict__ qk
         const int which = rem / (H * 4);
         rem -= which * H * 4;
         const int hh = rem >> 2, ch = rem & 3;
-        bf16_t* base = qkv + ((size_t)(t0 + pos) * 3 + which) * H * 64 + hh * 64;
+        bf16_t* base = x + (size_t)(t0 + pos) * tok_stride + (size_t)which * which_stride + hh * 64;
         float x1[8], x2[8], o1[8], o2[8];
         unpack8(*reinterpret_cast<const uint4*>(base + ch * 8), x1);
         unpack8(*reinterpret_cast<const uint4*>(base + 32 + ch * 8), x2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float c = cosv[pos * 32 + ch * 8 + e], s = sign * sinv[pos * 32 + ch * 8 + e];
-            o1[e] = x1[e] * c - x2[e] * s;
-            o2[e] = x2[e] * c + x1[e] * s;
+            const float c = cosv[pos * 32 + ch * 8 + e], sn = sign * sinv[pos * 32 + ch * 8 + e];
+            o1[e] = x1[e] * c - x2[e] * sn;
+            o2[e] = x2[e] * c + x1[e] * sn;
         }
         *reinterpret_cast<uint4*>(base + ch * 8) = pack8(o1);
         *reinterpret_cast<uint4*>(base + 32 + ch * 8) = pack8(o2);
@@ -464,17 +465,29 @@ int cx_pool_normalize_bwd(const float* demb, const float* emb, const float* norm
     return done();
 }
 
-int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
-                          int B, int H, int T, int max_seqlen, int sign, void* stream) {
-    if (B <= 0 || T <= 0) return CX_OK;
-    if (!rot_cos || !rot_sin) return CX_ERR_ARG;
-    long per_seq = (long)max_seqlen * 2 * H * 4;
+static int rotary_launch(uint16_t* x, long tok_stride, long which_stride, int nwhich, const int32_t* cu,
+                         const float* rot_cos, const float* rot_sin, int B, int H, int max_seqlen, int sign, void* stream) {
+    if (!rot_cos || !rot_sin || !x || !cu) return CX_ERR_ARG;
+    if ((tok_stride % 8) || (which_stride % 8)) return CX_ERR_ALIGN;
+    long per_seq = (long)max_seqlen * nwhich * H * 4;
     int gx = (int)((per_seq + 255) / 256);
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(rotary_qkv_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, qkv, cu_seqlens, rot_cos,
-                       rot_sin, B, H, T, sign >= 0 ? 1.f : -1.f);
+    hipLaunchKernelGGL(rotary_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, tok_stride, which_stride, nwhich,
+                       cu, rot_cos, rot_sin, H, sign >= 0 ? 1.f : -1.f);
     return done();
+}
+
+int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
+                          int B, int H, int T, int max_seqlen, int sign, void* stream) {
+    if (B <= 0 || T <= 0) return CX_OK;
+    return rotary_launch(qkv, 3L * H * 64, (long)H * 64, 2, cu_seqlens, rot_cos, rot_sin, B, H, max_seqlen, sign, stream);
+}
+
+int cx_rotary_apply(uint16_t* x, long tok_stride, const int32_t* cu_seqlens, const float* rot_cos,
+                    const float* rot_sin, int B, int H, int T, int max_seqlen, int sign, void* stream) {
+    if (B <= 0 || T <= 0) return CX_OK;
+    return rotary_launch(x, tok_stride, 0, 1, cu_seqlens, rot_cos, rot_sin, B, H, max_seqlen, sign, stream);
 }
 
 }  // extern "C"

@@ -124,6 +124,10 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                           int B, int H, int T, int max_seqlen, int sign, void* stream);
 
+/* apply_rotary_emb_func on one (T,H,64) view with token stride `tok_stride` elements (in place; sign=-1: backward). */
+int cx_rotary_apply(uint16_t* x, long tok_stride, const int32_t* cu_seqlens, const float* rot_cos,
+                    const float* rot_sin, int B, int H, int T, int max_seqlen, int sign, void* stream);
+
 /* ---- a9 BiEncoder pooling + normalize (sc/models/biencoder/modeling_biencoder.py:79-90,44-49,314-319) -----
  * mode 0 = mean over the sequence's tokens, 1 = cls (first token).  emb:(B,d) fp32 = x / max(||x||, 1e-12);
  * if normalize == 0 the raw pooled vector is written.  norm:(B) fp32 saved for backward. */

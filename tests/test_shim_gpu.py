@@ -1,0 +1,145 @@
+"""The flash_attn-surface ops (contrastors_amd.flash_attn_api) through torch autograd vs plain torch references."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import contrastors_amd.flash_attn_api as fa
+from contrastors_amd.flash_attn_api.layers.rotary import RotaryEmbedding, apply_rotary_emb_func, apply_rotary_emb_qkv_
+from contrastors_amd.flash_attn_api.ops.activations import swiglu
+from contrastors_amd.flash_attn_api.ops.fused_dense import FusedDense
+from contrastors_amd.flash_attn_api.ops.layer_norm import dropout_add_layer_norm, layer_norm
+from oracle import encoder_ref
+from tests.gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _r(*s, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*s, generator=g) * std).to(DEV)
+
+
+def test_varlen_attention_autograd():
+    lens, H = [100, 128, 37], 4
+    T = sum(lens)
+    qkv = _r(T, 3, H, 64, seed=1).to(torch.bfloat16).requires_grad_()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    scale = torch.tensor(1.0 / math.sqrt(64.0), device=DEV)  # contrastors passes a 0-dim tensor
+    out = fa.flash_attn_varlen_qkvpacked_func(qkv, cu, max(lens), 0.0, softmax_scale=scale, causal=False)
+    do = _r(T, H, 64, seed=2).to(torch.bfloat16)
+    out.backward(do)
+    ref_in = qkv.detach().float().requires_grad_()
+    outs, t0 = [], 0
+    for l in lens:
+        x = ref_in[t0:t0 + l]
+        s = torch.einsum("qhd,khd->hqk", x[:, 0], x[:, 1]) / 8.0
+        outs.append(torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), x[:, 2]))
+        t0 += l
+    ref = torch.cat(outs)
+    ref.backward(do.float())
+    assert rel_err(out.float(), ref) < 6e-3 and rel_err(qkv.grad.float(), ref_in.grad) < 1.5e-2
+
+
+def test_fixed_length_attention_vit_shape():
+    qkv = _r(3, 197, 3, 2, 64, seed=3).to(torch.bfloat16)
+    out = fa.flash_attn_qkvpacked_func(qkv)
+    q, k, v = qkv.float().unbind(2)
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q, k) / 8.0, -1), v)
+    assert out.shape == (3, 197, 2, 64) and rel_err(out.float(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("k_in,n_out,bias", [(768, 2304, False), (100, 36, True)])
+def test_fused_dense_matches_linear(k_in, n_out, bias):
+    torch.manual_seed(0)
+    fd = FusedDense(k_in, n_out, bias=bias).to(DEV)
+    ref = torch.nn.Linear(k_in, n_out, bias=bias).to(DEV)
+    ref.load_state_dict(fd.state_dict())
+    x = _r(5, 40, k_in, seed=4).to(torch.bfloat16).requires_grad_()
+    xr = x.detach().float().requires_grad_()
+    y = fd(x)
+    yr = ref(xr)
+    g = _r(5, 40, n_out, seed=5)
+    y.backward(g.to(torch.bfloat16))
+    yr.backward(g.to(torch.bfloat16).float())
+    assert y.dtype == torch.bfloat16 and rel_err(y.float(), yr) < 5e-3
+    assert rel_err(x.grad.float(), xr.grad) < 8e-3
+    assert rel_err(fd.weight.grad, ref.weight.grad) < 8e-3
+    if bias:
+        assert rel_err(fd.bias.grad, ref.bias.grad) < 5e-3
+
+
+@pytest.mark.parametrize("prenorm", [False, True])
+def test_dropout_add_layer_norm(prenorm):
+    d = 768
+    x0 = _r(4, 33, d, seed=6).to(torch.bfloat16).requires_grad_()
+    res = _r(4, 33, d, seed=7).to(torch.bfloat16).requires_grad_()
+    w = (1 + _r(d, seed=8, std=0.1)).requires_grad_()
+    b = _r(d, seed=9, std=0.1).requires_grad_()
+    out = dropout_add_layer_norm(x0, res, w, b, 0.0, 1e-12, prenorm=prenorm)
+    xr, rr = x0.detach().float().requires_grad_(), res.detach().float().requires_grad_()
+    wr, br = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    z = xr + rr
+    ref = torch.nn.functional.layer_norm(z, (d,), wr, br, 1e-12)
+    g = _r(4, 33, d, seed=10).to(torch.bfloat16)
+    if prenorm:
+        o, zz = out
+        g2 = _r(4, 33, d, seed=11).to(torch.bfloat16)
+        (o.float() * g.float()).sum().backward(retain_graph=True)
+        # second use of the residual stream: gradient flowing into z
+        x0.grad = res.grad = None
+        w.grad = b.grad = None
+        torch.autograd.backward([o, zz], [g, g2])
+        torch.autograd.backward([ref, z], [g.float(), g2.float()])
+        assert rel_err(zz.float(), z) < 4e-3
+    else:
+        o = out
+        o.backward(g)
+        ref.backward(g.float())
+    assert rel_err(o.float(), ref) < 4e-3
+    assert rel_err(x0.grad.float(), xr.grad) < 1e-2 and rel_err(res.grad.float(), rr.grad) < 1e-2
+    assert rel_err(w.grad, wr.grad) < 1e-2 and rel_err(b.grad, br.grad) < 1e-2
+    y = layer_norm(x0.detach(), w.detach(), b.detach(), 1e-12)
+    assert rel_err(y.float(), torch.nn.functional.layer_norm(x0.detach().float(), (d,), w.detach(), b.detach(), 1e-12)) < 4e-3
+
+
+def test_swiglu_and_rotary():
+    x = _r(7, 50, 512, seed=12).to(torch.bfloat16).requires_grad_()
+    y = _r(7, 50, 512, seed=13).to(torch.bfloat16).requires_grad_()
+    out = swiglu(x, y)
+    xr, yr = x.detach().float().requires_grad_(), y.detach().float().requires_grad_()
+    ref = torch.nn.functional.silu(xr) * yr
+    g = _r(7, 50, 512, seed=14).to(torch.bfloat16)
+    out.backward(g)
+    ref.backward(g.float())
+    assert rel_err(out.float(), ref) < 4e-3 and rel_err(x.grad.float(), xr.grad) < 6e-3
+    assert rel_err(y.grad.float(), yr.grad) < 6e-3
+    # varlen rotary on q (T,H,64): positions restart per sequence
+    lens, H = [40, 128, 9], 3
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    cos, sin = encoder_ref.rotary_tables(128, 64, 1000.0)
+    cos, sin = cos.to(DEV), sin.to(DEV)
+    q = _r(T, H, 64, seed=15).to(torch.bfloat16).requires_grad_()
+    qo = apply_rotary_emb_func(q, cos.to(torch.bfloat16), sin.to(torch.bfloat16), False, False, 0, cu, 128)
+    parts, t0 = [], 0
+    c16, s16 = cos.to(torch.bfloat16).float(), sin.to(torch.bfloat16).float()  # reference casts tables to bf16 (quirk 12)
+    qr = q.detach().float().requires_grad_()
+    for l in lens:
+        parts.append(encoder_ref.apply_rotary(qr[t0:t0 + l].unsqueeze(0), c16, s16)[0])
+        t0 += l
+    ref = torch.cat(parts)
+    gq = _r(T, H, 64, seed=16).to(torch.bfloat16)
+    qo.backward(gq)
+    ref.backward(gq.float())
+    assert rel_err(qo.float(), ref) < 4e-3 and rel_err(q.grad.float(), qr.grad) < 6e-3
+    # packed (B,S,3,H,64) in-place form + the module
+    qkv = _r(2, 64, 3, H, 64, seed=17).to(torch.bfloat16)
+    keep = qkv.clone()
+    rot = RotaryEmbedding(64, base=1000.0).to(DEV)
+    out = rot(qkv)
+    assert out.data_ptr() == qkv.data_ptr() and torch.equal(qkv[:, :, 2], keep[:, :, 2])
+    want_q = encoder_ref.apply_rotary(keep[:, :, 0].float(), c16, s16)
+    assert rel_err(qkv[:, :, 0].float(), want_q) < 4e-3
