@@ -1,0 +1,108 @@
+"""YAML -> Config for the contrastive text-text recipes (host-side mirror of sc/config.py:8-241 and sc/read.py:5-11).
+
+Field names and defaults follow the reference's pydantic models for the keys the north-star path reads
+(`train_args`, `model_args`, `data_args`); the reference's own YAMLs (e.g. configs/train/contrastive_pretrain.yaml)
+load unchanged -- unknown keys such as `use_fp8` are ignored exactly as there.  The two validators that guard this path
+are kept: Matryoshka + GradCache is rejected (config.py:70-77) and eval_strategy needs eval_steps (:49-68).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import yaml
+from pydantic import BaseModel, ConfigDict, model_validator
+
+
+class TrainArgs(BaseModel):
+    model_config = ConfigDict(extra="ignore", validate_assignment=True)
+    num_epochs: int = 1
+    num_train_steps: Optional[int] = None
+    learning_rate: float = 2e-4
+    weight_decay: float = 0.01
+    eps: Optional[float] = 1e-8
+    warmup_steps: Optional[int] = None
+    warmup_pct: Optional[float] = None
+    cooldown_steps: Optional[int] = None
+    checkpoint: Optional[str] = None
+    wandb: bool = False
+    wandb_project_name: str = ""
+    wandb_entity: str = ""
+    wandb_run_name: Optional[str] = None
+    log_grads_every: int = 100
+    log_lr_every: int = 10
+    save_every: Optional[int] = None
+    eval_steps: Optional[int] = None
+    eval_strategy: Optional[str] = None
+    output_dir: Optional[str] = None
+    gradient_accumulation_steps: Optional[int] = 1
+    schedule_type: str = "cosine"
+    max_grad_norm: float = 1.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    loss_fn: Optional[str] = "clip"
+    grad_cache: Optional[bool] = None
+    chunk_size: Optional[int] = None
+    clamp_logits: Optional[bool] = True
+    logit_max: Optional[float] = 100.0
+    matryoshka_dims: Optional[List[int]] = None
+    matryoshka_loss_weights: Optional[List[float]] = None
+    profile: Optional[bool] = False
+
+    @model_validator(mode="after")
+    def _checks(self):
+        if self.eval_strategy is not None and self.eval_strategy not in ("steps", "epochs"):
+            raise ValueError(f"Eval strategy {self.eval_strategy} not found in eval strategy registry")
+        if self.eval_strategy == "steps" and self.eval_steps is None:
+            raise ValueError("Eval steps must be set if eval strategy is set to steps")
+        if self.matryoshka_dims is not None and self.grad_cache:
+            raise ValueError("Matryoshka dims cannot be set if grad cache is set")
+        return self
+
+
+class DataArgs(BaseModel):
+    model_config = ConfigDict(extra="ignore")
+    shuffle: bool = False
+    workers: int = 0
+    batch_size: int = 16384
+    seed: int = 42
+    input_shards: Optional[str] = None
+    download: Optional[bool] = False
+    streaming: Optional[bool] = True
+
+
+class ModelArgs(BaseModel):
+    model_config = ConfigDict(extra="ignore", protected_namespaces=())
+    model_type: str = "encoder"
+    model_name: Optional[str] = "nomic-ai/nomic-bert-2048"
+    tokenizer_name: Optional[str] = "bert-base-uncased"
+    seq_len: int = 2048
+    logit_scale: float = 1 / 0.07
+    trainable_logit_scale: bool = False
+    pooling: str = "mean"
+    nomic_encoder: bool = True
+    add_prefix: bool = False
+    pretrained: bool = False
+    gradient_checkpointing: bool = False
+    projection_dim: Optional[int] = None
+    freeze: bool = False
+    hamming: bool = False
+
+    @model_validator(mode="after")
+    def _model_type(self):
+        if self.model_type not in ("encoder", "mlm", "glue", "locked_text", "image_text", "distill"):
+            raise ValueError(f"Model type {self.model_type} not found in model registry")
+        return self
+
+
+class Config(BaseModel):
+    model_config = ConfigDict(extra="ignore", protected_namespaces=())
+    train_args: TrainArgs
+    data_args: DataArgs = DataArgs()
+    model_args: ModelArgs = ModelArgs()
+    deepspeed: Optional[bool] = False
+    deepspeed_config: Optional[dict] = None
+
+
+def read_config(path: str) -> Config:
+    with open(path) as f:
+        return Config(**yaml.safe_load(f))

@@ -1,0 +1,65 @@
+"""`python -m contrastors_amd.train --config X.yaml --dtype bf16 [--key value ...]` (mirror of sc/train.py:51-131).
+
+torchrun / `python -m torch.distributed.run` launches one process per GPU; backend "nccl" is RCCL on ROCm.  CLI flags
+named like fields of train_args / model_args / data_args override the YAML (sc/train.py:87-94).  Data: the streaming
+shard loader is out of scope (no network here) -- `--synthetic-steps N` drives the trainer with synthetic batches of the
+loader's exact key contract.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+
+from .config import read_config
+from .trainers import TRAINER_REGISTRY, synthetic_batches
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16"])
+    ap.add_argument("--synthetic-steps", type=int, default=10)
+    ap.add_argument("--seq-len", type=int, default=128)
+    args, extra = ap.parse_known_args()
+    overrides = {}
+    for k, v in zip(extra[::2], extra[1::2]):
+        overrides[k.lstrip("-").replace("-", "_")] = v
+    return args, overrides
+
+
+def apply_overrides(config, overrides):
+    for section in (config.train_args, config.model_args, config.data_args):
+        for k, v in overrides.items():
+            if k in type(section).model_fields:
+                cur = getattr(section, k)
+                if isinstance(cur, bool):
+                    v = str(v).lower() in ("1", "true", "yes")
+                elif isinstance(cur, int):
+                    v = int(v)
+                elif isinstance(cur, float):
+                    v = float(v)
+                setattr(section, k, v)
+    return config
+
+
+def main():
+    args, overrides = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    config = apply_overrides(read_config(args.config), overrides)
+    trainer = TRAINER_REGISTRY[config.model_args.model_type](config, torch.bfloat16, total_steps=args.synthetic_steps)
+    per_rank = config.data_args.batch_size // world
+    trainer.train(synthetic_batches(args.synthetic_steps, per_rank, args.seq_len, rank=trainer.rank), log_every=1)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+"""TextTextTrainer on the native path (host-side mirror of sc/trainers/base.py:203-208,354-533 and
+sc/trainers/text_text.py:139-182,276-322,429-451 for the GradCache contrastive recipe).
+
+Kept: the method set (`get_model`, `get_optimizer`, `get_scheduler`, `forward_step`, `backward`, `training_step`,
+`train`), the batch contract of the streaming loader (sc/dataset/text_text_loader.py:601-660: `query_input_ids`,
+`query_attention_mask`, `document_input_ids`, `document_attention_mask`, optional `dataset_name`) and the step order
+(clip -> optimizer -> scheduler -> zero_grad).  Not rebuilt: S3 shard streaming, wandb, NanoBEIR eval, checkpoints
+(out of the hot path): `train()` consumes any iterable of batches.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .biencoder import BiEncoder, BiEncoderConfig, LogitScale
+from .config import Config
+from .loss import clip_loss, grad_cache_loss
+from .nomic_bert import NomicBertConfig
+
+
+def _lr_lambda(schedule: str, warmup: int, total: int):
+    def f(step: int) -> float:
+        if warmup and step < warmup:
+            return (step + 1) / warmup
+        if total <= warmup:
+            return 1.0
+        p = min(1.0, (step - warmup) / max(1, total - warmup))
+        if schedule == "cosine":
+            return 0.5 * (1.0 + math.cos(math.pi * p))
+        if schedule == "linear":
+            return 1.0 - p
+        return 1.0  # constant
+
+    return f
+
+
+class TextTextTrainer:
+    def __init__(self, config: Config, dtype=torch.bfloat16, device=None, trunk_config: Optional[NomicBertConfig] = None,
+                 total_steps: Optional[int] = None):
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the native path computes in bf16 with fp32 master weights (--dtype=bf16)")
+        self.config = config
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        torch.manual_seed(config.data_args.seed)
+        self.model = self.get_model(config, trunk_config)
+        self.total_steps = total_steps or config.train_args.num_train_steps or 10_000
+        self.optimizer = self.get_optimizer(config)
+        self.scheduler = self.get_scheduler(config, self.optimizer)
+        self.step = 0
+
+    # sc/trainers/text_text.py:139-182
+    def get_model(self, config: Config, trunk_config=None) -> Dict[str, torch.nn.Module]:
+        ma = config.model_args
+        bc = BiEncoderConfig(model_name=ma.model_name or "", pooling=ma.pooling, logit_scale=ma.logit_scale,
+                             trainable_logit_scale=ma.trainable_logit_scale, projection_dim=ma.projection_dim,
+                             freeze=ma.freeze, hamming=ma.hamming, nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
+                             trunk_config=trunk_config)
+        model = BiEncoder(bc, device=self.device).train()
+        model.broadcast_parameters(0)  # what DDP's constructor does
+        scale = LogitScale(SimpleNamespace(logit_scale=ma.logit_scale, trainable_logit_scale=ma.trainable_logit_scale))
+        return {"model": model, "logit_scale": scale.to(self.device)}
+
+    # sc/optimizer.py:7-47 (decay / no-decay groups, torch AdamW)
+    def get_optimizer(self, config: Config):
+        ta = config.train_args
+        groups = self.model["model"].param_groups(ta.weight_decay)
+        if self.model["logit_scale"].logit_scale.requires_grad:
+            groups[1]["params"].append(self.model["logit_scale"].logit_scale)
+        return torch.optim.AdamW(groups, lr=ta.learning_rate, betas=(ta.adam_beta1, ta.adam_beta2), eps=ta.eps)
+
+    # sc/trainers/base.py:228-265 (warmup_steps or warmup_pct is mandatory there too: quirk 22)
+    def get_scheduler(self, config: Config, optimizer):
+        ta = config.train_args
+        if ta.warmup_steps is None and ta.warmup_pct is None:
+            raise ValueError("warmup_steps or warmup_pct must be set")
+        warm = ta.warmup_steps if ta.warmup_steps is not None else int(ta.warmup_pct * self.total_steps)
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, _lr_lambda(ta.schedule_type, warm, self.total_steps))
+
+    def _inputs(self, batch, prefix):
+        out = {"input_ids": batch[f"{prefix}_input_ids"].to(self.device, non_blocking=True)}
+        m = batch.get(f"{prefix}_attention_mask")
+        if m is not None:
+            out["attention_mask"] = m.to(self.device, non_blocking=True)
+        if f"{prefix}_seqlens" in batch:
+            out["seqlens"] = batch[f"{prefix}_seqlens"]
+        return out
+
+    # sc/trainers/text_text.py:276-322 (grad cache) / :324-378 (direct)
+    def forward_step(self, batch) -> torch.Tensor:
+        ta = self.config.train_args
+        model, scale = self.model["model"], self.model["logit_scale"]
+        if "negative_input_ids" in batch:
+            raise ValueError("negatives must be folded into document_* (sc/trainers/text_text.py:346-347)")
+        q, d = self._inputs(batch, "query"), self._inputs(batch, "document")
+        if ta.grad_cache:
+            return grad_cache_loss(model, q, model, d, ta.chunk_size, scale)
+        qe = model(**q)["embedding"]
+        de = model(**d)["embedding"]
+        return clip_loss(qe, de, scale, gather_enabled=True)
+
+    def backward(self, loss: torch.Tensor):
+        if self.config.train_args.grad_cache:
+            return  # gradients were accumulated inside grad_cache_loss (text_text.py:292-302)
+        loss.backward()
+        self.model["model"].sync_gradients()
+
+    # sc/trainers/base.py:366-393
+    def training_step(self, batch) -> torch.Tensor:
+        ta = self.config.train_args
+        model = self.model["model"]
+        model.trunk.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)
+        loss = self.forward_step(batch)
+        self.backward(loss)
+        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        torch.nn.utils.clip_grad_norm_(params, ta.max_grad_norm)
+        self.optimizer.step()
+        self.scheduler.step()
+        model.trunk.sync_shadows()
+        self.step += 1
+        return loss.detach()
+
+    def train(self, batches: Iterable[dict], max_steps: Optional[int] = None, log_every: int = 0):
+        losses = []
+        for i, batch in enumerate(batches):
+            if max_steps is not None and i >= max_steps:
+                break
+            loss = self.training_step(batch)
+            losses.append(loss)
+            if log_every and (i + 1) % log_every == 0 and self.rank == 0:
+                print(f"step {self.step} loss {float(loss):.4f} lr {self.scheduler.get_last_lr()[0]:.3e}", flush=True)
+        return losses
+
+
+TRAINER_REGISTRY = {"encoder": TextTextTrainer}  # sc/trainers/__init__.py:9-17 (text-text entry)
+
+
+def synthetic_batches(n_steps: int, per_rank_batch: int, seq_len: int, vocab: int = 30522, seed: int = 1234,
+                      rank: int = 0, ragged: bool = False):
+    """Synthetic (query, document) batches with the streaming loader's keys (SURVEY.md §8d recipe)."""
+    g = torch.Generator().manual_seed(seed + rank)
+    for _ in range(n_steps):
+        b = {}
+        for side in ("query", "document"):
+            ids = torch.randint(min(1000, vocab // 2), vocab, (per_rank_batch, seq_len), generator=g)
+            ids[:, 0] = 101
+            lens = torch.randint(seq_len // 2, seq_len + 1, (per_rank_batch,), generator=g) if ragged else \
+                torch.full((per_rank_batch,), seq_len)
+            mask = (torch.arange(seq_len)[None] < lens[:, None]).long()
+            b[f"{side}_input_ids"] = ids * mask
+            b[f"{side}_attention_mask"] = mask
+            b[f"{side}_seqlens"] = lens.numpy()
+        b["dataset_name"] = "synthetic"
+        yield b

@@ -1,0 +1,66 @@
+"""Host logic that needs no GPU: the reference's own recipe YAML parses into our Config, validators, scheduler shape,
+varlen index construction, label arithmetic, synthetic batch contract."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from contrastors_amd.config import Config, TrainArgs, read_config
+from contrastors_amd.loss import make_labels
+from contrastors_amd.nomic_bert import VarlenBatch
+from contrastors_amd.trainers import _lr_lambda, synthetic_batches
+
+REF_YAML = Path("/root/reference/src/contrastors/configs/train/contrastive_pretrain.yaml")
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_reference_recipe_yaml_loads_unchanged():
+    cfg = read_config(str(REF_YAML))
+    assert cfg.train_args.grad_cache is True and cfg.train_args.chunk_size == 64
+    assert cfg.train_args.learning_rate == 2e-4 and cfg.train_args.schedule_type == "cosine"
+    assert cfg.model_args.logit_scale == 50 and cfg.model_args.pooling == "mean"
+    assert cfg.data_args.batch_size == 16384
+
+
+def test_validators_match_reference():
+    with pytest.raises(ValueError):  # sc/config.py:70-77
+        TrainArgs(grad_cache=True, matryoshka_dims=[768, 512])
+    with pytest.raises(ValueError):  # sc/config.py:57-68
+        TrainArgs(eval_strategy="steps")
+    with pytest.raises(ValueError):
+        Config(train_args=TrainArgs(), model_args={"model_type": "nope"})
+
+
+def test_scheduler_shapes():
+    f = _lr_lambda("cosine", 700, 10000)
+    assert f(0) == pytest.approx(1 / 700) and f(699) == pytest.approx(1.0) and f(10000) == pytest.approx(0.0, abs=1e-9)
+    g = _lr_lambda("linear", 10, 110)
+    assert g(60) == pytest.approx(0.5)
+
+
+def test_varlen_batch_from_lengths_matches_mask_path():
+    ids = torch.arange(4 * 6).view(4, 6)
+    lens = [6, 2, 5, 1]
+    mask = (torch.arange(6)[None] < torch.tensor(lens)[:, None]).long()
+    a = VarlenBatch.from_lengths(ids, lens)
+    b = VarlenBatch.from_mask(ids, mask)
+    assert a.T == b.T == 14 and a.max_seqlen == b.max_seqlen == 6
+    assert torch.equal(a.indices, b.indices) and torch.equal(a.cu_seqlens, b.cu_seqlens)
+    assert a.indices.dtype == torch.int32 and a.cu_seqlens.tolist() == [0, 6, 8, 13, 14]
+    full = VarlenBatch.from_lengths(ids, [6] * 4)
+    assert full.T == 24 and full.indices.tolist() == list(range(24))
+
+
+def test_labels_int64_with_negatives():
+    lab = make_labels(4, 4 * 8 * 2, 1, 2, "cpu")  # 1 positive + 7 negatives per query, rank 1 of 2
+    assert lab.dtype == torch.int64
+    np.testing.assert_array_equal(lab.numpy(), (np.arange(4) + 4) * 8)
+
+
+def test_synthetic_batches_follow_loader_contract():
+    b = next(synthetic_batches(1, 4, 16, ragged=True))
+    for k in ("query_input_ids", "query_attention_mask", "document_input_ids", "document_attention_mask", "dataset_name"):
+        assert k in b
+    assert b["query_input_ids"].dtype == torch.int64 and b["query_input_ids"].shape == (4, 16)
+    assert (b["query_input_ids"][b["query_attention_mask"] == 0] == 0).all()  # right padding with pad id 0
