@@ -64,6 +64,7 @@ _SIGS = {
     "cx_error_string": (C.c_char_p, [i32]),
     "cx_gemm_bf16_nt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "cx_gemm_bf16_nt_accum": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "cx_gemm_bf16_tn_accum": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_set_variant": (None, [i32]),
     "cx_gemm_get_variant": (i32, []),
     "cx_gemm_set_debug": (None, [i32]),
@@ -76,7 +77,7 @@ _SIGS = {
     "cx_cast_transpose_f32_to_bf16": (i32, [vp, vp, i32, i32, vp]),
     "cx_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "cx_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
-    "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "cx_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cx_embed_ln_bwd": (i32, [vp] * 15 + [i32, i32, i32, i32, vp]),
     "cx_swiglu_fwd": (i32, [vp, vp, i32, i32, i32, vp]),

@@ -151,3 +151,32 @@ class BiEncoder(torch.nn.Module):
         if proj_b:
             groups[1]["params"] += proj_b
         return groups
+
+
+class DualEncoder(torch.nn.Module):
+    """Two towers + bidirectional gathered InfoNCE (host-side mirror of
+    sc/models/dual_encoder/modeling_dual_encoder.py:36-68): both towers are called with normalize=False, L2-normalised,
+    all-gathered, and the loss is (CE(v -> all t) + CE(t -> all v)) / 2 * world_size with labels arange(n) + n*rank.
+    Each direction is one fused similarity+CE kernel (cx_infonce_fwd/bwd); logits are never materialised.  Towers are
+    any modules returning {"embedding": ...} (the native BiEncoder for text; a ViT tower is a later row of SURVEY §8)."""
+
+    def __init__(self, text: torch.nn.Module, vision: torch.nn.Module, logit_scale: LogitScale):
+        super().__init__()
+        self.text, self.vision, self.logit_scale = text, vision, logit_scale
+
+    def forward(self, text_inputs, vision_inputs):
+        from .loss import _FusedInfoNCE, _scale_of
+
+        text_emb = F.normalize(self.text(**text_inputs, normalize=False)["embedding"], dim=-1, p=2)
+        vision_emb = F.normalize(self.vision(**vision_inputs, normalize=False)["embedding"], dim=-1, p=2)
+        all_text, all_vis = gather_with_grad(text_emb), gather_with_grad(vision_emb)
+        inited = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank() if inited else 0
+        world = dist.get_world_size() if inited else 1
+        n = vision_emb.shape[0]
+        labels = torch.arange(n, device=vision_emb.device) + n * rank
+        scale, sp = _scale_of(self.logit_scale)
+        coef = 0.5 * world / n
+        loss = (_FusedInfoNCE.apply(vision_emb, all_text, labels, scale, coef, sp)
+                + _FusedInfoNCE.apply(text_emb, all_vis, labels, scale, coef, sp))
+        return {"loss": loss, "image_text_loss": loss}

@@ -60,10 +60,13 @@ int wgrad_split(int out_f, int in_f, long Tp) {
     return (int)s;
 }
 
-// gW(out_f,in_f) += dY^T X   via two explicit transposes (zero padded to Tp) and the NT kernel
+// gW(out_f,in_f) += dY^T X.  Natural-layout (transposing-read) kernel when the feature counts tile exactly, otherwise
+// two explicit transposes (zero padded to Tp) and the NT kernel.
 int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW, const CxChunkBuffers* b, int T,
           void* stream) {
     if (!gW) return CX_OK;
+    if ((out_f % 256) == 0 && (in_f % 128) == 0)
+        return cx_gemm_bf16_tn_accum(dY, X, gW, b->ws_f32, b->ws_floats, T, out_f, in_f, out_f, in_f, stream);
     const int Tp = (int)round_up(T, 64);
     CX_TRY(cx_transpose_bf16(dY, b->tr_a, T, out_f, out_f, Tp, Tp, stream));
     CX_TRY(cx_transpose_bf16(X, b->tr_b, T, in_f, in_f, Tp, Tp, stream));
@@ -124,6 +127,26 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
 
+    // The natural-layout wgrad kernel reduces over round_up(T,64) token rows: clear the pad rows of every operand.
+    const int Tp = (int)round_up(T, 64);
+    if (Tp > T) {
+        auto clear = [&](uint16_t* base, int width) {
+            return hipMemsetAsync(base + (size_t)T * width, 0, (size_t)(Tp - T) * width * sizeof(uint16_t),
+                                  (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+        };
+        CX_TRY(clear(buf->g_a, d));
+        CX_TRY(clear(buf->g_b, d));
+        CX_TRY(clear(buf->g_c, d));
+        CX_TRY(clear(buf->g_wide, 3 * d));   // used as (T,3d) and as (T,wfc1): clear for both widths
+        CX_TRY(clear(buf->g_wide, s.wfc1));
+        CX_TRY(clear(buf->h0, d));
+        for (int l = 0; l < L; ++l) {
+            CX_TRY(clear(s.act(l), I));
+            CX_TRY(clear(s.h1(l), d));
+            CX_TRY(clear(s.ctx(l), d));
+            CX_TRY(clear(s.h2(l), d));
+        }
+    }
     CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
                                  enc->normalize, stream));
     const uint16_t* da = buf->g_a;
@@ -133,7 +156,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
         const uint16_t* h_in = (l == 0) ? buf->h0 : s.h2(l - 1);
         // LN2: dz2 = grad of (mlp_out + h1)
         CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
-                                w.gln2_b, T, d, stream));
+                                w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
         // fc2
         if (w.gbfc2) CX_TRY(cx_bias_grad(buf->g_c, w.gbfc2, T, d, d, stream));
         CX_TRY(wgrad(buf->g_c, d, s.act(l), I, w.gWfc2, buf, T, stream));
@@ -151,7 +174,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
                                stream));
         // LN1: dout = dz2 (residual branch) + dh1 from the MLP
         CX_TRY(cx_layernorm_bwd(buf->g_c, buf->g_b, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), nullptr, buf->g_a,
-                                w.gln1_g, w.gln1_b, T, d, stream));
+                                w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
         // out_proj
         if (w.gbout) CX_TRY(cx_bias_grad(buf->g_a, w.gbout, T, d, d, stream));
         CX_TRY(wgrad(buf->g_a, d, s.ctx(l), d, w.gWout, buf, T, stream));

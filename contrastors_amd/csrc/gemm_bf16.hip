@@ -393,6 +393,156 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(GemmParams p) {
     }
 }
 
+// =====================================================================================================================
+// wgrad in its natural "TN" form:  G[o][i] (+)= sum_t dY[t][o] * A[t][i]   with dY:(T,O) and A:(T,I) row-major, i.e. the
+// reduction index t is the SLOW index of both operands.  Same 256x128x64 / 8-wave / 3-stage LDS-DMA pipeline as v2, but
+//   * a K-tile is 64 token rows: [64][256] bf16 of dY (512-B rows) + [64][128] of A (256-B rows), DMA'd with fully
+//     coalesced row segments (no explicit transposes, no transposed scratch);
+//   * MFMA fragments (8 consecutive t for one feature) are built with ds_read_b64_tr_b16: within a 16-lane group, lane p
+//     points at [t0 + p/4][f0 + 4*(p%4) .. +3] and receives column f0 + p, rows t0..t0+3 (pattern pinned on hardware by
+//     cx_probe_ds_read_tr16); two reads give the 8 k-values of a 32x32x16 operand;
+//   * rows t..t+3 of one 64-B column group would share banks, so the 16-B chunk index is XORed with (t&3)<<2 -- applied
+//     on the DMA source address, undone in the read address (guide §5.4 rule 21).
+// Tokens T..Tp-1 (Tp = round_up(T,64)) must be zero in both operands (the engine clears those rows).
+// =====================================================================================================================
+constexpr int TN_XROW = V2_BM * 2;  // 512 B per token row of the dY tile
+constexpr int TN_WROW = V2_BN * 2;  // 256 B per token row of the A tile
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
+// A/B fragment for feature block starting at column f0 (32 features) and token block t0 (16 tokens) of a tile whose
+// token rows are ROWB bytes: lane (g = lane>>4, p = lane&15) -> features f0 + 16*(g&1) + p, tokens t0 + 8*(g>>1) + {0..7}
+template <int ROWB>
+CX_DEVICE bf16x8_t tn_frag(const char* tile, int f0, int t0, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int t = t0 + 8 * (g >> 1) + (p >> 2);
+    const int f = f0 + 16 * (g & 1) + 4 * (p & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int tt = t + 4 * half;
+        const int chunk = (f >> 3) ^ ((tt & 3) << 2);
+        const char* addr = tile + tt * ROWB + chunk * 16 + (f & 4) * 2;
+        u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)addr);
+    }
+    return u.v;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_kernel(GemmParams p) {
+    // p.X = dY (T, M=O) ldx, p.W = A (T, N=I) ldw, p.K = Tp tokens, Out = fp32 partial slabs [split][M][N]
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tn = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tm = lid % p.tiles_m;
+    const int sk = lid / p.tiles_m;
+    const int m0 = tm * V2_BM, n0 = tn * V2_BN;
+    const int nk_total = p.K / BK;
+    const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
+    const int kt_end = (int)(((long)nk_total * (sk + 1)) / p.split_k);
+    const int nk = kt_end - kt_begin;
+
+    // DMA sources.  dY tile: instruction q (0..31) covers token rows 2q, 2q+1 (32 lanes x 16 B each);
+    // A tile: instruction q (0..15) covers token rows 4q..4q+3 (16 lanes each).
+    const bf16_t* xsrc[4];
+    const bf16_t* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = (j * 8 + wave) * 2 + (lane >> 5);
+        int c = (lane & 31) ^ ((t & 3) << 2);
+        int col = m0 + c * 8;
+        col = col + 8 <= p.M ? col : (p.M >= 8 ? p.M - 8 : 0);  // ragged feature tail: any in-bounds chunk (masked at store)
+        xsrc[j] = p.X + ((size_t)kt_begin * BK + t) * p.ldx + col;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = (j * 8 + wave) * 4 + (lane >> 4);
+        int c = (lane & 15) ^ ((t & 3) << 2);
+        int col = n0 + c * 8;
+        col = col + 8 <= p.N ? col : (p.N >= 8 ? p.N - 8 : 0);
+        wsrc[j] = p.W + ((size_t)kt_begin * BK + t) * p.ldw + col;
+    }
+    const size_t xstep = (size_t)BK * p.ldx, wstep = (size_t)BK * p.ldw;
+    auto issue = [&](int stage) {
+        char* base = dsm + stage * V2_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            xsrc[j] += xstep;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j],
+                                             (lds_void_ptr)(base + BK * TN_XROW + (j * 8 + wave) * 1024), 16, 0, 0);
+            wsrc[j] += wstep;
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    int st_cur = 0, st_fill = 2;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nk) issue(st_fill);
+        const char* xs = dsm + st_cur * V2_STAGE;
+        const char* ws = xs + BK * TN_XROW;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t wf[2], xf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                wf[b] = tn_frag<TN_WROW>(ws, wn * 64 + b * 32, ks * 16, lane);
+                xf[b] = tn_frag<TN_XROW>(xs, wm * 64 + b * 32, ks * 16, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        st_cur = (st_cur == V2_NSTAGE - 1) ? 0 : st_cur + 1;
+        st_fill = (st_fill == V2_NSTAGE - 1) ? 0 : st_fill + 1;
+    }
+
+    // acc[a][b][r]: m (out feature) = m0 + wm*64 + b*32 + l31, n (in feature) = n0 + wn*64 + a*32 + acc_row(r,hi)
+    float* part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = m0 + wm * 64 + b * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * hi;
+                if (n >= p.N) continue;
+                *reinterpret_cast<float4*>(part + (size_t)m * p.ldo + n) =
+                    make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+            }
+    }
+}
+
 // out[i] += sum_s part[s][i]   (float4 per thread; fixed summation order -> deterministic wgrad)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             long n4, long slab, int splits) {
@@ -578,6 +728,59 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, ws, Out, n4, slab,
                        (int)split);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+// wgrad without transposes: G(O,I) fp32 += dY(T,O)^T A(T,I).  Tp = round_up(T,64) rows of both operands are read; rows
+// T..Tp-1 MUST be zero.  O % 256 == 0 and I % 128 == 0 (all encoder shapes) -- otherwise use cx_gemm_bf16_nt_accum.
+int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float* ws, long ws_floats, int T, int O, int I,
+                          int ld_dy, int ld_a, void* stream) {
+    if (T <= 0 || O <= 0 || I <= 0) return CX_OK;
+    if ((O % V2_BM) != 0 || (I % V2_BN) != 0) return CX_ERR_SHAPE;
+    if ((ld_dy % 8) != 0 || (ld_a % 8) != 0) return CX_ERR_ALIGN;
+    if (!ws || !G) return CX_ERR_ARG;
+    const long slab = (long)O * I;
+    if (ws_floats < slab) return CX_ERR_SHAPE;
+    const int Tp = (T + BK - 1) / BK * BK;
+    GemmParams p;
+    p.X = dY; p.W = A; p.Out = ws; p.bias = nullptr;
+    p.M = O; p.N = I; p.K = Tp; p.ldx = ld_dy; p.ldw = ld_a; p.ldo = I;
+    p.tiles_m = O / V2_BM; p.tiles_n = I / V2_BN;
+    const long tiles = (long)p.tiles_m * p.tiles_n, nk = Tp / BK;
+    long split = (256 + tiles - 1) / tiles;
+    if (split > nk / 4) split = nk / 4;
+    if (split > ws_floats / slab) split = ws_floats / slab;
+    if (split < 1) split = 1;
+    p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tn_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, V2_NSTAGE * V2_STAGE) != hipSuccess)
+            return CX_ERR_LAUNCH;
+        attr_set = true;
+    }
+    int slot = -1;
+    if (g_prof.enabled) {
+        if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
+            slot = g_prof.used++;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev0[slot]) != hipSuccess || hipEventCreate(&g_prof.ev1[slot]) != hipSuccess)
+                    return CX_ERR_LAUNCH;
+                g_prof.created = slot + 1;
+            }
+            g_prof.flop[slot] = 2.0 * (double)T * (double)O * (double)I;
+            (void)hipEventRecord(g_prof.ev0[slot], (hipStream_t)stream);
+        }
+        ++g_prof.launches;
+    }
+    hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((int)(tiles * split)), dim3(512), V2_NSTAGE * V2_STAGE,
+                       (hipStream_t)stream, p);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return CX_ERR_LAUNCH;
+    const long n4 = slab / 4;
+    long g = (n4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, ws, G, n4, slab, (int)split);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 

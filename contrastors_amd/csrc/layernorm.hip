@@ -89,6 +89,50 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // Shared tail of both backward kernels: fold the per-wave dgamma/dbeta partials of one block and atomically add.
+// Two-stage variant used when the caller provides a workspace: block `blk` writes its column partials to
+// part[blk][0..D) (dgamma) and part[blk][D..2D) (dbeta) with plain stores; ln_param_reduce_kernel sums the blocks.
+template <int NCH>
+CX_DEVICE void store_param_partials(float (&dg)[NCH][4], float (&db)[NCH][4], float* part, float* smem) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            smem[(0 * 4 + wave) * D + (i * 64 + lane) * 4 + e] = dg[i][e];
+            smem[(1 * 4 + wave) * D + (i * 64 + lane) * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    float* mine = part + (size_t)blockIdx.x * 2 * D;
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c / D, col = c - which * D;
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sacc += smem[(which * 4 + w) * D + col];
+        mine[c] = sacc;
+    }
+}
+
+// 64 columns x 4 block-groups per workgroup: each thread sums every 4th block's partial for its column (independent,
+// unrolled loads), then the 4 groups are folded through LDS.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* dgamma, float* dbeta,
+                                                              int nblocks, int D) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float sacc = 0.f;
+    if (col < 2 * D) {
+#pragma unroll 4
+        for (int b = grp; b < nblocks; b += 4) sacc += part[(size_t)b * 2 * D + col];
+    }
+    red[grp][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (grp == 0 && col < 2 * D) {
+        const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float* dst = col < D ? dgamma : dbeta;
+        if (dst) dst[col < D ? col : col - D] += tot;
+    }
+}
+
 template <int NCH>
 CX_DEVICE void flush_param_grads(float (&dg)[NCH][4], float (&db)[NCH][4], float* dgamma, float* dbeta,
                                  float* smem /* [2][4][D] */) {
@@ -120,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i,
                                                      const bf16_t* __restrict__ dz_extra, bf16_t* __restrict__ dz,
-                                                     float* dgamma, float* dbeta, int rows) {
+                                                     float* dgamma, float* dbeta, float* part, int rows) {
     constexpr int D = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -174,7 +218,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             store4_bf16(dz + off, o);
         }
     }
-    flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
+    if (part) {
+        store_param_partials<NCH>(dg, db, part, smem);
+    } else {
+        flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
+    }
 }
 
 template <int NCH>
@@ -352,13 +400,26 @@ int cx_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* 
 
 int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
                      const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
-                     float* dbeta, int rows, int d, void* stream) {
+                     float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream) {
     if (rows <= 0) return CX_OK;
     if (!dout_a || !z || !gamma || !mean || !rstd || !dz) return CX_ERR_ARG;
     const size_t smem = (size_t)8 * d * sizeof(float);
-    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(ln_grid_bwd(rows)), dim3(256), smem,
-                                         (hipStream_t)stream, dout_a, dout_b, z, gamma, mean, rstd, dz_extra, dz,
-                                         dgamma, dbeta, rows));
+    // with a workspace: many blocks (bandwidth) + deterministic two-stage parameter-gradient reduction;
+    // without: one block per CU and 2*d atomics per block
+    int grid = ln_grid_bwd(rows);
+    float* part = nullptr;
+    if (ws && ws_floats >= (long)2 * d * 256) {
+        long cap = ws_floats / (2L * d);
+        grid = (rows + 3) / 4;
+        if (grid > 768) grid = 768;  // 3 blocks per CU: enough waves in flight for HBM, few enough partials to fold
+        if (grid > cap) grid = (int)cap;
+        part = ws;
+    }
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                         dout_b, z, gamma, mean, rstd, dz_extra, dz, dgamma, dbeta, part, rows));
+    if (part && (dgamma || dbeta))
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part,
+                           dgamma, dbeta, grid, d);
     return done();
 }
 

@@ -44,7 +44,7 @@ class _DropoutAddLN(torch.autograd.Function):
         db = torch.zeros(d, dtype=torch.float32, device=z.device)
         _C.check(_C.lib().cx_layernorm_bwd(do.data_ptr(), None, z.data_ptr(), w.data_ptr(), mean.data_ptr(),
                                            rstd.data_ptr(), _C.ptr(dze), dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                           rows, d, _C.cur_stream()), "layernorm bwd")
+                                           None, 0, rows, d, _C.cur_stream()), "layernorm bwd")
         dx0 = dz.view(shape).to(in_dtype)
         dres = None if res_dtype is None else dz.view(shape).to(res_dtype)
         return dx0, dres, dg.to(wdtype), db.to(wdtype), None, None

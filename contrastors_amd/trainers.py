@@ -18,6 +18,7 @@ import torch.distributed as dist
 
 from .biencoder import BiEncoder, BiEncoderConfig, LogitScale
 from .config import Config
+from .distributed import gather_with_grad
 from .loss import clip_loss, grad_cache_loss
 from .nomic_bert import NomicBertConfig
 
@@ -101,9 +102,21 @@ class TextTextTrainer:
         q, d = self._inputs(batch, "query"), self._inputs(batch, "document")
         if ta.grad_cache:
             return grad_cache_loss(model, q, model, d, ta.chunk_size, scale)
-        qe = model(**q)["embedding"]
-        de = model(**d)["embedding"]
-        return clip_loss(qe, de, scale, gather_enabled=True)
+        dims = ta.matryoshka_dims
+        normalize = dims is None  # sc/trainers/text_text.py:325
+        queries = model(**q, normalize=normalize)["embedding"]
+        all_documents = gather_with_grad(model(**d, normalize=normalize)["embedding"])
+        if not dims:
+            return clip_loss(queries, all_documents, scale)
+        # Matryoshka (text_text.py:352-369): one InfoNCE per prefix width on re-normalised prefixes, weighted sum.
+        # The fused loss kernel reads the (N, dim) prefix views in place (leading dimension 768).
+        weights = ta.matryoshka_loss_weights or [1.0] * len(dims)
+        loss = 0.0
+        for w, dim in zip(weights, dims):
+            rq = torch.nn.functional.normalize(queries[:, :dim], dim=-1)
+            rd = torch.nn.functional.normalize(all_documents[:, :dim], dim=-1)
+            loss = loss + w * clip_loss(rq, rd, scale)
+        return loss
 
     def backward(self, loss: torch.Tensor):
         if self.config.train_args.grad_cache:

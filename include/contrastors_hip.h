@@ -43,6 +43,10 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
  * Deterministic; no atomics. */
 int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, float* ws, long ws_floats, int M, int N,
                           int K, int ldx, int ldw, void* stream);
+/* wgrad in its natural layout, no transposes: G:(O,I) fp32 (ld = I) += dY:(T,O)^T A:(T,I).  The kernel reads
+ * round_up(T,64) token rows of both operands: rows T.. of that range must be ZERO.  O % 256 == 0, I % 128 == 0. */
+int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float* ws, long ws_floats, int T, int O, int I,
+                          int ld_dy, int ld_a, void* stream);
 void cx_gemm_set_variant(int v); /* 2 (default): 256x128 3-stage LDS-DMA ring; 3: persistent 256x256; 1: 128x128 2-stage */
 int cx_gemm_get_variant(void);
 void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0 skip the main-loop DMA, bit1 skip LDS reads + MFMA */
@@ -72,10 +76,11 @@ int cx_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* 
                      uint16_t* out, uint16_t* z_out, float* mean, float* rstd, int rows, int d, float eps,
                      void* stream);
 /* dout = dout_a + dout_b (dout_b may be NULL); dz_extra (may be NULL) is added to dz (pre-norm residual grad).
- * dz: bf16 (rows,d) (grad of x0 and of residual); dgamma/dbeta: fp32[d], atomically accumulated. */
+ * dz: bf16 (rows,d) (grad of x0 and of residual); dgamma/dbeta: fp32[d], accumulated (+=).  ws (may be NULL): fp32
+ * scratch of ws_floats >= 512*d floats enabling the deterministic two-stage reduction (else atomics are used). */
 int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
                      const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
-                     float* dbeta, int rows, int d, void* stream);
+                     float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream);
 
 /* ---- a11 BertEmbeddings + K6 embedding LayerNorm, on the unpadded token stream
  *          (sc/layers/embedding.py:594-615, sc/models/encoder/modeling_nomic_bert.py:531-535, K4 unpad_input

@@ -16,6 +16,7 @@ ap.add_argument("--chunk", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", type=str, default="")
 ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--tn", type=int, default=1)
 ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
 a = ap.parse_args()
 lib = _C.lib()
@@ -42,7 +43,13 @@ for name, (M, N, K) in shapes.items():
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if wg else torch.bfloat16)
     ws = torch.empty(16 * 768 * 768 if wg else 1, device=dev)
 
+    if wg and a.tn:
+        dyt, at = x.T.contiguous(), w.T.contiguous()  # (T, O), (T, I)
+
     def run():
+        if wg and a.tn:
+            return lib.cx_gemm_bf16_tn_accum(dyt.data_ptr(), at.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), K, M,
+                                             N, M, N, s)
         if wg:
             return lib.cx_gemm_bf16_nt_accum(x.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, N,
                                              K, K, K, s)

@@ -105,6 +105,25 @@ def test_gemm_swiglu_fused(M, I, K):
     assert rel_err(act3.float(), act.float()) < 2e-3
 
 
+@pytest.mark.parametrize("T,O,I", [(8192, 768, 3072), (8192, 2304, 768), (1000, 256, 128), (130, 1024, 256)])
+def test_wgrad_natural_layout_tn(T, O, I):
+    """G += dY^T A straight from the (T,features) row-major operands (ds_read_b64_tr_b16 fragments), vs torch."""
+    Tp = (T + 63) // 64 * 64
+    dy = torch.zeros(Tp, O, dtype=torch.bfloat16, device=DEV)
+    a = torch.zeros(Tp, I, dtype=torch.bfloat16, device=DEV)
+    dy[:T] = bf(_randn(T, O, seed=82, std=0.1))
+    a[:T] = bf(_randn(T, I, seed=83))
+    ws = torch.empty(max(2 * O * I, 16 * 768 * 768), device=DEV)
+    g = torch.ones(O, I, device=DEV)
+    for _ in range(2):
+        _C.check(L().cx_gemm_bf16_tn_accum(dy.data_ptr(), a.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), T, O, I,
+                                           O, I, S()))
+    ref = dy.float().T @ a.float()
+    e = rel_err(g - 1.0, 2 * ref)
+    report("wgrad_tn", T=T, O=O, I=I, e=e)
+    assert e < 1e-5
+
+
 def test_wgrad_shape_accum_deterministic():
     """wgrad form at the BASELINE chunk: dW(768,3072) += dY^T act over 8192 tokens; bit-identical across runs."""
     T, O, I = 8192, 768, 3072
@@ -181,8 +200,15 @@ def test_layernorm_fwd_bwd(d, rows):
     dz = torch.empty_like(x0)
     dg, dbeta = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
     _C.check(L().cx_layernorm_bwd(da.data_ptr(), db_.data_ptr(), z.data_ptr(), g.data_ptr(), mean.data_ptr(),
-                                  rstd.data_ptr(), None, dz.data_ptr(), dg.data_ptr(), dbeta.data_ptr(), rows, d,
-                                  S()))
+                                  rstd.data_ptr(), None, dz.data_ptr(), dg.data_ptr(), dbeta.data_ptr(), None, 0, rows,
+                                  d, S()))
+    # two-stage (workspace) parameter-gradient reduction: same numbers, accumulates on top of existing values
+    ws = torch.empty(512 * d, device=DEV)
+    dz2, dg2, db2 = torch.empty_like(x0), torch.ones(d, device=DEV), torch.ones(d, device=DEV)
+    _C.check(L().cx_layernorm_bwd(da.data_ptr(), db_.data_ptr(), z.data_ptr(), g.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), None, dz2.data_ptr(), dg2.data_ptr(), db2.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), rows, d, S()))
+    assert torch.equal(dz, dz2) and rel_err(dg2 - 1, dg) < 1e-5 and rel_err(db2 - 1, dbeta) < 1e-5
     e_dz, e_dg, e_db = rel_err(dz.float(), zr.grad), rel_err(dg, gr.grad), rel_err(dbeta, br.grad)
     report("layernorm", d=d, rows=rows, e_dz=e_dz, e_dg=e_dg, e_db=e_db)
     assert e_dz < 8e-3, "dz is stored in bf16 and xhat is rebuilt from bf16 z"

@@ -98,3 +98,47 @@ def test_grad_cache_loss_equals_full_batch_oracle(gold):
     report("grad_cache", loss_hip=loss.item(), loss_ref=ref.item(), worst_rel_grad=worst)
     assert e_loss < 2e-2, "loss through bf16 encoders at logit scale 20"
     assert worst < 8e-2
+
+
+def test_matryoshka_prefix_views_and_dual_encoder_loss():
+    """cfg 3 / cfg 4-5 loss forms: InfoNCE on strided prefix views (no copy) and the symmetric DualEncoder loss."""
+    from contrastors_amd.biencoder import DualEncoder
+
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(32, 768, generator=g).to(DEV).requires_grad_()
+    d = torch.randn(96, 768, generator=g).to(DEV).requires_grad_()  # 1 positive + 2 negatives
+    scale = LogitScale(SimpleNamespace(logit_scale=30.0, trainable_logit_scale=False)).to(DEV)
+    loss = 0.0
+    for dim in (768, 512, 256, 128):
+        loss = loss + clip_loss(torch.nn.functional.normalize(q[:, :dim], dim=-1),
+                                torch.nn.functional.normalize(d[:, :dim], dim=-1), scale)
+    loss.backward()
+    qr, dr = q.detach().double().requires_grad_(), d.detach().double().requires_grad_()
+    ref = 0.0
+    lab = torch.arange(32, device=DEV) * 3
+    for dim in (768, 512, 256, 128):
+        a, b = torch.nn.functional.normalize(qr[:, :dim], dim=-1), torch.nn.functional.normalize(dr[:, :dim], dim=-1)
+        ref = ref + torch.nn.functional.cross_entropy(a @ b.T * 30.0, lab)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
+    assert rel_err(q.grad, qr.grad) < 1e-4 and rel_err(d.grad, dr.grad) < 1e-4
+
+    class Tower(torch.nn.Module):
+        def __init__(self, w):
+            super().__init__()
+            self.w = torch.nn.Parameter(w)
+
+        def forward(self, x, normalize=True):
+            return {"embedding": x @ self.w}
+
+    wt, wv = torch.randn(64, 128, generator=g).to(DEV), torch.randn(48, 128, generator=g).to(DEV)
+    xt, xv = torch.randn(16, 64, generator=g).to(DEV), torch.randn(16, 48, generator=g).to(DEV)
+    de = DualEncoder(Tower(wt), Tower(wv), scale)
+    out = de({"x": xt}, {"x": xv})["loss"]
+    out.backward()
+    t = torch.nn.functional.normalize(xt.double() @ wt.double(), dim=-1)
+    v = torch.nn.functional.normalize(xv.double() @ wv.double(), dim=-1)
+    lab = torch.arange(16, device=DEV)
+    want = (torch.nn.functional.cross_entropy(v @ t.T * 30.0, lab) + torch.nn.functional.cross_entropy(t @ v.T * 30.0, lab)) / 2
+    assert abs(out.item() - want.item()) < 1e-5 * abs(want.item()) + 1e-6
+    assert torch.isfinite(de.text.w.grad).all() and torch.isfinite(de.vision.w.grad).all()
