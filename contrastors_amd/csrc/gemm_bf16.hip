@@ -571,6 +571,24 @@ hipError_t launch_v2_mode(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// split-K factor for `tiles` output tiles on 256 CUs (one resident workgroup per CU): maximise the fill of whole
+// rounds, lightly penalising extra partial slabs (each costs one more pass of the reduction kernel).
+long choose_split(long tiles, long max_split, int slots = 256) {
+    if (max_split < 1) max_split = 1;
+    long best = 1;
+    double best_score = -1.0;
+    for (long s = 1; s <= max_split; ++s) {
+        const long wgs = tiles * s;
+        const long rounds = (wgs + slots - 1) / slots;
+        const double score = (double)wgs / (double)(rounds * slots) - 0.006 * (double)s;
+        if (score > best_score + 1e-9) {
+            best_score = score;
+            best = s;
+        }
+    }
+    return best;
+}
+
 int largest_divisor_le(int n, int cap) {
     for (int d = cap < n ? cap : n; d >= 1; --d)
         if (n % d == 0) return d;
@@ -693,10 +711,10 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
                      : v2 ? (long)((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN)
                           : (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const long nk = K / BK;
-    long split = (((v2 || v3) ? 256 : 512) + tiles - 1) / tiles;  // fill every CU once (v2: 1 block/CU, v1: 2 blocks/CU)
-    if (split > nk / 4) split = nk / 4;                    // keep >= 4 K-tiles per slice (pipeline depth)
-    if (split > ws_floats / slab) split = ws_floats / slab;
-    if (split < 1) split = 1;
+    long max_split = nk / 4;                               // keep >= 4 K-tiles per slice (pipeline depth)
+    if (max_split > ws_floats / slab) max_split = ws_floats / slab;
+    if (max_split > 16) max_split = 16;
+    long split = choose_split(tiles, max_split, (v2 || v3) ? 256 : 512);
     int rc;
     if (v3) {
         GemmParams p;
@@ -747,10 +765,10 @@ int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float
     p.M = O; p.N = I; p.K = Tp; p.ldx = ld_dy; p.ldw = ld_a; p.ldo = I;
     p.tiles_m = O / V2_BM; p.tiles_n = I / V2_BN;
     const long tiles = (long)p.tiles_m * p.tiles_n, nk = Tp / BK;
-    long split = (256 + tiles - 1) / tiles;
-    if (split > nk / 4) split = nk / 4;
-    if (split > ws_floats / slab) split = ws_floats / slab;
-    if (split < 1) split = 1;
+    long max_split = nk / 4;
+    if (max_split > ws_floats / slab) max_split = ws_floats / slab;
+    if (max_split > 16) max_split = 16;
+    const long split = choose_split(tiles, max_split);
     p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
     static bool attr_set = false;
     if (!attr_set) {

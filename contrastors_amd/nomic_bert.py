@@ -128,8 +128,8 @@ class _ChunkArena:
             t["tr_a"] = torch.empty(wide, T_cap, **bf)
             t["tr_b"] = torch.empty(wide, T_cap, **bf)
             t["delta"] = torch.empty(T_cap * H, **f32)
-            # split-K workspace of the wgrad GEMMs: room for >= 2 slabs of the largest weight, 16 of the smallest
-            t["ws_f32"] = torch.empty(max(2 * wide * d, 16 * d * d), **f32)
+            # split-K workspace of the wgrad GEMMs (fp32 partial slabs): 8 slabs of the largest weight, 16 of the smallest
+            t["ws_f32"] = torch.empty(max(8 * wide * d, 16 * d * d), **f32)
         self.tensors = t
         self.desc = _C.CxChunkBuffers()
         self.desc.T_cap = T_cap

@@ -41,7 +41,7 @@ for name, (M, N, K) in shapes.items():
     w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     wg = name.endswith("wgrad")
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if wg else torch.bfloat16)
-    ws = torch.empty(16 * 768 * 768 if wg else 1, device=dev)
+    ws = torch.empty(8 * 6144 * 768 if wg else 1, device=dev)
 
     if wg and a.tn:
         dyt, at = x.T.contiguous(), w.T.contiguous()  # (T, O), (T, I)
