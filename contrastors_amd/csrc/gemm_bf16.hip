@@ -643,7 +643,7 @@ hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
 extern "C" {
 
 void cx_gemm_set_debug(int d) { g_dbg = d; }
-void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 3) ? v : 2; }
+void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 4) ? v : 2; }
 int cx_gemm_get_variant(void) { return g_variant; }
 void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }
 int cx_gemm_get_glds(void) { return g_use_glds; }
@@ -659,8 +659,9 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     GemmParams p;
     p.X = X; p.W = W; p.Out = Out; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
+    const bool v4 = (g_variant == 4) && g_use_glds && out_mode != OUT_F32_ATOMIC;
     const bool v3 = (g_variant == 3) && g_use_glds && out_mode != OUT_F32_ATOMIC;
-    const bool v2 = ((g_variant == 2) || (g_variant == 3 && !v3)) && g_use_glds;
+    const bool v2 = ((g_variant == 2) || (g_variant >= 3 && !v3 && !v4)) && g_use_glds;
     p.tiles_m = v2 ? (M + V2_BM - 1) / V2_BM : (M + BM - 1) / BM;
     p.tiles_n = v2 ? (N + V2_BN - 1) / V2_BN : (N + BN - 1) / BN;
     const int nk = K / BK;
@@ -687,7 +688,8 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
         }
         ++g_prof.launches;
     }
-    hipError_t e = v3 ? cx_launch_gemm_v3(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
+    hipError_t e = v4 ? cx_launch_gemm_v4(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
+                   : v3 ? cx_launch_gemm_v3(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
                    : v2 ? launch_v2(p, out_mode, (hipStream_t)stream)
                       : (g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
                                     : launch_mode<false>(p, out_mode, (hipStream_t)stream));
@@ -830,7 +832,8 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
         }
         ++g_prof.launches;
     }
-    hipError_t e = cx_launch_gemm_v3(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream);
+    hipError_t e = (g_variant == 4) ? cx_launch_gemm_v4(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream)
+                                    : cx_launch_gemm_v3(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream);
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }

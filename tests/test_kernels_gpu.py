@@ -44,11 +44,11 @@ def test_probe_ds_read_tr16_pattern():
 
 
 # ------------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", ["v3", "v2", "v1_glds", "v1_reg"])
+@pytest.mark.parametrize("variant", ["v4", "v3", "v2", "v1_glds", "v1_reg"])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
                                    (257, 6144, 768), (300, 768, 128)])
 def test_gemm_bf16_nt(variant, M, N, K):
-    L().cx_gemm_set_variant({"v3": 3, "v2": 2}.get(variant, 1))
+    L().cx_gemm_set_variant({"v4": 4, "v3": 3, "v2": 2}.get(variant, 1))
     L().cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
     try:
         x, w = bf(_randn(M, K, seed=1)), bf(_randn(N, K, seed=2, std=0.05))
@@ -77,9 +77,11 @@ def test_gemm_bf16_nt(variant, M, N, K):
         L().cx_gemm_set_glds(1)
 
 
+@pytest.mark.parametrize("variant", [2, 4])
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
-def test_gemm_swiglu_fused(M, I, K):
+def test_gemm_swiglu_fused(M, I, K, variant):
     """fc11 || fc12 GEMM with SwiGLU in the epilogue == standalone GEMM + swiglu (interleaved-by-32 weight rows)."""
+    L().cx_gemm_set_variant(variant)  # 2 -> fused epilogue runs on the v3 kernel, 4 -> on the v4 kernel
     x = bf(_randn(M, K, seed=90))
     w11, w12 = bf(_randn(I, K, seed=91, std=0.05)), bf(_randn(I, K, seed=92, std=0.05))
     wi = torch.stack([w11.view(I // 32, 32, K), w12.view(I // 32, 32, K)], 1).reshape(2 * I, K).contiguous()
