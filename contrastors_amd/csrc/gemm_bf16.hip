@@ -609,7 +609,7 @@ hipError_t launch_v2(const GemmParams& p_in, int out_mode, hipStream_t stream) {
 }
 
 int g_dbg = 0;
-int g_variant = 2;  // 3: v3 persistent 256x256;  2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
+int g_variant = 5;  // 5: v5 256x256x64 (default);  3: v3 persistent 256x256x32;  2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
 
 int g_use_glds = 1;
 
@@ -643,7 +643,7 @@ hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
 extern "C" {
 
 void cx_gemm_set_debug(int d) { g_dbg = d; }
-void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 4) ? v : 2; }
+void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 5) ? v : 5; }
 int cx_gemm_get_variant(void) { return g_variant; }
 void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }
 int cx_gemm_get_glds(void) { return g_use_glds; }
@@ -659,9 +659,10 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     GemmParams p;
     p.X = X; p.W = W; p.Out = Out; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
+    const bool v5 = (g_variant == 5) && g_use_glds && out_mode != OUT_F32_ATOMIC;
     const bool v4 = (g_variant == 4) && g_use_glds && out_mode != OUT_F32_ATOMIC;
     const bool v3 = (g_variant == 3) && g_use_glds && out_mode != OUT_F32_ATOMIC;
-    const bool v2 = ((g_variant == 2) || (g_variant >= 3 && !v3 && !v4)) && g_use_glds;
+    const bool v2 = ((g_variant == 2) || (g_variant >= 3 && !v3 && !v4 && !v5)) && g_use_glds;
     p.tiles_m = v2 ? (M + V2_BM - 1) / V2_BM : (M + BM - 1) / BM;
     p.tiles_n = v2 ? (N + V2_BN - 1) / V2_BN : (N + BN - 1) / BN;
     const int nk = K / BK;
@@ -688,7 +689,8 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
         }
         ++g_prof.launches;
     }
-    hipError_t e = v4 ? cx_launch_gemm_v4(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
+    hipError_t e = v5 ? cx_launch_gemm_v5(p, 0, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
+                   : v4 ? cx_launch_gemm_v4(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
                    : v3 ? cx_launch_gemm_v3(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
                    : v2 ? launch_v2(p, out_mode, (hipStream_t)stream)
                       : (g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
@@ -707,8 +709,9 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
     if (!ws || !Out) return CX_ERR_ARG;
     const long slab = (long)M * N;
     if (ws_floats < slab) return CX_ERR_SHAPE;
-    const bool v3 = (g_variant == 3) && g_use_glds;
-    const bool v2 = (g_variant == 2) && g_use_glds;
+    const bool v5 = (g_variant == 5) && g_use_glds;
+    const bool v3 = (g_variant == 3 || v5) && g_use_glds;  // same 256x256 tile count
+    const bool v2 = (g_variant == 2 || g_variant == 4) && g_use_glds;
     const long tiles = v3 ? (long)((M + 255) / 256) * ((N + 255) / 256)
                      : v2 ? (long)((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN)
                           : (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -724,8 +727,9 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
         p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = N;
         p.tiles_m = p.tiles_n = 0; p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
         split = p.split_k;
-        rc = cx_launch_gemm_v3(p, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream) == hipSuccess ? CX_OK
-                                                                                                          : CX_ERR_LAUNCH;
+        const hipError_t he = v5 ? cx_launch_gemm_v5(p, 0, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream)
+                                 : cx_launch_gemm_v3(p, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream);
+        rc = he == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
     } else if (v2) {
         GemmParams p;
         p.X = X; p.W = W; p.Out = ws; p.bias = nullptr;
@@ -757,6 +761,7 @@ int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float
                           int ld_dy, int ld_a, void* stream) {
     if (T <= 0 || O <= 0 || I <= 0) return CX_OK;
     if ((O % V2_BM) != 0 || (I % V2_BN) != 0) return CX_ERR_SHAPE;
+    const bool use_v5 = (g_variant == 5) && (I % 256) == 0;
     if ((ld_dy % 8) != 0 || (ld_a % 8) != 0) return CX_ERR_ALIGN;
     if (!ws || !G) return CX_ERR_ARG;
     const long slab = (long)O * I;
@@ -765,11 +770,11 @@ int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float
     GemmParams p;
     p.X = dY; p.W = A; p.Out = ws; p.bias = nullptr;
     p.M = O; p.N = I; p.K = Tp; p.ldx = ld_dy; p.ldw = ld_a; p.ldo = I;
-    p.tiles_m = O / V2_BM; p.tiles_n = I / V2_BN;
+    p.tiles_m = O / V2_BM; p.tiles_n = use_v5 ? I / 256 : I / V2_BN;
     const long tiles = (long)p.tiles_m * p.tiles_n, nk = Tp / BK;
     long max_split = nk / 4;
     if (max_split > ws_floats / slab) max_split = ws_floats / slab;
-    if (max_split > 16) max_split = 16;
+    if (max_split > 32) max_split = 32;
     const long split = choose_split(tiles, max_split);
     p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
     static bool attr_set = false;
@@ -793,8 +798,12 @@ int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float
         }
         ++g_prof.launches;
     }
-    hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((int)(tiles * split)), dim3(512), V2_NSTAGE * V2_STAGE,
-                       (hipStream_t)stream, p);
+    if (use_v5) {
+        if (cx_launch_gemm_v5(p, 1, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream) != hipSuccess) return CX_ERR_LAUNCH;
+    } else {
+        hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((int)(tiles * split)), dim3(512), V2_NSTAGE * V2_STAGE,
+                           (hipStream_t)stream, p);
+    }
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     if (hipGetLastError() != hipSuccess) return CX_ERR_LAUNCH;
     const long n4 = slab / 4;
@@ -832,7 +841,8 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
         }
         ++g_prof.launches;
     }
-    hipError_t e = (g_variant == 4) ? cx_launch_gemm_v4(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream)
+    hipError_t e = (g_variant == 5) ? cx_launch_gemm_v5(p, 0, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream)
+                   : (g_variant == 4) ? cx_launch_gemm_v4(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream)
                                     : cx_launch_gemm_v3(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream);
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;

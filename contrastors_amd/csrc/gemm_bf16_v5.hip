@@ -1,0 +1,320 @@
+// gemm_bf16_v5.hip -- 256x256x64 bf16 MFMA GEMM (K9), the tile shape the round-1 ablations asked for.
+//
+// Measured on v2 (256x128x64): the K loop is limited by the global->LDS request stream, which saturates near
+// 45 GB/s per CU whatever the prefetch depth (DMA-only loop == full loop; 64-B segments of v3 gained nothing) -- i.e.
+// by BYTES (128-B line requests) PER FLOP of the tile shape.  256x256x64 moves 64 KiB per 8.4 MFLOP instead of
+// 48 KiB per 4.2 MFLOP: 0.67x the requests per FLOP, always as whole 128-B lines.
+//
+// Structure: 8 waves as 2(M) x 4(N), 128x64 per wave = 4x2 MFMA 32x32x16 accumulators (128 VGPRs); two 64 KiB LDS
+// stages filled by LDS-DMA (global_load_lds, swizzle on the source address); the DMA of K-tile t+1 is issued right
+// after the barrier of iteration t and has the whole 32-MFMA/wave compute phase to land; one raw s_barrier per
+// K-tile.  Epilogues: LDS-staged coalesced bf16 rows / fp32 / fp32 split-K partial slabs / fused SwiGLU.
+// Three operand forms share the main loop:
+//   NT      Out[m][n] = sum_k X[m][k] W[n][k]          (forward, dgrad)
+//   SWIGLU  NT + silu(gate)*y epilogue                  (fc11 || fc12, rows interleaved by 32)
+//   TN      G[o][i]   = sum_t dY[t][o] A[t][i]          (wgrad in its natural layout, ds_read_b64_tr_b16 fragments)
+#include "cx_common.h"
+#include "../../include/contrastors_hip.h"
+#include "gemm_params.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
+constexpr int BM5 = 256, BN5 = 256, BK5 = 64;
+constexpr int XB5 = BM5 * BK5 * 2;           // 32 KiB
+constexpr int ST5 = (BM5 + BN5) * BK5 * 2;   // 64 KiB
+constexpr int NST5 = 2;
+constexpr int TNROW5 = 512;                  // bytes per token row of a [64 t][256 f] TN tile
+
+enum Form { FORM_NT = 0, FORM_TN = 1 };
+
+// TN fragment: see gemm_bf16.hip (tn_frag) -- lane (g = lane>>4, p = lane&15) -> feature f0 + 16*(g&1) + p,
+// tokens t0 + 8*(g>>1) + {0..7}; 16-B chunk index XORed with (t&3)<<2 (conflict-free, verified by PMC).
+CX_DEVICE bf16x8_t tn_frag5(const char* tile, int f0, int t0, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int t = t0 + 8 * (g >> 1) + (p >> 2);
+    const int f = f0 + 16 * (g & 1) + 4 * (p & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int tt = t + 4 * half;
+        const int chunk = (f >> 3) ^ ((tt & 3) << 2);
+        u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(tile + tt * TNROW5 + chunk * 16 + (f & 4) * 2));
+    }
+    return u.v;
+}
+
+template <int FORM, int OUT_MODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tn = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tm = lid % p.tiles_m;
+    const int sk = lid / p.tiles_m;
+    const int m0 = tm * BM5, n0 = tn * BN5;
+    const int nk_total = p.K / BK5;
+    const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
+    const int kt_end = (int)(((long)nk_total * (sk + 1)) / p.split_k);
+    const int nk = kt_end - kt_begin;
+
+    // ---- DMA sources: 64 instructions of 1 KiB per stage (32 X + 32 W), 4 + 4 per wave -------------------------
+    const bf16_t* xsrc[4];
+    const bf16_t* wsrc[4];
+    size_t xstep, wstep;
+    if constexpr (FORM == FORM_NT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // instruction q = j*8 + wave covers tile rows 8q..8q+7 (128 B each)
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gx = m0 + r, gw = n0 + r;
+            gx = gx < p.M ? gx : p.M - 1;
+            gw = gw < p.N ? gw : p.N - 1;
+            xsrc[j] = p.X + (size_t)gx * p.ldx + (size_t)kt_begin * BK5 + c * 8;
+            wsrc[j] = p.W + (size_t)gw * p.ldw + (size_t)kt_begin * BK5 + c * 8;
+        }
+        xstep = wstep = BK5;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // instruction q covers token rows 2q, 2q+1 of a [64 t][256 f] tile (512 B each)
+            const int t = (j * 8 + wave) * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((t & 3) << 2);
+            xsrc[j] = p.X + ((size_t)kt_begin * BK5 + t) * p.ldx + m0 + c * 8;
+            wsrc[j] = p.W + ((size_t)kt_begin * BK5 + t) * p.ldw + n0 + c * 8;
+        }
+        xstep = (size_t)BK5 * p.ldx;
+        wstep = (size_t)BK5 * p.ldw;
+    }
+    auto issue = [&](int stage) {
+        char* base = dsm + stage * ST5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            xsrc[j] += xstep;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + XB5 + (j * 8 + wave) * 1024), 16, 0,
+                                             0);
+            wsrc[j] += wstep;
+        }
+    };
+
+    f32x16_t acc[2][4];  // [n-block a][m-block b]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nk > 0) issue(0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of K-tile t has landed
+        __builtin_amdgcn_s_barrier();                      // ... everyone's has, and stage (t+1)&1 is no longer read
+        if (t + 1 < nk) issue((t + 1) & 1);
+        const char* xs = dsm + (t & 1) * ST5;
+        const char* ws = xs + XB5;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t wf[2], xf[4];
+            if constexpr (FORM == FORM_NT) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) xf[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[a] = tn_frag5(ws, wn * 64 + a * 32, ks * 16, lane);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) xf[b] = tn_frag5(xs, wm * 128 + b * 32, ks * 16, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- epilogue.  acc[a][b][r]: m = m0 + wm*128 + b*32 + l31,  n = n0 + wn*64 + a*32 + acc_row(r,hi) --------
+    const bool add_bias = (p.bias != nullptr) && (sk == 0);
+    constexpr int ROWB = 144, SLOT = 64 * ROWB;  // staging slot of one wave: 64 rows x 64 bf16 (+16 B pad)
+    if constexpr (OUT_MODE == GEMM_OUT_BF16 && EPI == GEMM_EPI_NONE) {
+        if ((p.ldo & 7) == 0) {
+            char* my = dsm + wave * SLOT;
+            __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages; slots are wave-private after
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {  // 64 of the wave's 128 rows per pass (8 x 9 KiB = 72 KiB of LDS)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int b = half * 2 + bb;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int nl = a * 32 + 8 * q + 4 * hi;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e] * p.alpha;
+                            if (add_bias) {
+                                const int n = n0 + wn * 64 + nl;
+                                if (n < p.N) {
+                                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                                }
+                            }
+                            uint2 pk;
+                            pk.x = pack_bf16x2(v[0], v[1]);
+                            pk.y = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(my + (bb * 32 + l31) * ROWB + nl * 2) = pk;
+                        }
+                }
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {  // in-order LDS: this wave reads back its own slot
+                    const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                    const int m = m0 + wm * 128 + half * 64 + row, n = n0 + wn * 64 + ch * 8;
+                    const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                    if (m < p.M) {
+                        bf16_t* dst = reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n;
+                        if (n + 8 <= p.N) {
+                            *reinterpret_cast<uint4*>(dst) = vv;
+                        } else if (n < p.N) {
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(vv.x, vv.y);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+    if constexpr (EPI == GEMM_EPI_SWIGLU) {
+        // a = 0: y rows, a = 1: gate rows of the same 32 activation columns (weight rows interleaved by 32).
+        // The activation tile of a wave (128 rows x 32 cols) is staged so each row leaves as one 64-B segment.
+        constexpr int AROWB = 80;  // 64 B + 16 B pad
+        char* my = dsm + wave * (128 * AROWB);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int m = m0 + wm * 128 + b * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + 8 * q + 4 * hi;  // column of y in the fused (interleaved) output
+                float y[4], g[4], o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = acc[0][b][4 * q + e];
+                    g[e] = acc[1][b][4 * q + e];
+                }
+                if (p.Out && m < p.M && n < p.N) {
+                    bf16_t* row = reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(y[0], y[1]); pk.y = pack_bf16x2(y[2], y[3]);
+                    *reinterpret_cast<uint2*>(row + n) = pk;
+                    pk.x = pack_bf16x2(g[0], g[1]); pk.y = pack_bf16x2(g[2], g[3]);
+                    *reinterpret_cast<uint2*>(row + n + 32) = pk;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {  // the standalone op sees bf16 y / gate (FusedDense outputs)
+                    const float yy = bf16_to_f32(f32_to_bf16(y[e])), gg = bf16_to_f32(f32_to_bf16(g[e]));
+                    o[e] = gg / (1.f + __expf(-gg)) * yy;
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(my + (b * 32 + l31) * AROWB + (8 * q + 4 * hi) * 2) = pk;
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {  // 16 rows x 4 chunks of 16 B per pass
+            const int row = ps * 16 + (lane >> 2), ch = lane & 3;
+            const int m = m0 + wm * 128 + row;
+            const int col = ((n0 + wn * 64) >> 1) + ch * 8;
+            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * AROWB + ch * 16);
+            if (m < p.M && 2 * col < p.N)
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out2) + (size_t)m * p.ldo2 + col) = vv;
+        }
+        return;
+    }
+    float* part = nullptr;
+    if constexpr (OUT_MODE == GEMM_OUT_F32_PARTIAL) part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int m = m0 + wm * 128 + b * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e] * p.alpha;
+                if (add_bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if constexpr (OUT_MODE == GEMM_OUT_BF16) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = pk;
+                } else if constexpr (OUT_MODE == GEMM_OUT_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.Out) + (size_t)m * p.ldo + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *reinterpret_cast<float4*>(part + (size_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+}
+
+template <int FORM, int OUT_MODE, int EPI>
+hipError_t launch5(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v5_kernel<FORM, OUT_MODE, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NST5 * ST5);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    hipLaunchKernelGGL((gemm_bf16_v5_kernel<FORM, OUT_MODE, EPI>), dim3(nwg), dim3(512), NST5 * ST5, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// form 0 = NT, 1 = TN (p.X = dY (T,M), p.W = A (T,N), p.K = tokens; M % 256 == 0 and N % 256 == 0 required).
+hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream) {
+    if ((p.K % BK5) != 0) return hipErrorInvalidValue;
+    p.tiles_m = (p.M + BM5 - 1) / BM5;
+    p.tiles_n = (p.N + BN5 - 1) / BN5;
+    if (p.split_k < 1) p.split_k = 1;
+    if (p.split_k > p.K / BK5) p.split_k = p.K / BK5;
+    if (form == 1) {
+        if ((p.M % BM5) != 0 || (p.N % BN5) != 0 || out_mode != GEMM_OUT_F32_PARTIAL) return hipErrorInvalidValue;
+        return launch5<FORM_TN, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE>(p, stream);
+    }
+    if (epi == GEMM_EPI_SWIGLU) {
+        if (out_mode != GEMM_OUT_BF16) return hipErrorInvalidValue;
+        return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_SWIGLU>(p, stream);
+    }
+    switch (out_mode) {
+        case GEMM_OUT_BF16: return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_NONE>(p, stream);
+        case GEMM_OUT_F32: return launch5<FORM_NT, GEMM_OUT_F32, GEMM_EPI_NONE>(p, stream);
+        case GEMM_OUT_F32_PARTIAL: return launch5<FORM_NT, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -47,7 +47,7 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
  * round_up(T,64) token rows of both operands: rows T.. of that range must be ZERO.  O % 256 == 0, I % 128 == 0. */
 int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float* ws, long ws_floats, int T, int O, int I,
                           int ld_dy, int ld_a, void* stream);
-void cx_gemm_set_variant(int v); /* 2 (default): 256x128 3-stage LDS-DMA ring; 3: persistent 256x256; 1: 128x128 2-stage */
+void cx_gemm_set_variant(int v); /* 5 (default): 256x256x64 2-stage; 2: 256x128x64 3-stage ring; 3/4: persistent experiments; 1: 128x128 */
 int cx_gemm_get_variant(void);
 void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0 skip the main-loop DMA, bit1 skip LDS reads + MFMA */
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by

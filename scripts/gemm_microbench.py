@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from contrastors_amd import _C  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variant", type=int, default=2)
+ap.add_argument("--variant", type=int, default=5)
 ap.add_argument("--glds", type=int, default=1)
 ap.add_argument("--chunk", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
