@@ -96,8 +96,9 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
         CX_TRY(cx_attn_varlen_fwd(s.qkv(sl), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(sl), s.lse(sl), Bc, H, T,
                                   max_seqlen, enc->softmax_scale, stream));
         CX_TRY(cx_gemm_bf16_nt(s.ctx(sl), w.Wout, s.z1(sl), w.bout, T, d, d, d, d, d, 0, 1, 1.f, stream));
-        CX_TRY(cx_layernorm_fwd(s.z1(sl), h_in, w.ln1_g, w.ln1_b, s.h1(sl), s.z1(sl), s.mean1(sl), s.rstd1(sl), T, d,
-                                enc->ln_eps, stream));
+        // z (= attn_out + residual) is only kept for backward; the no-grad pass skips that 1/4 of the LN traffic
+        CX_TRY(cx_layernorm_fwd(s.z1(sl), h_in, w.ln1_g, w.ln1_b, s.h1(sl), save_for_backward ? s.z1(sl) : nullptr,
+                                s.mean1(sl), s.rstd1(sl), T, d, enc->ln_eps, stream));
         if (enc->gated) {
             // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
             CX_TRY(cx_gemm_bf16_swiglu(s.h1(sl), w.Wfc1, save_for_backward ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d,
@@ -107,8 +108,8 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
             CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
         }
         CX_TRY(cx_gemm_bf16_nt(s.act(sl), w.Wfc2, s.z2(sl), w.bfc2, T, d, I, I, I, d, 0, 1, 1.f, stream));
-        CX_TRY(cx_layernorm_fwd(s.z2(sl), s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl), s.z2(sl), s.mean2(sl), s.rstd2(sl), T,
-                                d, enc->ln_eps, stream));
+        CX_TRY(cx_layernorm_fwd(s.z2(sl), s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl), save_for_backward ? s.z2(sl) : nullptr,
+                                s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
         h_in = s.h2(sl);
     }
     return cx_pool_normalize_fwd(h_in, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,

@@ -200,47 +200,61 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmParams p) {
         }
     }
     if constexpr (EPI == GEMM_EPI_SWIGLU) {
-        // a = 0: y rows, a = 1: gate rows of the same 32 activation columns (weight rows interleaved by 32).
-        // The activation tile of a wave (128 rows x 32 cols) is staged so each row leaves as one 64-B segment.
-        constexpr int AROWB = 80;  // 64 B + 16 B pad
-        char* my = dsm + wave * (128 * AROWB);
-        __builtin_amdgcn_s_barrier();
+        // a = 0: y rows, a = 1: gate rows of the same 32 activation columns (weight rows interleaved by 32), so the
+        // wave's 64 fused columns [y 0..31 | gate 0..31] are exactly one 128-B line per row of the (M, 2I) pre-activation
+        // tensor.  Both outputs leave through LDS staging as whole-line / half-line coalesced stores.
+        __builtin_amdgcn_s_barrier();  // operand stages are free; staging slots are wave-private from here on
+        if (p.Out) {
+            char* my = dsm + wave * SLOT;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int m = m0 + wm * 128 + b * 32 + l31;
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int b = half * 2 + bb;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(acc[a][b][4 * q], acc[a][b][4 * q + 1]);
+                            pk.y = pack_bf16x2(acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+                            *reinterpret_cast<uint2*>(my + (bb * 32 + l31) * ROWB + (a * 32 + 8 * q + 4 * hi) * 2) = pk;
+                        }
+                }
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                    const int m = m0 + wm * 128 + half * 64 + row, n = n0 + wn * 64 + ch * 8;
+                    const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                    if (m < p.M && n < p.N)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                }
+            }
+        }
+        constexpr int AROWB = 80;  // 64 B of activations per row + 16 B pad
+        char* mya = dsm + wave * (128 * AROWB);
+        if (p.Out) __builtin_amdgcn_s_barrier();  // the activation slots overlap other waves' pre-activation slots
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + 8 * q + 4 * hi;  // column of y in the fused (interleaved) output
-                float y[4], g[4], o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y[e] = acc[0][b][4 * q + e];
-                    g[e] = acc[1][b][4 * q + e];
-                }
-                if (p.Out && m < p.M && n < p.N) {
-                    bf16_t* row = reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo;
-                    uint2 pk;
-                    pk.x = pack_bf16x2(y[0], y[1]); pk.y = pack_bf16x2(y[2], y[3]);
-                    *reinterpret_cast<uint2*>(row + n) = pk;
-                    pk.x = pack_bf16x2(g[0], g[1]); pk.y = pack_bf16x2(g[2], g[3]);
-                    *reinterpret_cast<uint2*>(row + n + 32) = pk;
-                }
+                float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {  // the standalone op sees bf16 y / gate (FusedDense outputs)
-                    const float yy = bf16_to_f32(f32_to_bf16(y[e])), gg = bf16_to_f32(f32_to_bf16(g[e]));
+                    const float yy = bf16_to_f32(f32_to_bf16(acc[0][b][4 * q + e]));
+                    const float gg = bf16_to_f32(f32_to_bf16(acc[1][b][4 * q + e]));
                     o[e] = gg / (1.f + __expf(-gg)) * yy;
                 }
                 uint2 pk;
                 pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
-                *reinterpret_cast<uint2*>(my + (b * 32 + l31) * AROWB + (8 * q + 4 * hi) * 2) = pk;
+                *reinterpret_cast<uint2*>(mya + (b * 32 + l31) * AROWB + (8 * q + 4 * hi) * 2) = pk;
             }
-        }
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {  // 16 rows x 4 chunks of 16 B per pass
             const int row = ps * 16 + (lane >> 2), ch = lane & 3;
             const int m = m0 + wm * 128 + row;
             const int col = ((n0 + wn * 64) >> 1) + ch * 8;
-            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * AROWB + ch * 16);
+            const uint4 vv = *reinterpret_cast<const uint4*>(mya + row * AROWB + ch * 16);
             if (m < p.M && 2 * col < p.N)
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out2) + (size_t)m * p.ldo2 + col) = vv;
         }
