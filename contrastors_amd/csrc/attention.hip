@@ -236,6 +236,163 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------ forward, sequences <= 128
+// BERT-style contrastive batches (seq_len 128, the BASELINE metric) fit a whole (sequence, head) problem in one
+// workgroup: Q, K and V^T (128 keys) live in LDS at once.  All global loads are issued up front (one memory latency
+// instead of three), there is one barrier, and softmax is single-pass (no online rescale).
+constexpr int VT128_STRIDE = 264;  // bytes per d-row of the [64 d][128 keys] transposed V tile (+8 B pad)
+
+CX_DEVICE void rot8(const uint4& lo_in, const uint4& hi_in, const float4 (&c)[2], const float4 (&s)[2], uint4& lo,
+                    uint4& hi) {
+    float x1[8], x2[8], o1[8], o2[8];
+    unpack8(lo_in, x1);
+    unpack8(hi_in, x2);
+    const float cc[8] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w};
+    const float ss[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = x1[e] * cc[e] - x2[e] * ss[e];
+        o2[e] = x2[e] * cc[e] + x1[e] * ss[e];
+    }
+    lo = pack8(o1);
+    hi = pack8(o2);
+}
+
+CX_DEVICE bf16x8_t read_vt128_frag(const char* tile, int d, int blk16, int hi) {
+    const char* p = tile + d * VT128_STRIDE + (blk16 * 16 + 4 * hi) * 2;
+    union { uint2 u[2]; bf16x8_t v; } x;
+    x.u[0] = *reinterpret_cast<const uint2*>(p);
+    x.u[1] = *reinterpret_cast<const uint2*>(p + 16);
+    return x.v;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_s128_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[16384 + 16384 + 64 * VT128_STRIDE];
+    char* Qs = smem;
+    char* Ks = smem + 16384;
+    char* Vt = smem + 32768;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    if (len <= 0) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+
+    // ---- every global load first ----------------------------------------------------------------------------
+    uint4 qlo[2], qhi[2], klo[2], khi[2], v0[2], v1[2];
+    float4 cs[2][2], sn[2][2];
+    const int cp = tid & 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int r = it * 64 + (tid >> 2);
+        r = r < len ? r : len - 1;
+        const bf16_t* qrow = qbase + (size_t)(t0 + r) * tok_stride;
+        const bf16_t* krow = kbase + (size_t)(t0 + r) * tok_stride;
+        qlo[it] = *reinterpret_cast<const uint4*>(qrow + cp * 8);
+        qhi[it] = *reinterpret_cast<const uint4*>(qrow + 32 + cp * 8);
+        klo[it] = *reinterpret_cast<const uint4*>(krow + cp * 8);
+        khi[it] = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
+        if (p.cosv) {
+            const float* c = p.cosv + (size_t)r * 32 + cp * 8;
+            const float* s = p.sinv + (size_t)r * 32 + cp * 8;
+            cs[it][0] = *reinterpret_cast<const float4*>(c);
+            cs[it][1] = *reinterpret_cast<const float4*>(c + 4);
+            sn[it][0] = *reinterpret_cast<const float4*>(s);
+            sn[it][1] = *reinterpret_cast<const float4*>(s + 4);
+        }
+        int ka = it * 64 + 2 * (tid >> 3), kb2 = ka + 1;
+        ka = ka < len ? ka : len - 1;
+        kb2 = kb2 < len ? kb2 : len - 1;
+        v0[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + ka) * tok_stride + (tid & 7) * 8);
+        v1[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + kb2) * tok_stride + (tid & 7) * 8);
+    }
+    // ---- rotate, stage ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = it * 64 + (tid >> 2);
+        uint4 a_lo = qlo[it], a_hi = qhi[it], b_lo = klo[it], b_hi = khi[it];
+        if (p.cosv) {
+            rot8(qlo[it], qhi[it], cs[it], sn[it], a_lo, a_hi);
+            rot8(klo[it], khi[it], cs[it], sn[it], b_lo, b_hi);
+        }
+        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = a_lo;
+        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = a_hi;
+        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = b_lo;
+        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = b_hi;
+        const int kp = it * 32 + (tid >> 3), c8 = (tid & 7) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t w = (uint32_t)elem16(v0[it], e) | ((uint32_t)elem16(v1[it], e) << 16);
+            *reinterpret_cast<uint32_t*>(Vt + (c8 + e) * VT128_STRIDE + kp * 4) = w;
+        }
+    }
+    __syncthreads();
+
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
+    const float sc2 = p.scale * LOG2E;
+    float s[4][16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        f32x16_t a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + acc_row(r, hi);
+            s[kb][r] = key < len ? a[r] * sc2 : -INFINITY;
+            mx = fmaxf(mx, s[kb][r]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[kb][r] = exp2f(s[kb][r] - mx);
+            psum += s[kb][r];
+        }
+    f32x16_t acc_o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16x8_t pf = pack_frag(s[kb], half);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                acc_o[db] = mfma_bf16_32x32x16(read_vt128_frag(Vt, db * 32 + l31, kb * 2 + half, hi), pf, acc_o[db]);
+        }
+    const float l_tot = psum + __shfl_xor(psum, 32, 64);
+    const float inv = 1.f / l_tot;
+    const int q = wave * 32 + l31;
+    if (q < len) {
+        bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
+                pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
+            }
+        if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mx + log2f(l_tot)) * LN2;
+    }
+}
+
 // ------------------------------------------------------------------------------------- delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     const long total = (long)p.T * p.H * 8;
@@ -291,6 +448,7 @@ CX_DEVICE void store_unrotated(bf16_t* row, const f32x16_t (&acc)[2], float scal
         *reinterpret_cast<uint2*>(row + 32 + d) = pk;
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------------- dQ
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
@@ -569,8 +727,12 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     AttnParams p = {};
     p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
-    dim3 grid((max_seqlen + 127) / 128, H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (max_seqlen <= 128) {
+        hipLaunchKernelGGL(attn_fwd_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid((max_seqlen + 127) / 128, H, B);
+        hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     return done();
 }
 
