@@ -642,7 +642,10 @@ hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
 
 extern "C" {
 
-void cx_gemm_set_debug(int d) { g_dbg = d; }
+void cx_gemm_set_debug(int d) {
+    g_dbg = d;
+    cx_gemm_v5_set_persistent((d & 4) == 0);  // bit2: run the 256x256 kernel one-tile-per-workgroup (A/B of the persistent walk)
+}
 void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 5) ? v : 5; }
 int cx_gemm_get_variant(void) { return g_variant; }
 void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }

@@ -308,7 +308,287 @@ hipError_t launch5(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+
+// =====================================================================================================================
+// Persistent walk of the same 256x256x64 tile (NT forms with bf16 output): 256 workgroups, each loops over its tiles
+// and keeps the two-stage DMA pipeline running ACROSS tile boundaries -- the first K-tile of the next output tile is
+// already in flight while the current tile's epilogue runs, and the epilogue's global stores drain underneath the next
+// tile's first K-step.  vmcnt is shared by DMA loads and stores, so the kernel never counts across them: at a tile end
+// it waits (vmcnt(0)) for the already-issued first DMA group of the next tile BEFORE issuing the epilogue stores (that
+// group has had a whole compute phase to land), and skips the wait of the following iteration; one iteration later the
+// ordinary vmcnt(0) also covers the stores, which have had a full K-step to drain.
+// The epilogue stages through the stage consumed last (64 KiB), a quarter (32 rows per wave) at a time.
+// =====================================================================================================================
+// LDS map of the persistent kernel (all 160 KiB): three 32 KiB X slots (ring of 3) + two 32 KiB W slots (ring of 2).
+// X runs TWO K-tiles ahead, W one: 96 KiB of DMA in flight per CU instead of 64 KiB (the two-stage kernel is latency-
+// bound at 64 KiB / ~2 us = 32 GB/s/CU; the request pipe sustains ~45 GB/s/CU).  Issue order per iteration is
+// [W of t+1][X of t+2], so "everything but the newest X group" = s_waitcnt vmcnt(4) -- loads retire in order among
+// loads, and any still-pending epilogue store only makes that wait longer, never shorter.
+constexpr int XS5 = 32768;
+constexpr int PERS_LDS = 5 * XS5;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / BK5;
+    // tile order: workgroup b runs on XCD b%8; per round an XCD takes 32 consecutive tiles (n fastest: shared X panel)
+    const int per_xcd = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    auto tile_of = [&](int round) { return (round * 8 + xcd) * per_xcd + idx; };
+
+    // ---- two independent DMA cursors (X two K-tiles ahead, W one) ------------------------------------------------
+    const bf16_t* xsrc[4];
+    const bf16_t* wsrc[4];
+    int lx_round = 0, lx_kt = 0, lx_slot = 0;
+    int lw_round = 0, lw_kt = 0, lw_slot = 0;
+    int x_issued = 0, g = 0;  // X groups issued so far / index of the current iteration
+    bool lx_live, lw_live;
+    auto x_setup = [&](int tile) {
+        const int tm = tile / p.tiles_n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gx = tm * BM5 + r;
+            gx = gx < p.M ? gx : p.M - 1;
+            xsrc[j] = p.X + (size_t)gx * p.ldx + c * 8;
+        }
+    };
+    auto w_setup = [&](int tile) {
+        const int tn = tile % p.tiles_n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gw = tn * BN5 + r;
+            gw = gw < p.N ? gw : p.N - 1;
+            wsrc[j] = p.W + (size_t)gw * p.ldw + c * 8;
+        }
+    };
+    auto issue_x = [&]() {  // next X K-tile -> X slot ring
+        char* base = dsm + lx_slot * XS5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            xsrc[j] += BK5;
+        }
+        lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+        ++x_issued;
+        if (++lx_kt == nk) {
+            lx_kt = 0;
+            const int t = tile_of(++lx_round);
+            lx_live = t < ntiles;
+            if (lx_live) x_setup(t);
+        }
+    };
+    auto issue_w = [&]() {
+        char* base = dsm + 3 * XS5 + lw_slot * XS5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            wsrc[j] += BK5;
+        }
+        lw_slot ^= 1;
+        if (++lw_kt == nk) {
+            lw_kt = 0;
+            const int t = tile_of(++lw_round);
+            lw_live = t < ntiles;
+            if (lw_live) w_setup(t);
+        }
+    };
+
+    f32x16_t acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    zero_acc();
+
+    int cp_round = 0, cp_kt = 0;
+    int cp_tile = tile_of(0);
+    lx_live = lw_live = cp_tile < ntiles;
+    if (lx_live) {
+        x_setup(cp_tile);
+        w_setup(cp_tile);
+        issue_x();               // X of iteration 0
+        issue_w();               // W of iteration 0
+        if (lx_live) issue_x();  // X of iteration 1
+    }
+    int xs_slot = 0, ws_slot = 0;
+    bool landed = false;  // the operands of the coming iteration are already known to have landed (waited at tile end)
+    constexpr int ROWB = 144, QSLOT = 32 * ROWB;  // quarter staging slot of one wave: 32 rows x 64 bf16 (+16 B pad)
+
+#pragma unroll 1
+    while (cp_tile < ntiles) {
+        // Operands X_g and W_g of this iteration: the only DMA group younger than W_g is X_{g+1} (4 ops), if issued.
+        if (!landed) {
+            if (x_issued > g + 1) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        landed = false;
+        __builtin_amdgcn_s_barrier();
+        if (lw_live) issue_w();  // W of iteration +1   (its slot was consumed in iteration -1)
+        if (lx_live) issue_x();  // X of iteration +2   (its slot was consumed in iteration -1)
+        const char* xs = dsm + xs_slot * XS5;
+        const char* ws = dsm + 3 * XS5 + ws_slot * XS5;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t wf[2], xf[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) wf[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xf[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        if (++cp_kt == nk) {
+            // ---- epilogue.  Free LDS: the X slot and the W slot just consumed (32 KiB each); waves 0-3 stage in the
+            // former, waves 4-7 in the latter.  Every in-flight DMA group targets other slots.
+            const int tn = cp_tile % p.tiles_n, tm = cp_tile / p.tiles_n;
+            const int m0 = tm * BM5, n0 = tn * BN5;
+            char* area = (wave < 4) ? dsm + xs_slot * XS5 : dsm + 3 * XS5 + ws_slot * XS5;
+            char* my = area + (wave & 3) * QSLOT;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every DMA group issued so far (>= 1 compute phase old)
+            landed = true;
+            __builtin_amdgcn_s_barrier();  // every wave is done reading the consumed slots
+            if constexpr (EPI == GEMM_EPI_NONE) {
+                const bool add_bias = p.bias != nullptr;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int nl = a * 32 + 8 * q + 4 * hi;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * q + e] * p.alpha;
+                            if (add_bias) {
+                                const int n = n0 + wn * 64 + nl;
+                                if (n < p.N) {
+                                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                                }
+                            }
+                            uint2 pk;
+                            pk.x = pack_bf16x2(v[0], v[1]);
+                            pk.y = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(my + l31 * ROWB + nl * 2) = pk;
+                        }
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                        const int m = m0 + wm * 128 + b * 32 + row, n = n0 + wn * 64 + ch * 8;
+                        const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                        if (m < p.M && n + 8 <= p.N)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                    }
+                }
+            } else {
+                // SwiGLU: optional pre-activation pair (whole 128-B lines), then the activation (64-B row segments)
+                if (p.Out) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint2 pk;
+                                pk.x = pack_bf16x2(acc[a][b][4 * q], acc[a][b][4 * q + 1]);
+                                pk.y = pack_bf16x2(acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+                                *reinterpret_cast<uint2*>(my + l31 * ROWB + (a * 32 + 8 * q + 4 * hi) * 2) = pk;
+                            }
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                            const int m = m0 + wm * 128 + b * 32 + row, n = n0 + wn * 64 + ch * 8;
+                            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                            if (m < p.M && n < p.N)
+                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                        }
+                    }
+                }
+                constexpr int AROWB = 80, HSLOT = 64 * AROWB;  // activation staging: 64 rows x 32 cols per wave per pass
+                char* mya = area + (wave & 3) * HSLOT;         // 4 x 5 KiB = 20 KiB <= 32 KiB per area
+                if (p.Out) __builtin_amdgcn_s_barrier();       // activation slots overlap neighbours' quarter slots
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int b = half * 2 + bb;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float yy = bf16_to_f32(f32_to_bf16(acc[0][b][4 * q + e]));
+                                const float gg = bf16_to_f32(f32_to_bf16(acc[1][b][4 * q + e]));
+                                o[e] = gg / (1.f + __expf(-gg)) * yy;
+                            }
+                            uint2 pk;
+                            pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+                            *reinterpret_cast<uint2*>(mya + (bb * 32 + l31) * AROWB + (8 * q + 4 * hi) * 2) = pk;
+                        }
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = ps * 16 + (lane >> 2), ch = lane & 3;
+                        const int m = m0 + wm * 128 + half * 64 + row;
+                        const int col = ((n0 + wn * 64) >> 1) + ch * 8;
+                        const uint4 vv = *reinterpret_cast<const uint4*>(mya + row * AROWB + ch * 16);
+                        if (m < p.M && 2 * col < p.N)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out2) + (size_t)m * p.ldo2 + col) = vv;
+                    }
+                }
+            }
+            zero_acc();
+            cp_kt = 0;
+            cp_tile = tile_of(++cp_round);
+        }
+        xs_slot = xs_slot == 2 ? 0 : xs_slot + 1;
+        ws_slot ^= 1;
+        ++g;
+    }
+}
+
+template <int EPI>
+hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v5p_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PERS_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
+    hipLaunchKernelGGL((gemm_bf16_v5p_kernel<EPI>), dim3(grid), dim3(512), PERS_LDS, stream, p);
+    return hipGetLastError();
+}
+
+bool g_v5_persistent = true;
+
 }  // namespace
+
+void cx_gemm_v5_set_persistent(bool on) { g_v5_persistent = on; }
 
 // form 0 = NT, 1 = TN (p.X = dY (T,M), p.W = A (T,N), p.K = tokens; M % 256 == 0 and N % 256 == 0 required).
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream) {
@@ -321,10 +601,13 @@ hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipS
         if ((p.M % BM5) != 0 || (p.N % BN5) != 0 || out_mode != GEMM_OUT_F32_PARTIAL) return hipErrorInvalidValue;
         return launch5<FORM_TN, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE>(p, stream);
     }
+    const bool pers = g_v5_persistent && p.split_k == 1 && (p.N % 8) == 0;
     if (epi == GEMM_EPI_SWIGLU) {
         if (out_mode != GEMM_OUT_BF16) return hipErrorInvalidValue;
+        if (pers && (p.ldo % 8) == 0 && (p.ldo2 % 8) == 0) return launch5p<GEMM_EPI_SWIGLU>(p, stream);
         return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_SWIGLU>(p, stream);
     }
+    if (out_mode == GEMM_OUT_BF16 && pers && (p.ldo % 8) == 0) return launch5p<GEMM_EPI_NONE>(p, stream);
     switch (out_mode) {
         case GEMM_OUT_BF16: return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_NONE>(p, stream);
         case GEMM_OUT_F32: return launch5<FORM_NT, GEMM_OUT_F32, GEMM_EPI_NONE>(p, stream);

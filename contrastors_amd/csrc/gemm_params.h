@@ -24,3 +24,4 @@ struct GemmParams {
 hipError_t cx_launch_gemm_v3(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v4(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream);
+void cx_gemm_v5_set_persistent(bool on);

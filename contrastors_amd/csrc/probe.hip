@@ -38,9 +38,52 @@ __global__ void probe_tr16_kernel(const uint16_t* in, uint16_t* out) {
     for (int e = 0; e < 4; ++e) out[lane * 4 + e] = u.h[e];
 }
 
+// ---- global -> LDS DMA throughput probe ---------------------------------------------------------------------------
+// 512-thread workgroups, one per CU.  Each iteration every wave issues `per_wave` global_load_lds_dwordx4 (1 KiB
+// each), waits, and hits a barrier -- the skeleton of the GEMM main loop without MFMA.  Address pattern per
+// instruction: 8 rows x 128 B with `row_stride` bytes between rows (row_stride = 128 -> one contiguous KiB).
+// `span` bytes per workgroup are walked cyclically (small span = L2/L1 resident, huge span = HBM stream).
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+__global__ __launch_bounds__(512, 2) void probe_dma_kernel(const char* __restrict__ src, long wg_stride, long span,
+                                                           long row_stride, int per_wave, int iters, int depth,
+                                                           float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* base = src + (long)blockIdx.x * wg_stride;
+    const long instr_bytes = (row_stride == 128) ? 1024 : 8 * row_stride;  // address range one instruction spans
+    long off = (long)wave * per_wave * instr_bytes;
+    const long lane_off = (long)(lane >> 3) * row_stride + (lane & 7) * 16;
+    for (int it = 0; it < iters; ++it) {
+        for (int j = 0; j < per_wave; ++j) {
+            const char* g = base + (off % span) + lane_off;
+            __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)(dsm + ((it % depth) * 8 * per_wave + wave * per_wave + j) * 1024),
+                                             16, 0, 0);
+            off += instr_bytes;
+        }
+        off += (long)7 * per_wave * instr_bytes;  // the other 7 waves' share
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (threadIdx.x == 0 && sink) sink[blockIdx.x] = reinterpret_cast<float*>(dsm)[0];
+}
+
 }  // namespace
 
 extern "C" {
+int cx_probe_dma_bw(const void* src, long wg_stride, long span, long row_stride, int per_wave, int iters, int depth,
+                    int nwg, float* sink, void* stream) {
+    const int lds = depth * 8 * per_wave * 1024;
+    if (lds > 160 * 1024) return CX_ERR_SHAPE;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess)
+        return CX_ERR_LAUNCH;
+    hipLaunchKernelGGL(probe_dma_kernel, dim3(nwg), dim3(512), lds, (hipStream_t)stream, (const char*)src, wg_stride, span,
+                       row_stride, per_wave, iters, depth, sink);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
 int cx_probe_mfma_layout(float* out_32x32, void* stream) {
     hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_32x32);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;

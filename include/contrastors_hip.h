@@ -49,7 +49,7 @@ int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float
                           int ld_dy, int ld_a, void* stream);
 void cx_gemm_set_variant(int v); /* 5 (default): 256x256x64 2-stage; 2: 256x128x64 3-stage ring; 3/4: persistent experiments; 1: 128x128 */
 int cx_gemm_get_variant(void);
-void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0 skip the main-loop DMA, bit1 skip LDS reads + MFMA */
+void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0/bit1 ablate the v2 main loop; bit2 = non-persistent v5 */
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
  * (2*M*N*K) of exactly the sampled launches. */
@@ -242,6 +242,9 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
 /* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
 int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);
+/* global->LDS DMA throughput probe (scripts/dma_probe.py): see probe.hip */
+int cx_probe_dma_bw(const void* src, long wg_stride, long span, long row_stride, int per_wave, int iters, int depth,
+                    int nwg, float* sink, void* stream);
 
 #ifdef __cplusplus
 }
