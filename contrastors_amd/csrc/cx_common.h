@@ -25,16 +25,15 @@ CX_DEVICE float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 
 CX_DEVICE float bf16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
 CX_DEVICE float bf16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
 
-// round-to-nearest-even, NaN preserved (quiet)
-CX_DEVICE bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, NaN stays NaN).
+typedef float cx_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cx_bf16x2 __attribute__((ext_vector_type(2)));
 CX_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const cx_f32x2 v = {lo, hi};
+    const cx_bf16x2 r = __builtin_convertvector(v, cx_bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
 }
+CX_DEVICE bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)

@@ -642,6 +642,7 @@ hipError_t launch_mode(const GemmParams& p, int out_mode, hipStream_t stream) {
 
 extern "C" {
 
+void cx_gemm_set_trace(void* buf) { cx_gemm_v5_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_set_debug(int d) {
     g_dbg = d;
     cx_gemm_v5_set_persistent((d & 4) == 0);  // bit2: run the 256x256 kernel one-tile-per-workgroup (A/B of the persistent walk)

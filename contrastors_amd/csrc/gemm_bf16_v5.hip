@@ -371,37 +371,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
             wsrc[j] = p.W + (size_t)gw * p.ldw + c * 8;
         }
     };
-    auto issue_x = [&]() {  // next X K-tile -> X slot ring
+    // A K-tile of either operand is 4 DMA instructions per wave.  They are issued in two halves so that the main loop
+    // can spread them between MFMA groups: back-to-back DMA instructions stall the wave at issue (the vector-memory
+    // front end accepts ~1 KiB-instruction per ~30 clk per CU), and that stall would serialise with the MFMA phase.
+    auto issue_x_half = [&](int h) {  // next X K-tile -> X slot ring
         char* base = dsm + lx_slot * XS5;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * h + jj;
             __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
             xsrc[j] += BK5;
         }
-        lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
-        ++x_issued;
-        if (++lx_kt == nk) {
-            lx_kt = 0;
-            const int t = tile_of(++lx_round);
-            lx_live = t < ntiles;
-            if (lx_live) x_setup(t);
+        if (h == 1) {
+            lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+            ++x_issued;
+            if (++lx_kt == nk) {
+                lx_kt = 0;
+                const int t = tile_of(++lx_round);
+                lx_live = t < ntiles;
+                if (lx_live) x_setup(t);
+            }
         }
     };
-    auto issue_w = [&]() {
+    auto issue_w_half = [&](int h) {
         char* base = dsm + 3 * XS5 + lw_slot * XS5;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * h + jj;
             __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
             wsrc[j] += BK5;
         }
-        lw_slot ^= 1;
-        if (++lw_kt == nk) {
-            lw_kt = 0;
-            const int t = tile_of(++lw_round);
-            lw_live = t < ntiles;
-            if (lw_live) w_setup(t);
+        if (h == 1) {
+            lw_slot ^= 1;
+            if (++lw_kt == nk) {
+                lw_kt = 0;
+                const int t = tile_of(++lw_round);
+                lw_live = t < ntiles;
+                if (lw_live) w_setup(t);
+            }
         }
     };
+    auto issue_x = [&]() { issue_x_half(0); issue_x_half(1); };
+    auto issue_w = [&]() { issue_w_half(0); issue_w_half(1); };
 
     f32x16_t acc[2][4];
     auto zero_acc = [&]() {
@@ -428,8 +439,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
     bool landed = false;  // the operands of the coming iteration are already known to have landed (waited at tile end)
     constexpr int ROWB = 144, QSLOT = 32 * ROWB;  // quarter staging slot of one wave: 32 rows x 64 bf16 (+16 B pad)
 
+    const bool tracing = p.trace != nullptr;  // wave-uniform; the timers add an lgkmcnt(0) at phase boundaries only
+    long long t_wait = 0, t_comp = 0, t_epi = 0, t_epi_wait = 0, t0 = 0, t1 = 0;
 #pragma unroll 1
     while (cp_tile < ntiles) {
+        if (tracing) t0 = __builtin_amdgcn_s_memtime();
         // Operands X_g and W_g of this iteration: the only DMA group younger than W_g is X_{g+1} (4 ops), if issued.
         if (!landed) {
             if (x_issued > g + 1) {
@@ -440,8 +454,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
         }
         landed = false;
         __builtin_amdgcn_s_barrier();
-        if (lw_live) issue_w();  // W of iteration +1   (its slot was consumed in iteration -1)
-        if (lx_live) issue_x();  // X of iteration +2   (its slot was consumed in iteration -1)
+        if (tracing) { t1 = __builtin_amdgcn_s_memtime(); t_wait += t1 - t0; }
+        // DMA of this iteration: W of iteration +1 (k-steps 0,1) then X of iteration +2 (k-steps 2,3); both target
+        // slots consumed in iteration -1.  Issue order W before X keeps the vmcnt(4) accounting above.
+        const bool w_go = lw_live, x_go = lx_live;
+        const bool spread = !(p.dbg & 8);
+        if (!spread) {
+            if (w_go) issue_w();
+            if (x_go) issue_x();
+        }
         const char* xs = dsm + xs_slot * XS5;
         const char* ws = dsm + 3 * XS5 + ws_slot * XS5;
         __builtin_amdgcn_s_setprio(1);
@@ -452,12 +473,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
             for (int a = 0; a < 2; ++a) wf[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
 #pragma unroll
             for (int b = 0; b < 4; ++b) xf[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
+            if (spread) {
+                if (ks < 2) {
+                    if (w_go) issue_w_half(ks);
+                } else {
+                    if (x_go) issue_x_half(ks - 2);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
         }
         __builtin_amdgcn_s_setprio(0);
+        if (tracing) { t0 = __builtin_amdgcn_s_memtime(); t_comp += t0 - t1; }
 
         if (++cp_kt == nk) {
             // ---- epilogue.  Free LDS: the X slot and the W slot just consumed (32 KiB each); waves 0-3 stage in the
@@ -469,6 +498,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every DMA group issued so far (>= 1 compute phase old)
             landed = true;
             __builtin_amdgcn_s_barrier();  // every wave is done reading the consumed slots
+            if (tracing) t_epi_wait += __builtin_amdgcn_s_memtime() - t0;
             if constexpr (EPI == GEMM_EPI_NONE) {
                 const bool add_bias = p.bias != nullptr;
 #pragma unroll
@@ -562,12 +592,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
             zero_acc();
             cp_kt = 0;
             cp_tile = tile_of(++cp_round);
+            if (tracing) { t1 = __builtin_amdgcn_s_memtime(); t_epi += t1 - t0; }
         }
         xs_slot = xs_slot == 2 ? 0 : xs_slot + 1;
         ws_slot ^= 1;
         ++g;
     }
+    if (tracing && lane == 0) {
+        long long* o = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = t_wait; o[1] = t_comp; o[2] = t_epi; o[3] = g; o[4] = t_epi_wait;
+    }
 }
+
+long long* g_v5_trace = nullptr;
 
 template <int EPI>
 hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
@@ -580,7 +617,9 @@ hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
     }
     const int ntiles = p.tiles_m * p.tiles_n;
     int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
-    hipLaunchKernelGGL((gemm_bf16_v5p_kernel<EPI>), dim3(grid), dim3(512), PERS_LDS, stream, p);
+    GemmParams q = p;
+    q.trace = g_v5_trace;
+    hipLaunchKernelGGL((gemm_bf16_v5p_kernel<EPI>), dim3(grid), dim3(512), PERS_LDS, stream, q);
     return hipGetLastError();
 }
 
@@ -589,6 +628,7 @@ bool g_v5_persistent = true;
 }  // namespace
 
 void cx_gemm_v5_set_persistent(bool on) { g_v5_persistent = on; }
+void cx_gemm_v5_set_trace(long long* buf) { g_v5_trace = buf; }
 
 // form 0 = NT, 1 = TN (p.X = dY (T,M), p.W = A (T,N), p.K = tokens; M % 256 == 0 and N % 256 == 0 required).
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream) {

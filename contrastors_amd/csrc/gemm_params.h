@@ -19,9 +19,11 @@ struct GemmParams {
     void* Out2; // SwiGLU epilogue: activation output (M, N/2) bf16
     int ldo2;
     int sup_m, sup_n;  // v2: L2 super-tile (sup_m x sup_n tiles walked together); 0 = plain row-major order
+    long long* trace;  // v5p only (set by its launcher): per-workgroup phase cycle counters, or nullptr
 };
 
 hipError_t cx_launch_gemm_v3(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v4(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream);
 void cx_gemm_v5_set_persistent(bool on);
+void cx_gemm_v5_set_trace(long long* buf);  // 4 counters per workgroup: wait, compute, epilogue cycles, iterations

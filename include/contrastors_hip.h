@@ -50,6 +50,9 @@ int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float
 void cx_gemm_set_variant(int v); /* 5 (default): 256x256x64 2-stage; 2: 256x128x64 3-stage ring; 3/4: persistent experiments; 1: 128x128 */
 int cx_gemm_get_variant(void);
 void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0/bit1 ablate the v2 main loop; bit2 = non-persistent v5 */
+/* in-kernel phase timers of the persistent 256x256x64 kernel: buf = int64[grid*8 waves*8] {wait, compute, epilogue
+   cycles, iterations, epilogue DMA-wait cycles, -, -, -} per wave, or NULL to disable (scripts/gemm_trace.py) */
+void cx_gemm_set_trace(void* buf);
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
  * (2*M*N*K) of exactly the sampled launches. */
