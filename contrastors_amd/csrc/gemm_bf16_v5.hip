@@ -327,7 +327,7 @@ hipError_t launch5(const GemmParams& p, hipStream_t stream) {
 constexpr int XS5 = 32768;
 constexpr int PERS_LDS = 5 * XS5;
 
-template <int EPI>
+template <int EPI, bool TRACE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x;
@@ -436,69 +436,99 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
         if (lx_live) issue_x();  // X of iteration 1
     }
     int xs_slot = 0, ws_slot = 0;
-    bool landed = false;  // the operands of the coming iteration are already known to have landed (waited at tile end)
     constexpr int ROWB = 144, QSLOT = 32 * ROWB;  // quarter staging slot of one wave: 32 rows x 64 bf16 (+16 B pad)
 
-    const bool tracing = p.trace != nullptr;  // wave-uniform; the timers add an lgkmcnt(0) at phase boundaries only
+    // Fragments are double-buffered (F0/F1) and read one k-step ahead of the MFMAs that consume them, across the
+    // iteration boundary too: the LDS round trip never sits between two MFMA groups of the same wave.
+    struct Frags { bf16x8_t w[2], x[4]; };
+    Frags F0, F1;
+    auto read_frags = [&](Frags& f, const char* xs, const char* ws, int ks) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) f.w[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) f.x[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
+    };
+    // One k-step = 8 MFMAs.  The reads of the NEXT k-step are issued after the first of them: the lgkmcnt wait the
+    // compiler places in front of that first MFMA then never covers reads that were only just issued.
+    auto mma_head = [&](const Frags& f) { acc[0][0] = mfma_bf16_32x32x16(f.w[0], f.x[0], acc[0][0]); };
+    auto mma_tail = [&](const Frags& f) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (a + b) acc[a][b] = mfma_bf16_32x32x16(f.w[a], f.x[b], acc[a][b]);
+    };
+
+    constexpr bool tracing = TRACE;  // separate instantiation: the timers' SMEM reads would force lgkmcnt(0) waits
     long long t_wait = 0, t_comp = 0, t_epi = 0, t_epi_wait = 0, t0 = 0, t1 = 0;
+    if (cp_tile < ntiles) {
+        // operands of iteration 0 (X_0, W_0); the only younger group is X_1 (4 ops), if issued
+        if (x_issued > 1) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        read_frags(F0, dsm, dsm + 3 * XS5, 0);
+    }
+    if constexpr (tracing) t1 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     while (cp_tile < ntiles) {
-        if (tracing) t0 = __builtin_amdgcn_s_memtime();
-        // Operands X_g and W_g of this iteration: the only DMA group younger than W_g is X_{g+1} (4 ops), if issued.
-        if (!landed) {
-            if (x_issued > g + 1) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        landed = false;
-        __builtin_amdgcn_s_barrier();
-        if (tracing) { t1 = __builtin_amdgcn_s_memtime(); t_wait += t1 - t0; }
         // DMA of this iteration: W of iteration +1 (k-steps 0,1) then X of iteration +2 (k-steps 2,3); both target
-        // slots consumed in iteration -1.  Issue order W before X keeps the vmcnt(4) accounting above.
+        // slots consumed in iteration -1.  W before X keeps the vmcnt accounting below: at the end of iteration g the
+        // operands of g+1 are everything except the 4 newest ops (X_{g+2}).
         const bool w_go = lw_live, x_go = lx_live;
-        const bool spread = !(p.dbg & 8);
-        if (!spread) {
-            if (w_go) issue_w();
-            if (x_go) issue_x();
-        }
         const char* xs = dsm + xs_slot * XS5;
         const char* ws = dsm + 3 * XS5 + ws_slot * XS5;
+        const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
+        const bool tile_end = cp_kt + 1 == nk;
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t wf[2], xf[4];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) wf[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
-#pragma unroll
-            for (int b = 0; b < 4; ++b) xf[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
-            if (spread) {
-                if (ks < 2) {
-                    if (w_go) issue_w_half(ks);
-                } else {
-                    if (x_go) issue_x_half(ks - 2);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
-        }
+        mma_head(F0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(F1, xs, ws, 1);
+        if (w_go) issue_w_half(0);
+        mma_tail(F0);
+        mma_head(F1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(F0, xs, ws, 2);
+        if (w_go) issue_w_half(1);
+        mma_tail(F1);
+        mma_head(F0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(F1, xs, ws, 3);
+        if (x_go) issue_x_half(0);
+        mma_tail(F0);
+        if (x_go) issue_x_half(1);
         __builtin_amdgcn_s_setprio(0);
-        if (tracing) { t0 = __builtin_amdgcn_s_memtime(); t_comp += t0 - t1; }
+        if constexpr (tracing) { t0 = __builtin_amdgcn_s_memtime(); t_comp += t0 - t1; }
+        // this wave's reads of the current slots are complete (F1 has landed) ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ... and so are its DMA writes of the next iteration's operands (everything, at a tile end: the epilogue's
+        // global stores must not be mixed into the DMA accounting)
+        if (tracing && (p.dbg & 16) && !tile_end) {
+            // experiment (trace build only): no DMA wait -> what is left of t_wait is barrier skew; results are wrong
+        } else if (x_go && !tile_end) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if constexpr (tracing) { t1 = __builtin_amdgcn_s_memtime(); t_wait += t1 - t0; }
+        __builtin_amdgcn_s_setprio(1);
+        mma_head(F1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!tile_end) read_frags(F0, dsm + nxs_slot * XS5, dsm + 3 * XS5 + nws_slot * XS5, 0);
+        mma_tail(F1);
+        __builtin_amdgcn_s_setprio(0);
 
-        if (++cp_kt == nk) {
+        if (tile_end) {
             // ---- epilogue.  Free LDS: the X slot and the W slot just consumed (32 KiB each); waves 0-3 stage in the
             // former, waves 4-7 in the latter.  Every in-flight DMA group targets other slots.
             const int tn = cp_tile % p.tiles_n, tm = cp_tile / p.tiles_n;
             const int m0 = tm * BM5, n0 = tn * BN5;
             char* area = (wave < 4) ? dsm + xs_slot * XS5 : dsm + 3 * XS5 + ws_slot * XS5;
             char* my = area + (wave & 3) * QSLOT;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every DMA group issued so far (>= 1 compute phase old)
-            landed = true;
-            __builtin_amdgcn_s_barrier();  // every wave is done reading the consumed slots
-            if (tracing) t_epi_wait += __builtin_amdgcn_s_memtime() - t0;
+            if constexpr (tracing) t0 = __builtin_amdgcn_s_memtime();
             if constexpr (EPI == GEMM_EPI_NONE) {
                 const bool add_bias = p.bias != nullptr;
 #pragma unroll
@@ -590,12 +620,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
                 }
             }
             zero_acc();
-            cp_kt = 0;
+            cp_kt = -1;
             cp_tile = tile_of(++cp_round);
-            if (tracing) { t1 = __builtin_amdgcn_s_memtime(); t_epi += t1 - t0; }
+            // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
+            __builtin_amdgcn_s_barrier();
+            if (cp_tile < ntiles) read_frags(F0, dsm + nxs_slot * XS5, dsm + 3 * XS5 + nws_slot * XS5, 0);
+            if constexpr (tracing) { t1 = __builtin_amdgcn_s_memtime(); t_epi += t1 - t0; }
         }
-        xs_slot = xs_slot == 2 ? 0 : xs_slot + 1;
-        ws_slot ^= 1;
+        ++cp_kt;
+        xs_slot = nxs_slot;
+        ws_slot = nws_slot;
         ++g;
     }
     if (tracing && lane == 0) {
@@ -606,21 +640,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
 
 long long* g_v5_trace = nullptr;
 
-template <int EPI>
-hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
+template <int EPI, bool TRACE>
+hipError_t launch5p_t(const GemmParams& q, int grid, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v5p_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v5p_kernel<EPI, TRACE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PERS_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_bf16_v5p_kernel<EPI, TRACE>), dim3(grid), dim3(512), PERS_LDS, stream, q);
+    return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
     const int ntiles = p.tiles_m * p.tiles_n;
-    int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
+    const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
     GemmParams q = p;
     q.trace = g_v5_trace;
-    hipLaunchKernelGGL((gemm_bf16_v5p_kernel<EPI>), dim3(grid), dim3(512), PERS_LDS, stream, q);
-    return hipGetLastError();
+    return q.trace ? launch5p_t<EPI, true>(q, grid, stream) : launch5p_t<EPI, false>(q, grid, stream);
 }
 
 bool g_v5_persistent = true;
