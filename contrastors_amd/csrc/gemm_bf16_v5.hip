@@ -6,9 +6,8 @@
 // 48 KiB per 4.2 MFLOP: 0.67x the requests per FLOP, always as whole 128-B lines.
 //
 // Structure: 8 waves as 2(M) x 4(N), 128x64 per wave = 4x2 MFMA 32x32x16 accumulators (128 VGPRs); two 64 KiB LDS
-// stages filled by LDS-DMA (global_load_lds, swizzle on the source address); the DMA of K-tile t+1 is issued right
-// after the barrier of iteration t and has the whole 32-MFMA/wave compute phase to land; one raw s_barrier per
-// K-tile.  Epilogues: LDS-staged coalesced bf16 rows / fp32 / fp32 split-K partial slabs / fused SwiGLU.
+// stages filled by LDS-DMA (global_load_lds, swizzle on the source address); the DMA of K-tile t+1 is issued in two
+// halves between the MFMA groups of iteration t; fragments are read one k-step ahead; one raw s_barrier per K-tile.  Epilogues: LDS-staged coalesced bf16 rows / fp32 / fp32 split-K partial slabs / fused SwiGLU.
 // Three operand forms share the main loop:
 //   NT      Out[m][n] = sum_k X[m][k] W[n][k]          (forward, dgrad)
 //   SWIGLU  NT + silu(gate)*y epilogue                  (fc11 || fc12, rows interleaved by 32)
@@ -95,17 +94,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmParams p) {
         xstep = (size_t)BK5 * p.ldx;
         wstep = (size_t)BK5 * p.ldw;
     }
-    auto issue = [&](int stage) {
+    // One K-tile = 8 DMA instructions per wave; issued as an X half and a W half between MFMA groups (back-to-back DMA
+    // instructions stall the wave at issue, and that stall would serialise with the MFMA phase).
+    auto issue_x = [&](int stage) {
         char* base = dsm + stage * ST5;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
             xsrc[j] += xstep;
         }
+    };
+    auto issue_w = [&](int stage) {
+        char* base = dsm + stage * ST5 + XB5;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + XB5 + (j * 8 + wave) * 1024), 16, 0,
-                                             0);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
             wsrc[j] += wstep;
         }
     };
@@ -118,33 +121,71 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (nk > 0) issue(0);
-    for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of K-tile t has landed
-        __builtin_amdgcn_s_barrier();                      // ... everyone's has, and stage (t+1)&1 is no longer read
-        if (t + 1 < nk) issue((t + 1) & 1);
-        const char* xs = dsm + (t & 1) * ST5;
+    // Fragments are double-buffered and read one k-step ahead of the MFMAs that consume them (across the K-tile boundary
+    // too); the reads of the next k-step are issued after the first MFMA of the current one, so the lgkmcnt wait in
+    // front of that MFMA never covers reads that were only just issued.
+    struct Frags { bf16x8_t w[2], x[4]; };
+    Frags F0, F1;
+    auto read_frags = [&](Frags& f, int stage, int ks) {
+        const char* xs = dsm + stage * ST5;
         const char* ws = xs + XB5;
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (FORM == FORM_NT) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t wf[2], xf[4];
-            if constexpr (FORM == FORM_NT) {
+            for (int a = 0; a < 2; ++a) f.w[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
 #pragma unroll
-                for (int a = 0; a < 2; ++a) wf[a] = lds_read_frag(ws, tile64_off(wn * 64 + a * 32 + l31, ks * 2 + hi));
+            for (int b = 0; b < 4; ++b) f.x[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
+        } else {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) xf[b] = lds_read_frag(xs, tile64_off(wm * 128 + b * 32 + l31, ks * 2 + hi));
-            } else {
+            for (int a = 0; a < 2; ++a) f.w[a] = tn_frag5(ws, wn * 64 + a * 32, ks * 16, lane);
 #pragma unroll
-                for (int a = 0; a < 2; ++a) wf[a] = tn_frag5(ws, wn * 64 + a * 32, ks * 16, lane);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) xf[b] = tn_frag5(xs, wm * 128 + b * 32, ks * 16, lane);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_32x32x16(wf[a], xf[b], acc[a][b]);
+            for (int b = 0; b < 4; ++b) f.x[b] = tn_frag5(xs, wm * 128 + b * 32, ks * 16, lane);
         }
+    };
+    auto mma_head = [&](const Frags& f) { acc[0][0] = mfma_bf16_32x32x16(f.w[0], f.x[0], acc[0][0]); };
+    auto mma_tail = [&](const Frags& f) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (a + b) acc[a][b] = mfma_bf16_32x32x16(f.w[a], f.x[b], acc[a][b]);
+    };
+
+    if (nk > 0) {
+        issue_x(0);
+        issue_w(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(F0, 0, 0);
+    }
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk;
+        const int cur = t & 1, nxt = cur ^ 1;  // stage nxt was consumed in iteration t-1 (barrier at its end)
+        __builtin_amdgcn_s_setprio(1);
+        mma_head(F0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(F1, cur, 1);
+        if (more) issue_x(nxt);
+        mma_tail(F0);
+        mma_head(F1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(F0, cur, 2);
+        if (more) issue_w(nxt);
+        mma_tail(F1);
+        mma_head(F0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(F1, cur, 3);
+        mma_tail(F0);
+        __builtin_amdgcn_s_setprio(0);
+        // this wave's reads of stage cur are complete and its share of K-tile t+1 has landed ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... everyone's
+        __builtin_amdgcn_s_setprio(1);
+        mma_head(F1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_frags(F0, nxt, 0);
+        mma_tail(F1);
         __builtin_amdgcn_s_setprio(0);
     }
 
