@@ -645,10 +645,14 @@ extern "C" {
 void cx_gemm_set_trace(void* buf) { cx_gemm_v5_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_set_debug(int d) {
     g_dbg = d;
-    cx_gemm_v5_set_persistent((d & 4) == 0);  // bit2: run the 256x256 kernel one-tile-per-workgroup (A/B of the persistent walk)
+    cx_gemm_v5_set_persistent((d & 4) == 0);
+    cx_gemm_v6_force_groups((d >> 8) & 15);  // bits 8..11: force the v6 XCD-grid N-group count (1, 2, 4, 8)  // bit2: run the 256x256 kernel one-tile-per-workgroup (A/B of the persistent walk)
 }
-void cx_gemm_set_variant(int v) { g_variant = (v >= 1 && v <= 5) ? v : 5; }
-int cx_gemm_get_variant(void) { return g_variant; }
+void cx_gemm_set_variant(int v) {  // 6 = variant 5 with the one-wave-per-SIMD kernel (v6) for the persistent NT forms
+    cx_gemm_v5_set_use_v6(v == 6);
+    g_variant = (v >= 1 && v <= 5) ? v : 5;  // out-of-range (incl. 6) -> the default family
+}
+int cx_gemm_get_variant(void) { return (g_variant == 5 && cx_gemm_v5_get_use_v6()) ? 6 : g_variant; }
 void cx_gemm_set_glds(int enable) { g_use_glds = enable ? 1 : 0; }
 int cx_gemm_get_glds(void) { return g_use_glds; }
 

@@ -412,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
             wsrc[j] = p.W + (size_t)gw * p.ldw + c * 8;
         }
     };
+    const bool no_dma = TRACE && (p.dbg & 1);  // experiment (trace build only): main loop without DMA, results wrong
     // A K-tile of either operand is 4 DMA instructions per wave.  They are issued in two halves so that the main loop
     // can spread them between MFMA groups: back-to-back DMA instructions stall the wave at issue (the vector-memory
     // front end accepts ~1 KiB-instruction per ~30 clk per CU), and that stall would serialise with the MFMA phase.
@@ -420,7 +421,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * h + jj;
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            if (!no_dma)
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
             xsrc[j] += BK5;
         }
         if (h == 1) {
@@ -439,7 +441,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5p_kernel(GemmParams p) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * h + jj;
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
+            if (!no_dma)
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(base + (j * 8 + wave) * 1024), 16, 0, 0);
             wsrc[j] += BK5;
         }
         if (h == 1) {
@@ -704,8 +707,12 @@ hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
 }
 
 bool g_v5_persistent = true;
+bool g_v5_use_v6 = true;  // default: persistent NT forms run on the one-wave-per-SIMD kernel (gemm_bf16_v6.hip)
 
 }  // namespace
+
+void cx_gemm_v5_set_use_v6(bool on) { g_v5_use_v6 = on; }
+bool cx_gemm_v5_get_use_v6(void) { return g_v5_use_v6; }
 
 void cx_gemm_v5_set_persistent(bool on) { g_v5_persistent = on; }
 void cx_gemm_v5_set_trace(long long* buf) { g_v5_trace = buf; }
@@ -724,10 +731,12 @@ hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipS
     const bool pers = g_v5_persistent && p.split_k == 1 && (p.N % 8) == 0;
     if (epi == GEMM_EPI_SWIGLU) {
         if (out_mode != GEMM_OUT_BF16) return hipErrorInvalidValue;
-        if (pers && (p.ldo % 8) == 0 && (p.ldo2 % 8) == 0) return launch5p<GEMM_EPI_SWIGLU>(p, stream);
+        if (pers && (p.ldo % 8) == 0 && (p.ldo2 % 8) == 0)
+            return (g_v5_use_v6 && !g_v5_trace) ? cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU, stream) : launch5p<GEMM_EPI_SWIGLU>(p, stream);
         return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_SWIGLU>(p, stream);
     }
-    if (out_mode == GEMM_OUT_BF16 && pers && (p.ldo % 8) == 0) return launch5p<GEMM_EPI_NONE>(p, stream);
+    if (out_mode == GEMM_OUT_BF16 && pers && (p.ldo % 8) == 0)
+        return (g_v5_use_v6 && !g_v5_trace) ? cx_launch_gemm_v6(p, GEMM_EPI_NONE, stream) : launch5p<GEMM_EPI_NONE>(p, stream);
     switch (out_mode) {
         case GEMM_OUT_BF16: return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_NONE>(p, stream);
         case GEMM_OUT_F32: return launch5<FORM_NT, GEMM_OUT_F32, GEMM_EPI_NONE>(p, stream);

@@ -1,0 +1,404 @@
+// gemm_bf16_v6.hip -- persistent 256x256x64 bf16 MFMA GEMM with ONE wave per SIMD (K10).
+//
+// What the phase trace of the 8-wave kernel (gemm_bf16_v5.hip) showed: with two waves per SIMD sharing one MFMA pipe
+// and one barrier per K-tile, the pipe is busy ~64% of the steady-state loop even with the DMA removed -- the two waves
+// fall out of phase (one waits ~600 cycles at every barrier) and the 64x128 wave tile needs 192 ds_read_b128 per
+// K-tile, which together with the 64 KiB of LDS-DMA writes keeps the LDS array busy for most of the iteration.
+//
+// Here a workgroup is 4 waves as 2(M) x 2(N), each owning a 128x128 sub-tile: 4x4 MFMA 32x32x16 accumulators = 256
+// fp32 registers, which live in the AGPR half of the unified 512-entry register file (one wave per SIMD).  Per K-tile a
+// wave issues 64 MFMAs against 32 ds_read_b128 (0.5 reads per MFMA instead of 0.75) and there is no second wave to
+// fall out of phase with.  Everything is software-pipelined in the instruction stream of that one wave: fragments are
+// read one k-step ahead, the 16 DMA instructions of the next K-tiles are spread between MFMAs, and the only
+// synchronisation per K-tile is one raw s_barrier across the 4 waves.
+//
+// LDS map (160 KiB), DMA accounting and the epilogue staging follow the 8-wave persistent kernel: three 32 KiB X slots
+// (X runs two K-tiles ahead), two 32 KiB W slots (one ahead), issue order per iteration [W of t+1][X of t+2] so that
+// "operands of t+1 landed" == s_waitcnt vmcnt(8); at a tile end vmcnt(0) so the epilogue's global stores never mix into
+// the count; epilogue staged through the two slots consumed last, 32 output rows per wave per pass.
+#include "cx_common.h"
+#include "../../include/contrastors_hip.h"
+#include "gemm_params.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+constexpr int BM6 = 256, BN6 = 256, BK6 = 64;
+constexpr int XS6 = 32768;          // one operand K-tile: 256 rows x 128 B
+constexpr int LDS6 = 5 * XS6;       // 3 X slots + 2 W slots
+
+struct Frags6 {
+    bf16x8_t w[4], x[4];
+};
+
+#include "gemm_v6_acc.inc"
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / BK6;
+    // Tile order.  Workgroup b runs on XCD b%8 (own 4 MiB L2).  The 8 XCDs form a gm x gn grid over the tile matrix
+    // (gn = p.sup_n N-groups): XCD (xi, xj) owns M-panels [m_lo, m_hi) x N-tiles [n_lo, n_hi) and its workgroups walk
+    // that block n-fastest, 32 (= workgroups per XCD) consecutive tiles per round.  With gn > 1 an XCD touches only its
+    // slice of W, which then stays L2-resident across rounds instead of being re-streamed for every M-panel.
+    const int per_xcd = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int gn = p.sup_n > 0 ? p.sup_n : 1, gm = 8 / gn;
+    const int xi = xcd / gn, xj = xcd - xi * gn;
+    const int m_lo = p.tiles_m * xi / gm, m_hi = p.tiles_m * (xi + 1) / gm;
+    const int n_lo = p.tiles_n * xj / gn, n_wd = p.tiles_n * (xj + 1) / gn - n_lo;
+    const int nloc = (m_hi - m_lo) * n_wd;
+    auto tile_of = [&](int round) {
+        const int l = round * per_xcd + idx;
+        if (l >= nloc) return ntiles;
+        const int q = l / n_wd;
+        return (m_lo + q) * p.tiles_n + n_lo + (l - q * n_wd);
+    };
+
+    // ---- DMA cursors.  A K-tile of one operand = 32 instructions of 1 KiB (8 rows x 128 B), 8 per wave ---------------
+    const bf16_t* xsrc[8];
+    const bf16_t* wsrc[8];
+    int lx_round = 0, lx_kt = 0, lx_slot = 0;
+    int lw_round = 0, lw_kt = 0, lw_slot = 0;
+    bool lx_live, lw_live;
+    auto x_setup = [&](int tile) {
+        const int tm = tile / p.tiles_n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = (j * 4 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gx = tm * BM6 + r;
+            gx = gx < p.M ? gx : p.M - 1;
+            xsrc[j] = p.X + (size_t)gx * p.ldx + c * 8;
+        }
+    };
+    auto w_setup = [&](int tile) {
+        const int tn = tile % p.tiles_n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = (j * 4 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gw = tn * BN6 + r;
+            gw = gw < p.N ? gw : p.N - 1;
+            wsrc[j] = p.W + (size_t)gw * p.ldw + c * 8;
+        }
+    };
+    // one DMA instruction of the next X / W K-tile (j = 0..7); the cursor advances with the last one
+    auto issue_x1 = [&](int j) {
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(dsm + lx_slot * XS6 + (j * 4 + wave) * 1024), 16, 0, 0);
+        xsrc[j] += BK6;
+    };
+    auto x_advance = [&]() {
+        lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+        if (++lx_kt == nk) {
+            lx_kt = 0;
+            const int t = tile_of(++lx_round);
+            lx_live = t < ntiles;
+            if (lx_live) x_setup(t);
+        }
+    };
+    auto issue_w1 = [&](int j) {
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(dsm + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024), 16, 0, 0);
+        wsrc[j] += BK6;
+    };
+    auto w_advance = [&]() {
+        lw_slot ^= 1;
+        if (++lw_kt == nk) {
+            lw_kt = 0;
+            const int t = tile_of(++lw_round);
+            lw_live = t < ntiles;
+            if (lw_live) w_setup(t);
+        }
+    };
+
+    // Accumulators: block (a = n-block, b = m-block) is index i = 4b + a of gemm_v6_acc.inc, pinned to physical AGPRs
+    // a[16i : 16i+15] and invisible to the compiler: written only by the MFMA asm (the first k-step of a tile uses the
+    // C = 0 form, so nothing is ever zeroed), read only by v6_read_block in the epilogue.
+
+    int cp_round = 0, cp_kt = 0;
+    int cp_tile = tile_of(0);
+    lx_live = lw_live = cp_tile < ntiles;
+    bool x1_issued = false;
+    if (lx_live) {
+        x_setup(cp_tile);
+        w_setup(cp_tile);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_x1(j);  // X of iteration 0
+        x_advance();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_w1(j);  // W of iteration 0
+        w_advance();
+        if (lx_live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) issue_x1(j);  // X of iteration 1
+            x_advance();
+            x1_issued = true;
+        }
+    }
+    int xs_slot = 0, ws_slot = 0;
+
+    Frags6 F0, F1;
+    // fragment i of k-step ks: i = 0..3 -> W n-blocks, 4..7 -> X m-blocks
+    auto read_one = [&](Frags6& f, const char* xs, const char* ws, int ks, int i) {
+        if (i < 4)
+            f.w[i] = lds_read_frag(ws, tile64_off(wn * 128 + i * 32 + l31, ks * 2 + hi));
+        else
+            f.x[i - 4] = lds_read_frag(xs, tile64_off(wm * 128 + (i - 4) * 32 + l31, ks * 2 + hi));
+    };
+    // i-th MFMA of a k-step: a = i & 3, b = i >> 2 (block index == i)
+    auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 3], f.x[i >> 2]); };
+    auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]); };
+    // One k-step: 16 MFMAs on `cur`; after the first one, the 8 reads of the next k-step (into `nxt`) and up to 4 DMA
+    // instructions are interleaved one per MFMA, the rest of the MFMAs follow back to back.
+    // dma_kind: 0 none, 1 W instructions j0..j0+3, 2 X instructions j0..j0+3
+#define CX_KSTEP(MMA, cur, nxt, rxs, rws, rks, dma_kind, j0)                                           \
+    do {                                                                                              \
+        MMA(cur, 0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                            \
+            read_one(nxt, rxs, rws, rks, i_);                                                         \
+            MMA(cur, 1 + i_);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                            \
+            if ((dma_kind) == 1 && w_go) issue_w1((j0) + i_);                                         \
+            if ((dma_kind) == 2 && x_go) issue_x1((j0) + i_);                                         \
+            MMA(cur, 9 + i_);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        MMA(cur, 13);                                                                                 \
+        MMA(cur, 14);                                                                                 \
+        MMA(cur, 15);                                                                                 \
+    } while (0)
+
+    if (cp_tile < ntiles) {
+        // operands of iteration 0 (X_0, W_0); the only younger group is X_1 (8 ops), if issued
+        if (x1_issued) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) read_one(F0, dsm, dsm + 3 * XS6, 0, i);
+    }
+
+    // One K-tile of the current output tile.  `first` (compile time) selects the C = 0 MFMA form for its first k-step:
+    // the first K-tile of every output tile is a peeled copy of this body, so the accumulators are DEFINED there and
+    // only ever updated in place afterwards (no zeroing, no conditional definitions for the register allocator).
+    int pxs_slot = 0, pws_slot = 0;  // slots consumed by the K-tile just finished (the epilogue's staging space)
+    auto kt_body = [&](auto first) {
+        // DMA of this iteration: W of iteration +1 (k-steps 0,1), X of iteration +2 (k-steps 2,3); both target slots
+        // consumed in iteration -1.
+        const bool w_go = lw_live, x_go = lx_live;
+        const char* xs = dsm + xs_slot * XS6;
+        const char* ws = dsm + (3 + ws_slot) * XS6;
+        const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
+        const bool tile_end = cp_kt + 1 == nk;
+        if constexpr (decltype(first)::value) {
+            CX_KSTEP(mma1z, F0, F1, xs, ws, 1, 1, 0);
+        } else {
+            CX_KSTEP(mma1, F0, F1, xs, ws, 1, 1, 0);
+        }
+        CX_KSTEP(mma1, F1, F0, xs, ws, 2, 1, 4);
+        if (w_go) w_advance();
+        CX_KSTEP(mma1, F0, F1, xs, ws, 3, 2, 0);
+        // this wave's reads of the current slots are complete (F1 has landed) ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ... and so are its DMA writes of the next iteration's operands: everything but the 4 X instructions issued in
+        // k-step 2 (the other 4 of that K-tile follow below); everything at a tile end (epilogue stores must not mix
+        // into the DMA accounting)
+        if (x_go && !tile_end) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* nxs = dsm + nxs_slot * XS6;
+        const char* nws = dsm + (3 + nws_slot) * XS6;
+        // (at a tile end these reads fetch the first fragments of the next tile: its operands have landed too)
+        CX_KSTEP(mma1, F1, F0, nxs, nws, 0, 2, 4);
+        if (x_go) x_advance();
+        ++cp_kt;
+        pxs_slot = xs_slot;
+        pws_slot = ws_slot;
+        xs_slot = nxs_slot;
+        ws_slot = nws_slot;
+    };
+
+#pragma unroll 1
+    while (cp_tile < ntiles) {
+        cp_kt = 0;
+        kt_body(std::true_type{});
+#pragma unroll 1
+        while (cp_kt < nk) kt_body(std::false_type{});
+
+        {
+            // MFMA results are read by VALU below; the hazard recogniser does not see through the inline asm
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            // ---- epilogue.  Free LDS: the X slot and the W slot just consumed (32 KiB each); waves 0,1 stage in the
+            // former, waves 2,3 in the latter (16 KiB per wave).  In-flight DMA targets other slots.
+            const int tn = cp_tile % p.tiles_n, tm = cp_tile / p.tiles_n;
+            const int m0 = tm * BM6 + wm * 128, n0 = tn * BN6 + wn * 128;
+            char* my = ((wave < 2) ? dsm + pxs_slot * XS6 : dsm + (3 + pws_slot) * XS6) + (wave & 1) * 16384;
+            constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
+            if constexpr (EPI == GEMM_EPI_NONE) {
+                const bool add_bias = p.bias != nullptr;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        float blk[16];
+                        v6_read_block(4 * b + a, blk);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int nl = a * 32 + 8 * q + 4 * hi;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = blk[4 * q + e] * p.alpha;
+                            if (add_bias) {
+                                const int n = n0 + nl;
+                                if (n < p.N) {
+                                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                                }
+                            }
+                            uint2 pk;
+                            pk.x = pack_bf16x2(v[0], v[1]);
+                            pk.y = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(my + l31 * ROWB + nl * 2) = pk;
+                        }
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < 8; ++ps) {
+                        const int row = ps * 4 + (lane >> 4), ch = lane & 15;
+                        const int m = m0 + b * 32 + row, n = n0 + ch * 8;
+                        const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                        if (m < p.M && n + 8 <= p.N)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                    }
+                }
+            } else {
+                // SwiGLU: weight rows interleaved by 32, so the wave's 128 fused columns are [y0 | g0 | y1 | g1] (32 each)
+                // = one 256-B run per row of the (M, 2I) pre-activation tensor and 64 activation columns.
+                constexpr int AROWB = 144;      // 32 staged rows x 64 bf16 (+16 B pad) = 4608 B
+                char* mya = my + 32 * ROWB;     // separate region: no hazard against the pre-activation staging
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {  // (y, gate) block pair -> 32 activation columns
+                        float yb[16], gb[16];
+                        v6_read_block(4 * b + 2 * pr, yb);
+                        v6_read_block(4 * b + 2 * pr + 1, gb);
+                        if (p.Out) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint2 pk;
+                                pk.x = pack_bf16x2(yb[4 * q], yb[4 * q + 1]);
+                                pk.y = pack_bf16x2(yb[4 * q + 2], yb[4 * q + 3]);
+                                *reinterpret_cast<uint2*>(my + l31 * ROWB + (2 * pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                pk.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
+                                pk.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
+                                *reinterpret_cast<uint2*>(my + l31 * ROWB + ((2 * pr + 1) * 32 + 8 * q + 4 * hi) * 2) = pk;
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {  // the standalone op sees bf16 y / gate (FusedDense outputs)
+                                const float yy = bf16_to_f32(f32_to_bf16(yb[4 * q + e]));
+                                const float gg = bf16_to_f32(f32_to_bf16(gb[4 * q + e]));
+                                o[e] = gg / (1.f + __expf(-gg)) * yy;
+                            }
+                            uint2 pk;
+                            pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+                            *reinterpret_cast<uint2*>(mya + l31 * AROWB + (pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                        }
+                    }
+                    if (p.Out) {
+#pragma unroll
+                        for (int ps = 0; ps < 8; ++ps) {
+                            const int row = ps * 4 + (lane >> 4), ch = lane & 15;
+                            const int m = m0 + b * 32 + row, n = n0 + ch * 8;
+                            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                            if (m < p.M && n < p.N)
+                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                        }
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                        const int m = m0 + b * 32 + row;
+                        const int col = (n0 >> 1) + ch * 8;
+                        const uint4 vv = *reinterpret_cast<const uint4*>(mya + row * AROWB + ch * 16);
+                        if (m < p.M && 2 * col < p.N)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out2) + (size_t)m * p.ldo2 + col) = vv;
+                    }
+                }
+            }
+            cp_tile = tile_of(++cp_round);
+            // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+#undef CX_KSTEP
+}
+
+template <int EPI>
+hipError_t launch6(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI>), dim3(grid), dim3(256), LDS6, stream, p);
+    return hipGetLastError();
+}
+
+int g_v6_force_gn = 0;  // experiments: 1, 2, 4 or 8 forces the N-group count; 0 = heuristic
+
+// N-groups of the XCD grid: the estimated L2-miss traffic is gn * |X| (every X panel is fetched by the gn XCDs of its
+// grid row) + (8 / gn) * |W| when an XCD's W slice (tiles_n / gn row-blocks of 256 x K) can stay L2-resident, and
+// rounds * slice * 8 otherwise; even splits only (no load imbalance between XCDs).
+int cx_gemm_v6_groups(int tiles_m, int tiles_n, int K) {
+    if (g_v6_force_gn) return g_v6_force_gn;
+    const double xb = (double)tiles_m * 256 * K * 2, wb = (double)tiles_n * 256 * K * 2;
+    int best = 1;
+    double best_cost = 0;
+    for (int gn = 1; gn <= 8; gn *= 2) {
+        const int gm = 8 / gn;
+        if ((tiles_n % gn) != 0 || (tiles_m % gm) != 0) continue;
+        const double slice = wb / gn;
+        const double rounds = (double)tiles_m / gm * (tiles_n / gn) / 32.0;
+        const double wcost = slice <= 2.5 * 1048576 ? gm * wb : (rounds < 1 ? 1 : rounds) * slice * 8;
+        const double cost = gn * xb + wcost;
+        if (gn == 1 || cost < best_cost) { best = gn; best_cost = cost; }
+    }
+    return best;
+}
+
+}  // namespace
+
+void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
+
+// NT forms with bf16 output (plain / bias / alpha, or fused SwiGLU), K % 64 == 0, N % 8 == 0, split_k == 1.
+hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
+    p.tiles_m = (p.M + BM6 - 1) / BM6;
+    p.tiles_n = (p.N + BN6 - 1) / BN6;
+    p.sup_n = cx_gemm_v6_groups(p.tiles_m, p.tiles_n, p.K);
+    return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream) : launch6<GEMM_EPI_NONE>(p, stream);
+}

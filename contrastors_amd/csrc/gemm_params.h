@@ -25,5 +25,9 @@ struct GemmParams {
 hipError_t cx_launch_gemm_v3(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v4(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream);
+hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream);
+void cx_gemm_v6_force_groups(int gn);
 void cx_gemm_v5_set_persistent(bool on);
+void cx_gemm_v5_set_use_v6(bool on);
+bool cx_gemm_v5_get_use_v6(void);
 void cx_gemm_v5_set_trace(long long* buf);  // 4 counters per workgroup: wait, compute, epilogue cycles, iterations

@@ -10,13 +10,14 @@ import torch  # noqa: E402
 from contrastors_amd import _C  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variant", type=int, default=5)
+ap.add_argument("--variant", type=int, default=6)
 ap.add_argument("--glds", type=int, default=1)
 ap.add_argument("--chunk", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", type=str, default="")
 ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--tn", type=int, default=1)
+ap.add_argument("--zeros", type=int, default=0, help="all-zero operands: no switching power, clocks stay high")
 ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
 a = ap.parse_args()
 lib = _C.lib()
@@ -39,6 +40,8 @@ for name, (M, N, K) in shapes.items():
         continue
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    if a.zeros:
+        x.zero_(); w.zero_()
     wg = name.endswith("wgrad")
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if wg else torch.bfloat16)
     ws = torch.empty(8 * 6144 * 768 if wg else 1, device=dev)

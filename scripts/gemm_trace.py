@@ -12,6 +12,7 @@ from contrastors_amd import _C  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunk", type=int, default=512)
 ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--zeros", type=int, default=0)
 ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
 a = ap.parse_args()
 lib = _C.lib()
@@ -27,6 +28,8 @@ print("shape        us      TF   | per wave, cycles/iteration: wait  compute  ep
 for name, (M, N, K) in shapes.items():
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    if a.zeros:
+        x.zero_(); w.zero_()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     run = lambda: lib.cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, M, N, K, K, K, N, 0, 1, 1.0, s)
     for _ in range(2):

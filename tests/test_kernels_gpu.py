@@ -44,11 +44,11 @@ def test_probe_ds_read_tr16_pattern():
 
 
 # ------------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", ["v5", "v4", "v3", "v2", "v1_glds", "v1_reg"])
+@pytest.mark.parametrize("variant", ["v6", "v5", "v4", "v3", "v2", "v1_glds", "v1_reg"])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
                                    (257, 6144, 768), (300, 768, 128)])
 def test_gemm_bf16_nt(variant, M, N, K):
-    L().cx_gemm_set_variant({"v5": 5, "v4": 4, "v3": 3, "v2": 2}.get(variant, 1))
+    L().cx_gemm_set_variant({"v6": 6, "v5": 5, "v4": 4, "v3": 3, "v2": 2}.get(variant, 1))
     L().cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
     try:
         x, w = bf(_randn(M, K, seed=1)), bf(_randn(N, K, seed=2, std=0.05))
@@ -73,11 +73,11 @@ def test_gemm_bf16_nt(variant, M, N, K):
         assert e16 < 4e-3, "bf16-out GEMM: one bf16 rounding (2^-9 rel) of the fp32 result"
         assert eacc < 1e-5 and eacc2 < 1e-5
     finally:
-        L().cx_gemm_set_variant(5)
+        L().cx_gemm_set_variant(6)
         L().cx_gemm_set_glds(1)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6])
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
 def test_gemm_swiglu_fused(M, I, K, variant):
     """fc11 || fc12 GEMM with SwiGLU in the epilogue == standalone GEMM + swiglu (interleaved-by-32 weight rows)."""
@@ -125,7 +125,7 @@ def test_wgrad_natural_layout_tn(T, O, I, variant):
     ref = dy.float().T @ a.float()
     e = rel_err(g - 1.0, 2 * ref)
     report("wgrad_tn", T=T, O=O, I=I, e=e)
-    L().cx_gemm_set_variant(5)
+    L().cx_gemm_set_variant(6)
     assert e < 1e-5
 
 
