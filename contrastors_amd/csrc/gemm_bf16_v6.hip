@@ -203,7 +203,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const char* xs = dsm + xs_slot * XS6;
         const char* ws = dsm + (3 + ws_slot) * XS6;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
-        const bool tile_end = cp_kt + 1 == nk;
         if constexpr (decltype(first)::value) {
             CX_KSTEP(mma1z, F0, F1, xs, ws, 1, 1, 0);
         } else {
@@ -215,9 +214,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // this wave's reads of the current slots are complete (F1 has landed) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ... and so are its DMA writes of the next iteration's operands: everything but the 4 X instructions issued in
-        // k-step 2 (the other 4 of that K-tile follow below); everything at a tile end (epilogue stores must not mix
-        // into the DMA accounting)
-        if (x_go && !tile_end) {
+        // k-step 2 (the other 4 of that K-tile follow below).  "All but the newest 4" stays correct across a tile end:
+        // the epilogue's global stores are older than the next iteration's newest 4 and retire in order with them (gfx9
+        // has one in-order vmcnt for loads and stores), so they can only make that wait stronger, never weaker.
+        if (x_go) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
