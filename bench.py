@@ -197,6 +197,16 @@ def main():
     lib.cx_prof_gemm_collect(C.byref(ms), C.byref(fl), C.byref(n_t), C.byref(n_all))
     lib.cx_prof_gemm_config(0, 1)
     if rank == 0:
+        # HBM bytes per GEMM launch: not measurable from inside the process; taken from the committed rocprofv3 PMC
+        # passes of this same command line (scripts/gpu_round.sh PMC=1 -> scripts/pmc_traffic.py) when they were
+        # collected at the same launch sizes (same GradCache chunk), else null.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_gemm_traffic.json")))
+            if tj.get("grad_cache_chunk") == min(args.chunk_size, b):
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1_pmc_gemm_traffic.json"
+        except (OSError, ValueError, KeyError):
+            pass
         pairs_per_s = G * args.steps / dt
         achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
         out = {
@@ -209,8 +219,10 @@ def main():
                        "global_batch": G, "pairs_per_gpu": b, "seq_len": S, "grad_cache_chunk": args.chunk_size,
                        "n_layer": cfg.n_layer, "parallelism": f"dp{world}", "loss_last_step": float(loss.item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "gemm_bf16_nt_kernel (cx_gemm_bf16_nt: fwd, dgrad and wgrad launches)",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
+                         "traffic_source": traffic_src,
+                         "kernel": "bf16 GEMM family: gemm_bf16_v6_kernel (fwd, dgrad, fused SwiGLU fc1) + "
+                                   "gemm_bf16_v5_kernel<TN> (wgrad)",
                          "launches_timed": n_t.value, "launches_total": n_all.value,
                          "avg_launch_us": 1e3 * ms.value / max(1, n_t.value),
                          "algorithmic_flop_per_launch": fl.value / max(1, n_t.value),

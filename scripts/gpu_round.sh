@@ -36,10 +36,11 @@ if [[ $mode == prof || $mode == all ]]; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $out -o bench -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --global-batch 2048 --no-cpu-baseline} > $out/run.log 2>&1; echo "prof exit $?" >> $out/run.log)
   if [[ -n "${PMC:-}" ]]; then
     for ctr in FETCH_SIZE WRITE_SIZE; do
-      (cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o b -- python $OLDPWD/bench.py --steps 1 --warmup 0 --global-batch 512 --no-cpu-baseline > $out/pmc_$ctr.log 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o b -- python $OLDPWD/bench.py --steps 1 --warmup 0 --global-batch ${PMC_BATCH:-1024} --no-cpu-baseline > $out/pmc_$ctr.log 2>&1)
       python $OLDPWD/scripts/pmc_summary.py $out/pmc_$ctr/b_counter_collection.csv $ctr > $out/pmc_${ctr}_summary.txt 2>&1
       rm -rf $out/pmc_$ctr
     done
+    python $OLDPWD/scripts/pmc_traffic.py $out/pmc_FETCH_SIZE_summary.txt $out/pmc_WRITE_SIZE_summary.txt ${PMC_BATCH:-1024} > $out/pmc_gemm_traffic.json 2>&1
   fi
   tail -3 $out/run.log
   find $out -name "*kernel_stats*" | head
