@@ -43,6 +43,11 @@ class CxEncoderDesc(C.Structure):
         ("rot_cos", vp), ("rot_sin", vp),
         ("layers", C.POINTER(CxLayerWeights)),
         ("pool_mode", i32), ("normalize", i32),
+        ("prenorm", i32),
+        ("lnf_g", vp), ("lnf_b", vp), ("glnf_g", vp), ("glnf_b", vp),
+        ("Wpatch", vp), ("bpatch", vp), ("cls_token", vp), ("vit_pos", vp),
+        ("gWpatch", vp), ("gbpatch", vp), ("gcls_token", vp), ("gvit_pos", vp),
+        ("patch_dim", i32),
     ]
 
 
@@ -54,7 +59,7 @@ class CxChunkBuffers(C.Structure):
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
             "ws_f32",
         )
-    ] + [("ws_floats", i64)]
+    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.
@@ -93,6 +98,12 @@ _SIGS = {
     "cx_rotary_apply": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_pool_normalize_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "cx_pool_normalize_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cx_vit_patchify": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_vit_assemble_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cx_vit_assemble_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cx_vit_forward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, vp, i32, i32, i32, i32, i32,
+                             i32, vp, vp]),
+    "cx_vit_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, i32, vp, vp, vp]),
     "cx_infonce_ws_floats": (i64, [i32, i32]),
     "cx_infonce_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_infonce_bwd": (i32, [vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

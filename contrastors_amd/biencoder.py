@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .distributed import gather_with_grad
 from .nomic_bert import NomicBertConfig, NomicBertEngine, VarlenBatch, _EncodeFn
+from .vit import ViTConfig, ViTEngine, _VitEncodeFn
 
 
 @dataclass
@@ -37,7 +38,7 @@ class BiEncoderConfig:
     gradient_checkpointing: bool = False
     encoder: bool = True
     seq_len: int = 2048
-    trunk_config: Optional[NomicBertConfig] = None  # no hub access: the architecture is given explicitly
+    trunk_config: Optional[object] = None  # NomicBertConfig or ViTConfig: no hub access, the architecture is explicit
 
 
 class LogitScale(torch.nn.Module):
@@ -62,6 +63,8 @@ def _default_trunk_config(name: str) -> NomicBertConfig:
         return NomicBertConfig.nomic_bert_2048()
     if "bert-base" in name:
         return NomicBertConfig.bert_base_uncased()
+    if "vit-base-patch16-224" in name or "vit_base_patch16_224" in name:
+        return ViTConfig.vit_base_patch16_224()
     raise ValueError(f"no offline architecture table entry for {name!r}; pass BiEncoderConfig.trunk_config")
 
 
@@ -74,7 +77,9 @@ class BiEncoder(torch.nn.Module):
         if config.pooling not in ("mean", "cls"):
             raise NotImplementedError(f"pooling={config.pooling!r}")
         trunk_cfg = config.trunk_config or _default_trunk_config(config.model_name)
-        self.trunk = NomicBertEngine(trunk_cfg, device=device, pooling=config.pooling, normalize=True, seed=seed)
+        self.is_vision = isinstance(trunk_cfg, ViTConfig)  # image tower: `input_ids` carries the pixel tensor
+        engine_cls = ViTEngine if self.is_vision else NomicBertEngine
+        self.trunk = engine_cls(trunk_cfg, device=device, pooling=config.pooling, normalize=True, seed=seed)
         self.frozen_trunk = bool(config.freeze)
         if self.frozen_trunk:
             self.trunk.eval()
@@ -98,14 +103,21 @@ class BiEncoder(torch.nn.Module):
                 seqlens=None, **kwargs):
         plain = (not self.hamming) and isinstance(self.proj, torch.nn.Identity) and not binarize
         eng_norm = bool(normalize) and plain
-        if seqlens is not None:
-            vb = VarlenBatch.from_lengths(input_ids, seqlens)
+        differentiable = torch.is_grad_enabled() and self.training and not self.frozen_trunk
+        if self.is_vision:  # (B, 3, H, W) pixels, no mask (modeling_biencoder.py:84-86)
+            if differentiable:
+                emb = _VitEncodeFn.apply(self.trunk.flat_decay, self.trunk, input_ids, eng_norm)
+            else:
+                emb, _ = self.trunk.forward_chunk(input_ids, False, eng_norm)
         else:
-            vb = VarlenBatch.from_mask(input_ids, attention_mask)
-        if torch.is_grad_enabled() and self.training and not self.frozen_trunk:
-            emb = _EncodeFn.apply(self.trunk.flat_decay, self.trunk, vb, eng_norm)
-        else:
-            emb, _ = self.trunk.forward_chunk(vb, False, eng_norm)
+            if seqlens is not None:
+                vb = VarlenBatch.from_lengths(input_ids, seqlens)
+            else:
+                vb = VarlenBatch.from_mask(input_ids, attention_mask)
+            if differentiable:
+                emb = _EncodeFn.apply(self.trunk.flat_decay, self.trunk, vb, eng_norm)
+            else:
+                emb, _ = self.trunk.forward_chunk(vb, False, eng_norm)
         if not plain:
             if self.hamming:  # LayerNorm without affine on the pooled vector (modeling_biencoder.py:282-285,307)
                 emb = F.layer_norm(emb, (emb.shape[-1],))
@@ -158,7 +170,7 @@ class DualEncoder(torch.nn.Module):
     sc/models/dual_encoder/modeling_dual_encoder.py:36-68): both towers are called with normalize=False, L2-normalised,
     all-gathered, and the loss is (CE(v -> all t) + CE(t -> all v)) / 2 * world_size with labels arange(n) + n*rank.
     Each direction is one fused similarity+CE kernel (cx_infonce_fwd/bwd); logits are never materialised.  Towers are
-    any modules returning {"embedding": ...} (the native BiEncoder for text; a ViT tower is a later row of SURVEY §8)."""
+    any modules returning {"embedding": ...}: the native BiEncoder over a NomicBertEngine (text) or a ViTEngine (image)."""
 
     def __init__(self, text: torch.nn.Module, vision: torch.nn.Module, logit_scale: LogitScale):
         super().__init__()

@@ -1,5 +1,6 @@
 // engine.hip -- native encoder runtime: one C call enqueues a whole GradCache chunk forward or backward
-// (embeddings -> L post-norm transformer blocks -> pooling -> L2 normalise) on a HIP stream.
+// (embeddings -> L post-norm or pre-norm transformer blocks -> pooling -> L2 normalise) on a HIP stream; text trunks
+// (cx_encoder_*) and the ViT image tower (cx_vit_*) share the block schedule.
 //
 // Mirrors, as a kernel schedule over a caller-owned activation arena, what the reference expresses as python
 // module calls: NomicBertModel.forward (sc/models/encoder/modeling_nomic_bert.py:515-587), NomicBertEncoder.forward
@@ -73,6 +74,170 @@ int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW,
     return cx_gemm_bf16_nt_accum(b->tr_a, b->tr_b, gW, b->ws_f32, b->ws_floats, out_f, in_f, Tp, Tp, Tp, stream);
 }
 
+// ---- transformer blocks, forward.  h0: (T,d) input embeddings.  Returns the final hidden states in *h_final. ------
+// post-norm (sc/layers/block.py:389-463):  h = LN1(attn(h) + h);  h = LN2(mlp(h) + h)
+// pre-norm  (sc/layers/block.py:293-388):  r = x + r;  h = LN1(r);  x = attn(h);  r = x + r;  h = LN2(r);  x = mlp(h);
+//           after the last block  h = ln_f(x + r)  (sc/models/vit/vit.py:253-263).
+// Buffers in pre-norm mode: z1/z2 hold the residual stream r at the two LayerNorms (the GEMM producing x writes into
+// the slot the LayerNorm then completes in place), h1/h2 the normalised inputs of attention / MLP.
+int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Slots& s, const uint16_t* h0,
+                   const int32_t* cu_seqlens, int Bc, int T, int max_seqlen, int save, const uint16_t** h_final,
+                   void* stream) {
+    const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
+    auto mlp = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out) -> int {
+        if (enc->gated) {
+            // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
+            CX_TRY(cx_gemm_bf16_swiglu(x, w.Wfc1, save ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d, s.wfc1, I, stream));
+        } else {
+            CX_TRY(cx_gemm_bf16_nt(x, w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
+            CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
+        }
+        return cx_gemm_bf16_nt(s.act(sl), w.Wfc2, out, w.bfc2, T, d, I, I, I, d, 0, 1, 1.f, stream);
+    };
+    auto attn = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out) -> int {
+        CX_TRY(cx_gemm_bf16_nt(x, w.Wqkv, s.qkv(sl), w.bqkv, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.f, stream));
+        CX_TRY(cx_attn_varlen_fwd(s.qkv(sl), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(sl), s.lse(sl), Bc, H, T,
+                                  max_seqlen, enc->softmax_scale, stream));
+        return cx_gemm_bf16_nt(s.ctx(sl), w.Wout, out, w.bout, T, d, d, d, d, d, 0, 1, 1.f, stream);
+    };
+    if (!enc->prenorm) {
+        const uint16_t* h_in = h0;
+        for (int l = 0; l < L; ++l) {
+            const CxLayerWeights& w = enc->layers[l];
+            const int sl = save ? l : 0;
+            CX_TRY(attn(w, h_in, sl, s.z1(sl)));
+            // z (= attn_out + residual) is only kept for backward; the no-grad pass skips that 1/4 of the LN traffic
+            CX_TRY(cx_layernorm_fwd(s.z1(sl), h_in, w.ln1_g, w.ln1_b, s.h1(sl), save ? s.z1(sl) : nullptr, s.mean1(sl),
+                                    s.rstd1(sl), T, d, enc->ln_eps, stream));
+            CX_TRY(mlp(w, s.h1(sl), sl, s.z2(sl)));
+            CX_TRY(cx_layernorm_fwd(s.z2(sl), s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl), save ? s.z2(sl) : nullptr,
+                                    s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
+            h_in = s.h2(sl);
+        }
+        *h_final = h_in;
+        return CX_OK;
+    }
+    if (!buf->zf || !buf->hf || !buf->meanf || !buf->rstdf || !enc->lnf_g || !enc->lnf_b) return CX_ERR_ARG;
+    const uint16_t* x = h0;        // output of the previous sub-layer (the embeddings for the first block)
+    const uint16_t* r = nullptr;   // residual stream
+    for (int l = 0; l < L; ++l) {
+        const CxLayerWeights& w = enc->layers[l];
+        const int sl = save ? l : 0;
+        CX_TRY(cx_layernorm_fwd(x, r, w.ln1_g, w.ln1_b, s.h1(sl), s.z1(sl), s.mean1(sl), s.rstd1(sl), T, d, enc->ln_eps,
+                                stream));
+        CX_TRY(attn(w, s.h1(sl), sl, s.z2(sl)));
+        CX_TRY(cx_layernorm_fwd(s.z2(sl), s.z1(sl), w.ln2_g, w.ln2_b, s.h2(sl), s.z2(sl), s.mean2(sl), s.rstd2(sl), T, d,
+                                enc->ln_eps, stream));
+        // the MLP output lands where the next LayerNorm completes it in place: the next block's z1 slot, or zf
+        uint16_t* nxt = (l + 1 < L) ? s.z1(save ? l + 1 : 0) : buf->zf;
+        CX_TRY(mlp(w, s.h2(sl), sl, nxt));
+        x = nxt;
+        r = s.z2(sl);
+    }
+    CX_TRY(cx_layernorm_fwd(x, r, enc->lnf_g, enc->lnf_b, buf->hf, buf->zf, buf->meanf, buf->rstdf, T, d, enc->ln_eps,
+                            stream));
+    *h_final = buf->hf;
+    return CX_OK;
+}
+
+int check_bwd_buffers(const CxChunkBuffers* buf) {
+    return (!buf->g_a || !buf->g_b || !buf->g_c || !buf->g_wide || !buf->g_act || !buf->tr_a || !buf->tr_b || !buf->delta ||
+            !buf->ws_f32) ? CX_ERR_ARG : CX_OK;
+}
+
+// The natural-layout wgrad kernel reduces over round_up(T,64) token rows: clear the pad rows of every operand.
+int clear_pad_rows(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Slots& s, int T, void* stream) {
+    const int Tp = (int)round_up(T, 64);
+    if (Tp == T) return CX_OK;
+    const int d = enc->d, I = enc->d_inner, L = enc->n_layer;
+    auto clear = [&](uint16_t* base, int width) {
+        return hipMemsetAsync(base + (size_t)T * width, 0, (size_t)(Tp - T) * width * sizeof(uint16_t),
+                              (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+    };
+    CX_TRY(clear(buf->g_a, d));
+    CX_TRY(clear(buf->g_b, d));
+    CX_TRY(clear(buf->g_c, d));
+    CX_TRY(clear(buf->g_wide, 3 * d));   // used as (T,3d) and as (T,wfc1): clear for both widths
+    CX_TRY(clear(buf->g_wide, s.wfc1));
+    CX_TRY(clear(buf->h0, d));
+    for (int l = 0; l < L; ++l) {
+        CX_TRY(clear(s.act(l), I));
+        CX_TRY(clear(s.h1(l), d));
+        CX_TRY(clear(s.ctx(l), d));
+        CX_TRY(clear(s.h2(l), d));
+    }
+    return CX_OK;
+}
+
+// ---- transformer blocks, backward.  In: gradient of the final hidden states in buf->g_a.  Out: the gradient of the
+// input embeddings as the sum of *da and *db (db may come back NULL). -------------------------------------------------
+int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Slots& s, const int32_t* cu_seqlens, int Bc,
+                    int T, int max_seqlen, const uint16_t** da_out, const uint16_t** db_out, void* stream) {
+    const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
+    // MLP backward: dm -> gradients of fc2 / fc1 parameters, d(mlp input) into buf->g_b
+    auto mlp_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dm, const uint16_t* mlp_in) -> int {
+        if (w.gbfc2) CX_TRY(cx_bias_grad(dm, w.gbfc2, T, d, d, stream));
+        CX_TRY(wgrad(dm, d, s.act(l), I, w.gWfc2, buf, T, stream));
+        CX_TRY(cx_gemm_bf16_nt(dm, w.Wfc2T, buf->g_act, nullptr, T, I, d, d, d, I, 0, 1, 1.f, stream));
+        if (enc->gated) {
+            CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
+        } else {
+            CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), w.bfc1, buf->g_wide, T, I, stream));
+            if (w.gbfc1) CX_TRY(cx_bias_grad(buf->g_wide, w.gbfc1, T, I, I, stream));
+        }
+        CX_TRY(wgrad(buf->g_wide, s.wfc1, mlp_in, d, w.gWfc1, buf, T, stream));
+        return cx_gemm_bf16_nt(buf->g_wide, w.Wfc1T, buf->g_b, nullptr, T, d, s.wfc1, s.wfc1, s.wfc1, d, 0, 1, 1.f, stream);
+    };
+    // attention backward: dx (grad of the out_proj output) -> parameter gradients, d(attention input) into buf->g_b
+    auto attn_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dx, const uint16_t* attn_in) -> int {
+        if (w.gbout) CX_TRY(cx_bias_grad(dx, w.gbout, T, d, d, stream));
+        CX_TRY(wgrad(dx, d, s.ctx(l), d, w.gWout, buf, T, stream));
+        CX_TRY(cx_gemm_bf16_nt(dx, w.WoutT, buf->g_b, nullptr, T, d, d, d, d, d, 0, 1, 1.f, stream));
+        // attention core (+ inverse rotary)
+        CX_TRY(cx_attn_varlen_bwd(buf->g_b, s.qkv(l), s.ctx(l), s.lse(l), cu_seqlens, enc->rot_cos, enc->rot_sin,
+                                  buf->delta, buf->g_wide, Bc, H, T, max_seqlen, enc->softmax_scale, stream));
+        if (w.gbqkv) CX_TRY(cx_bias_grad(buf->g_wide, w.gbqkv, T, 3 * d, 3 * d, stream));
+        CX_TRY(wgrad(buf->g_wide, 3 * d, attn_in, d, w.gWqkv, buf, T, stream));
+        return cx_gemm_bf16_nt(buf->g_wide, w.WqkvT, buf->g_b, nullptr, T, d, 3 * d, 3 * d, 3 * d, d, 0, 1, 1.f, stream);
+    };
+    if (!enc->prenorm) {
+        const uint16_t* da = buf->g_a;
+        const uint16_t* db = nullptr;
+        for (int l = L - 1; l >= 0; --l) {
+            const CxLayerWeights& w = enc->layers[l];
+            const uint16_t* h_in = (l == 0) ? buf->h0 : s.h2(l - 1);
+            // LN2: dz2 = grad of (mlp_out + h1)
+            CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
+                                    w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+            CX_TRY(mlp_bwd(w, l, buf->g_c, s.h1(l)));
+            // LN1: dout = dz2 (residual branch) + dh1 from the MLP
+            CX_TRY(cx_layernorm_bwd(buf->g_c, buf->g_b, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), nullptr, buf->g_a,
+                                    w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+            CX_TRY(attn_bwd(w, l, buf->g_a, h_in));
+            da = buf->g_a;  // dz1: residual branch into h_in
+            db = buf->g_b;  // attention branch into h_in
+        }
+        *da_out = da;
+        *db_out = db;
+        return CX_OK;
+    }
+    // pre-norm: the gradient of the residual stream r rides along as dz_extra of every LayerNorm backward
+    CX_TRY(cx_layernorm_bwd(buf->g_a, nullptr, buf->zf, enc->lnf_g, buf->meanf, buf->rstdf, nullptr, buf->g_c, enc->glnf_g,
+                            enc->glnf_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+    for (int l = L - 1; l >= 0; --l) {   // invariant: buf->g_c = d(x_l + r_l) = gradient of both the MLP output and r
+        const CxLayerWeights& w = enc->layers[l];
+        CX_TRY(mlp_bwd(w, l, buf->g_c, s.h2(l)));                       // -> g_b = d h2
+        CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), /*dz_extra*/ buf->g_c,
+                                buf->g_a, w.gln2_g, w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+        CX_TRY(attn_bwd(w, l, buf->g_a, s.h1(l)));                      // -> g_b = d h1
+        CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), /*dz_extra*/ buf->g_a,
+                                buf->g_c, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+    }
+    *da_out = buf->g_c;
+    *db_out = nullptr;
+    return CX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -83,36 +248,13 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
     if (Bc <= 0 || T <= 0) return CX_OK;
     CX_TRY(check_desc(enc, buf, T));
     (void)hipGetLastError();  // a stale error of some earlier, unrelated runtime call must not fail this launch train
-    const int d = enc->d, I = enc->d_inner, H = enc->n_head;
+    const int d = enc->d, I = enc->d_inner;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
-
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
-    const uint16_t* h_in = buf->h0;
-    for (int l = 0; l < enc->n_layer; ++l) {
-        const CxLayerWeights& w = enc->layers[l];
-        const int sl = save_for_backward ? l : 0;
-        CX_TRY(cx_gemm_bf16_nt(h_in, w.Wqkv, s.qkv(sl), w.bqkv, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.f, stream));
-        CX_TRY(cx_attn_varlen_fwd(s.qkv(sl), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(sl), s.lse(sl), Bc, H, T,
-                                  max_seqlen, enc->softmax_scale, stream));
-        CX_TRY(cx_gemm_bf16_nt(s.ctx(sl), w.Wout, s.z1(sl), w.bout, T, d, d, d, d, d, 0, 1, 1.f, stream));
-        // z (= attn_out + residual) is only kept for backward; the no-grad pass skips that 1/4 of the LN traffic
-        CX_TRY(cx_layernorm_fwd(s.z1(sl), h_in, w.ln1_g, w.ln1_b, s.h1(sl), save_for_backward ? s.z1(sl) : nullptr,
-                                s.mean1(sl), s.rstd1(sl), T, d, enc->ln_eps, stream));
-        if (enc->gated) {
-            // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
-            CX_TRY(cx_gemm_bf16_swiglu(s.h1(sl), w.Wfc1, save_for_backward ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d,
-                                       s.wfc1, I, stream));
-        } else {
-            CX_TRY(cx_gemm_bf16_nt(s.h1(sl), w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
-            CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
-        }
-        CX_TRY(cx_gemm_bf16_nt(s.act(sl), w.Wfc2, s.z2(sl), w.bfc2, T, d, I, I, I, d, 0, 1, 1.f, stream));
-        CX_TRY(cx_layernorm_fwd(s.z2(sl), s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl), save_for_backward ? s.z2(sl) : nullptr,
-                                s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
-        h_in = s.h2(sl);
-    }
-    return cx_pool_normalize_fwd(h_in, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
+    const uint16_t* h_final = nullptr;
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, save_for_backward, &h_final, stream));
+    return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
                                  stream);
 }
 
@@ -121,79 +263,75 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
                         const float* demb, const float* emb_out, void* stream) {
     if (Bc <= 0 || T <= 0) return CX_OK;
     CX_TRY(check_desc(enc, buf, T));
-    if (!demb || !emb_out || !buf->g_a || !buf->g_b || !buf->g_c || !buf->g_wide || !buf->g_act || !buf->tr_a ||
-        !buf->tr_b || !buf->delta || !buf->ws_f32)
-        return CX_ERR_ARG;
+    if (!demb || !emb_out) return CX_ERR_ARG;
+    CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
-    const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
+    const int d = enc->d, I = enc->d_inner;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
-
-    // The natural-layout wgrad kernel reduces over round_up(T,64) token rows: clear the pad rows of every operand.
-    const int Tp = (int)round_up(T, 64);
-    if (Tp > T) {
-        auto clear = [&](uint16_t* base, int width) {
-            return hipMemsetAsync(base + (size_t)T * width, 0, (size_t)(Tp - T) * width * sizeof(uint16_t),
-                                  (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
-        };
-        CX_TRY(clear(buf->g_a, d));
-        CX_TRY(clear(buf->g_b, d));
-        CX_TRY(clear(buf->g_c, d));
-        CX_TRY(clear(buf->g_wide, 3 * d));   // used as (T,3d) and as (T,wfc1): clear for both widths
-        CX_TRY(clear(buf->g_wide, s.wfc1));
-        CX_TRY(clear(buf->h0, d));
-        for (int l = 0; l < L; ++l) {
-            CX_TRY(clear(s.act(l), I));
-            CX_TRY(clear(s.h1(l), d));
-            CX_TRY(clear(s.ctx(l), d));
-            CX_TRY(clear(s.h2(l), d));
-        }
-    }
+    CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
                                  enc->normalize, stream));
-    const uint16_t* da = buf->g_a;
+    const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
-    for (int l = L - 1; l >= 0; --l) {
-        const CxLayerWeights& w = enc->layers[l];
-        const uint16_t* h_in = (l == 0) ? buf->h0 : s.h2(l - 1);
-        // LN2: dz2 = grad of (mlp_out + h1)
-        CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
-                                w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
-        // fc2
-        if (w.gbfc2) CX_TRY(cx_bias_grad(buf->g_c, w.gbfc2, T, d, d, stream));
-        CX_TRY(wgrad(buf->g_c, d, s.act(l), I, w.gWfc2, buf, T, stream));
-        CX_TRY(cx_gemm_bf16_nt(buf->g_c, w.Wfc2T, buf->g_act, nullptr, T, I, d, d, d, I, 0, 1, 1.f, stream));
-        // activation
-        if (enc->gated) {
-            CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
-        } else {
-            CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), w.bfc1, buf->g_wide, T, I, stream));
-            if (w.gbfc1) CX_TRY(cx_bias_grad(buf->g_wide, w.gbfc1, T, I, I, stream));
-        }
-        // fc1
-        CX_TRY(wgrad(buf->g_wide, s.wfc1, s.h1(l), d, w.gWfc1, buf, T, stream));
-        CX_TRY(cx_gemm_bf16_nt(buf->g_wide, w.Wfc1T, buf->g_b, nullptr, T, d, s.wfc1, s.wfc1, s.wfc1, d, 0, 1, 1.f,
-                               stream));
-        // LN1: dout = dz2 (residual branch) + dh1 from the MLP
-        CX_TRY(cx_layernorm_bwd(buf->g_c, buf->g_b, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), nullptr, buf->g_a,
-                                w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
-        // out_proj
-        if (w.gbout) CX_TRY(cx_bias_grad(buf->g_a, w.gbout, T, d, d, stream));
-        CX_TRY(wgrad(buf->g_a, d, s.ctx(l), d, w.gWout, buf, T, stream));
-        CX_TRY(cx_gemm_bf16_nt(buf->g_a, w.WoutT, buf->g_b, nullptr, T, d, d, d, d, d, 0, 1, 1.f, stream));
-        // attention core (+ inverse rotary)
-        CX_TRY(cx_attn_varlen_bwd(buf->g_b, s.qkv(l), s.ctx(l), s.lse(l), cu_seqlens, enc->rot_cos, enc->rot_sin,
-                                  buf->delta, buf->g_wide, Bc, H, T, max_seqlen, enc->softmax_scale, stream));
-        // Wqkv
-        if (w.gbqkv) CX_TRY(cx_bias_grad(buf->g_wide, w.gbqkv, T, 3 * d, 3 * d, stream));
-        CX_TRY(wgrad(buf->g_wide, 3 * d, h_in, d, w.gWqkv, buf, T, stream));
-        CX_TRY(cx_gemm_bf16_nt(buf->g_wide, w.WqkvT, buf->g_b, nullptr, T, d, 3 * d, 3 * d, 3 * d, d, 0, 1, 1.f,
-                               stream));
-        da = buf->g_a;  // dz1: residual branch into h_in
-        db = buf->g_b;  // attention branch into h_in
-    }
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
     return cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                            enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);
+}
+
+// ---- ViT image tower -------------------------------------------------------------------------------------------------
+int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
+                   const int32_t* cu_seqlens, int Bc, int Cc, int H, int W, int patch, int save_for_backward,
+                   float* emb_out, void* stream) {
+    if (Bc <= 0) return CX_OK;
+    if (!enc || !buf || patch <= 0 || (H % patch) || (W % patch)) return CX_ERR_ARG;
+    const int P = (H / patch) * (W / patch), S = P + 1, T = Bc * S;
+    CX_TRY(check_desc(enc, buf, T));
+    if (!enc->Wpatch || !enc->cls_token || !enc->vit_pos || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
+    if (enc->patch_dim != Cc * patch * patch || (enc->patch_dim % 64) != 0) return CX_ERR_SHAPE;
+    (void)hipGetLastError();
+    const int d = enc->d, I = enc->d_inner;
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
+    CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
+                           enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
+    CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
+    const uint16_t* h_final = nullptr;
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, save_for_backward, &h_final, stream));
+    return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
+                                 stream);
+}
+
+int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc, int n_patch,
+                    const float* demb, const float* emb_out, void* stream) {
+    if (Bc <= 0) return CX_OK;
+    if (!enc || !buf || n_patch <= 0) return CX_ERR_ARG;
+    const int P = n_patch, S = P + 1, T = Bc * S;
+    CX_TRY(check_desc(enc, buf, T));
+    if (!demb || !emb_out || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
+    CX_TRY(check_bwd_buffers(buf));
+    (void)hipGetLastError();
+    const int d = enc->d, I = enc->d_inner;
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
+    CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
+                                 enc->normalize, stream));
+    const uint16_t* da = nullptr;
+    const uint16_t* db = nullptr;
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, S, &da, &db, stream));
+    if (db) return CX_ERR_ARG;  // (post-norm ViT would need the two branches summed first; no such model family)
+    // d(embeddings) -> cls / position gradients and the contiguous d(projection) rows; pad rows of both wgrad operands
+    // (patch_in was written by the forward of this chunk and is still intact) are cleared for the 64-row reduction
+    const int Tp = Bc * P, Tpp = (int)round_up(Tp, 64);
+    if (Tpp > Tp) {
+        if (hipMemsetAsync(buf->patch_proj + (size_t)Tp * d, 0, (size_t)(Tpp - Tp) * d * 2, (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(buf->patch_in + (size_t)Tp * enc->patch_dim, 0, (size_t)(Tpp - Tp) * enc->patch_dim * 2,
+                           (hipStream_t)stream) != hipSuccess)
+            return CX_ERR_LAUNCH;
+    }
+    CX_TRY(cx_vit_assemble_bwd(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, stream));
+    if (enc->gbpatch) CX_TRY(cx_bias_grad(buf->patch_proj, enc->gbpatch, Tp, d, d, stream));
+    return wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream);
 }
 
 int cx_abi_version(void) { return 1; }

@@ -119,8 +119,17 @@ class _ChunkArena:
         t["yg"] = torch.empty(n_slots, T_cap, wfc1, **bf)
         t["act"] = torch.empty(n_slots, T_cap, I, **bf)
         t["pool_norm"] = torch.empty(B_cap, **f32)
+        patch_dim = int(getattr(cfg, "patch_dim", 0) or 0)
+        if getattr(cfg, "prenorm", False):  # input / output / statistics of the final LayerNorm
+            t["zf"] = torch.empty(T_cap, d, **bf)
+            t["hf"] = torch.empty(T_cap, d, **bf)
+            t["meanf"] = torch.empty(T_cap, **f32)
+            t["rstdf"] = torch.empty(T_cap, **f32)
+        if patch_dim:  # ViT front end: patchified pixels and their projection
+            t["patch_in"] = torch.empty(T_cap, patch_dim, **bf)
+            t["patch_proj"] = torch.empty(T_cap, d, **bf)
         if with_backward:
-            wide = max(3 * d, wfc1)
+            wide = max(3 * d, wfc1, patch_dim)
             for n in ("g_a", "g_b", "g_c"):
                 t[n] = torch.empty(T_cap, d, **bf)
             t["g_wide"] = torch.empty(T_cap, wide, **bf)
@@ -212,28 +221,7 @@ class NomicBertEngine(torch.nn.Module):
             raise NotImplementedError(f"pooling={pooling}")
         self.pool_mode = 0 if pooling == "mean" else 1
         self.normalize_default = bool(normalize)
-        cfg = config
-        d, I, L = cfg.n_embd, cfg.n_inner, cfg.n_layer
-        wfc1 = 2 * I if cfg.gated else I
-
-        # ---- parameter registry: (storage name, shape) --------------------------------------------------------
-        decay: List[Tuple[str, Tuple[int, ...]]] = [("embeddings.word_embeddings.weight", (cfg.vocab_size, d))]
-        if cfg.rotary_emb_fraction == 0.0:
-            decay.append(("embeddings.position_embeddings.weight", (cfg.max_position_embeddings, d)))
-        decay.append(("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, d)))
-        nodecay: List[Tuple[str, Tuple[int, ...]]] = [("emb_ln.weight", (d,)), ("emb_ln.bias", (d,))]
-        for l in range(L):
-            p = f"encoder.layers.{l}."
-            decay += [(p + "attn.Wqkv.weight", (3 * d, d)), (p + "attn.out_proj.weight", (d, d)),
-                      (p + "mlp.fc1_fused.weight", (wfc1, d)), (p + "mlp.fc2.weight", (d, I))]
-            if cfg.qkv_proj_bias:
-                nodecay += [(p + "attn.Wqkv.bias", (3 * d,)), (p + "attn.out_proj.bias", (d,))]
-            if cfg.mlp_fc1_bias:
-                nodecay.append((p + "mlp.fc1_fused.bias", (wfc1,)))
-            if cfg.mlp_fc2_bias:
-                nodecay.append((p + "mlp.fc2.bias", (d,)))
-            nodecay += [(p + "norm1.weight", (d,)), (p + "norm1.bias", (d,)),
-                        (p + "norm2.weight", (d,)), (p + "norm2.bias", (d,))]
+        decay, nodecay = self._param_specs()
         self._layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
         for name, shape in decay:
@@ -244,7 +232,7 @@ class NomicBertEngine(torch.nn.Module):
             self._layout[name] = (off, shape)
             off += _round_up(int(np.prod(shape)), 64)
         self.n_total = off
-        self._linear_names = [n for n, s in decay if ".layers." in n]
+        self._linear_names = [n for n, s in decay if self._is_linear(n)]
         self._lin_begin = self._layout[self._linear_names[0]][0]
         self._lin_end = self.n_decay
 
@@ -269,6 +257,46 @@ class NomicBertEngine(torch.nn.Module):
         self.sync_shadows()
 
     # ------------------------------------------------------------------------------------------------ parameters
+    _LAYER_PREFIX = "encoder.layers.{l}."
+
+    def _layer_specs(self, l: int):
+        """(decay, no-decay) parameter specs of transformer block l, keyed like the reference."""
+        cfg = self.config
+        d, I = cfg.n_embd, cfg.n_inner
+        wfc1 = 2 * I if cfg.gated else I
+        p = self._LAYER_PREFIX.format(l=l)
+        decay = [(p + "attn.Wqkv.weight", (3 * d, d)), (p + "attn.out_proj.weight", (d, d)),
+                 (p + "mlp.fc1_fused.weight", (wfc1, d)), (p + "mlp.fc2.weight", (d, I))]
+        nodecay = []
+        if cfg.qkv_proj_bias:
+            nodecay += [(p + "attn.Wqkv.bias", (3 * d,)), (p + "attn.out_proj.bias", (d,))]
+        if cfg.mlp_fc1_bias:
+            nodecay.append((p + "mlp.fc1_fused.bias", (wfc1,)))
+        if cfg.mlp_fc2_bias:
+            nodecay.append((p + "mlp.fc2.bias", (d,)))
+        nodecay += [(p + "norm1.weight", (d,)), (p + "norm1.bias", (d,)),
+                    (p + "norm2.weight", (d,)), (p + "norm2.bias", (d,))]
+        return decay, nodecay
+
+    def _param_specs(self):
+        """Parameter registry: (storage name, shape) lists for the decay / no-decay groups of sc/optimizer.py:16-25.
+        Every Linear weight that needs a bf16 shadow sits at the END of the decay list (one contiguous region)."""
+        cfg = self.config
+        d = cfg.n_embd
+        decay: List[Tuple[str, Tuple[int, ...]]] = [("embeddings.word_embeddings.weight", (cfg.vocab_size, d))]
+        if cfg.rotary_emb_fraction == 0.0:
+            decay.append(("embeddings.position_embeddings.weight", (cfg.max_position_embeddings, d)))
+        decay.append(("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, d)))
+        nodecay: List[Tuple[str, Tuple[int, ...]]] = [("emb_ln.weight", (d,)), ("emb_ln.bias", (d,))]
+        for l in range(cfg.n_layer):
+            dl, nl = self._layer_specs(l)
+            decay += dl
+            nodecay += nl
+        return decay, nodecay
+
+    def _is_linear(self, name: str) -> bool:
+        return ".layers." in name or name.startswith("layers.")
+
     def p(self, name: str) -> torch.Tensor:
         off, shape = self._layout[name]
         return self.flat_param[off: off + int(np.prod(shape))].view(shape)
@@ -398,7 +426,7 @@ class NomicBertEngine(torch.nn.Module):
         P = lambda n: self.p(n).data_ptr() if n in self._layout else None  # noqa: E731
         G = lambda n: self.g(n).data_ptr() if n in self._layout else None  # noqa: E731
         for l in range(L):
-            pre = f"encoder.layers.{l}."
+            pre = self._LAYER_PREFIX.format(l=l)
             lw = self._layers_arr[l]
             for fld, nm in (("Wqkv", "attn.Wqkv.weight"), ("Wout", "attn.out_proj.weight"),
                             ("Wfc1", "mlp.fc1_fused.weight"), ("Wfc2", "mlp.fc2.weight")):
@@ -415,8 +443,9 @@ class NomicBertEngine(torch.nn.Module):
                 setattr(lw, "g" + fld, G(pre + nm))
         e = _C.CxEncoderDesc()
         e.n_layer, e.d, e.n_head, e.d_inner, e.gated = L, cfg.n_embd, cfg.n_head, cfg.n_inner, int(cfg.gated)
-        e.vocab, e.padding_idx = cfg.vocab_size, cfg.pad_token_id
-        e.max_pos = cfg.max_position_embeddings if cfg.rotary_emb_fraction == 0 else cfg.n_positions
+        e.vocab, e.padding_idx = getattr(cfg, "vocab_size", 0), getattr(cfg, "pad_token_id", 0)
+        e.max_pos = (getattr(cfg, "max_position_embeddings", 0) if cfg.rotary_emb_fraction == 0
+                     else getattr(cfg, "n_positions", 0))
         e.ln_eps = cfg.layer_norm_epsilon
         e.softmax_scale = 1.0 / math.sqrt(64.0)  # 1/norm_factor, sc/layers/attention.py:44-48,163
         e.word_emb = P("embeddings.word_embeddings.weight")

@@ -200,6 +200,16 @@ typedef struct CxEncoderDesc {
     const float* rot_cos; const float* rot_sin; /* NULL when rotary_emb_fraction == 0 */
     const CxLayerWeights* layers;              /* HOST array of n_layer entries (device pointers inside) */
     int pool_mode, normalize;
+    /* ---- pre-norm trunks (sc/layers/block.py:293-388) and the ViT image tower (sc/models/vit/vit.py:176-276) ---- */
+    int prenorm;                               /* 0: post-norm blocks (BERT family); 1: pre-norm blocks + final LN */
+    const float* lnf_g; const float* lnf_b;    /* final LayerNorm ln_f (prenorm only) */
+    float* glnf_g; float* glnf_b;
+    const uint16_t* Wpatch;                    /* ViT: bf16 (d, patch_dim) patch projection; NULL for text trunks */
+    const float* bpatch;                       /* fp32[d] or NULL */
+    const float* cls_token;                    /* fp32[d] */
+    const float* vit_pos;                      /* fp32 (n_patch + 1, d) */
+    float* gWpatch; float* gbpatch; float* gcls_token; float* gvit_pos;
+    int patch_dim;                             /* C * p * p */
 } CxEncoderDesc;
 
 /* Per-chunk activation arena (device memory owned by the caller).  save_for_backward = 0 lets every layer reuse
@@ -229,6 +239,11 @@ typedef struct CxChunkBuffers {
     float* delta;               /* (H,T) */
     float* ws_f32;              /* split-K workspace for the wgrad GEMMs */
     long ws_floats;
+    /* pre-norm trunks: input of / output of the final LayerNorm (single slot), its statistics */
+    uint16_t* zf; uint16_t* hf; float* meanf; float* rstdf;
+    /* ViT front end: patchified pixels (Bc*n_patch rounded up to 64 rows, patch_dim) and their projection (.., d);
+     * patch_proj doubles as the gradient of the projection in backward */
+    uint16_t* patch_in; uint16_t* patch_proj;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.
@@ -241,6 +256,23 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
 int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
                         const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
                         const float* demb, const float* emb_out, void* stream);
+
+/* ---- ViT image tower (sc/models/vit/vit.py:176-276 ViTModel.forward, sc/layers/embedding.py:465-516
+ *      PatchEmbedding.forward, sc/models/biencoder/modeling_biencoder.py:287-319 pooling): one call per chunk.
+ * pixels: (Bc, C, H, W) fp32 or bf16 (pixels_bf16 != 0) device tensor; n_patch = (H/p)*(W/p); sequences have
+ * n_patch + 1 tokens ([cls] first); cu_seqlens: (Bc+1) int32 = multiples of n_patch + 1.  desc->prenorm selects the
+ * block order (ViT-B/16: 1), desc->Wpatch etc. must be set.  backward accumulates every parameter gradient. */
+int cx_vit_patchify(const void* pixels, int pixels_bf16, uint16_t* patches, int B, int C, int H, int W, int patch,
+                    void* stream);
+int cx_vit_assemble_fwd(const uint16_t* proj, const float* cls_token, const float* pos_embed, uint16_t* out, int B,
+                        int P, int d, void* stream);
+int cx_vit_assemble_bwd(const uint16_t* dz, uint16_t* dproj, float* gcls, float* gpos, int B, int P, int d,
+                        void* stream);
+int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
+                   const int32_t* cu_seqlens, int Bc, int C, int H, int W, int patch, int save_for_backward,
+                   float* emb_out, void* stream);
+int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc,
+                    int n_patch, const float* demb, const float* emb_out, void* stream);
 
 /* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */

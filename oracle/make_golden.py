@@ -19,7 +19,7 @@ import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from oracle import encoder_ref, ref_import  # noqa: E402
+from oracle import encoder_ref, ref_import, vit_ref  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 
@@ -97,6 +97,58 @@ def gen_encoder(name, cfgd, seed):
                         probe=probe.numpy(), weight_checksum=checksum(sd), **keep,
                         **{"cfg/" + k: np.array(v) for k, v in cfgd.items()})
     print(name, "hidden", tuple(hid.shape), "emb norm", float(emb.norm()))
+
+
+TINY_VIT = dict(n_embd=256, n_layer=2, n_head=4, n_inner=512, img_size=32, patch_size=8, num_channels=3,
+                layer_norm_epsilon=1e-6)
+
+
+def gen_vit(name, cfgd, seed):
+    """tests/golden/vit_tiny.npz: the reference ViTModel (sc/models/vit/vit.py) run on CPU in fp32."""
+    from transformers import GPT2Config
+
+    vit = ref_import.load_vit()
+    cfg = cfg_ns(cfgd)
+    c = GPT2Config(
+        n_embd=cfg.n_embd, n_layer=cfg.n_layer, n_head=cfg.n_head, n_inner=cfg.n_inner, activation_function="gelu",
+        vocab_size=0, n_positions=0, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+        layer_norm_epsilon=cfg.layer_norm_epsilon, initializer_range=0.02, bos_token_id=None, eos_token_id=None,
+        drop_path_rate=0.0, prepre_layernom=False, layer_scale=False, layer_scale_init=None, img_size=cfg.img_size,
+        patch_size=cfg.patch_size, num_channels=cfg.num_channels, prenorm=True, parallel_block=False,
+        parallel_block_tied_norm=False, rotary_emb_fraction=0, tie_word_embeddings=False, fused_dropout_add_ln=False,
+        fused_bias_fc=False, patch_embed_bias=True, use_flash_attn=False, qkv_proj_bias=True, mlp_fc1_bias=True,
+        mlp_fc2_bias=True, use_rms_norm=False, causal=False, hidden_features_scaling_factor=1.0, mask_token=False,
+        learned_pos_embedding=False, patch_dropout=0, sinusoidal_pos_embedding=False)
+    m = vit.ViTModel(c).float()
+    sd = vit_ref.random_state_dict(cfg, seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    pixels = torch.randn(5, cfg.num_channels, cfg.img_size, cfg.img_size, generator=g)
+    hid = m(pixels).last_hidden_state
+    out = {}
+    for pooling in ("cls", "mean"):
+        m.zero_grad()
+        # BiEncoder pooling restated (modeling_biencoder.py:44-49,79-90,317) on the REFERENCE hidden states
+        e = hid[:, 0] if pooling == "cls" else hid.mean(1)
+        emb = torch.nn.functional.normalize(e, dim=-1)
+        probe = torch.randn(emb.shape, generator=torch.Generator().manual_seed(seed + 2))
+        (emb * probe).sum().backward(retain_graph=True)
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        out[f"{pooling}/embedding"] = emb.detach().numpy()
+        out[f"{pooling}/probe"] = probe.numpy()
+        for k, gten in grads.items():
+            out[f"{pooling}/gnorm/" + k] = np.array(float(gten.norm()))
+        out[f"{pooling}/g/embeddings.cls_token"] = grads["embeddings.cls_token"].numpy()
+        out[f"{pooling}/g/embeddings.pos_embed"] = grads["embeddings.pos_embed"].numpy()
+        out[f"{pooling}/g/embeddings.proj.weight[:16,:16]"] = grads["embeddings.proj.weight"][:16, :16].numpy()
+        out[f"{pooling}/g/layers.0.attn.Wqkv.weight[:16,:16]"] = grads["layers.0.attn.Wqkv.weight"][:16, :16].numpy()
+        out[f"{pooling}/g/layers.1.mlp.fc2.weight[:16,:16]"] = grads["layers.1.mlp.fc2.weight"][:16, :16].numpy()
+        out[f"{pooling}/g/ln_f.weight"] = grads["ln_f.weight"].numpy()
+    np.savez_compressed(GOLD / f"{name}.npz", seed=seed, pixels=pixels.numpy(), hidden=hid.detach().numpy(),
+                        weight_checksum=checksum(sd), **out, **{"cfg/" + k: np.array(v) for k, v in cfgd.items()})
+    print(name, "hidden", tuple(hid.shape))
 
 
 class _Scale(torch.nn.Module):
@@ -200,7 +252,11 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     GOLD.mkdir(parents=True, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixture
+        gen_vit("vit_tiny", TINY_VIT, 5)
+        sys.exit(0)
     gen_encoder("encoder_nomic_tiny", TINY_NOMIC, 1)
     gen_encoder("encoder_bert_tiny", TINY_BERT, 2)
     gen_clip_loss_single()
     gen_multirank()
+    gen_vit("vit_tiny", TINY_VIT, 5)

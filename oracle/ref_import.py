@@ -50,3 +50,65 @@ def load():
         return m
 
     return ref_loss, _load("configuration_hf_nomic_bert"), _load("modeling_hf_nomic_bert")
+
+
+def load_vit():
+    """-> the reference's sc/models/vit/vit.py module, importable on a CPU-only host: `flash_attn` names come from
+    this repo's shim (import only), `torchvision.ops.StochasticDepth` (p = 0 here) and `megablocks` are stubbed, and
+    the attention core the reference takes from the third-party flash-attn package is replaced by the exact softmax
+    attention it implements (fp32).  Everything else that runs is the reference's own python."""
+    load()
+    import torch
+
+    import contrastors_amd.flash_attn_api as fa
+
+    fa.install()
+
+    def synth(name, path):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [str(path)]
+            sys.modules[name] = m
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__spec__ = M.ModuleSpec(name, None)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules.setdefault(name, m)
+        return sys.modules[name]
+
+    synth("contrastors.models", REF_ROOT / "models")
+    synth("contrastors.models.vit", REF_ROOT / "models" / "vit")
+
+    class StochasticDepth(torch.nn.Module):
+        def __init__(self, p, mode):
+            super().__init__()
+            assert p == 0
+            self.p = p
+
+        def forward(self, x):
+            return x
+
+    class _Absent:
+        def __init__(self, *a, **k):
+            raise RuntimeError("megablocks is not available")
+
+    ops = stub("torchvision.ops", StochasticDepth=StochasticDepth)
+    stub("torchvision", ops=ops)
+    layers = stub("megablocks.layers", dmoe=types.SimpleNamespace(dMoE=_Absent, ParallelDroplessMLP=_Absent))
+    stub("megablocks", layers=layers)
+    stub("megablocks.layers.arguments", Arguments=_Absent)
+    stub("megablocks.layers.dmoe", dMoE=_Absent, ParallelDroplessMLP=_Absent)
+    vit = importlib.import_module("contrastors.models.vit.vit")
+    ratt = importlib.import_module("contrastors.layers.attention")
+
+    def exact_qkvpacked(qkv, dropout_p=0.0, softmax_scale=None, causal=False, return_attn_probs=False, **kw):
+        assert dropout_p == 0.0 and not causal
+        q, k, v = qkv.unbind(2)  # (B, S, H, D)
+        sc = float(softmax_scale) if softmax_scale is not None else q.shape[-1] ** -0.5
+        att = torch.einsum("bshd,bthd->bhst", q, k) * sc
+        return torch.einsum("bhst,bthd->bshd", att.softmax(-1), v)
+
+    ratt.flash_attn_qkvpacked_func = exact_qkvpacked
+    return vit

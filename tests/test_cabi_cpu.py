@@ -41,14 +41,16 @@ def test_ctypes_struct_layout_matches_c(tmp_path, built):
     src = tmp_path / "layout.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "contrastors_hip.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu\\n\", sizeof(CxLayerWeights), sizeof(CxEncoderDesc),"
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(CxLayerWeights), sizeof(CxEncoderDesc),"
         " sizeof(CxChunkBuffers), offsetof(CxEncoderDesc, layers), offsetof(CxEncoderDesc, word_emb),"
-        " offsetof(CxChunkBuffers, delta)); return 0;}\n")
+        " offsetof(CxChunkBuffers, delta), offsetof(CxEncoderDesc, patch_dim), offsetof(CxEncoderDesc, Wpatch),"
+        " offsetof(CxChunkBuffers, patch_proj)); return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     want = [C.sizeof(_C.CxLayerWeights), C.sizeof(_C.CxEncoderDesc), C.sizeof(_C.CxChunkBuffers),
-            _C.CxEncoderDesc.layers.offset, _C.CxEncoderDesc.word_emb.offset, _C.CxChunkBuffers.delta.offset]
+            _C.CxEncoderDesc.layers.offset, _C.CxEncoderDesc.word_emb.offset, _C.CxChunkBuffers.delta.offset,
+            _C.CxEncoderDesc.patch_dim.offset, _C.CxEncoderDesc.Wpatch.offset, _C.CxChunkBuffers.patch_proj.offset]
     assert got == want
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import encoder_ref, infonce_ref
+from oracle import encoder_ref, infonce_ref, vit_ref
 
 
 def _cfg(g):
@@ -113,3 +113,33 @@ def test_gradcache_ddp_two_ranks(gold):
         if k.startswith("r0/gnorm/"):
             n = k[len("r0/gnorm/"):]
             assert abs(float(sd[n].grad.norm()) - float(g[k])) <= 2e-3 * max(1e-3, float(g[k])), n
+
+
+def test_vit_restatement_matches_reference(gold):
+    """oracle/vit_ref.py vs the reference's own ViTModel python (sc/models/vit/vit.py) on CPU fp32: hidden states,
+    pooled embeddings for both poolings, every parameter-gradient norm and five gradient slices."""
+    g = gold("vit_tiny")
+    cfg = _cfg(g)
+    sd = vit_ref.random_state_dict(cfg, int(g["seed"]))
+    cs = np.array([float(sum(v.double().sum() for v in sd.values())),
+                   float(sum((v.double() ** 2).sum() for v in sd.values()))])
+    np.testing.assert_allclose(cs, g["weight_checksum"], rtol=1e-12)
+    for v in sd.values():
+        v.requires_grad_(True)
+    pix = torch.from_numpy(g["pixels"])
+    np.testing.assert_allclose(vit_ref.vit_hidden(sd, cfg, pix).detach().numpy(), g["hidden"], atol=2e-5, rtol=1e-4)
+    for pooling in ("cls", "mean"):
+        for v in sd.values():
+            v.grad = None
+        emb = vit_ref.vit_embedding(sd, cfg, pix, pooling)
+        np.testing.assert_allclose(emb.detach().numpy(), g[f"{pooling}/embedding"], atol=2e-6)
+        (emb * torch.from_numpy(g[f"{pooling}/probe"])).sum().backward()
+        for k in g.files:
+            if k.startswith(f"{pooling}/gnorm/"):
+                n = k[len(pooling) + 7:]
+                assert abs(float(sd[n].grad.norm()) - float(g[k])) <= 1e-4 * max(1.0, float(g[k])), n
+        for n, sl in (("embeddings.cls_token", None), ("embeddings.pos_embed", None), ("ln_f.weight", None),
+                      ("embeddings.proj.weight", 16), ("layers.0.attn.Wqkv.weight", 16), ("layers.1.mlp.fc2.weight", 16)):
+            got = sd[n].grad if sl is None else sd[n].grad[:sl, :sl]
+            key = f"{pooling}/g/{n}" + ("" if sl is None else "[:16,:16]")
+            np.testing.assert_allclose(got.numpy(), g[key], atol=2e-5, rtol=1e-4)

@@ -1,0 +1,148 @@
+"""ViT image tower (cx_vit_forward / cx_vit_backward: patchify, patch projection, cls + position embeddings, pre-norm
+blocks, ln_f, pooling) vs (1) the golden fixture produced by the reference's own ViTModel python and (2) the fp32 oracle
+at the ViT-B/16 architecture of BASELINE configs 4/5, judged with the reference's tolerance rule
+err(new) <= 3 * err(bf16 eager) (tests/test_flash_vit.py:55-67)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from contrastors_amd.vit import ViTConfig, ViTEngine
+from oracle import vit_ref
+from tests.gpu_util import max_err, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _oracle(sd, ns, pix, pooling, bf16):
+    sdd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        emb = vit_ref.vit_embedding(sdd, ns, pix, pooling)
+    return emb.float(), sdd
+
+
+def _run(cfg, ns, sd, pix, pooling, probe):
+    eng = ViTEngine(cfg, device=DEV, pooling=pooling)
+    eng.load_reference_state_dict(sd)
+    eng.train()
+    emb, arena = eng.forward_chunk(pix, True)
+    emb2, _ = eng.forward_chunk(pix, False)
+    assert torch.equal(emb, emb2), "no-grad (single slot) forward must equal the saving forward"
+    eng.zero_grad()
+    eng.backward_chunk(pix, arena, probe)
+    return emb, eng.reference_grad_dict()
+
+
+@pytest.mark.parametrize("pooling", ["cls", "mean"])
+def test_vit_matches_reference_golden(gold, pooling):
+    g = gold("vit_tiny")
+    d = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg/")}
+    cfg, ns = ViTConfig(**d), SimpleNamespace(**d)
+    sd = vit_ref.random_state_dict(ns, int(g["seed"]))
+    pix = torch.from_numpy(g["pixels"]).to(DEV)
+    probe = torch.from_numpy(g[f"{pooling}/probe"]).to(DEV)
+    emb, grads = _run(cfg, ns, sd, pix, pooling, probe)
+    gold_emb = torch.from_numpy(g[f"{pooling}/embedding"]).to(DEV)
+    emb16, sd16 = _oracle(sd, ns, pix, pooling, True)
+    (emb16 * probe).sum().backward()
+    e_hip, e_b = max_err(emb, gold_emb), max_err(emb16, gold_emb)
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith(f"{pooling}/gnorm/"):
+            continue
+        n = k[len(pooling) + 7:]
+        want, got, bf = float(g[k]), float(grads[n].norm()), float(sd16[n].grad.norm())
+        worst = max(worst, abs(got - want) / max(want, 1e-6))
+        assert abs(got - want) <= 3 * abs(bf - want) + 2e-2 * want + 1e-5, f"{n}: |grad| {got} vs reference {want} (bf16 {bf})"
+    errs = {}
+    for n, sl in (("embeddings.cls_token", None), ("embeddings.pos_embed", None), ("ln_f.weight", None),
+                  ("embeddings.proj.weight", 16), ("layers.0.attn.Wqkv.weight", 16), ("layers.1.mlp.fc2.weight", 16)):
+        got = grads[n] if sl is None else grads[n][:sl, :sl]
+        key = f"{pooling}/g/{n}" + ("" if sl is None else "[:16,:16]")
+        errs[n] = rel_err(got.reshape(-1), torch.from_numpy(g[key]).to(DEV).reshape(-1))
+    report("vit_golden", pooling=pooling, e_emb_hip=e_hip, e_emb_bf16=e_b, worst_gnorm_rel=worst, **errs)
+    assert e_hip <= 5e-3 and e_hip <= 3 * e_b + 1e-4
+    assert all(v < 5e-2 for v in errs.values()), errs
+
+
+def test_vit_b16_vs_oracle():
+    """ViT-B/16 at 224x224 (197 tokens per image, T not a multiple of 64), B = 3, fp32 oracle as judge."""
+    cfg = ViTConfig.vit_base_patch16_224(n_layer=4)  # 4 of the 12 identical blocks: oracle runtime
+    ns = SimpleNamespace(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    sd = vit_ref.random_state_dict(ns, 9)
+    g = torch.Generator().manual_seed(10)
+    pix = torch.randn(3, 3, 224, 224, generator=g).to(DEV)
+    probe = torch.randn(3, cfg.n_embd, generator=g).to(DEV)
+    emb, grads = _run(cfg, ns, sd, pix, "cls", probe)
+    ref, sd32 = _oracle(sd, ns, pix, "cls", False)
+    ref16, sd16 = _oracle(sd, ns, pix, "cls", True)
+    (ref * probe).sum().backward()
+    (ref16 * probe).sum().backward()
+    e_hip, e_b = max_err(emb, ref), max_err(ref16, ref)
+    worst_ratio, worst_name = 0.0, ""
+    for n, gh in grads.items():
+        eh, eb = rel_err(gh.reshape(-1), sd32[n].grad.reshape(-1)), rel_err(sd16[n].grad.float().reshape(-1), sd32[n].grad.reshape(-1))
+        if eh / (eb + 1e-4) > worst_ratio:
+            worst_ratio, worst_name = eh / (eb + 1e-4), n
+        assert eh <= 3 * eb + 2e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    report("vit_b16", e_emb_hip=e_hip, e_emb_bf16=e_b, worst_grad_ratio=worst_ratio, worst_grad_name=worst_name)
+    assert e_hip <= 3 * e_b + 1e-4
+
+
+def test_vit_bf16_pixels_and_errors():
+    cfg = ViTConfig(n_embd=256, n_layer=1, n_head=4, n_inner=512, img_size=32, patch_size=8)
+    eng = ViTEngine(cfg, device=DEV, seed=1).eval()
+    pix = torch.randn(4, 3, 32, 32, device=DEV)
+    a = eng(pix)
+    b = eng(pix.to(torch.bfloat16))
+    assert max_err(a, b) < 2e-2
+    with pytest.raises(ValueError):
+        eng(torch.randn(4, 3, 64, 64, device=DEV))
+    with pytest.raises(NotImplementedError):
+        ViTConfig(resid_pdrop=0.1)
+
+
+def test_dual_encoder_native_towers_clip_step():
+    """BASELINE config 5 in miniature: CLIP-style DualEncoder with a native ViT image tower and a native BERT-family
+    text tower, both trained (sc/models/dual_encoder/modeling_dual_encoder.py:36-68), vs the fp32 oracle towers."""
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from oracle import encoder_ref
+
+    vcfg = ViTConfig(n_embd=256, n_layer=2, n_head=4, n_inner=512, img_size=32, patch_size=8, layer_norm_epsilon=1e-6)
+    tcfg = NomicBertConfig.bert_base_uncased(vocab_size=512, n_embd=256, n_layer=2, n_head=4, n_inner=512,
+                                             max_position_embeddings=64)
+    vns = SimpleNamespace(**{k: getattr(vcfg, k) for k in vcfg.__dataclass_fields__})
+    tns = SimpleNamespace(**{k: getattr(tcfg, k) for k in tcfg.__dataclass_fields__})
+    vsd, tsd = vit_ref.random_state_dict(vns, 21), encoder_ref.random_state_dict(tns, 22)
+    vision = BiEncoder(BiEncoderConfig(pooling="cls", trunk_config=vcfg), device=DEV)
+    text = BiEncoder(BiEncoderConfig(pooling="mean", trunk_config=tcfg), device=DEV)
+    vision.trunk.load_reference_state_dict(vsd)
+    text.trunk.load_reference_state_dict(tsd)
+    de = DualEncoder(text, vision, LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=False)).to(DEV)).train()
+    g = torch.Generator().manual_seed(23)
+    n = 8
+    pix = torch.randn(n, 3, 32, 32, generator=g).to(DEV)
+    ids = torch.randint(3, 512, (n, 16), generator=g).to(DEV)
+    mask = torch.ones(n, 16, dtype=torch.long, device=DEV)
+    vision.trunk.zero_grad()
+    text.trunk.zero_grad()
+    out = de({"input_ids": ids, "attention_mask": mask}, {"input_ids": pix})
+    out["loss"].backward()
+    # oracle: same towers in fp32, symmetric InfoNCE
+    vs = {k: v.to(DEV).requires_grad_() for k, v in vsd.items()}
+    ts = {k: v.to(DEV).requires_grad_() for k, v in tsd.items()}
+    ve = vit_ref.vit_embedding(vs, vns, pix, "cls")
+    te = encoder_ref.biencoder_embedding(ts, tns, ids, mask)
+    labels = torch.arange(n, device=DEV)
+    ref = 0.5 * (torch.nn.functional.cross_entropy(20.0 * ve @ te.T, labels)
+                 + torch.nn.functional.cross_entropy(20.0 * te @ ve.T, labels))
+    ref.backward()
+    e_loss = abs(float(out["loss"]) - float(ref))
+    gv, gt = vision.trunk.reference_grad_dict(), text.trunk.reference_grad_dict()
+    e_v = rel_err(gv["embeddings.proj.weight"], vs["embeddings.proj.weight"].grad)
+    e_t = rel_err(gt["encoder.layers.0.attn.Wqkv.weight"], ts["encoder.layers.0.attn.Wqkv.weight"].grad)
+    report("dual_encoder_native", loss=float(out["loss"]), ref=float(ref), e_loss=e_loss, e_vproj=e_v, e_tqkv=e_t)
+    assert e_loss < 2e-2 and e_v < 5e-2 and e_t < 5e-2
