@@ -99,6 +99,10 @@ class Config(BaseModel):
     train_args: TrainArgs
     data_args: DataArgs = DataArgs()
     model_args: ModelArgs = ModelArgs()
+    # image-text recipes (sc/config.py:238-240): one ModelArgs per tower; `tower_model_args` (three towers) is not built
+    text_model_args: Optional[ModelArgs] = None
+    vision_model_args: Optional[ModelArgs] = None
+    tower_model_args: Optional[ModelArgs] = None
     deepspeed: Optional[bool] = False
     deepspeed_config: Optional[dict] = None
 

@@ -1,4 +1,4 @@
-"""TextTextTrainer on the native path (host-side mirror of sc/trainers/base.py:203-208,354-533 and
+"""TextTextTrainer / ImageTextTrainer on the native path (host-side mirror of sc/trainers/base.py:203-208,354-533 and
 sc/trainers/text_text.py:139-182,276-322,429-451 for the GradCache contrastive recipe).
 
 Kept: the method set (`get_model`, `get_optimizer`, `get_scheduler`, `forward_step`, `backward`, `training_step`,
@@ -13,10 +13,11 @@ import math
 from types import SimpleNamespace
 from typing import Dict, Iterable, Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
-from .biencoder import BiEncoder, BiEncoderConfig, LogitScale
+from .biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
 from .config import Config
 from .distributed import gather_with_grad
 from .loss import clip_loss, grad_cache_loss
@@ -152,7 +153,94 @@ class TextTextTrainer:
         return losses
 
 
-TRAINER_REGISTRY = {"encoder": TextTextTrainer}  # sc/trainers/__init__.py:9-17 (text-text entry)
+class ImageTextTrainer(TextTextTrainer):
+    """CLIP-style / LiT image-text contrastive training (host-side mirror of sc/trainers/image_text.py:24-196) on the
+    native towers: `DualEncoder(text BiEncoder, vision BiEncoder over a ViTEngine, LogitScale)`.  A tower with
+    `freeze: true` (LiT's image tower) runs forward-only and is left out of the optimizer and the gradient all-reduce.
+    Batches carry {"text": {...BiEncoder kwargs...}, "vision": {"input_ids": pixels (B,3,H,W)}} as in the reference."""
+
+    def __init__(self, config: Config, dtype=torch.bfloat16, device=None, text_trunk_config=None,
+                 vision_trunk_config=None, total_steps: Optional[int] = None):
+        self._trunks = (text_trunk_config, vision_trunk_config)
+        super().__init__(config, dtype=dtype, device=device, total_steps=total_steps)
+
+    # sc/trainers/image_text.py:53-68 + sc/models/dual_encoder/modeling_dual_encoder.py:10-24
+    def get_model(self, config: Config, trunk_config=None) -> Dict[str, torch.nn.Module]:
+        if config.text_model_args is None or config.vision_model_args is None:
+            raise ValueError("image_text needs text_model_args and vision_model_args")
+        if config.tower_model_args is not None:
+            raise NotImplementedError("three-tower image-text training")
+        towers = []
+        for ma, trunk in zip((config.text_model_args, config.vision_model_args), self._trunks):
+            bc = BiEncoderConfig(model_name=ma.model_name or "", pooling=ma.pooling, logit_scale=ma.logit_scale,
+                                 trainable_logit_scale=ma.trainable_logit_scale, projection_dim=ma.projection_dim,
+                                 freeze=ma.freeze, hamming=ma.hamming, nomic_encoder=ma.nomic_encoder,
+                                 seq_len=ma.seq_len, trunk_config=trunk)
+            tower = BiEncoder(bc, device=self.device).train()
+            tower.broadcast_parameters(0)
+            towers.append(tower)
+        va = config.vision_model_args  # the reference takes the logit scale from the image tower's args
+        scale = LogitScale(SimpleNamespace(logit_scale=va.logit_scale, trainable_logit_scale=va.trainable_logit_scale))
+        model = DualEncoder(towers[0], towers[1], scale.to(self.device)).train()
+        return {"model": model}
+
+    def _trainable_towers(self):
+        m = self.model["model"]
+        return [t for t in (m.text, m.vision) if not t.frozen_trunk]
+
+    def get_optimizer(self, config: Config):
+        ta = config.train_args
+        groups = [{"params": [], "weight_decay": ta.weight_decay}, {"params": [], "weight_decay": 0.0}]
+        for t in self._trainable_towers():
+            g = t.param_groups(ta.weight_decay)
+            groups[0]["params"] += g[0]["params"]
+            groups[1]["params"] += g[1]["params"]
+        ls = self.model["model"].logit_scale.logit_scale
+        if ls.requires_grad:
+            groups[1]["params"].append(ls)
+        return torch.optim.AdamW(groups, lr=ta.learning_rate, betas=(ta.adam_beta1, ta.adam_beta2), eps=ta.eps)
+
+    # sc/trainers/image_text.py:154-178
+    def forward_step(self, batch):
+        if self.config.train_args.grad_cache:
+            raise NotImplementedError("Grad cache not supported for three towers")  # the reference's own refusal
+        text = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch["text"].items()}
+        vision = {k: v.to(self.device, non_blocking=True) for k, v in batch["vision"].items()}
+        return self.model["model"](text, vision)
+
+    def backward(self, loss):
+        loss["loss"].backward()
+        for t in self._trainable_towers():
+            t.sync_gradients()
+        ls = self.model["model"].logit_scale.logit_scale
+        if ls.grad is not None and self.distributed and self.world > 1:
+            dist.all_reduce(ls.grad)
+            ls.grad.div_(self.world)
+
+    # sc/trainers/base.py:366-393 + image_text.py:180-196 (logit clamp)
+    def training_step(self, batch) -> torch.Tensor:
+        ta = self.config.train_args
+        for t in self._trainable_towers():
+            t.trunk.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)
+        out = self.forward_step(batch)
+        self.backward(out)
+        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        torch.nn.utils.clip_grad_norm_(params, ta.max_grad_norm)
+        self.optimizer.step()
+        self.scheduler.step()
+        for t in self._trainable_towers():
+            t.trunk.sync_shadows()
+        ls = self.model["model"].logit_scale.logit_scale
+        if ta.clamp_logits and ls.requires_grad:
+            with torch.no_grad():
+                ls.clamp_(0, float(np.log(ta.logit_max)))
+        self.step += 1
+        return out["loss"].detach()
+
+
+# sc/trainers/__init__.py:9-17 (the contrastive entries; mlm / glue / distill trainers are outside the hot path)
+TRAINER_REGISTRY = {"encoder": TextTextTrainer, "image_text": ImageTextTrainer, "locked_text": ImageTextTrainer}
 
 
 def synthetic_batches(n_steps: int, per_rank_batch: int, seq_len: int, vocab: int = 30522, seed: int = 1234,

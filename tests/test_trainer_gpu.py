@@ -36,3 +36,33 @@ def test_gradcache_and_direct_steps_agree_and_learn():
     for bt in batches[1:]:
         last = float(a.training_step(batches[0]))  # overfit one batch: the loss must go down
     assert last < first - 0.05
+
+
+@pytest.mark.parametrize("lit", [False, True])
+def test_image_text_trainer_clip_and_lit(lit):
+    """BASELINE configs 5 (CLIP: both towers trained) and 4 (LiT: frozen image tower) in miniature on the native towers:
+    a few steps on one batch reduce the symmetric InfoNCE loss; a frozen tower's parameters do not move."""
+    from contrastors_amd.trainers import ImageTextTrainer
+    from contrastors_amd.vit import ViTConfig
+
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-3, weight_decay=0.01, warmup_steps=1, grad_cache=False,
+                                      schedule_type="linear", max_grad_norm=1.0, clamp_logits=True),
+                 data_args=DataArgs(batch_size=16, seed=7),
+                 text_model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny-text"),
+                 vision_model_args=ModelArgs(logit_scale=20.0, pooling="cls", model_name="tiny-vit", freeze=lit,
+                                             trainable_logit_scale=True))
+    tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
+    vc = ViTConfig(n_embd=256, n_layer=2, n_head=4, n_inner=512, img_size=32, patch_size=8)
+    tr = ImageTextTrainer(cfg, torch.bfloat16, device="cuda", text_trunk_config=tc, vision_trunk_config=vc, total_steps=20)
+    g = torch.Generator().manual_seed(3)
+    batch = {"text": {"input_ids": torch.randint(3, 512, (16, 24), generator=g),
+                      "attention_mask": torch.ones(16, 24, dtype=torch.long)},
+             "vision": {"input_ids": torch.randn(16, 3, 32, 32, generator=g)}}
+    v0 = tr.model["model"].vision.trunk.flat_param.clone()
+    t0 = tr.model["model"].text.trunk.flat_param.clone()
+    losses = [float(tr.training_step(batch)) for _ in range(6)]
+    assert all(map(lambda x: x == x, losses)) and losses[-1] < losses[0] - 0.05, losses
+    moved_v = float((tr.model["model"].vision.trunk.flat_param - v0).abs().max())
+    moved_t = float((tr.model["model"].text.trunk.flat_param - t0).abs().max())
+    assert moved_t > 0
+    assert (moved_v == 0.0) if lit else (moved_v > 0)
