@@ -33,7 +33,7 @@ if [[ $mode == prof || $mode == all ]]; then
   export TMPDIR=/tmp
   out=$PWD/gpurun_out/prof
   rm -rf $out; mkdir -p $out
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $out -o bench -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --global-batch 2048 --no-cpu-baseline} > $out/run.log 2>&1; echo "prof exit $?" >> $out/run.log)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench -- python $OLDPWD/bench.py ${PROF_ARGS:---steps 1 --warmup 1 --no-cpu-baseline} > $out/run.log 2>&1; echo "prof exit $?" >> $out/run.log)
   if [[ -n "${PMC:-}" ]]; then
     for ctr in FETCH_SIZE WRITE_SIZE; do
       (cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o b -- python $OLDPWD/bench.py --steps 1 --warmup 0 --global-batch ${PMC_BATCH:-1024} --no-cpu-baseline > $out/pmc_$ctr.log 2>&1)
@@ -46,6 +46,8 @@ if [[ $mode == prof || $mode == all ]]; then
   find $out -name "*kernel_stats*" | head
   f=$(find $out -name "*kernel_stats*.csv" | head -1)
   [[ -n "$f" ]] && head -25 "$f"
+  t=$(find $out -name "*kernel_trace*.csv" | head -1)
+  [[ -n "$t" ]] && python $OLDPWD/scripts/prof_summary.py "$t" > $out/kernel_summary.txt 2>&1
   # keep the merge-back small: drop the raw per-dispatch trace if it is large
   find $out -name "*kernel_trace*.csv" -size +20M -delete
 fi
