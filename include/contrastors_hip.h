@@ -274,6 +274,16 @@ int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const vo
 int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc,
                     int n_patch, const float* demb, const float* emb_out, void* stream);
 
+/* ---- K12  fused softmax cross-entropy over a vocabulary-sized class axis (flash_attn.losses.cross_entropy.
+ *      CrossEntropyLoss, csrc/xentropy; sc/models/encoder/modeling_nomic_bert.py:603-610).  logits: (N, V) bf16
+ *      (logits_bf16 != 0) or fp32, row stride ld; labels int64[N] (== ignore_index -> loss 0, zero gradient).
+ *      fwd: loss[i] = lse_i - s*logit[i][label_i], lse[i] = log sum_j exp(s*logit[i][j]), s = logit_scale.
+ *      bwd: dlogits = dloss[i] * s * (softmax - onehot); dlogits may alias logits (inplace_backward). */
+int cx_xent_fwd(const void* logits, int logits_bf16, const int64_t* labels, float* loss, float* lse, int N, int V,
+                long ld, float logit_scale, long ignore_index, void* stream);
+int cx_xent_bwd(const float* dloss, const void* logits, int logits_bf16, const float* lse, const int64_t* labels,
+                void* dlogits, int N, int V, long ld, long ld_d, float logit_scale, long ignore_index, void* stream);
+
 /* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
 int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);

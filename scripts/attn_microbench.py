@@ -1,0 +1,51 @@
+"""Time cx_attn_varlen_fwd / bwd (head_dim 64, non-causal, rotary on) at a few sequence lengths.
+usage: python scripts/attn_microbench.py [--tokens 131072]"""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from contrastors_amd import _C  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tokens", type=int, default=131072)
+ap.add_argument("--heads", type=int, default=12)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+lib = _C.lib()
+s = torch.cuda.current_stream().cuda_stream
+H, D = a.heads, 64
+print("S      B     fwd us   fwd TF    bwd us   bwd TF   (FLOP: fwd 4*S*S*D per seq-head, bwd 2.5x)")
+for S in (128, 197, 512, 2048, 8192):
+    B = max(1, a.tokens // S)
+    T = B * S
+    qkv = (torch.randn(T, 3 * H * D, device="cuda") * 0.5).to(torch.bfloat16)
+    cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device="cuda")
+    inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+    cos, sin = torch.cos(fr).cuda().contiguous(), torch.sin(fr).cuda().contiguous()
+    out = torch.empty(T, H * D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(H * T, device="cuda")
+    dout = torch.randn_like(out)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(H * T, device="cuda")
+    fwd = lambda: lib.cx_attn_varlen_fwd(qkv.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), out.data_ptr(),
+                                         lse.data_ptr(), B, H, T, S, 0.125, s)
+    bwd = lambda: lib.cx_attn_varlen_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(),
+                                         cos.data_ptr(), sin.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, H, T, S,
+                                         0.125, s)
+    res = []
+    for fn in (fwd, bwd):
+        assert fn() == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) * 1e3 / a.reps)
+    fl = 4.0 * S * S * D * B * H
+    print(f"{S:5d} {B:5d} {res[0]:9.1f} {fl/res[0]/1e6:8.1f} {res[1]:9.1f} {2.5*fl/res[1]/1e6:8.1f}")

@@ -11,7 +11,7 @@ from contrastors_amd.flash_attn_api.ops.activations import swiglu
 from contrastors_amd.flash_attn_api.ops.fused_dense import FusedDense
 from contrastors_amd.flash_attn_api.ops.layer_norm import dropout_add_layer_norm, layer_norm
 from oracle import encoder_ref
-from tests.gpu_util import rel_err
+from tests.gpu_util import max_err, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -143,3 +143,32 @@ def test_swiglu_and_rotary():
     assert out.data_ptr() == qkv.data_ptr() and torch.equal(qkv[:, :, 2], keep[:, :, 2])
     want_q = encoder_ref.apply_rotary(keep[:, :, 0].float(), c16, s16)
     assert rel_err(qkv[:, :, 0].float(), want_q) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N,V,inplace", [(1000, 30528, True), (37, 30522, False), (64, 512, False)])
+def test_cross_entropy_k12(dtype, N, V, inplace):
+    """flash_attn.losses.cross_entropy.CrossEntropyLoss on cx_xent_fwd/bwd vs torch fp32 (ignore_index rows included)."""
+    from contrastors_amd.flash_attn_api.losses.cross_entropy import CrossEntropyLoss
+
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(N, V, generator=g) * 3).to(DEV).to(dtype)
+    labels = torch.randint(0, V, (N,), generator=g)
+    labels[::7] = -100
+    labels = labels.to(DEV)
+    ref_in = logits.float().clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, labels, ignore_index=-100)
+    ref.backward()
+    x = logits.clone().requires_grad_()
+    xin = x * 1.0  # a non-leaf the in-place backward is allowed to overwrite
+    loss = CrossEntropyLoss(inplace_backward=inplace)(xin, labels)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < (2e-3 if dtype == torch.bfloat16 else 1e-5) * max(1.0, abs(float(ref)))
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(x.grad.float(), ref_in.grad) < tol
+    assert float(x.grad[::7].abs().max()) == 0.0
+    per_row = CrossEntropyLoss(reduction="none")(logits, labels)
+    want = torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=-100, reduction="none")
+    assert max_err(per_row, want) < (5e-2 if dtype == torch.bfloat16 else 1e-4)
+    with pytest.raises(NotImplementedError):
+        CrossEntropyLoss(label_smoothing=0.1)
