@@ -726,6 +726,7 @@ hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipS
     if (p.split_k > p.K / BK5) p.split_k = p.K / BK5;
     if (form == 1) {
         if ((p.M % BM5) != 0 || (p.N % BN5) != 0 || out_mode != GEMM_OUT_F32_PARTIAL) return hipErrorInvalidValue;
+        if (g_v5_use_v6) return cx_launch_gemm_v6_tn(p, stream);
         return launch5<FORM_TN, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE>(p, stream);
     }
     const bool pers = g_v5_persistent && p.split_k == 1 && (p.N % 8) == 0;

@@ -253,39 +253,52 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
             if constexpr (EPI == GEMM_EPI_NONE) {
                 const bool add_bias = p.bias != nullptr;
+                // `plain` (compile time): alpha == 1 and no bias -- the forward / dgrad launches of bias-free models;
+                // saves 256 multiplies per lane per tile in an epilogue that is VALU-issue-bound (one wave per SIMD)
+                auto store_tile = [&](auto plain) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
+                    for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        float blk[16];
-                        v6_read_block(4 * b + a, blk);
+                        for (int a = 0; a < 4; ++a) {
+                            float blk[16];
+                            v6_read_block(4 * b + a, blk);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int nl = a * 32 + 8 * q + 4 * hi;
-                            float v[4];
+                            for (int q = 0; q < 4; ++q) {
+                                const int nl = a * 32 + 8 * q + 4 * hi;
+                                float v[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = blk[4 * q + e] * p.alpha;
-                            if (add_bias) {
-                                const int n = n0 + nl;
-                                if (n < p.N) {
-                                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                                for (int e = 0; e < 4; ++e) v[e] = blk[4 * q + e];
+                                if constexpr (!decltype(plain)::value) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                                    if (add_bias) {
+                                        const int n = n0 + nl;
+                                        if (n < p.N) {
+                                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                                            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                                        }
+                                    }
                                 }
+                                uint2 pk;
+                                pk.x = pack_bf16x2(v[0], v[1]);
+                                pk.y = pack_bf16x2(v[2], v[3]);
+                                *reinterpret_cast<uint2*>(my + l31 * ROWB + nl * 2) = pk;
                             }
-                            uint2 pk;
-                            pk.x = pack_bf16x2(v[0], v[1]);
-                            pk.y = pack_bf16x2(v[2], v[3]);
-                            *reinterpret_cast<uint2*>(my + l31 * ROWB + nl * 2) = pk;
+                        }
+#pragma unroll
+                        for (int ps = 0; ps < 8; ++ps) {
+                            const int row = ps * 4 + (lane >> 4), ch = lane & 15;
+                            const int m = m0 + b * 32 + row, n = n0 + ch * 8;
+                            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                            if (m < p.M && n + 8 <= p.N)
+                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
                         }
                     }
-#pragma unroll
-                    for (int ps = 0; ps < 8; ++ps) {
-                        const int row = ps * 4 + (lane >> 4), ch = lane & 15;
-                        const int m = m0 + b * 32 + row, n = n0 + ch * 8;
-                        const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
-                        if (m < p.M && n + 8 <= p.N)
-                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
-                    }
+                };
+                if (p.alpha == 1.f && !add_bias) {
+                    store_tile(std::true_type{});
+                } else {
+                    store_tile(std::false_type{});
                 }
             } else {
                 // SwiGLU: weight rows interleaved by 32, so the wave's 128 fused columns are [y0 | g0 | y1 | g1] (32 each)
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             for (int e = 0; e < 4; ++e) {  // the standalone op sees bf16 y / gate (FusedDense outputs)
                                 const float yy = bf16_to_f32(f32_to_bf16(yb[4 * q + e]));
                                 const float gg = bf16_to_f32(f32_to_bf16(gb[4 * q + e]));
-                                o[e] = gg / (1.f + __expf(-gg)) * yy;
+                                o[e] = gg * yy * __builtin_amdgcn_rcpf(1.f + __expf(-gg));  // 1-ulp rcp: far below bf16
                             }
                             uint2 pk;
                             pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
@@ -369,6 +382,221 @@ hipError_t launch6(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// =====================================================================================================================
+// TN form (wgrad): G[o][i] = sum_t dY[t][o] * A[t][i], both operands in their natural (tokens, features) layout, K =
+// tokens.  Same one-wave-per-SIMD structure; one (output tile, K slice) unit per workgroup (a unit is hundreds of
+// K-tiles long, so nothing is gained by walking units persistently), the same 3 X + 2 W slot ring, fragments through
+// ds_read_b64_tr_b16 (transposing read; conflict-free 16-B-chunk XOR, see gemm_bf16_v5.hip tn_frag5), fp32 split-K
+// partial slabs stored straight from the AGPRs (global_store_dwordx4 a[..]) -- no VGPR copy, no LDS staging.
+// =====================================================================================================================
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr6;
+constexpr int TNROW6 = 512;      // bytes per token row of a [64 t][256 f] tile
+
+CX_DEVICE bf16x8_t tn_frag6(const char* tile, int f0, int t0, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int t = t0 + 8 * (g >> 1) + (p >> 2);
+    const int f = f0 + 16 * (g & 1) + 4 * (p & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int tt = t + 4 * half;
+        const int chunk = (f >> 3) ^ ((tt & 3) << 2);
+        u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(tile + tt * TNROW6 + chunk * 16 + (f & 4) * 2));
+    }
+    return u.v;
+}
+
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6tn_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tn = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tm = lid % p.tiles_m;
+    const int sk = lid / p.tiles_m;
+    const int m0 = tm * BM6, n0 = tn * BN6;
+    const int nk_total = p.K / BK6;
+    const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
+    const int kt_end = (int)(((long)nk_total * (sk + 1)) / p.split_k);
+    const int nk = kt_end - kt_begin;
+    if (nk <= 0) return;  // (split_k <= K tiles is enforced by the launcher)
+
+    // DMA: instruction q = j*4 + wave covers token rows 2q, 2q+1 of a [64 t][256 f] tile (512 B each).  Ring as in the
+    // NT kernel: three X slots (dY runs two K-tiles ahead), two W slots (A one ahead).
+    const bf16_t* xsrc[8];
+    const bf16_t* wsrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = (j * 4 + wave) * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ ((t & 3) << 2);
+        xsrc[j] = p.X + ((size_t)kt_begin * BK6 + t) * p.ldx + m0 + c * 8;
+        wsrc[j] = p.W + ((size_t)kt_begin * BK6 + t) * p.ldw + n0 + c * 8;
+    }
+    const size_t xstep = (size_t)BK6 * p.ldx, wstep = (size_t)BK6 * p.ldw;
+    int lx_slot = 0, lw_slot = 0;
+    // The LDS-DMA is issued through inline asm here, not the builtin: knowing that VMEM writes LDS, the compiler puts
+    // s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every iteration (the transposing-read intrinsic
+    // carries no alias information), which would serialise the whole DMA pipeline.  Every DMA wait in this kernel is an
+    // explicit counted s_waitcnt + barrier.  (M0 = LDS destination of the wave; nothing else in this kernel uses M0.)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)dsm;
+    auto dma1 = [&](const bf16_t* src, uint32_t lds_byte) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory");
+    };
+    auto issue_x1 = [&](int j) {
+        dma1(xsrc[j], lds0 + lx_slot * XS6 + (j * 4 + wave) * 1024);
+        xsrc[j] += xstep;
+    };
+    auto issue_w1 = [&](int j) {
+        dma1(wsrc[j], lds0 + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024);
+        wsrc[j] += wstep;
+    };
+
+    // L2 prefetch: both operands stream from HBM here (activations, not weights) and a DMA issued one or two K-tiles
+    // ahead does not cover the HBM latency under load.  One dword load per 128-B line of a K-tile (256 lines per operand
+    // = one load instruction per wave per operand) pulls it into L2 two iterations before its DMA is issued; the loaded
+    // value is never used (pf_sink keeps the destination register reserved).
+    constexpr int PF_X = 4, PF_W = 3;  // X's DMA runs two K-tiles ahead, W's one
+    const int pf_row = (wave * 64 + lane) >> 2, pf_line = (wave * 64 + lane) & 3;
+    const bf16_t* xpf = p.X + ((size_t)(kt_begin + PF_X) * BK6 + pf_row) * p.ldx + m0 + pf_line * 64;
+    const bf16_t* wpf = p.W + ((size_t)(kt_begin + PF_W) * BK6 + pf_row) * p.ldw + n0 + pf_line * 64;
+    uint32_t pf_sink = 0;
+
+    // Fragment addressing (tn_frag6 with everything lane-dependent hoisted): with one wave per SIMD the instruction
+    // stream is issue-bound, so each fragment must cost one VALU add + two transposing reads, not a dozen integer ops.
+    // byte offset inside a tile = tt*512 + chunk*16 + (f&4)*2 with tt = 16*ks + 4*half + tl, (tt&3) == (tl&3):
+    //   lane part  = tl*512 + (((f0 + fl) >> 3) ^ ((tl&3) << 2))*16 + (fl&4)*2   (one VGPR per fragment index)
+    //   immediate  = ks*8192 + half*2048
+    Frags6 F0, F1;
+    uint32_t woff[4], xoff[4];
+    {
+        const int g = lane >> 4, pp = lane & 15;
+        const int tl = 8 * (g >> 1) + (pp >> 2), fl = 16 * (g & 1) + 4 * (pp & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fw = wn * 128 + i * 32 + fl, fx = wm * 128 + i * 32 + fl;
+            woff[i] = tl * TNROW6 + (((fw >> 3) ^ ((tl & 3) << 2)) << 4) + (fw & 4) * 2;
+            xoff[i] = tl * TNROW6 + (((fx >> 3) ^ ((tl & 3) << 2)) << 4) + (fx & 4) * 2;
+        }
+    }
+    auto tr_pair = [&](const char* base, int ks) -> bf16x8_t {
+        union { bf16x4_t h[2]; bf16x8_t v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(base + ks * 8192));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(base + ks * 8192 + 2048));
+        return u.v;
+    };
+    auto read_one = [&](Frags6& f, int xslot, int wslot, int ks, int i) {
+        if (i < 4)
+            f.w[i] = tr_pair(dsm + (3 + wslot) * XS6 + woff[i], ks);
+        else
+            f.x[i - 4] = tr_pair(dsm + xslot * XS6 + xoff[i - 4], ks);
+    };
+    auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 3], f.x[i >> 2]); };
+    auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]); };
+    // one k-step: 16 MFMAs on `cur`; the 8 fragments (16 transposing reads) of the next k-step and 4 DMA instructions
+    // ride between them.  dma_kind: 1 = W instructions j0..j0+3 (if w_go), 2 = X instructions (if x_go)
+#define CX_TN_KSTEP(MMA, cur, nxt, rx, rw, rks, dma_kind, j0)                                           \
+    do {                                                                                              \
+        MMA(cur, 0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                            \
+            read_one(nxt, rx, rw, rks, i_);                                                           \
+            MMA(cur, 1 + i_);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                            \
+            if ((dma_kind) == 1 && w_go) issue_w1((j0) + i_);                                         \
+            if ((dma_kind) == 2 && x_go) issue_x1((j0) + i_);                                         \
+            MMA(cur, 9 + i_);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        MMA(cur, 13);                                                                                 \
+        MMA(cur, 14);                                                                                 \
+        MMA(cur, 15);                                                                                 \
+    } while (0)
+
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_x1(j);  // X of K-tile 0
+    lx_slot = 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_w1(j);  // W of K-tile 0
+    lw_slot = 1;
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_x1(j);  // X of K-tile 1
+        lx_slot = 2;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_one(F0, 0, 0, 0, i);
+
+    int xs_slot = 0, ws_slot = 0;
+    // K-tile body (see the NT kernel): DMA of this iteration = W of K-tile t+1 (k-steps 0,1) and X of K-tile t+2
+    // (k-step 2 and, after the barrier, k-step 3); `first` selects the C = 0 MFMA form.
+    auto kt_body = [&](auto first, int t) {
+        const bool w_go = t + 1 < nk, x_go = t + 2 < nk;
+        const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
+        if constexpr (decltype(first)::value) {
+            CX_TN_KSTEP(mma1z, F0, F1, xs_slot, ws_slot, 1, 1, 0);
+        } else {
+            CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 1, 1, 0);
+        }
+        CX_TN_KSTEP(mma1, F1, F0, xs_slot, ws_slot, 2, 1, 4);
+        if (w_go) lw_slot ^= 1;
+        CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 3, 2, 0);
+        // L2 prefetches: the newest VMEM operations of this iteration (allowed to stay outstanding below)
+        const bool pf_x = t + PF_X < nk, pf_w = t + PF_W < nk;
+        if (pf_x) {
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(xpf) : "memory");
+            xpf += xstep;
+        }
+        if (pf_w) {
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(wpf) : "memory");
+            wpf += wstep;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the current slots are complete ...
+        // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions of k-step 2 and the prefetches
+        if (!x_go) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (pf_x) {       // pf_x implies pf_w
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (pf_w) {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // (after the last K-tile these reads fetch garbage from a landed slot; F0 is not used again)
+        CX_TN_KSTEP(mma1, F1, F0, nxs_slot, nws_slot, 0, 2, 4);
+        if (x_go) lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+        xs_slot = nxs_slot;
+        ws_slot = nws_slot;
+    };
+    kt_body(std::true_type{}, 0);
+#pragma unroll 1
+    for (int t = 1; t < nk; ++t) kt_body(std::false_type{}, t);
+#undef CX_TN_KSTEP
+
+    // ---- epilogue: fp32 partial slab of this K slice, straight from the AGPRs.  block (a, b): rows m0 + wm*128 + b*32
+    // + l31, columns n0 + wn*128 + a*32 + 8q + 4hi (+0..3)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // MFMA -> VMEM read of the accumulators
+    if (pf_sink == 0x7fc12345u && p.dbg == -1) reinterpret_cast<volatile uint32_t*>(p.Out)[0] = pf_sink;  // keeps pf_sink live
+    float* part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float* rowp = part + (size_t)(m0 + wm * 128 + b * 32 + l31) * p.ldo + n0 + wn * 128 + 4 * hi;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) v6_store_block_f32(4 * b + a, rowp + a * 32);
+    }
+}
+
 int g_v6_force_gn = 0;  // experiments: 1, 2, 4 or 8 forces the N-group count; 0 = heuristic
 
 // N-groups of the XCD grid: the estimated L2-miss traffic is gn * |X| (every X panel is fetched by the gn XCDs of its
@@ -394,6 +622,22 @@ int cx_gemm_v6_groups(int tiles_m, int tiles_n, int K) {
 }  // namespace
 
 void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
+
+// TN wgrad form: p.X = dY (T, M), p.W = A (T, N), p.K = tokens, p.Out = fp32 partial slabs [split_k][M][ldo];
+// M % 256 == 0, N % 256 == 0, K % 64 == 0, 1 <= split_k <= K / 64 (checked by the caller).
+hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v6tn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.tiles_m = p.M / BM6;
+    p.tiles_n = p.N / BN6;
+    hipLaunchKernelGGL(gemm_bf16_v6tn_kernel, dim3(p.tiles_m * p.tiles_n * p.split_k), dim3(256), LDS6, stream, p);
+    return hipGetLastError();
+}
 
 // NT forms with bf16 output (plain / bias / alpha, or fused SwiGLU), K % 64 == 0, N % 8 == 0, split_k == 1.
 hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {

@@ -107,7 +107,7 @@ def test_gemm_swiglu_fused(M, I, K, variant):
     assert rel_err(act3.float(), act.float()) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [2, 5])
+@pytest.mark.parametrize("variant", [2, 5, 6])
 @pytest.mark.parametrize("T,O,I", [(8192, 768, 3072), (8192, 2304, 768), (1000, 256, 128), (130, 1024, 256)])
 def test_wgrad_natural_layout_tn(T, O, I, variant):
     """G += dY^T A straight from the (T,features) row-major operands (ds_read_b64_tr_b16 fragments), vs torch."""
