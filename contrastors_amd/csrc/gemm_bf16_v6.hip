@@ -93,8 +93,16 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
     };
     // one DMA instruction of the next X / W K-tile (j = 0..7); the cursor advances with the last one
+    // LDS-DMA through inline asm, not the builtin: the compiler, knowing that VMEM writes LDS, guards LDS accesses it
+    // cannot disambiguate with s_waitcnt vmcnt(0) -- in front of the first staging write of every epilogue here (a full
+    // DMA round trip per tile), in front of every transposing read in the TN kernel below.  All DMA waits in this file
+    // are explicit counted s_waitcnt + barrier.  (M0 = the wave's LDS destination; nothing else here uses M0.)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)dsm;
+    auto dma1 = [&](const bf16_t* src, uint32_t lds_byte) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory");
+    };
     auto issue_x1 = [&](int j) {
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)xsrc[j], (lds_void_ptr)(dsm + lx_slot * XS6 + (j * 4 + wave) * 1024), 16, 0, 0);
+        dma1(xsrc[j], lds0 + lx_slot * XS6 + (j * 4 + wave) * 1024);
         xsrc[j] += BK6;
     };
     auto x_advance = [&]() {
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
     };
     auto issue_w1 = [&](int j) {
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)wsrc[j], (lds_void_ptr)(dsm + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024), 16, 0, 0);
+        dma1(wsrc[j], lds0 + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024);
         wsrc[j] += BK6;
     };
     auto w_advance = [&]() {
@@ -439,10 +447,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
     const size_t xstep = (size_t)BK6 * p.ldx, wstep = (size_t)BK6 * p.ldw;
     int lx_slot = 0, lw_slot = 0;
-    // The LDS-DMA is issued through inline asm here, not the builtin: knowing that VMEM writes LDS, the compiler puts
-    // s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every iteration (the transposing-read intrinsic
-    // carries no alias information), which would serialise the whole DMA pipeline.  Every DMA wait in this kernel is an
-    // explicit counted s_waitcnt + barrier.  (M0 = LDS destination of the wave; nothing else in this kernel uses M0.)
+    // LDS-DMA through inline asm (see the NT kernel): with the builtin the compiler puts s_waitcnt vmcnt(0) in front of
+    // the first ds_read_b64_tr_b16 of every iteration (the intrinsic carries no alias information), serialising the ring.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)dsm;
     auto dma1 = [&](const bf16_t* src, uint32_t lds_byte) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory");
