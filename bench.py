@@ -222,7 +222,7 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
                          "kernel": "bf16 GEMM family: gemm_bf16_v6_kernel (fwd, dgrad, fused SwiGLU fc1) + "
-                                   "gemm_bf16_v5_kernel<TN> (wgrad)",
+                                   "gemm_bf16_v6tn_kernel (wgrad)",
                          "launches_timed": n_t.value, "launches_total": n_all.value,
                          "avg_launch_us": 1e3 * ms.value / max(1, n_t.value),
                          "algorithmic_flop_per_launch": fl.value / max(1, n_t.value),

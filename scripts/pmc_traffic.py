@@ -8,7 +8,7 @@ import json
 import re
 import sys
 
-GEMM = ("gemm_bf16_v6_kernel", "gemm_bf16_v5_kernel", "gemm_bf16_v5p_kernel")
+GEMM = ("gemm_bf16_v6", "gemm_bf16_v5")  # v6 NT / SwiGLU / TN (v6tn) and the earlier generations
 
 
 def parse(path):
