@@ -152,6 +152,38 @@ class BiEncoder(torch.nn.Module):
 
         return contextlib.nullcontext()
 
+    # ---- weights on disk (sc/trainers/base.py:275-290 save_model / load_model; HF `save_pretrained` layout) --------
+    def save_pretrained(self, output_dir: str):
+        """model.safetensors with the reference's state-dict keys (`trunk.<reference key>`, `proj.*`) + config.json:
+        the reference's BiEncoder / eager twin load it unchanged (tests/test_huggingface.py:30-34 key contract)."""
+        import dataclasses
+        import json
+        import os
+
+        from safetensors.torch import save_file
+
+        os.makedirs(output_dir, exist_ok=True)
+        sd = {f"trunk.{k}": v.detach().cpu().contiguous() for k, v in self.trunk.reference_state_dict().items()}
+        sd.update({f"proj.{k}": v.detach().cpu().contiguous() for k, v in self.proj.state_dict().items()})
+        save_file(sd, os.path.join(output_dir, "model.safetensors"))
+        cfg = {k: v for k, v in dataclasses.asdict(self.config).items() if k != "trunk_config"}
+        cfg["trunk_config"] = dataclasses.asdict(self.trunk.config)
+        cfg["trunk_type"] = type(self.trunk.config).__name__
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+
+    def load_pretrained(self, model_path: str, strict: bool = True):
+        import os
+
+        from safetensors.torch import load_file
+
+        sd = load_file(os.path.join(model_path, "model.safetensors"))
+        self.trunk.load_reference_state_dict({k[6:]: v for k, v in sd.items() if k.startswith("trunk.")}, strict=strict)
+        proj = {k[5:]: v for k, v in sd.items() if k.startswith("proj.")}
+        if proj:
+            self.proj.load_state_dict(proj)
+        return self
+
     def param_groups(self, weight_decay: float):
         """decay / no-decay groups of sc/optimizer.py:16-25 over the flat buffers."""
         groups = [{"params": [self.trunk.flat_decay], "weight_decay": weight_decay},

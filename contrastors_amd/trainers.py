@@ -141,6 +141,42 @@ class TextTextTrainer:
         self.step += 1
         return loss.detach()
 
+    # ---- checkpoint / resume (sc/trainers/base.py:275-344: <dir>/model, optimizer.pt, scheduler.pt,
+    #      random_states_<rank>.pt; the streaming loader's per-rank offsets are the data side's business) ------------
+    def _towers(self):
+        m = self.model["model"]
+        return {"model": m} if hasattr(m, "trunk") else {"text": m.text, "vision": m.vision}
+
+    def save_state(self, output_dir: str):
+        import os
+        import random
+
+        os.makedirs(output_dir, exist_ok=True)
+        if self.rank == 0:
+            for name, tower in self._towers().items():
+                tower.save_pretrained(os.path.join(output_dir, name))
+            torch.save(self.optimizer.state_dict(), os.path.join(output_dir, "optimizer.pt"))
+            torch.save({"scheduler": self.scheduler.state_dict(), "step": self.step},
+                       os.path.join(output_dir, "scheduler.pt"))
+        torch.save({"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "random": random.getstate(),
+                    "cuda": torch.cuda.get_rng_state_all()}, os.path.join(output_dir, f"random_states_{self.rank}.pt"))
+
+    def load_state(self, input_dir: str):
+        import os
+        import random
+
+        for name, tower in self._towers().items():
+            tower.load_pretrained(os.path.join(input_dir, name))
+        self.optimizer.load_state_dict(torch.load(os.path.join(input_dir, "optimizer.pt"), map_location=self.device))
+        sch = torch.load(os.path.join(input_dir, "scheduler.pt"))
+        self.scheduler.load_state_dict(sch["scheduler"])
+        self.step = int(sch["step"])
+        rs = torch.load(os.path.join(input_dir, f"random_states_{self.rank}.pt"), weights_only=False)
+        torch.set_rng_state(rs["torch"])
+        np.random.set_state(rs["numpy"])
+        random.setstate(rs["random"])
+        torch.cuda.set_rng_state_all(rs["cuda"])
+
     def train(self, batches: Iterable[dict], max_steps: Optional[int] = None, log_every: int = 0):
         losses = []
         for i, batch in enumerate(batches):
