@@ -21,6 +21,10 @@ constexpr int TSTRIDE = 136;  // bytes per row of a transposed [64 d][64 idx] ti
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+// v_exp_f32 directly: the libm wrapper adds denormal-range fix-ups (4-5 extra VALU ops per element) that a softmax
+// probability (<= 1, flushed to 0 below 2^-126 either way once rounded to bf16) does not need.
+CX_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 CX_DEVICE void unpack8(const uint4& v, float (&f)[8]) {
     f[0] = bf16lo_to_f32(v.x); f[1] = bf16hi_to_f32(v.x);
     f[2] = bf16lo_to_f32(v.y); f[3] = bf16hi_to_f32(v.y);
@@ -190,13 +194,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = fast_exp2(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[kb][r] = exp2f(s[kb][r] - m_new);
+                s[kb][r] = fast_exp2(s[kb][r] - m_new);
                 psum += s[kb][r];
             }
         l_run = l_run * alpha + psum;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128_kernel(AttnParams p) {
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[kb][r] = exp2f(s[kb][r] - mx);
+            s[kb][r] = fast_exp2(s[kb][r] - mx);
             psum += s[kb][r];
         }
     f32x16_t acc_o[2];
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + kb * 32 + acc_row(r, hi);
-                const float pr = key < len ? exp2f(a_s[r] * sc2 - lse2) : 0.f;
+                const float pr = key < len ? fast_exp2(a_s[r] * sc2 - lse2) : 0.f;
                 ds[r] = pr * (a_dp[r] - dl);
             }
 #pragma unroll
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
-                    const float pv = key_ok ? exp2f(a_s[r] * sc2 - ll[e]) : 0.f;
+                    const float pv = key_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
                     pr[r] = pv;
                     ds[r] = pv * (a_dp[r] - dd[e]);
                 }
@@ -712,11 +716,270 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------- backward, sequences <= 128
+// Same idea as attn_fwd_s128_kernel: one workgroup owns a whole (sequence, head) problem, EVERY global load is issued
+// before anything is staged (one HBM latency per workgroup instead of three serial load -> LDS -> compute phases), and
+// the whole key / query range is processed from LDS in one pass.  Thread (kp = tid >> 2, cp = tid & 3) owns the row pair
+// (2kp, 2kp+1) and the 16-B chunks cp and cp+4 of Q, K, V and dO: the same cos/sin values rotate its Q and K rows.
+struct RowPairLoads {
+    uint4 lo[2], hi[2];  // [row of the pair]
+};
+CX_DEVICE void load_pair_raw(const bf16_t* base, size_t stride, int t0, int ra, int rb, int cp, RowPairLoads& o) {
+    const bf16_t* a = base + (size_t)(t0 + ra) * stride;
+    const bf16_t* b = base + (size_t)(t0 + rb) * stride;
+    o.lo[0] = *reinterpret_cast<const uint4*>(a + cp * 8);
+    o.hi[0] = *reinterpret_cast<const uint4*>(a + 32 + cp * 8);
+    o.lo[1] = *reinterpret_cast<const uint4*>(b + cp * 8);
+    o.hi[1] = *reinterpret_cast<const uint4*>(b + 32 + cp * 8);
+}
+struct CosSin {
+    float4 c[2][2], s[2][2];  // [row of the pair][half of the 8 columns]
+};
+CX_DEVICE void load_cossin(const float* cosv, const float* sinv, int ra, int rb, int cp, CosSin& o) {
+    const int rows[2] = {ra, rb};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* c = cosv + (size_t)rows[i] * 32 + cp * 8;
+        const float* sn = sinv + (size_t)rows[i] * 32 + cp * 8;
+        o.c[i][0] = *reinterpret_cast<const float4*>(c);
+        o.c[i][1] = *reinterpret_cast<const float4*>(c + 4);
+        o.s[i][0] = *reinterpret_cast<const float4*>(sn);
+        o.s[i][1] = *reinterpret_cast<const float4*>(sn + 4);
+    }
+}
+CX_DEVICE void rotate_pair(RowPairLoads& x, const CosSin& cs) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        uint4 lo, hi;
+        rot8(x.lo[i], x.hi[i], cs.c[i], cs.s[i], lo, hi);
+        x.lo[i] = lo;
+        x.hi[i] = hi;
+    }
+}
+CX_DEVICE void stage_rows(char* tile, int kp, int cp, const RowPairLoads& x) {  // row-major [128][64], tile64 swizzle
+    *reinterpret_cast<uint4*>(tile + tile64_off(2 * kp, cp)) = x.lo[0];
+    *reinterpret_cast<uint4*>(tile + tile64_off(2 * kp, cp + 4)) = x.hi[0];
+    *reinterpret_cast<uint4*>(tile + tile64_off(2 * kp + 1, cp)) = x.lo[1];
+    *reinterpret_cast<uint4*>(tile + tile64_off(2 * kp + 1, cp + 4)) = x.hi[1];
+}
+CX_DEVICE void stage_transposed128(char* tile, int kp, int cp, const RowPairLoads& x) {  // [64 d][128 idx], stride 264
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t wl = (uint32_t)elem16(x.lo[0], e) | ((uint32_t)elem16(x.lo[1], e) << 16);
+        const uint32_t wh = (uint32_t)elem16(x.hi[0], e) | ((uint32_t)elem16(x.hi[1], e) << 16);
+        *reinterpret_cast<uint32_t*>(tile + (cp * 8 + e) * VT128_STRIDE + kp * 4) = wl;
+        *reinterpret_cast<uint32_t*>(tile + (32 + cp * 8 + e) * VT128_STRIDE + kp * 4) = wh;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_s128_kernel(AttnParams p) {
+    // phase 1: Qs | dOs (only to build the register fragments);  phase 2: Ks | Vs alias them, Kt is separate
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 64 * VT128_STRIDE];
+    char* A0 = smem;
+    char* A1 = smem + 16384;
+    char* Kt = smem + 32768;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    if (len <= 0) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const bf16_t* dobase = p.dout + (size_t)h * DH;
+    const int kp = tid >> 2, cp = tid & 3;
+    int ra = 2 * kp, rb = ra + 1;
+    ra = ra < len ? ra : len - 1;
+    rb = rb < len ? rb : len - 1;
+
+    // ---- every global load first ----
+    RowPairLoads q, k, v, dO;
+    CosSin cs;
+    load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
+    load_pair_raw(dobase, o_stride, t0, ra, rb, cp, dO);
+    load_pair_raw(kbase, tok_stride, t0, ra, rb, cp, k);
+    load_pair_raw(vbase, tok_stride, t0, ra, rb, cp, v);
+    if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
+    const int qrow = wave * 32 + l31;
+    const int qc = qrow < len ? qrow : len - 1;
+    const float lse2 = p.lse[(size_t)h * p.T + t0 + qc] * LOG2E;
+    const float dl = p.delta[(size_t)h * p.T + t0 + qc];
+
+    if (p.cosv) rotate_pair(q, cs);
+    stage_rows(A0, kp, cp, q);
+    stage_rows(A1, kp, cp, dO);
+    __syncthreads();
+    bf16x8_t qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = lds_read_frag(A0, tile64_off(qrow, ks * 2 + hi));
+        dof[ks] = lds_read_frag(A1, tile64_off(qrow, ks * 2 + hi));
+    }
+    __syncthreads();
+    if (p.cosv) rotate_pair(k, cs);
+    stage_rows(A0, kp, cp, k);
+    stage_rows(A1, kp, cp, v);
+    stage_transposed128(Kt, kp, cp, k);
+    __syncthreads();
+
+    const float sc2 = p.scale * LOG2E;
+    f32x16_t acc_dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        f32x16_t a_s, a_dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a_s = mfma_bf16_32x32x16(lds_read_frag(A0, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a_s);
+            a_dp = mfma_bf16_32x32x16(lds_read_frag(A1, tile64_off(kb * 32 + l31, ks * 2 + hi)), dof[ks], a_dp);
+        }
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + acc_row(r, hi);
+            const float pr = key < len ? fast_exp2(a_s[r] * sc2 - lse2) : 0.f;
+            ds[r] = pr * (a_dp[r] - dl);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16x8_t dsf = pack_frag(ds, half);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                acc_dq[db] = mfma_bf16_32x32x16(read_vt128_frag(Kt, db * 32 + l31, kb * 2 + half, hi), dsf, acc_dq[db]);
+        }
+    }
+    if (qrow < len)
+        store_unrotated(p.dqkv + (size_t)(t0 + qrow) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, qrow,
+                        hi);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p) {
+    // phase 1: Ks | Vs (register fragments);  phase 2: Qs | dOs alias them, Qt | dOt | lse | delta are separate
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 2 * 64 * VT128_STRIDE + 1024];
+    char* A0 = smem;
+    char* A1 = smem + 16384;
+    char* Qt = smem + 32768;
+    char* dOt = Qt + 64 * VT128_STRIDE;
+    float* lse_s = reinterpret_cast<float*>(dOt + 64 * VT128_STRIDE);
+    float* dl_s = lse_s + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    if (len <= 0) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const bf16_t* dobase = p.dout + (size_t)h * DH;
+    const int kp = tid >> 2, cp = tid & 3;
+    int ra = 2 * kp, rb = ra + 1;
+    ra = ra < len ? ra : len - 1;
+    rb = rb < len ? rb : len - 1;
+
+    // ---- every global load first ----
+    RowPairLoads q, k, v, dO;
+    CosSin cs;
+    load_pair_raw(kbase, tok_stride, t0, ra, rb, cp, k);
+    load_pair_raw(vbase, tok_stride, t0, ra, rb, cp, v);
+    load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
+    load_pair_raw(dobase, o_stride, t0, ra, rb, cp, dO);
+    if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
+    float lse_v = 0.f, dl_v = 0.f;
+    if (tid < 128) {
+        const bool ok = tid < len;
+        const int r = ok ? tid : len - 1;
+        // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
+        lse_v = ok ? p.lse[(size_t)h * p.T + t0 + r] * LOG2E : INFINITY;
+        dl_v = p.delta[(size_t)h * p.T + t0 + r];
+    }
+
+    if (p.cosv) rotate_pair(k, cs);
+    stage_rows(A0, kp, cp, k);
+    stage_rows(A1, kp, cp, v);
+    __syncthreads();
+    const int key = wave * 32 + l31;
+    const bool key_ok = key < len;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = lds_read_frag(A0, tile64_off(key, ks * 2 + hi));
+        vf[ks] = lds_read_frag(A1, tile64_off(key, ks * 2 + hi));
+    }
+    __syncthreads();
+    if (p.cosv) rotate_pair(q, cs);
+    stage_rows(A0, kp, cp, q);
+    stage_rows(A1, kp, cp, dO);
+    stage_transposed128(Qt, kp, cp, q);
+    stage_transposed128(dOt, kp, cp, dO);
+    if (tid < 128) {
+        lse_s[tid] = lse_v;
+        dl_s[tid] = dl_v;
+    }
+    __syncthreads();
+
+    const float sc2 = p.scale * LOG2E;
+    f32x16_t acc_dk[2], acc_dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        f32x16_t a_s, a_dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a_s = mfma_bf16_32x32x16(lds_read_frag(A0, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
+            a_dp = mfma_bf16_32x32x16(lds_read_frag(A1, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
+        }
+        float pr[16], ds[16];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int row = qb * 32 + 8 * qd + 4 * hi;
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + row);
+            const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
+            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * qd + e;
+                const float pv = key_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
+                pr[r] = pv;
+                ds[r] = pv * (a_dp[r] - dd[e]);
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                acc_dv[db] = mfma_bf16_32x32x16(read_vt128_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
+                acc_dk[db] = mfma_bf16_32x32x16(read_vt128_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
+            }
+        }
+    }
+    if (key_ok) {
+        bf16_t* krow = p.dqkv + (size_t)(t0 + key) * tok_stride + (size_t)(p.H + h) * DH;
+        bf16_t* vrow = krow + (size_t)p.H * DH;
+        store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, key, hi);
+        store_unrotated(vrow, acc_dv, 1.f, nullptr, nullptr, 0, hi);
+    }
+}
+
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
+
+bool g_bwd_s128 = true;  // A/B switch (cx_attn_set_bwd_s128): one-pass kernels for max_seqlen <= 128
 
 }  // namespace
 
 extern "C" {
+
+void cx_attn_set_bwd_s128(int on) { g_bwd_s128 = on != 0; }
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
@@ -751,6 +1014,11 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    if (max_seqlen <= 128 && g_bwd_s128) {
+        hipLaunchKernelGGL(attn_bwd_dq_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+        return done();
+    }
     dim3 grid((max_seqlen + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
