@@ -971,15 +971,244 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p)
     }
 }
 
+// ----------------------------------------------------------------- backward, sequences <= 128, ONE fused kernel
+// dQ, dK, dV (and delta) of a whole (sequence, head) problem in one workgroup, reading Q, K, V, dO, O from HBM once
+// (the two-kernel form reads qkv and dO twice and runs a separate delta pass: 2.2 GB vs 1.4 GB per 131072-token call).
+// S and dP are computed once, in the key-owner orientation (lane = key); dV and dK follow from registers as in
+// attn_bwd_dkv; dS goes through LDS as a [key][query] tile and comes back through the transposing LDS read
+// (ds_read_b64_tr_b16) as the B operand of dQ^T = K^T dS -- the re-orientation that otherwise costs a second S / dP.
+// 116 KiB of LDS -> one workgroup (4 waves, one per SIMD, 512 registers each) per CU: the workgroup is persistent and
+// L2-prefetches the NEXT problem while the current one is computed.
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_attn;
+constexpr int DSROW = 256;  // bytes per key row of the [128 key][128 query] dS tile
+
+CX_DEVICE bf16x8_t ds_tr_frag(const char* tile, int q0, int k0, int lane) {  // B[k = k0 + 8*(lane>>5) + e][j = q0 + (lane&31)]
+    const int g = lane >> 4, pp = lane & 15;
+    const int t = k0 + 8 * (g >> 1) + (pp >> 2);
+    const int f = q0 + 16 * (g & 1) + 4 * (pp & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int tt = t + 4 * half;
+        const int chunk = (f >> 3) ^ ((tt & 3) << 2);
+        u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + tt * DSROW + chunk * 16 + (f & 4) * 2));
+    }
+    return u.v;
+}
+// A[i = d][k = k0 + 8*hi + e] of a transposed [64 d][128 k] tile (k contiguous): the plain reduction-index order, to
+// pair with ds_tr_frag (read_vt128_frag uses the accumulator-register order instead)
+CX_DEVICE bf16x8_t read_vt128_linear(const char* tile, int d, int k0, int hi) {
+    const char* p = tile + d * VT128_STRIDE + (k0 + 8 * hi) * 2;
+    union { uint2 u[2]; bf16x8_t v; } x;
+    x.u[0] = *reinterpret_cast<const uint2*>(p);
+    x.u[1] = *reinterpret_cast<const uint2*>(p + 8);
+    return x.v;
+}
+
+constexpr int FUSED_LDS = 32768 + 3 * 64 * VT128_STRIDE + 32768 + 1024;
+
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_fused_s128_kernel(AttnParams p,
+                                                                                                               int B) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                         // [128][64] row-major (tile64 swizzle)
+    char* dOs = smem + 16384;
+    char* Qt = smem + 32768;                 // [64 d][128 q]
+    char* dOt = Qt + 64 * VT128_STRIDE;
+    char* Kt = dOt + 64 * VT128_STRIDE;      // [64 d][128 k]
+    char* dSs = Kt + 64 * VT128_STRIDE;      // [128 k][128 q]; K / V row-major staging aliases it (phase 1 only)
+    float* lse_s = reinterpret_cast<float*>(dSs + 32768);
+    float* dl_s = lse_s + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int kp = tid >> 2, cp = tid & 3;
+    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
+    const int n_units = B * p.H;
+
+    RowPairLoads q, k, v, dO, o;
+    CosSin cs;
+    float lse_v = 0.f;
+    auto issue_loads = [&](int u) {  // unit u = (b, h)
+        const int b = u / p.H, h = u - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        if (len <= 0) return;
+        int ra = 2 * kp, rb = ra + 1;
+        ra = ra < len ? ra : len - 1;
+        rb = rb < len ? rb : len - 1;
+        const bf16_t* qbase = p.qkv + (size_t)h * DH;
+        load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, k);
+        load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, v);
+        load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
+        load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dO);
+        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
+        if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
+        if (tid < 128) {
+            const bool ok = tid < len;
+            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
+            lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
+        }
+    };
+
+    // L2 prefetch of the NEXT problem: one dword load per 128-B line (each (row, tensor, head) is exactly one line), issued
+    // once the current problem sits in LDS; its real loads at the top of the next iteration then pay L2, not HBM,
+    // latency.  (Prefetching into registers instead makes the allocator park the values in AGPRs, which needs the data
+    // at once.)  The loaded values are never used; pf_sink keeps the destination register reserved.
+    uint32_t pf_sink = 0;
+    auto l2_prefetch = [&](int un) {
+        const int b = un / p.H, h = un - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        if (tid < len && tid < 128) {
+            const bf16_t* qrow = p.qkv + (size_t)(t0 + tid) * tok_stride + (size_t)h * DH;
+            const bf16_t* krow = qrow + (size_t)p.H * DH;
+            const bf16_t* vrow = krow + (size_t)p.H * DH;
+            const bf16_t* drow = p.dout + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
+            const bf16_t* orow = p.out + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(qrow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(krow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(vrow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(drow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(orow) : "memory");
+        }
+    };
+
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int b = u / p.H, h = u - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        if (len <= 0) continue;  // (uniform per workgroup)
+        issue_loads(u);
+        // ---- delta = rowsum(dO * O): this thread holds 16 of the 64 columns of rows (2kp, 2kp+1) ----
+        float dpart[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float a[8], c[8], acc = 0.f;
+            unpack8(dO.lo[i], a); unpack8(o.lo[i], c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
+            unpack8(dO.hi[i], a); unpack8(o.hi[i], c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            dpart[i] = acc;
+        }
+        // ---- phase 1: K, V row-major -> the key-owner fragments of this wave ----
+        if (p.cosv) { rotate_pair(k, cs); rotate_pair(q, cs); }
+        stage_rows(dSs, kp, cp, k);
+        stage_rows(dSs + 16384, kp, cp, v);
+        stage_transposed128(Kt, kp, cp, k);
+        stage_rows(Qs, kp, cp, q);
+        stage_rows(dOs, kp, cp, dO);
+        stage_transposed128(Qt, kp, cp, q);
+        stage_transposed128(dOt, kp, cp, dO);
+        if (cp == 0) {
+            dl_s[2 * kp] = dpart[0];
+            dl_s[2 * kp + 1] = dpart[1];
+        }
+        if (tid < 128) lse_s[tid] = lse_v;
+        if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
+        __syncthreads();
+        const int row = wave * 32 + l31;  // this lane's key (dK, dV) and later its query (dQ)
+        const bool row_ok = row < len;
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = lds_read_frag(dSs, tile64_off(row, ks * 2 + hi));
+            vf[ks] = lds_read_frag(dSs + 16384, tile64_off(row, ks * 2 + hi));
+        }
+        __syncthreads();  // the K / V staging area becomes the dS tile
+
+        const float sc2 = p.scale * LOG2E;
+        f32x16_t acc_dk[2], acc_dv[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
+        // two query blocks at a time: four independent MFMA accumulation chains (one wave per SIMD has nobody else to
+        // cover the latency of a dependent chain)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            f32x16_t a_s[2], a_dp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a_s[j][r] = a_dp[j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int qb = 2 * qp + j;
+                    a_s[j] = mfma_bf16_32x32x16(lds_read_frag(Qs, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s[j]);
+                    a_dp[j] = mfma_bf16_32x32x16(lds_read_frag(dOs, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int qb = 2 * qp + j;
+                float pr[16], ds[16];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int qrow = qb * 32 + 8 * qd + 4 * hi;
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qrow);
+                    const float4 d4 = *reinterpret_cast<const float4*>(dl_s + qrow);
+                    const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * qd + e;
+                        const float pv = row_ok ? fast_exp2(a_s[j][r] * sc2 - ll[e]) : 0.f;
+                        pr[r] = pv;
+                        ds[r] = pv * (a_dp[j][r] - dd[e]);
+                    }
+                    // dS[key = row][queries qrow .. qrow+3] -> the [key][query] tile (swizzled like the GEMM's TN tiles)
+                    uint2 pk;
+                    pk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
+                    pk.y = pack_bf16x2(ds[4 * qd + 2], ds[4 * qd + 3]);
+                    *reinterpret_cast<uint2*>(dSs + row * DSROW + (((qrow >> 3) ^ ((row & 3) << 2)) << 4) + (qrow & 4) * 2) = pk;
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        acc_dv[db] = mfma_bf16_32x32x16(read_vt128_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
+                        acc_dk[db] = mfma_bf16_32x32x16(read_vt128_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
+                    }
+                }
+            }
+        }
+        if (row_ok) {
+            bf16_t* krow = p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)(p.H + h) * DH;
+            store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, row, hi);
+            store_unrotated(krow + (size_t)p.H * DH, acc_dv, 1.f, nullptr, nullptr, 0, hi);
+        }
+        __syncthreads();  // the dS tile is complete
+
+        // ---- dQ^T[d][q] = sum_k K^T[d][k] dS[k][q] for this wave's 32 queries ----
+        f32x16_t acc_dq[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const bf16x8_t dsf = ds_tr_frag(dSs, wave * 32, kc * 16, lane);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                acc_dq[db] = mfma_bf16_32x32x16(read_vt128_linear(Kt, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
+        }
+        if (row_ok)
+            store_unrotated(p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, row,
+                            hi);
+        __syncthreads();  // LDS is restaged by the next problem
+    }
+    if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
+}
+
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
 
-bool g_bwd_s128 = true;  // A/B switch (cx_attn_set_bwd_s128): one-pass kernels for max_seqlen <= 128
+int g_bwd_s128 = 2;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 2 fused persistent kernel, 1 one-pass dq + dkv, 0 general
 
 }  // namespace
 
 extern "C" {
 
-void cx_attn_set_bwd_s128(int on) { g_bwd_s128 = on != 0; }
+void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
@@ -1010,6 +1239,19 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
+    if (max_seqlen <= 128 && g_bwd_s128 == 2) {  // one fused persistent kernel (computes delta itself)
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_s128_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) != hipSuccess)
+                return CX_ERR_LAUNCH;
+            attr_set = true;
+        }
+        const int n_units = B * H;
+        hipLaunchKernelGGL(attn_bwd_fused_s128_kernel, dim3(n_units < 256 ? n_units : 256), dim3(256), FUSED_LDS,
+                           (hipStream_t)stream, p, B);
+        return done();
+    }
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;

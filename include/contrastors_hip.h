@@ -128,8 +128,9 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
                        const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
                        uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
-/* experiments: 0 = general backward kernels also for max_seqlen <= 128 (default 1 = one-pass S<=128 kernels) */
-void cx_attn_set_bwd_s128(int on);
+/* backward kernel choice for max_seqlen <= 128: 2 = fused persistent kernel (default; `delta` is not written),
+ * 1 = one-pass dq + dkv kernels, 0 = the general kernels */
+void cx_attn_set_bwd_s128(int mode);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                           int B, int H, int T, int max_seqlen, int sign, void* stream);
