@@ -981,6 +981,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p)
 // L2-prefetches the NEXT problem while the current one is computed.
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_attn;
 constexpr int DSROW = 256;  // bytes per key row of the [128 key][128 query] dS tile
+// 16-B chunk swizzle of the dS tile: 4 row bits permute the 16 chunks of a row, so that the writers (32 keys x 8 B per
+// instruction) and the transposing readers (4 rows x 32 B per 16-lane group) are both spread over the banks
+CX_DEVICE int ds_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 CX_DEVICE bf16x8_t ds_tr_frag(const char* tile, int q0, int k0, int lane) {  // B[k = k0 + 8*(lane>>5) + e][j = q0 + (lane&31)]
     const int g = lane >> 4, pp = lane & 15;
@@ -990,7 +993,7 @@ CX_DEVICE bf16x8_t ds_tr_frag(const char* tile, int q0, int k0, int lane) {  // 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int tt = t + 4 * half;
-        const int chunk = (f >> 3) ^ ((tt & 3) << 2);
+        const int chunk = (f >> 3) ^ ds_swz(tt);
         u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + tt * DSROW + chunk * 16 + (f & 4) * 2));
     }
     return u.v;
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     uint2 pk;
                     pk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
                     pk.y = pack_bf16x2(ds[4 * qd + 2], ds[4 * qd + 3]);
-                    *reinterpret_cast<uint2*>(dSs + row * DSROW + (((qrow >> 3) ^ ((row & 3) << 2)) << 4) + (qrow & 4) * 2) = pk;
+                    *reinterpret_cast<uint2*>(dSs + row * DSROW + (((qrow >> 3) ^ ds_swz(row)) << 4) + (qrow & 4) * 2) = pk;
                 }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
