@@ -1203,15 +1203,223 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
 }
 
+// ------------------------------------------------ backward, sequences <= 128, fused, TWO workgroups per CU (80 KiB)
+// Same algorithm as attn_bwd_fused_s128_kernel with an LDS diet so that two workgroups share a CU (two waves per SIMD:
+// one workgroup's VALU / LDS / wait phases overlap the other's MFMA phases).  Every tile is [row][128 idx] bf16 with a
+// 256-B row stride and ONE swizzle (16-B chunk ^ ds_swz(row)) that serves all access patterns:
+//   Qt, dOt [64 d][128 q]: S / dP A-operands through the transposing read, dK / dV A-operands as 2 x 8 B per row
+//   Kt      [64 d][128 k]: dQ A-operand, one 16-B read per row       dS [128 k][128 q]: dQ B-operand, transposing read
+// LDS map: R0 Qt | R1 dOt | R2 lse, delta (phase D) then Kt (dQ) | R3 K, V row-major (fragments) then dS.
+constexpr int SWROW = 256;
+CX_DEVICE int sw_off(int row, int idx) { return row * SWROW + ((((idx >> 3) ^ ds_swz(row)) << 4)) + (idx & 7) * 2; }
+CX_DEVICE void stage_transposed_sw(char* tile, int kp, int cp, const RowPairLoads& x) {  // rows (2kp, 2kp+1) -> T[d][idx]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t wl = (uint32_t)elem16(x.lo[0], e) | ((uint32_t)elem16(x.lo[1], e) << 16);
+        const uint32_t wh = (uint32_t)elem16(x.hi[0], e) | ((uint32_t)elem16(x.hi[1], e) << 16);
+        *reinterpret_cast<uint32_t*>(tile + sw_off(cp * 8 + e, 2 * kp)) = wl;
+        *reinterpret_cast<uint32_t*>(tile + sw_off(32 + cp * 8 + e, 2 * kp)) = wh;
+    }
+}
+// fragment [k = t0 + 8*(lane>>5) + e][j = f0 + (lane&31)] of a swizzled [t][f] tile through the transposing read
+CX_DEVICE bf16x8_t sw_tr_frag(const char* tile, int f0, int t0, int lane) {
+    const int g = lane >> 4, pp = lane & 15;
+    const int t = t0 + 8 * (g >> 1) + (pp >> 2);
+    const int f = f0 + 16 * (g & 1) + 4 * (pp & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + sw_off(t, f)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + sw_off(t + 4, f)));
+    return u.v;
+}
+// A[i = row][k in accumulator-register order: i0 + {0..3}, i0 + 8 + {0..3}], i0 = blk16*16 + 4*hi  (pairs with pack_frag)
+CX_DEVICE bf16x8_t sw_perm_frag(const char* tile, int row, int blk16, int hi) {
+    const int i0 = blk16 * 16 + 4 * hi;
+    union { uint2 u[2]; bf16x8_t v; } x;
+    x.u[0] = *reinterpret_cast<const uint2*>(tile + sw_off(row, i0));
+    x.u[1] = *reinterpret_cast<const uint2*>(tile + sw_off(row, i0 + 8));
+    return x.v;
+}
+// A[i = row][k = k0 + 8*hi + e]: one 16-B chunk
+CX_DEVICE bf16x8_t sw_linear_frag(const char* tile, int row, int k0, int hi) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + sw_off(row, k0 + 8 * hi));
+}
+
+constexpr int FUSED2_LDS = 16384 * 3 + 32768;  // 80 KiB
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams p, int B) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qt = smem;
+    char* dOt = smem + 16384;
+    char* R2 = smem + 32768;                 // lse | delta during phase D, Kt afterwards
+    char* R3 = smem + 49152;                 // K | V row-major (tile64) for the fragments, dS afterwards
+    float* lse_s = reinterpret_cast<float*>(R2);
+    float* dl_s = lse_s + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int kp = tid >> 2, cp = tid & 3;
+    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
+    const int n_units = B * p.H;
+    uint32_t pf_sink = 0;
+    auto l2_prefetch = [&](int un) {
+        const int b = un / p.H, h = un - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        if (tid < len && tid < 128) {
+            const bf16_t* qrow = p.qkv + (size_t)(t0 + tid) * tok_stride + (size_t)h * DH;
+            const bf16_t* krow = qrow + (size_t)p.H * DH;
+            const bf16_t* vrow = krow + (size_t)p.H * DH;
+            const bf16_t* drow = p.dout + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
+            const bf16_t* orow = p.out + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(qrow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(krow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(vrow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(drow) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(orow) : "memory");
+        }
+    };
+
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int b = u / p.H, h = u - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        if (len <= 0) continue;  // (uniform per workgroup)
+        int ra = 2 * kp, rb = ra + 1;
+        ra = ra < len ? ra : len - 1;
+        rb = rb < len ? rb : len - 1;
+        const bf16_t* qbase = p.qkv + (size_t)h * DH;
+        RowPairLoads q, k, v, dO, o;
+        CosSin cs;
+        load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, k);
+        load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, v);
+        load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
+        load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dO);
+        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
+        if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
+        float lse_v = 0.f;
+        if (tid < 128) {
+            const bool ok = tid < len;
+            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
+            lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
+        }
+        // ---- K, V row-major (for this wave's key fragments), then everything that depends on dO / O / Q ----
+        if (p.cosv) rotate_pair(k, cs);
+        stage_rows(R3, kp, cp, k);
+        stage_rows(R3 + 16384, kp, cp, v);
+        float dpart[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // delta = rowsum(dO * O): 16 of the 64 columns of rows (2kp, 2kp+1) per thread
+            float a[8], c[8], acc = 0.f;
+            unpack8(dO.lo[i], a); unpack8(o.lo[i], c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
+            unpack8(dO.hi[i], a); unpack8(o.hi[i], c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            dpart[i] = acc;
+        }
+        if (p.cosv) rotate_pair(q, cs);
+        stage_transposed_sw(Qt, kp, cp, q);
+        stage_transposed_sw(dOt, kp, cp, dO);
+        if (cp == 0) {
+            dl_s[2 * kp] = dpart[0];
+            dl_s[2 * kp + 1] = dpart[1];
+        }
+        if (tid < 128) lse_s[tid] = lse_v;
+        if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
+        __syncthreads();
+        const int row = wave * 32 + l31;  // this lane's key (dK, dV) and later its query (dQ)
+        const bool row_ok = row < len;
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = lds_read_frag(R3, tile64_off(row, ks * 2 + hi));
+            vf[ks] = lds_read_frag(R3 + 16384, tile64_off(row, ks * 2 + hi));
+        }
+        __syncthreads();  // R3 becomes the dS tile
+
+        const float sc2 = p.scale * LOG2E;
+        f32x16_t acc_dk[2], acc_dv[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
+#pragma unroll 1  // (rolled: unrolling makes the compiler hoist ~100 loop-invariant LDS addresses and spill)
+        for (int qb = 0; qb < 4; ++qb) {
+            f32x16_t a_s, a_dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                a_s = mfma_bf16_32x32x16(sw_tr_frag(Qt, qb * 32, ks * 16, lane), kf[ks], a_s);
+                a_dp = mfma_bf16_32x32x16(sw_tr_frag(dOt, qb * 32, ks * 16, lane), vf[ks], a_dp);
+            }
+            float pr[16], ds[16];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int qrow = qb * 32 + 8 * qd + 4 * hi;
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qrow);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + qrow);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const float pv = row_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
+                    pr[r] = pv;
+                    ds[r] = pv * (a_dp[r] - dd[e]);
+                }
+                uint2 pk;  // dS[key = row][queries qrow .. qrow+3]
+                pk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
+                pk.y = pack_bf16x2(ds[4 * qd + 2], ds[4 * qd + 3]);
+                *reinterpret_cast<uint2*>(R3 + sw_off(row, qrow)) = pk;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    acc_dv[db] = mfma_bf16_32x32x16(sw_perm_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
+                    acc_dk[db] = mfma_bf16_32x32x16(sw_perm_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
+                }
+            }
+        }
+        if (row_ok) {
+            bf16_t* krow = p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)(p.H + h) * DH;
+            store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, row, hi);
+            store_unrotated(krow + (size_t)p.H * DH, acc_dv, 1.f, nullptr, nullptr, 0, hi);
+        }
+        __syncthreads();  // the dS tile is complete, lse / delta are dead: R2 becomes Kt
+        stage_transposed_sw(R2, kp, cp, k);
+        __syncthreads();
+
+        // ---- dQ^T[d][q] = sum_k K^T[d][k] dS[k][q] for this wave's 32 queries ----
+        f32x16_t acc_dq[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
+#pragma unroll 2
+        for (int kc = 0; kc < 8; ++kc) {
+            const bf16x8_t dsf = sw_tr_frag(R3, wave * 32, kc * 16, lane);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                acc_dq[db] = mfma_bf16_32x32x16(sw_linear_frag(R2, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
+        }
+        if (row_ok)
+            store_unrotated(p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, row,
+                            hi);
+        __syncthreads();  // LDS is restaged by the next problem
+    }
+    if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
+}
+
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
 
-int g_bwd_s128 = 2;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 2 fused persistent kernel, 1 one-pass dq + dkv, 0 general
+int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
 
 }  // namespace
 
 extern "C" {
 
-void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
+void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 3) ? mode : 3; }
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
@@ -1242,6 +1450,19 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
+    if (max_seqlen <= 128 && g_bwd_s128 == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, FUSED2_LDS) != hipSuccess)
+                return CX_ERR_LAUNCH;
+            attr_set2 = true;
+        }
+        const int n_units = B * H;
+        hipLaunchKernelGGL(attn_bwd_fused2_s128_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
+                           (hipStream_t)stream, p, B);
+        return done();
+    }
     if (max_seqlen <= 128 && g_bwd_s128 == 2) {  // one fused persistent kernel (computes delta itself)
         static bool attr_set = false;
         if (!attr_set) {

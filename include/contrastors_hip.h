@@ -128,8 +128,9 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
                        const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
                        uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
-/* backward kernel choice for max_seqlen <= 128: 2 = fused persistent kernel (default; `delta` is not written),
- * 1 = one-pass dq + dkv kernels, 0 = the general kernels */
+/* backward kernel choice for max_seqlen <= 128: 3 = fused persistent kernel with an 80 KiB LDS layout, two workgroups
+ * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
+ * 0 = the general kernels */
 void cx_attn_set_bwd_s128(int mode);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
