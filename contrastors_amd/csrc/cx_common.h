@@ -35,6 +35,20 @@ CX_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
 }
 CX_DEVICE bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
+// erf-GELU pieces on v_exp_f32 / v_rcp_f32: erf(x) = sign(x) (1 - poly(t) exp(-x^2)), t = 1 / (1 + 0.3275911 |x|)
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- two orders below a bf16 ulp).  libm's erff costs ~40 VALU ops per
+// element and made both GELU kernels VALU-bound at a third of HBM speed.  For gelu the argument is v / sqrt(2), so
+// exp(-x^2) = exp(-v^2 / 2) is also the Gaussian of the derivative: `gauss` is returned for reuse.
+CX_DEVICE float gelu_cdf(float v, float& gauss) {
+    const float av = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * 0.70710678118654752f * av);
+    const float poly =
+        t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    gauss = __builtin_amdgcn_exp2f(-0.72134752044448170f * v * v);  // exp(-v^2 / 2)
+    const float erf_abs = 1.f - poly * gauss;
+    return 0.5f * (1.f + copysignf(erf_abs, v));
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------

@@ -178,10 +178,16 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const bf16_t* __rest
         const int c = (int)(i - t * chunks) * 8;
         float x[8], o[8];
         unpack8(*reinterpret_cast<const uint4*>(pre + t * (long)I + c), x);
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {  // two 16-B loads, not eight scalar ones (the kernel was VMEM-issue-bound on them)
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = x[e] + (bias ? bias[c + e] : 0.f);
-            o[e] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+            const float v = x[e] + bb[e];
+            float gauss;
+            o[e] = v * gelu_cdf(v, gauss);
         }
         *reinterpret_cast<uint4*>(act + t * (long)I + c) = pack8(o);
     }
@@ -200,12 +206,17 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const bf16_t* __rest
         float x[8], d[8], o[8];
         unpack8(*reinterpret_cast<const uint4*>(pre + t * (long)I + c), x);
         unpack8(*reinterpret_cast<const uint4*>(dact + t * (long)I + c), d);
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = x[e] + (bias ? bias[c + e] : 0.f);
-            const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-            const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
-            o[e] = d[e] * (cdf + v * pdf);
+            const float v = x[e] + bb[e];
+            float gauss;
+            const float cdf = gelu_cdf(v, gauss);
+            o[e] = d[e] * (cdf + v * 0.3989422804014327f * gauss);
         }
         *reinterpret_cast<uint4*>(dpre + t * (long)I + c) = pack8(o);
     }

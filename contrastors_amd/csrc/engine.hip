@@ -74,6 +74,11 @@ int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW,
     return cx_gemm_bf16_nt_accum(b->tr_a, b->tr_b, gW, b->ws_f32, b->ws_floats, out_f, in_f, Tp, Tp, Tp, stream);
 }
 
+// true when cx_gemm_bf16_bias_gelu covers the fc1 shape (keep in sync with its checks)
+bool gelu_fused_shape(int T, int N, int K) {
+    return T > 0 && (K % 64) == 0 && (N % 8) == 0 && cx_gemm_get_variant() == 6;
+}
+
 // ---- transformer blocks, forward.  h0: (T,d) input embeddings.  Returns the final hidden states in *h_final. ------
 // post-norm (sc/layers/block.py:389-463):  h = LN1(attn(h) + h);  h = LN2(mlp(h) + h)
 // pre-norm  (sc/layers/block.py:293-388):  r = x + r;  h = LN1(r);  x = attn(h);  r = x + r;  h = LN2(r);  x = mlp(h);
@@ -89,8 +94,16 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
             // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
             CX_TRY(cx_gemm_bf16_swiglu(x, w.Wfc1, save ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d, s.wfc1, I, stream));
         } else {
-            CX_TRY(cx_gemm_bf16_nt(x, w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
-            CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
+            // bias + erf-GELU in the GEMM epilogue; yg then holds the biased pre-activation, which backward reads with a
+            // NULL bias.  Shapes the fused kernel does not cover take the two-kernel route (yg without the bias).
+            const int rc = cx_gemm_bf16_bias_gelu(x, w.Wfc1, w.bfc1, save ? s.yg(sl) : nullptr, s.act(sl), T, s.wfc1, d, d, d,
+                                                  s.wfc1, I, stream);
+            if (rc == CX_ERR_SHAPE) {
+                CX_TRY(cx_gemm_bf16_nt(x, w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
+                CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
+            } else {
+                CX_TRY(rc);
+            }
         }
         return cx_gemm_bf16_nt(s.act(sl), w.Wfc2, out, w.bfc2, T, d, I, I, I, d, 0, 1, 1.f, stream);
     };
@@ -182,7 +195,9 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         if (enc->gated) {
             CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
         } else {
-            CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), w.bfc1, buf->g_wide, T, I, stream));
+            // (yg holds the biased pre-activation when the forward took the fused kernel: same predicate as there)
+            CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide, T, I,
+                                    stream));
             if (w.gbfc1) CX_TRY(cx_bias_grad(buf->g_wide, w.gbfc1, T, I, I, stream));
         }
         CX_TRY(wgrad(buf->g_wide, s.wfc1, mlp_in, d, w.gWfc1, buf, T, stream));

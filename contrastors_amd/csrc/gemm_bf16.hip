@@ -856,6 +856,40 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
+// fc1 of the plain (GELU) MLP with bias + erf-GELU fused into the epilogue.  Pre: (M, N) bf16 pre-activation = X W^T +
+// bias (optional, may be NULL: the no-grad pass), Act: (M, N) bf16 = gelu(Pre).  Returns CX_ERR_SHAPE when the fused
+// kernel does not cover the shape (caller then runs GEMM + cx_bias_gelu_fwd).
+int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M,
+                           int N, int K, int ldx, int ldw, int ld_pre, int ld_act, void* stream) {
+    if (M <= 0 || N <= 0) return CX_OK;
+    if (!Act) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (N % 8) != 0 || (ld_act % 8) != 0 || (Pre && (ld_pre % 8) != 0)) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (cx_gemm_get_variant() != 6) return CX_ERR_SHAPE;
+    GemmParams p;
+    p.X = X; p.W = W; p.Out = Pre; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ld_pre;
+    p.tiles_m = p.tiles_n = 0; p.split_k = 1; p.alpha = 1.f; p.dbg = g_dbg;
+    p.Out2 = Act; p.ldo2 = ld_act; p.sup_m = p.sup_n = 0; p.trace = nullptr;
+    int slot = -1;
+    if (g_prof.enabled) {
+        if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
+            slot = g_prof.used++;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev0[slot]) != hipSuccess || hipEventCreate(&g_prof.ev1[slot]) != hipSuccess)
+                    return CX_ERR_LAUNCH;
+                g_prof.created = slot + 1;
+            }
+            g_prof.flop[slot] = 2.0 * (double)M * (double)N * (double)K;
+            (void)hipEventRecord(g_prof.ev0[slot], (hipStream_t)stream);
+        }
+        ++g_prof.launches;
+    }
+    const hipError_t e = cx_launch_gemm_v6(p, GEMM_EPI_GELU, (hipStream_t)stream);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
+    return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
 int cx_prof_gemm_config(int enable, int stride) {
     g_prof.enabled = enable != 0;
     g_prof.stride = stride > 0 ? stride : 1;

@@ -308,6 +308,59 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 } else {
                     store_tile(std::false_type{});
                 }
+            } else if constexpr (EPI == GEMM_EPI_GELU) {
+                // fc1 of the plain MLP (sc/layers/mlp.py:30-34): pre = acc + bias (bf16, kept for backward when p.Out is
+                // set), act = gelu_erf(pre).  The standalone op sees the bf16-rounded pre-activation; so does this one.
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float pre[4][16];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        v6_read_block(4 * b + a, pre[a]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = n0 + a * 32 + 8 * q + 4 * hi;
+                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
+                            pre[a][4 * q] = bf16_to_f32(f32_to_bf16(pre[a][4 * q] + bv.x));
+                            pre[a][4 * q + 1] = bf16_to_f32(f32_to_bf16(pre[a][4 * q + 1] + bv.y));
+                            pre[a][4 * q + 2] = bf16_to_f32(f32_to_bf16(pre[a][4 * q + 2] + bv.z));
+                            pre[a][4 * q + 3] = bf16_to_f32(f32_to_bf16(pre[a][4 * q + 3] + bv.w));
+                        }
+                    }
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {  // 0: pre-activation (optional), 1: activation
+                        bf16_t* outp = reinterpret_cast<bf16_t*>(which == 0 ? p.Out : p.Out2);
+                        const int ldo = which == 0 ? p.ldo : p.ldo2;
+                        if (!outp) continue;
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float v[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[e] = pre[a][4 * q + e];
+                                    if (which == 1) {
+                                        float gauss;
+                                        v[e] *= gelu_cdf(v[e], gauss);
+                                    }
+                                }
+                                uint2 pk;
+                                pk.x = pack_bf16x2(v[0], v[1]);
+                                pk.y = pack_bf16x2(v[2], v[3]);
+                                *reinterpret_cast<uint2*>(my + l31 * ROWB + (a * 32 + 8 * q + 4 * hi) * 2) = pk;
+                            }
+#pragma unroll
+                        for (int ps = 0; ps < 8; ++ps) {
+                            const int row = ps * 4 + (lane >> 4), ch = lane & 15;
+                            const int m = m0 + b * 32 + row, n = n0 + ch * 8;
+                            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                            if (m < p.M && n + 8 <= p.N)
+                                *reinterpret_cast<uint4*>(outp + (size_t)m * ldo + n) = vv;
+                        }
+                    }
+                }
             } else {
                 // SwiGLU: weight rows interleaved by 32, so the wave's 128 fused columns are [y0 | g0 | y1 | g1] (32 each)
                 // = one 256-B run per row of the (M, 2I) pre-activation tensor and 64 activation columns.
@@ -650,5 +703,7 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     p.tiles_m = (p.M + BM6 - 1) / BM6;
     p.tiles_n = (p.N + BN6 - 1) / BN6;
     p.sup_n = cx_gemm_v6_groups(p.tiles_m, p.tiles_n, p.K);
-    return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream) : launch6<GEMM_EPI_NONE>(p, stream);
+    return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
+           : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
+                                  : launch6<GEMM_EPI_NONE>(p, stream);
 }

@@ -109,6 +109,11 @@ int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T
  * NULL):(M,2I) receives the pre-activation pair in the interleaved layout (kept for backward). */
 int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint16_t* Act, int M, int I, int K, int ldx,
                         int ldw, int ld_yg, int ld_act, void* stream);
+/* fc1 of the plain MLP (sc/layers/mlp.py:30-34: fc2(gelu(fc1 x)), erf GELU, block.py:181-189) with bias + GELU fused
+ * into the GEMM epilogue: Pre (M,N) bf16 = X W^T + bias (optional: NULL in the no-grad pass), Act (M,N) = gelu(Pre).
+ * CX_ERR_SHAPE = shape not covered by the fused kernel (run cx_gemm_bf16_nt + cx_bias_gelu_fwd instead). */
+int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M,
+                           int N, int K, int ldx, int ldw, int ld_pre, int ld_act, void* stream);
 /* act = gelu_erf(pre + bias); bias fp32[I] may be NULL.  backward: dpre = dact * gelu'(pre + bias). */
 int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream);
 int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, int T, int I,

@@ -450,3 +450,25 @@ def test_sgemm_nt():
     c = torch.empty(300, 200, device=DEV)
     _C.check(L().cx_sgemm_nt(a.data_ptr(), b.data_ptr(), c.data_ptr(), 300, 200, 160, 160, 160, 200, S()))
     assert rel_err(c, a.double() @ b.double().T) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
+def test_gemm_bias_gelu_fused(M, N, K):
+    """fc1 + bias + erf-GELU in the GEMM epilogue == GEMM, then bias + GELU in fp32 (one bf16 rounding each)."""
+    L().cx_gemm_set_variant(6)
+    x, w = bf(_randn(M, K, seed=70)), bf(_randn(N, K, seed=71, std=0.05))
+    bias = _randn(N, seed=72)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    act = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_gemm_bf16_bias_gelu(x.data_ptr(), w.data_ptr(), bias.data_ptr(), pre.data_ptr(), act.data_ptr(), M, N, K,
+                                        K, K, N, N, S()))
+    ref_pre = x.float() @ w.float().T + bias
+    assert rel_err(pre.float(), ref_pre) < 4e-3
+    # the activation is defined on the bf16-rounded pre-activation (what the unfused op sees)
+    ref_act = torch.nn.functional.gelu(pre.float())
+    assert rel_err(act.float(), ref_act) < 4e-3
+    assert max_err(act.float(), ref_act) < 2e-2
+    act2 = torch.empty_like(act)
+    _C.check(L().cx_gemm_bf16_bias_gelu(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, act2.data_ptr(), M, N, K, K, K, N,
+                                        N, S()))
+    assert torch.equal(act, act2), "no-grad variant (no pre-activation store) must give identical activations"
