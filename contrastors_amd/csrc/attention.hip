@@ -64,6 +64,23 @@ CX_DEVICE void load_row_pair(const bf16_t* row, int cp, const float* cosv, const
     }
 }
 
+// The rotation half of load_row_pair for data that was loaded earlier (register prefetch of the next chunk).
+CX_DEVICE void rotate_loaded(uint4& lo, uint4& hi, int cp, const float* cosv, const float* sinv, int pos) {
+    if (!cosv) return;
+    float x1[8], x2[8], o1[8], o2[8];
+    unpack8(lo, x1);
+    unpack8(hi, x2);
+    const float* c = cosv + (size_t)pos * 32 + cp * 8;
+    const float* s = sinv + (size_t)pos * 32 + cp * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = x1[e] * c[e] - x2[e] * s[e];
+        o2[e] = x2[e] * c[e] + x1[e] * s[e];
+    }
+    lo = pack8(o1);
+    hi = pack8(o2);
+}
+
 // Write the 8 columns [c8, c8+8) of rows (2*kp, 2*kp+1) into a transposed tile: T[d][idx] at byte d*TSTRIDE+idx*2.
 CX_DEVICE void write_transposed_pair(char* tile, int kp, int c8, const uint4& r0, const uint4& r1) {
 #pragma unroll
@@ -151,26 +168,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
 
+    // The next K / V chunk is loaded into registers while the current one is computed from LDS (the global latency of
+    // every chunk used to sit between two barriers).  K item = (row, chunk pair), V item = (key pair, 8-column chunk).
+    uint4 k_lo, k_hi, v_r0, v_r1;
+    auto prefetch = [&](int kv0) {
+        const int r = tid >> 2, cp = tid & 3;
+        int tk = kv0 + r;
+        tk = tk < len ? tk : len - 1;
+        const bf16_t* krow = kbase + (size_t)(t0 + tk) * tok_stride;
+        k_lo = *reinterpret_cast<const uint4*>(krow + cp * 8);
+        k_hi = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
+        const int kp = tid >> 3, c = tid & 7;
+        int k0i = kv0 + 2 * kp, k1i = k0i + 1;
+        k0i = k0i < len ? k0i : len - 1;
+        k1i = k1i < len ? k1i : len - 1;
+        v_r0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k0i) * tok_stride + c * 8);
+        v_r1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k1i) * tok_stride + c * 8);
+    };
+    prefetch(0);
     for (int kv0 = 0; kv0 < len; kv0 += 64) {
-        {   // K tile (rotated, row-major): 64 rows x 4 chunk pairs = one item per thread
+        {
             const int r = tid >> 2, cp = tid & 3;
             int tk = kv0 + r;
             tk = tk < len ? tk : len - 1;
-            uint4 lo, hi4;
-            load_row_pair(kbase + (size_t)(t0 + tk) * tok_stride, cp, p.cosv, p.sinv, tk, lo, hi4);
-            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
-        }
-        {   // V tile, transposed: thread = (key pair, 8-column chunk)
-            const int kp = tid >> 3, c = tid & 7;
-            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
-            k0i = k0i < len ? k0i : len - 1;
-            k1i = k1i < len ? k1i : len - 1;
-            const uint4 r0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k0i) * tok_stride + c * 8);
-            const uint4 r1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k1i) * tok_stride + c * 8);
-            write_transposed_pair(Vt, kp, c * 8, r0, r1);
+            rotate_loaded(k_lo, k_hi, cp, p.cosv, p.sinv, tk);
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = k_lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = k_hi;
+            write_transposed_pair(Vt, tid >> 3, (tid & 7) * 8, v_r0, v_r1);
         }
         __syncthreads();
+        if (kv0 + 64 < len) prefetch(kv0 + 64);
 
         float s[2][16];
 #pragma unroll
