@@ -191,9 +191,17 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
     auto mlp_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dm, const uint16_t* mlp_in) -> int {
         if (w.gbfc2) CX_TRY(cx_bias_grad(dm, w.gbfc2, T, d, d, stream));
         CX_TRY(wgrad(dm, d, s.act(l), I, w.gWfc2, buf, T, stream));
-        CX_TRY(cx_gemm_bf16_nt(dm, w.Wfc2T, buf->g_act, nullptr, T, I, d, d, d, I, 0, 1, 1.f, stream));
+        int fused = CX_ERR_SHAPE;
+        if (enc->gated)  // fc2 dgrad + SwiGLU backward in one kernel: d(act) never touches HBM
+            fused = cx_gemm_bf16_swiglu_bwd(dm, w.Wfc2T, s.yg(l), buf->g_wide, T, I, d, d, d, s.wfc1, stream);
+        if (fused != CX_ERR_SHAPE) {
+            CX_TRY(fused);
+        } else {
+            CX_TRY(cx_gemm_bf16_nt(dm, w.Wfc2T, buf->g_act, nullptr, T, I, d, d, d, I, 0, 1, 1.f, stream));
+        }
         if (enc->gated) {
-            CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
+            if (fused == CX_ERR_SHAPE)
+                CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
         } else {
             // (yg holds the biased pre-activation when the forward took the fused kernel: same predicate as there)
             CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide, T, I,

@@ -890,6 +890,40 @@ int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bi
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
+// fc2 dgrad of the gated MLP with the SwiGLU backward fused into the epilogue: dYG (M, 2I) = swiglu'(YG) * (dY W^T), where
+// W: (I, K) is the transposed fc2 shadow (the NT operand of the dgrad GEMM).  d(act) is never materialised.  Returns
+// CX_ERR_SHAPE when the fused kernel does not cover the shape (I % 256, K % 64) -> run the GEMM and cx_swiglu_bwd.
+int cx_gemm_bf16_swiglu_bwd(const uint16_t* dY, const uint16_t* W, const uint16_t* YG, uint16_t* dYG, int M, int I, int K,
+                            int ldx, int ldw, int ld_yg, void* stream) {
+    if (M <= 0 || I <= 0) return CX_OK;
+    if (!dY || !W || !YG || !dYG) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (I % 256) != 0 || (ld_yg % 8) != 0 || ld_yg < 2 * I) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (cx_gemm_get_variant() != 6) return CX_ERR_SHAPE;
+    GemmParams p;
+    p.X = dY; p.W = W; p.Out = dYG; p.bias = nullptr;
+    p.M = M; p.N = I; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ld_yg;
+    p.tiles_m = p.tiles_n = 0; p.split_k = 1; p.alpha = 1.f; p.dbg = g_dbg;
+    p.Out2 = const_cast<uint16_t*>(YG); p.ldo2 = ld_yg; p.sup_m = p.sup_n = 0; p.trace = nullptr;
+    int slot = -1;
+    if (g_prof.enabled) {
+        if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
+            slot = g_prof.used++;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev0[slot]) != hipSuccess || hipEventCreate(&g_prof.ev1[slot]) != hipSuccess)
+                    return CX_ERR_LAUNCH;
+                g_prof.created = slot + 1;
+            }
+            g_prof.flop[slot] = 2.0 * (double)M * (double)I * (double)K;
+            (void)hipEventRecord(g_prof.ev0[slot], (hipStream_t)stream);
+        }
+        ++g_prof.launches;
+    }
+    const hipError_t e = cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD, (hipStream_t)stream);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
+    return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
 int cx_prof_gemm_config(int enable, int stride) {
     g_prof.enabled = enable != 0;
     g_prof.stride = stride > 0 ? stride : 1;

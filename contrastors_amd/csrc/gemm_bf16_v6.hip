@@ -308,6 +308,79 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 } else {
                     store_tile(std::false_type{});
                 }
+            } else if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
+                // fc2 dgrad with the SwiGLU backward in the epilogue (sc/layers/mlp.py:75 swiglu, its autograd): the tile
+                // is d(act) for 128 activation columns of this wave = 256 columns [y0|g0|y1|g1|y2|g2|y3|g3] of the
+                // pre-activation tensor YG (p.Out2, input) and of its gradient dYG (p.Out).  d(act) is never written; the
+                // HBM-bound elementwise pass (read YG + d(act), write dYG) now overlaps other workgroups' MFMA phases.
+                // Per pass of 32 rows: YG block -> LDS (coalesced 16-B loads), every lane updates its (row, 4 columns)
+                // cells in place, dYG block LDS -> HBM (coalesced).  [32 rows][512 B], 16-B chunk index ^ row.
+                const bf16_t* yg_in = reinterpret_cast<const bf16_t*>(p.Out2);
+                bf16_t* dyg = reinterpret_cast<bf16_t*>(p.Out);
+                const int c0 = 2 * n0;  // first pre-activation column of this wave
+                auto cell = [&](int row, int colbyte) { return my + row * 512 + ((((colbyte >> 4) ^ row) & 31) << 4) + (colbyte & 15); };
+#pragma unroll 1
+                for (int b = 0; b < 4; ++b) {
+                    // 2 x 8 loads in flight, held in NAMED registers (an L2 prefetch during the last K-tile and 4 x 4 groups measured slower) (a `uint4 in[16]` array lands in scratch memory here)
+                    const int lrow = lane >> 5, lch = lane & 31;
+#define CX_YG_LOAD(i)                                                                                   \
+    uint4 in##i;                                                                                      \
+    {                                                                                                 \
+        int m_ = m0 + b * 32 + (i) * 2 + lrow;                                                        \
+        m_ = m_ < p.M ? m_ : p.M - 1;                                                                 \
+        in##i = *reinterpret_cast<const uint4*>(yg_in + (size_t)m_ * p.ldo2 + c0 + lch * 8);          \
+    }
+#define CX_YG_STAGE(i) *reinterpret_cast<uint4*>(cell((i) * 2 + lrow, lch * 16)) = in##i;
+                    {
+                        CX_YG_LOAD(0) CX_YG_LOAD(1) CX_YG_LOAD(2) CX_YG_LOAD(3) CX_YG_LOAD(4) CX_YG_LOAD(5) CX_YG_LOAD(6)
+                        CX_YG_LOAD(7)
+                        CX_YG_STAGE(0) CX_YG_STAGE(1) CX_YG_STAGE(2) CX_YG_STAGE(3) CX_YG_STAGE(4) CX_YG_STAGE(5)
+                        CX_YG_STAGE(6) CX_YG_STAGE(7)
+                    }
+                    {
+                        CX_YG_LOAD(8) CX_YG_LOAD(9) CX_YG_LOAD(10) CX_YG_LOAD(11) CX_YG_LOAD(12) CX_YG_LOAD(13)
+                        CX_YG_LOAD(14) CX_YG_LOAD(15)
+                        CX_YG_STAGE(8) CX_YG_STAGE(9) CX_YG_STAGE(10) CX_YG_STAGE(11) CX_YG_STAGE(12) CX_YG_STAGE(13)
+                        CX_YG_STAGE(14) CX_YG_STAGE(15)
+                    }
+#undef CX_YG_LOAD
+#undef CX_YG_STAGE
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        float da[16];
+                        v6_read_block(4 * b + a, da);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            char* py = cell(l31, (a * 64 + 8 * q + 4 * hi) * 2);
+                            char* pg = cell(l31, (a * 64 + 32 + 8 * q + 4 * hi) * 2);
+                            const uint2 yy = *reinterpret_cast<const uint2*>(py);
+                            const uint2 gg = *reinterpret_cast<const uint2*>(pg);
+                            const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
+                            const float g[4] = {bf16lo_to_f32(gg.x), bf16hi_to_f32(gg.x), bf16lo_to_f32(gg.y), bf16hi_to_f32(gg.y)};
+                            float dy[4], dg[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = bf16_to_f32(f32_to_bf16(da[4 * q + e]));  // the standalone op sees bf16 d(act)
+                                const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
+                                const float gs = g[e] * sg;
+                                dy[e] = gs * d;
+                                dg[e] = (sg + gs * (1.f - sg)) * d * y[e];
+                            }
+                            uint2 o;
+                            o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);
+                            *reinterpret_cast<uint2*>(py) = o;
+                            o.x = pack_bf16x2(dg[0], dg[1]); o.y = pack_bf16x2(dg[2], dg[3]);
+                            *reinterpret_cast<uint2*>(pg) = o;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = i * 2 + (lane >> 5), ch = lane & 31;
+                        const int m = m0 + b * 32 + row;
+                        const uint4 vv = *reinterpret_cast<const uint4*>(cell(row, ch * 16));
+                        if (m < p.M) *reinterpret_cast<uint4*>(dyg + (size_t)m * p.ldo + c0 + ch * 8) = vv;
+                    }
+                }
             } else if constexpr (EPI == GEMM_EPI_GELU) {
                 // fc1 of the plain MLP (sc/layers/mlp.py:30-34): pre = acc + bias (bf16, kept for backward when p.Out is
                 // set), act = gelu_erf(pre).  The standalone op sees the bf16-rounded pre-activation; so does this one.
@@ -705,5 +778,6 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     p.sup_n = cx_gemm_v6_groups(p.tiles_m, p.tiles_n, p.K);
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
            : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
+           : epi == GEMM_EPI_SWIGLU_BWD ? launch6<GEMM_EPI_SWIGLU_BWD>(p, stream)
                                   : launch6<GEMM_EPI_NONE>(p, stream);
 }

@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 enum { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_F32_ATOMIC = 2, GEMM_OUT_F32_PARTIAL = 3 };
-enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1, GEMM_EPI_GELU = 2 };  // GELU: Out2 = gelu(acc + bias), Out (optional) = acc + bias
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1, GEMM_EPI_GELU = 2, GEMM_EPI_SWIGLU_BWD = 3 };  // GELU: Out2 = gelu(acc + bias), Out (optional) = acc + bias
+// SWIGLU_BWD: acc = d(act); Out2 = YG (INPUT, (M, 2N) interleaved by 32), Out = dYG (same layout)
 
 struct GemmParams {
     const uint16_t* X;

@@ -114,6 +114,12 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
  * CX_ERR_SHAPE = shape not covered by the fused kernel (run cx_gemm_bf16_nt + cx_bias_gelu_fwd instead). */
 int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M,
                            int N, int K, int ldx, int ldw, int ld_pre, int ld_act, void* stream);
+/* fc2 dgrad of the gated MLP with the backward of `swiglu` (flash_attn.ops.activations, sc/layers/mlp.py:75) fused into
+ * the epilogue: dYG (M, 2I) = d swiglu(YG) applied to dAct = dY W^T, YG / dYG in the interleaved-by-32 layout of
+ * cx_gemm_bf16_swiglu; W: (I, K) row-major (the transposed fc2 weight).  dAct is never written to memory.
+ * CX_ERR_SHAPE = shape not covered (needs I % 256 == 0, K % 64 == 0): run cx_gemm_bf16_nt + cx_swiglu_bwd instead. */
+int cx_gemm_bf16_swiglu_bwd(const uint16_t* dY, const uint16_t* W, const uint16_t* YG, uint16_t* dYG, int M, int I, int K,
+                            int ldx, int ldw, int ld_yg, void* stream);
 /* act = gelu_erf(pre + bias); bias fp32[I] may be NULL.  backward: dpre = dact * gelu'(pre + bias). */
 int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream);
 int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, int T, int I,

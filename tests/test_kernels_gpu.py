@@ -472,3 +472,26 @@ def test_gemm_bias_gelu_fused(M, N, K):
     _C.check(L().cx_gemm_bf16_bias_gelu(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, act2.data_ptr(), M, N, K, K, K, N,
                                         N, S()))
     assert torch.equal(act, act2), "no-grad variant (no pre-activation store) must give identical activations"
+
+
+@pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (1000, 512, 256), (257, 256, 64)])
+def test_gemm_swiglu_bwd_fused(M, I, K):
+    """fc2 dgrad with the SwiGLU backward in the epilogue == dgrad GEMM (bf16 d(act)) followed by cx_swiglu_bwd."""
+    L().cx_gemm_set_variant(6)
+    dy = bf(_randn(M, K, seed=80))
+    w = bf(_randn(I, K, seed=81, std=0.05))          # transposed fc2 weight: (I, d)
+    yg = bf(_randn(M, 2 * I, seed=82))               # interleaved-by-32 [y | g] pre-activations
+    got = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_gemm_bf16_swiglu_bwd(dy.data_ptr(), w.data_ptr(), yg.data_ptr(), got.data_ptr(), M, I, K, K, K, 2 * I,
+                                         S()), "cx_gemm_bf16_swiglu_bwd")
+    dact = gemm(dy, w, out_mode=0)                   # (M, I) bf16
+    want = torch.empty_like(got)
+    _C.check(L().cx_swiglu_bwd(dact.data_ptr(), yg.data_ptr(), want.data_ptr(), M, I, 1, S()), "cx_swiglu_bwd")
+    assert rel_err(got.float(), want.float()) < 2e-3
+    # and against plain torch on the bf16 inputs
+    v = yg.view(M, I // 32, 2, 32).float()
+    y, g = v[:, :, 0].reshape(M, I), v[:, :, 1].reshape(M, I)
+    d = dact.float()
+    sg = torch.sigmoid(g)
+    ref = torch.stack([(g * sg * d).view(M, I // 32, 32), ((sg * (1 + g * (1 - sg))) * d * y).view(M, I // 32, 32)], 2)
+    assert rel_err(got.float(), ref.reshape(M, 2 * I)) < 6e-3
