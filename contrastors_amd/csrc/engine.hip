@@ -74,6 +74,21 @@ int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW,
     return cx_gemm_bf16_nt_accum(b->tr_a, b->tr_b, gW, b->ws_f32, b->ws_floats, out_f, in_f, Tp, Tp, Tp, stream);
 }
 
+// out = x W^T + bias (+ residual when the fused epilogue covers the shape).  *folded tells the caller whether the
+// residual is already in `out` (then the LayerNorm that follows gets residual = NULL).
+int proj_residual(const uint16_t* x, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* out, int T,
+                  int N, int K, bool* folded, void* stream) {
+    *folded = false;
+    if (residual) {
+        const int rc = cx_gemm_bf16_nt_residual(x, W, out, bias, residual, T, N, K, K, K, N, N, stream);
+        if (rc != CX_ERR_SHAPE) {
+            *folded = rc == CX_OK;
+            return rc;
+        }
+    }
+    return cx_gemm_bf16_nt(x, W, out, bias, T, N, K, K, K, N, 0, 1, 1.f, stream);
+}
+
 // true when cx_gemm_bf16_bias_gelu covers the fc1 shape (keep in sync with its checks)
 bool gelu_fused_shape(int T, int N, int K) {
     return T > 0 && (K % 64) == 0 && (N % 8) == 0 && cx_gemm_get_variant() == 6;
@@ -89,7 +104,9 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
                    const int32_t* cu_seqlens, int Bc, int T, int max_seqlen, int save, const uint16_t** h_final,
                    void* stream) {
     const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
-    auto mlp = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out) -> int {
+    // (`residual`: added to the fc2 / out_proj output in the GEMM epilogue when possible; *folded reports it)
+    auto mlp = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out, const uint16_t* residual,
+                   bool* folded) -> int {
         if (enc->gated) {
             // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
             CX_TRY(cx_gemm_bf16_swiglu(x, w.Wfc1, save ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d, s.wfc1, I, stream));
@@ -105,26 +122,30 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
                 CX_TRY(rc);
             }
         }
-        return cx_gemm_bf16_nt(s.act(sl), w.Wfc2, out, w.bfc2, T, d, I, I, I, d, 0, 1, 1.f, stream);
+        return proj_residual(s.act(sl), w.Wfc2, w.bfc2, residual, out, T, d, I, folded, stream);
     };
-    auto attn = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out) -> int {
+    auto attn = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out, const uint16_t* residual,
+                    bool* folded) -> int {
         CX_TRY(cx_gemm_bf16_nt(x, w.Wqkv, s.qkv(sl), w.bqkv, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.f, stream));
         CX_TRY(cx_attn_varlen_fwd(s.qkv(sl), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(sl), s.lse(sl), Bc, H, T,
                                   max_seqlen, enc->softmax_scale, stream));
-        return cx_gemm_bf16_nt(s.ctx(sl), w.Wout, out, w.bout, T, d, d, d, d, d, 0, 1, 1.f, stream);
+        return proj_residual(s.ctx(sl), w.Wout, w.bout, residual, out, T, d, d, folded, stream);
     };
     if (!enc->prenorm) {
         const uint16_t* h_in = h0;
         for (int l = 0; l < L; ++l) {
             const CxLayerWeights& w = enc->layers[l];
             const int sl = save ? l : 0;
-            CX_TRY(attn(w, h_in, sl, s.z1(sl)));
-            // z (= attn_out + residual) is only kept for backward; the no-grad pass skips that 1/4 of the LN traffic
-            CX_TRY(cx_layernorm_fwd(s.z1(sl), h_in, w.ln1_g, w.ln1_b, s.h1(sl), save ? s.z1(sl) : nullptr, s.mean1(sl),
-                                    s.rstd1(sl), T, d, enc->ln_eps, stream));
-            CX_TRY(mlp(w, s.h1(sl), sl, s.z2(sl)));
-            CX_TRY(cx_layernorm_fwd(s.z2(sl), s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl), save ? s.z2(sl) : nullptr,
-                                    s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
+            // z = sublayer output + residual: added in the projection's epilogue when the fused kernel covers the shape
+            // (then z is complete in place and the LayerNorm reads one stream), else by the LayerNorm kernel, which
+            // writes z only when backward needs it.
+            bool f1 = false, f2 = false;
+            CX_TRY(attn(w, h_in, sl, s.z1(sl), h_in, &f1));
+            CX_TRY(cx_layernorm_fwd(s.z1(sl), f1 ? nullptr : h_in, w.ln1_g, w.ln1_b, s.h1(sl),
+                                    (save && !f1) ? s.z1(sl) : nullptr, s.mean1(sl), s.rstd1(sl), T, d, enc->ln_eps, stream));
+            CX_TRY(mlp(w, s.h1(sl), sl, s.z2(sl), s.h1(sl), &f2));
+            CX_TRY(cx_layernorm_fwd(s.z2(sl), f2 ? nullptr : s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl),
+                                    (save && !f2) ? s.z2(sl) : nullptr, s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
             h_in = s.h2(sl);
         }
         *h_final = h_in;
@@ -133,22 +154,27 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
     if (!buf->zf || !buf->hf || !buf->meanf || !buf->rstdf || !enc->lnf_g || !enc->lnf_b) return CX_ERR_ARG;
     const uint16_t* x = h0;        // output of the previous sub-layer (the embeddings for the first block)
     const uint16_t* r = nullptr;   // residual stream
+    bool r_folded = false;         // the residual stream was already added into x by a GEMM epilogue
     for (int l = 0; l < L; ++l) {
         const CxLayerWeights& w = enc->layers[l];
         const int sl = save ? l : 0;
-        CX_TRY(cx_layernorm_fwd(x, r, w.ln1_g, w.ln1_b, s.h1(sl), s.z1(sl), s.mean1(sl), s.rstd1(sl), T, d, enc->ln_eps,
-                                stream));
-        CX_TRY(attn(w, s.h1(sl), sl, s.z2(sl)));
-        CX_TRY(cx_layernorm_fwd(s.z2(sl), s.z1(sl), w.ln2_g, w.ln2_b, s.h2(sl), s.z2(sl), s.mean2(sl), s.rstd2(sl), T, d,
-                                enc->ln_eps, stream));
+        // (when the previous fc2 folded the residual in, x == z1(sl) already holds the complete residual stream; for the
+        // first block x = h0 is copied into z1 by the kernel)
+        CX_TRY(cx_layernorm_fwd(x, r, w.ln1_g, w.ln1_b, s.h1(sl), (r_folded && x == s.z1(sl)) ? nullptr : s.z1(sl), s.mean1(sl),
+                                s.rstd1(sl), T, d, enc->ln_eps, stream));
+        bool f1 = false, f2 = false;
+        CX_TRY(attn(w, s.h1(sl), sl, s.z2(sl), s.z1(sl), &f1));
+        CX_TRY(cx_layernorm_fwd(s.z2(sl), f1 ? nullptr : s.z1(sl), w.ln2_g, w.ln2_b, s.h2(sl), f1 ? nullptr : s.z2(sl),
+                                s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
         // the MLP output lands where the next LayerNorm completes it in place: the next block's z1 slot, or zf
         uint16_t* nxt = (l + 1 < L) ? s.z1(save ? l + 1 : 0) : buf->zf;
-        CX_TRY(mlp(w, s.h2(sl), sl, nxt));
+        CX_TRY(mlp(w, s.h2(sl), sl, nxt, s.z2(sl), &f2));
         x = nxt;
-        r = s.z2(sl);
+        r = f2 ? nullptr : s.z2(sl);   // already folded into x by the fc2 epilogue
+        r_folded = f2;
     }
-    CX_TRY(cx_layernorm_fwd(x, r, enc->lnf_g, enc->lnf_b, buf->hf, buf->zf, buf->meanf, buf->rstdf, T, d, enc->ln_eps,
-                            stream));
+    CX_TRY(cx_layernorm_fwd(x, r, enc->lnf_g, enc->lnf_b, buf->hf, r_folded ? nullptr : buf->zf, buf->meanf, buf->rstdf, T,
+                            d, enc->ln_eps, stream));
     *h_final = buf->hf;
     return CX_OK;
 }

@@ -856,6 +856,40 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
+// Out (M,N) bf16 = bf16(bf16(X W^T + bias) + Residual): a projection whose output feeds `x0 + residual -> LayerNorm`
+// (out_proj and fc2 of every block).  CX_ERR_SHAPE when the one-wave-per-SIMD kernel does not cover the shape.
+int cx_gemm_bf16_nt_residual(const uint16_t* X, const uint16_t* W, uint16_t* Out, const float* bias,
+                             const uint16_t* Residual, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
+                             void* stream) {
+    if (M <= 0 || N <= 0) return CX_OK;
+    if (!Residual || !Out) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (N % 8) != 0 || (ldo % 8) != 0 || (ldr % 8) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (cx_gemm_get_variant() != 6) return CX_ERR_SHAPE;
+    GemmParams p;
+    p.X = X; p.W = W; p.Out = Out; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
+    p.tiles_m = p.tiles_n = 0; p.split_k = 1; p.alpha = 1.f; p.dbg = g_dbg;
+    p.Out2 = const_cast<uint16_t*>(Residual); p.ldo2 = ldr; p.sup_m = p.sup_n = 0; p.trace = nullptr;
+    int slot = -1;
+    if (g_prof.enabled) {
+        if ((g_prof.launches % g_prof.stride) == 0 && g_prof.used < GemmProf::CAP) {
+            slot = g_prof.used++;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev0[slot]) != hipSuccess || hipEventCreate(&g_prof.ev1[slot]) != hipSuccess)
+                    return CX_ERR_LAUNCH;
+                g_prof.created = slot + 1;
+            }
+            g_prof.flop[slot] = 2.0 * (double)M * (double)N * (double)K;
+            (void)hipEventRecord(g_prof.ev0[slot], (hipStream_t)stream);
+        }
+        ++g_prof.launches;
+    }
+    const hipError_t e = cx_launch_gemm_v6(p, GEMM_EPI_NONE, (hipStream_t)stream);
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
+    return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
 // fc1 of the plain (GELU) MLP with bias + erf-GELU fused into the epilogue.  Pre: (M, N) bf16 pre-activation = X W^T +
 // bias (optional, may be NULL: the no-grad pass), Act: (M, N) bf16 = gelu(Pre).  Returns CX_ERR_SHAPE when the fused
 // kernel does not cover the shape (caller then runs GEMM + cx_bias_gelu_fwd).

@@ -263,9 +263,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 const bool add_bias = p.bias != nullptr;
                 // `plain` (compile time): alpha == 1 and no bias -- the forward / dgrad launches of bias-free models;
                 // saves 256 multiplies per lane per tile in an epilogue that is VALU-issue-bound (one wave per SIMD)
+                // optional residual (p.Out2, same (M, N) bf16 layout as the output): Out = bf16(bf16(result) + residual) --
+                // the `x0 + residual` of dropout_add_layer_norm (sc/layers/block.py:422-431) moves from the HBM-bound
+                // LayerNorm kernel into this epilogue, where it overlaps other workgroups' MFMA phases.
+                const bf16_t* resid = reinterpret_cast<const bf16_t*>(p.Out2);
                 auto store_tile = [&](auto plain) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
+                        uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {}, r4 = {}, r5 = {}, r6 = {}, r7 = {};
+                        if (resid) {  // issued before the conversion work below; named registers (see SWIGLU_BWD)
+#define CX_RES_LOAD(ps, dst)                                                                              \
+    {                                                                                                 \
+        int m_ = m0 + b * 32 + (ps) * 4 + (lane >> 4);                                                \
+        m_ = m_ < p.M ? m_ : p.M - 1;                                                                 \
+        int n_ = n0 + (lane & 15) * 8;                                                                \
+        n_ = n_ + 8 <= p.N ? n_ : 0;                                                                  \
+        dst = *reinterpret_cast<const uint4*>(resid + (size_t)m_ * p.ldo2 + n_);                      \
+    }
+                            CX_RES_LOAD(0, r0) CX_RES_LOAD(1, r1) CX_RES_LOAD(2, r2) CX_RES_LOAD(3, r3)
+                            CX_RES_LOAD(4, r4) CX_RES_LOAD(5, r5) CX_RES_LOAD(6, r6) CX_RES_LOAD(7, r7)
+#undef CX_RES_LOAD
+                        }
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             float blk[16];
@@ -297,7 +315,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         for (int ps = 0; ps < 8; ++ps) {
                             const int row = ps * 4 + (lane >> 4), ch = lane & 15;
                             const int m = m0 + b * 32 + row, n = n0 + ch * 8;
-                            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                            uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                            if (resid) {
+                                const uint4 rr = ps == 0 ? r0 : ps == 1 ? r1 : ps == 2 ? r2 : ps == 3 ? r3 : ps == 4 ? r4 : ps == 5 ? r5
+                                                 : ps == 6 ? r6 : r7;
+                                vv.x = pack_bf16x2(bf16lo_to_f32(vv.x) + bf16lo_to_f32(rr.x), bf16hi_to_f32(vv.x) + bf16hi_to_f32(rr.x));
+                                vv.y = pack_bf16x2(bf16lo_to_f32(vv.y) + bf16lo_to_f32(rr.y), bf16hi_to_f32(vv.y) + bf16hi_to_f32(rr.y));
+                                vv.z = pack_bf16x2(bf16lo_to_f32(vv.z) + bf16lo_to_f32(rr.z), bf16hi_to_f32(vv.z) + bf16hi_to_f32(rr.z));
+                                vv.w = pack_bf16x2(bf16lo_to_f32(vv.w) + bf16lo_to_f32(rr.w), bf16hi_to_f32(vv.w) + bf16hi_to_f32(rr.w));
+                            }
                             if (m < p.M && n + 8 <= p.N)
                                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
                         }

@@ -107,6 +107,13 @@ int cx_swiglu_fwd(const uint16_t* yg, uint16_t* act, int T, int I, int layout, v
 int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T, int I, int layout, void* stream);
 /* K9 + K10 fused: Act:(M,I) = silu(X Wg^T) * (X Wy^T) in one pass, W:(2I,K) rows interleaved by 32 as above; YG (may be
  * NULL):(M,2I) receives the pre-activation pair in the interleaved layout (kept for backward). */
+/* Projection whose output is the `x0` of `dropout_add_layer_norm(x0, residual, ...)` (sc/layers/block.py:422-431,
+ * 453-462: out_proj and fc2 of every block): Out = bf16(bf16(X W^T + bias) + Residual), i.e. the residual add leaves the
+ * LayerNorm kernel (call cx_layernorm_fwd with x0 = Out, residual = NULL).  Residual: (M, N) bf16, leading dim ldr.
+ * CX_ERR_SHAPE = shape not covered by the fused kernel (use cx_gemm_bf16_nt and pass the residual to the LayerNorm). */
+int cx_gemm_bf16_nt_residual(const uint16_t* X, const uint16_t* W, uint16_t* Out, const float* bias,
+                             const uint16_t* Residual, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
+                             void* stream);
 int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint16_t* Act, int M, int I, int K, int ldx,
                         int ldw, int ld_yg, int ld_act, void* stream);
 /* fc1 of the plain MLP (sc/layers/mlp.py:30-34: fc2(gelu(fc1 x)), erf GELU, block.py:181-189) with bias + GELU fused

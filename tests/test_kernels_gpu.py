@@ -495,3 +495,20 @@ def test_gemm_swiglu_bwd_fused(M, I, K):
     sg = torch.sigmoid(g)
     ref = torch.stack([(g * sg * d).view(M, I // 32, 32), ((sg * (1 + g * (1 - sg))) * d * y).view(M, I // 32, 32)], 2)
     assert rel_err(got.float(), ref.reshape(M, 2 * I)) < 6e-3
+
+
+@pytest.mark.parametrize("with_bias", [False, True])
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1000, 768, 3072), (257, 264, 64)])
+def test_gemm_residual_fused(M, N, K, with_bias):
+    """Projection + residual add in the GEMM epilogue == bf16 GEMM output, then fp32 add, one more bf16 rounding."""
+    L().cx_gemm_set_variant(6)
+    x, w = bf(_randn(M, K, seed=60)), bf(_randn(N, K, seed=61, std=0.05))
+    res = bf(_randn(M, N, seed=62))
+    bias = _randn(N, seed=63) if with_bias else None
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_gemm_bf16_nt_residual(x.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr() if with_bias else None,
+                                          res.data_ptr(), M, N, K, K, K, N, N, S()), "cx_gemm_bf16_nt_residual")
+    base = gemm(x, w, bias=bias, out_mode=0)
+    want = (base.float() + res.float()).to(torch.bfloat16)
+    assert rel_err(out.float(), want.float()) < 1e-3
+    assert float((out.float() - want.float()).abs().max()) <= 0.0625  # at most one bf16 ulp of O(4) values
