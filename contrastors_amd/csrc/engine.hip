@@ -214,7 +214,10 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                     int T, int max_seqlen, const uint16_t** da_out, const uint16_t** db_out, void* stream) {
     const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
     // MLP backward: dm -> gradients of fc2 / fc1 parameters, d(mlp input) into buf->g_b
-    auto mlp_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dm, const uint16_t* mlp_in) -> int {
+    // `add` (optional): the residual-branch gradient that the following LayerNorm backward would add to this dgrad
+    // output; folded into the last GEMM's epilogue when the fused kernel covers the shape (*folded).
+    auto mlp_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dm, const uint16_t* mlp_in, const uint16_t* add,
+                       bool* folded) -> int {
         if (w.gbfc2) CX_TRY(cx_bias_grad(dm, w.gbfc2, T, d, d, stream));
         CX_TRY(wgrad(dm, d, s.act(l), I, w.gWfc2, buf, T, stream));
         int fused = CX_ERR_SHAPE;
@@ -235,10 +238,11 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
             if (w.gbfc1) CX_TRY(cx_bias_grad(buf->g_wide, w.gbfc1, T, I, I, stream));
         }
         CX_TRY(wgrad(buf->g_wide, s.wfc1, mlp_in, d, w.gWfc1, buf, T, stream));
-        return cx_gemm_bf16_nt(buf->g_wide, w.Wfc1T, buf->g_b, nullptr, T, d, s.wfc1, s.wfc1, s.wfc1, d, 0, 1, 1.f, stream);
+        return proj_residual(buf->g_wide, w.Wfc1T, nullptr, add, buf->g_b, T, d, s.wfc1, folded, stream);
     };
     // attention backward: dx (grad of the out_proj output) -> parameter gradients, d(attention input) into buf->g_b
-    auto attn_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dx, const uint16_t* attn_in) -> int {
+    auto attn_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dx, const uint16_t* attn_in, const uint16_t* add,
+                        bool* folded) -> int {
         if (w.gbout) CX_TRY(cx_bias_grad(dx, w.gbout, T, d, d, stream));
         CX_TRY(wgrad(dx, d, s.ctx(l), d, w.gWout, buf, T, stream));
         CX_TRY(cx_gemm_bf16_nt(dx, w.WoutT, buf->g_b, nullptr, T, d, d, d, d, d, 0, 1, 1.f, stream));
@@ -247,7 +251,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                                   buf->delta, buf->g_wide, Bc, H, T, max_seqlen, enc->softmax_scale, stream));
         if (w.gbqkv) CX_TRY(cx_bias_grad(buf->g_wide, w.gbqkv, T, 3 * d, 3 * d, stream));
         CX_TRY(wgrad(buf->g_wide, 3 * d, attn_in, d, w.gWqkv, buf, T, stream));
-        return cx_gemm_bf16_nt(buf->g_wide, w.WqkvT, buf->g_b, nullptr, T, d, 3 * d, 3 * d, 3 * d, d, 0, 1, 1.f, stream);
+        return proj_residual(buf->g_wide, w.WqkvT, nullptr, add, buf->g_b, T, d, 3 * d, folded, stream);
     };
     if (!enc->prenorm) {
         const uint16_t* da = buf->g_a;
@@ -258,13 +262,15 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
             // LN2: dz2 = grad of (mlp_out + h1)
             CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
                                     w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
-            CX_TRY(mlp_bwd(w, l, buf->g_c, s.h1(l)));
-            // LN1: dout = dz2 (residual branch) + dh1 from the MLP
-            CX_TRY(cx_layernorm_bwd(buf->g_c, buf->g_b, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), nullptr, buf->g_a,
-                                    w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
-            CX_TRY(attn_bwd(w, l, buf->g_a, h_in));
-            da = buf->g_a;  // dz1: residual branch into h_in
-            db = buf->g_b;  // attention branch into h_in
+            bool f1 = false, f2 = false;
+            CX_TRY(mlp_bwd(w, l, buf->g_c, s.h1(l), buf->g_c, &f1));
+            // LN1: dout = dz2 (residual branch) + dh1 from the MLP (already summed in g_b when the fc1 dgrad folded it)
+            CX_TRY(cx_layernorm_bwd(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l),
+                                    s.rstd1(l), nullptr, buf->g_a, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d,
+                                    stream));
+            CX_TRY(attn_bwd(w, l, buf->g_a, h_in, buf->g_a, &f2));
+            da = f2 ? buf->g_b : buf->g_a;  // dz1 (residual branch into h_in) [+ the attention branch when folded]
+            db = f2 ? nullptr : buf->g_b;   // attention branch into h_in
         }
         *da_out = da;
         *db_out = db;
@@ -275,10 +281,11 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                             enc->glnf_b, buf->ws_f32, buf->ws_floats, T, d, stream));
     for (int l = L - 1; l >= 0; --l) {   // invariant: buf->g_c = d(x_l + r_l) = gradient of both the MLP output and r
         const CxLayerWeights& w = enc->layers[l];
-        CX_TRY(mlp_bwd(w, l, buf->g_c, s.h2(l)));                       // -> g_b = d h2
+        bool unused = false;
+        CX_TRY(mlp_bwd(w, l, buf->g_c, s.h2(l), nullptr, &unused));    // -> g_b = d h2
         CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), /*dz_extra*/ buf->g_c,
                                 buf->g_a, w.gln2_g, w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
-        CX_TRY(attn_bwd(w, l, buf->g_a, s.h1(l)));                      // -> g_b = d h1
+        CX_TRY(attn_bwd(w, l, buf->g_a, s.h1(l), nullptr, &unused));   // -> g_b = d h1
         CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), /*dz_extra*/ buf->g_a,
                                 buf->g_c, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
     }
