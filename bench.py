@@ -130,10 +130,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    # test hook (tests/test_distributed_gpu.py): several ranks may share one GPU with gloo carrying the device tensors;
+    # the product launch is always one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("CX_BENCH_BACKEND", "nccl")
+    if os.environ.get("CX_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from contrastors_amd import _C
     from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
