@@ -147,6 +147,7 @@ def main():
     from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
     from contrastors_amd.loss import grad_cache_loss
     from contrastors_amd.nomic_bert import NomicBertConfig
+    from contrastors_amd.optimizer import FusedAdamW
 
     lib = _C.lib()
     G, S = args.global_batch, args.seq_len
@@ -157,7 +158,7 @@ def main():
                                       trunk_config=cfg), device=dev, seed=0).train()
     tower.broadcast_parameters(0)
     scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(dev)
-    opt = torch.optim.AdamW(tower.param_groups(0.01), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    opt = FusedAdamW(tower.param_groups(0.01), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
     total_steps, warm = 12000, 700  # contrastive_pretrain.yaml: cosine, warmup 700
     sched = torch.optim.lr_scheduler.LambdaLR(
         opt, lambda s: (s + 1) / warm if s < warm else 0.5 * (1 + math.cos(math.pi * (s - warm) / (total_steps - warm))))
@@ -171,13 +172,11 @@ def main():
     lens = [S] * b
     q_in = {"input_ids": q_ids.to(dev), "seqlens": lens}
     d_in = {"input_ids": d_ids.to(dev), "seqlens": lens}
-    params = [p for grp in opt.param_groups for p in grp["params"]]
 
     def step():
         tower.trunk.zero_grad()
         loss = grad_cache_loss(tower, q_in, tower, d_in, args.chunk_size, scale)
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
+        opt.step(max_grad_norm=1.0)  # global-norm clip + AdamW fused (cx_grad_sq_norm + cx_adamw_clip_step)
         sched.step()
         tower.trunk.sync_shadows()
         return loss

@@ -22,6 +22,7 @@ from .config import Config
 from .distributed import gather_with_grad
 from .loss import clip_loss, grad_cache_loss
 from .nomic_bert import NomicBertConfig
+from .optimizer import FusedAdamW
 
 
 def _lr_lambda(schedule: str, warmup: int, total: int):
@@ -75,7 +76,11 @@ class TextTextTrainer:
         groups = self.model["model"].param_groups(ta.weight_decay)
         if self.model["logit_scale"].logit_scale.requires_grad:
             groups[1]["params"].append(self.model["logit_scale"].logit_scale)
-        return torch.optim.AdamW(groups, lr=ta.learning_rate, betas=(ta.adam_beta1, ta.adam_beta2), eps=ta.eps)
+        return FusedAdamW(groups, lr=ta.learning_rate, betas=(ta.adam_beta1, ta.adam_beta2), eps=ta.eps)
+
+    # sc/trainers/base.py:362-385: clip_grad_norm_(max_grad_norm) (skipped when None / <= 0) + optimizer.step(), fused
+    def _clip_and_step(self):
+        self.optimizer.step(max_grad_norm=self.config.train_args.max_grad_norm)
 
     # sc/trainers/base.py:228-265 (warmup_steps or warmup_pct is mandatory there too: quirk 22)
     def get_scheduler(self, config: Config, optimizer):
@@ -133,9 +138,7 @@ class TextTextTrainer:
         self.optimizer.zero_grad(set_to_none=False)
         loss = self.forward_step(batch)
         self.backward(loss)
-        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
-        torch.nn.utils.clip_grad_norm_(params, ta.max_grad_norm)
-        self.optimizer.step()
+        self._clip_and_step()
         self.scheduler.step()
         model.trunk.sync_shadows()
         self.step += 1
@@ -234,7 +237,7 @@ class ImageTextTrainer(TextTextTrainer):
         ls = self.model["model"].logit_scale.logit_scale
         if ls.requires_grad:
             groups[1]["params"].append(ls)
-        return torch.optim.AdamW(groups, lr=ta.learning_rate, betas=(ta.adam_beta1, ta.adam_beta2), eps=ta.eps)
+        return FusedAdamW(groups, lr=ta.learning_rate, betas=(ta.adam_beta1, ta.adam_beta2), eps=ta.eps)
 
     # sc/trainers/image_text.py:154-178
     def forward_step(self, batch):
@@ -261,9 +264,7 @@ class ImageTextTrainer(TextTextTrainer):
         self.optimizer.zero_grad(set_to_none=False)
         out = self.forward_step(batch)
         self.backward(out)
-        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
-        torch.nn.utils.clip_grad_norm_(params, ta.max_grad_norm)
-        self.optimizer.step()
+        self._clip_and_step()
         self.scheduler.step()
         for t in self._trainable_towers():
             t.trunk.sync_shadows()

@@ -306,6 +306,17 @@ int cx_xent_fwd(const void* logits, int logits_bf16, const int64_t* labels, floa
 int cx_xent_bwd(const float* dloss, const void* logits, int logits_bf16, const float* lse, const int64_t* labels,
                 void* dlogits, int N, int V, long ld, long ld_d, float logit_scale, long ignore_index, void* stream);
 
+/* ---- fused optimizer tail of training_step (replaces torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step as
+ *      sc/trainers/base.py:362-385 and sc/optimizer.py:7-47 use them).  fp32, 16-B aligned contiguous buffers.
+ *      cx_grad_sq_norm ADDS sum(grad^2) to *sq_norm_accum (device double, zeroed by the caller; call once per gradient
+ *      tensor).  cx_adamw_clip_step applies one AdamW step (amsgrad off, decoupled decay, bias correction for the
+ *      1-based `step`) to `param` using grad * min(1, max_norm / (sqrt(*sq_norm) + 1e-6)); sq_norm NULL or
+ *      max_norm <= 0 = no clipping.  The clip coefficient is derived on the device: no host synchronisation. */
+int cx_grad_sq_norm(const float* grad, long n, double* sq_norm_accum, void* stream);
+int cx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, long step, const double* sq_norm, float max_norm,
+                       void* stream);
+
 /* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
 int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);

@@ -512,3 +512,48 @@ def test_gemm_residual_fused(M, N, K, with_bias):
     want = (base.float() + res.float()).to(torch.bfloat16)
     assert rel_err(out.float(), want.float()) < 1e-3
     assert float((out.float() - want.float()).abs().max()) <= 0.0625  # at most one bf16 ulp of O(4) values
+
+
+# ---- fused optimizer tail (optimizer.hip) vs torch.optim.AdamW + clip_grad_norm_ -----------------------------------
+@pytest.mark.parametrize("n,max_norm,wd", [(1 << 20, 1.0, 0.01), (4099, 0.05, 0.0), (3, None, 0.1), (786432 + 2, 1e9, 0.01)])
+def test_fused_adamw_clip_matches_torch(n, max_norm, wd):
+    from contrastors_amd.optimizer import FusedAdamW
+
+    torch.manual_seed(n)
+    base = torch.randn(n + 8, device="cuda")
+    p_ref = torch.nn.Parameter(base[:n].clone())
+    p_new = torch.nn.Parameter(base[:n].clone())
+    extra_ref = torch.nn.Parameter(base[n:n + 8].clone())  # a second tensor: the norm is global over all of them
+    extra_new = torch.nn.Parameter(base[n:n + 8].clone())
+    ref = torch.optim.AdamW([{"params": [p_ref], "weight_decay": wd}, {"params": [extra_ref], "weight_decay": 0.0}],
+                            lr=3e-3, betas=(0.9, 0.98), eps=1e-8)
+    new = FusedAdamW([{"params": [p_new], "weight_decay": wd}, {"params": [extra_new], "weight_decay": 0.0}],
+                     lr=3e-3, betas=(0.9, 0.98), eps=1e-8)
+    sched_ref = torch.optim.lr_scheduler.LambdaLR(ref, lambda s: 1.0 / (1 + s))
+    sched_new = torch.optim.lr_scheduler.LambdaLR(new, lambda s: 1.0 / (1 + s))
+    for it in range(4):
+        g = torch.randn(n + 8, device="cuda") * (0.5 + it)
+        p_ref.grad, extra_ref.grad = g[:n].clone(), g[n:].clone()
+        p_new.grad, extra_new.grad = g[:n].clone(), g[n:].clone()
+        if max_norm is not None:
+            total = torch.nn.utils.clip_grad_norm_([p_ref, extra_ref], max_norm)
+        ref.step()
+        new.step(max_grad_norm=max_norm)
+        sched_ref.step()
+        sched_new.step()
+        if max_norm is not None:
+            assert abs(float(new.last_grad_norm) - float(total)) <= 1e-5 * float(total)
+        # the fused step must not have touched the gradient (the reference's clip scales it in place; nothing reads it after)
+        assert torch.equal(p_new.grad, g[:n])
+        assert float((p_new - p_ref).detach().abs().max()) <= 2e-6 * (1 + float(p_ref.detach().abs().max()))
+        assert float((extra_new - extra_ref).detach().abs().max()) <= 2e-6 * (1 + float(extra_ref.detach().abs().max()))
+    sr, sn = ref.state[p_ref], new.state[p_new]
+    assert float(sr["step"]) == float(sn["step"]) == 4
+    torch.testing.assert_close(sn["exp_avg"], sr["exp_avg"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(sn["exp_avg_sq"], sr["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+    # state dicts are interchangeable with torch.optim.AdamW's (optimizer.pt of save_state / load_state)
+    ref2 = torch.optim.AdamW([{"params": [torch.nn.Parameter(p_new.detach().clone())], "weight_decay": wd},
+                              {"params": [torch.nn.Parameter(extra_new.detach().clone())], "weight_decay": 0.0}],
+                             lr=3e-3, betas=(0.9, 0.98), eps=1e-8)
+    ref2.load_state_dict(new.state_dict())
+    assert float(ref2.state[ref2.param_groups[0]["params"][0]]["step"]) == 4
