@@ -54,6 +54,8 @@ class NomicBertConfig:
     causal: bool = False
     use_rms_norm: bool = False
     max_position_embeddings: int = 512  # learned absolute positions when rotary_emb_fraction == 0
+    rotary_scaling_factor: Optional[float] = None  # Dynamic-NTK rotary beyond max_trained_positions (attention.py:52-60)
+    max_trained_positions: int = 2048
 
     def __post_init__(self):
         if self.prenorm or self.causal or self.use_rms_norm or self.rotary_emb_interleaved:
@@ -410,14 +412,42 @@ class NomicBertEngine(torch.nn.Module):
     def _build_rotary(self):
         cfg = self.config
         self.rot_cos = self.rot_sin = None
+        self._rot_len = 0
         if cfg.rotary_emb_fraction > 0:
-            dim = 64
             # flash_attn RotaryEmbedding: inv_freq = 1/base^(arange(0,dim,2)/dim), fp32
-            inv_freq = 1.0 / (cfg.rotary_emb_base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
-            t = torch.arange(cfg.n_positions, dtype=torch.float32)
-            freqs = torch.outer(t, inv_freq)
-            self.rot_cos = torch.cos(freqs).contiguous().to(self.device_)
-            self.rot_sin = torch.sin(freqs).contiguous().to(self.device_)
+            self._inv_freq = self._rot_inv_freq(cfg.rotary_emb_base)
+            # Dynamic NTK builds its table on demand (the reference's cache does too); plain rotary covers n_positions
+            self._rot_tables(0 if cfg.rotary_scaling_factor else cfg.n_positions)
+
+    @staticmethod
+    def _rot_inv_freq(base: float) -> torch.Tensor:
+        dim = 64
+        return 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+
+    def _rot_tables(self, seqlen: int):
+        if seqlen <= 0:
+            return
+        freqs = torch.outer(torch.arange(seqlen, dtype=torch.float32), self._inv_freq)
+        self.rot_cos = torch.cos(freqs).contiguous().to(self.device_)
+        self.rot_sin = torch.sin(freqs).contiguous().to(self.device_)
+        self._rot_len = seqlen
+        if getattr(self, "_desc", None) is not None:
+            self._desc.rot_cos, self._desc.rot_sin = self.rot_cos.data_ptr(), self.rot_sin.data_ptr()
+            self._desc.max_pos = seqlen
+
+    def _update_rotary(self, max_seqlen: int):
+        """DynamicNTKRotaryEmbedding._update_cos_sin_cache (sc/layers/embedding.py:810-865) with its state machine: a
+        batch longer than max_trained_positions re-bases inv_freq (and that stays), the table is rebuilt only when a
+        longer sequence than the cached one arrives."""
+        cfg = self.config
+        if not cfg.rotary_scaling_factor or self.rot_cos is None and cfg.rotary_emb_fraction == 0:
+            return
+        f, mx, dim = cfg.rotary_scaling_factor, cfg.max_trained_positions, 64
+        if max_seqlen > mx:
+            self._inv_freq = self._rot_inv_freq(cfg.rotary_emb_base * ((f * max_seqlen / mx) - (f - 1)) ** (dim / (dim - 2)))
+        if max_seqlen > self._rot_len:
+            torch.cuda.current_stream().synchronize()  # in-flight chunks still read the old tables
+            self._rot_tables(max_seqlen)
 
     def _build_desc(self):
         cfg = self.config
@@ -485,7 +515,9 @@ class NomicBertEngine(torch.nn.Module):
                       out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[_ChunkArena]]:
         """Enqueue one chunk forward.  Returns (embeddings (B,d) fp32, arena holding the saved activations)."""
         d = self.config.n_embd
-        if vb.S > (self.config.n_positions if self.rot_cos is not None else self.config.max_position_embeddings):
+        if self.config.rotary_emb_fraction > 0 and self.config.rotary_scaling_factor:
+            self._update_rotary(vb.max_seqlen)
+        elif vb.S > (self.config.n_positions if self.rot_cos is not None else self.config.max_position_embeddings):
             raise ValueError("sequence longer than the position table")
         if out is None:
             out = torch.empty(vb.B, d, dtype=torch.float32, device=self.device_)

@@ -19,8 +19,13 @@ import torch
 import torch.nn.functional as F
 
 
-def rotary_tables(seqlen: int, dim: int, base: float, dtype=torch.float32):
-    """cos/sin (seqlen, dim/2): modeling_hf_nomic_bert.py:1148-1183 (fp32 positions and inverse frequencies)."""
+def rotary_tables(seqlen: int, dim: int, base: float, dtype=torch.float32, scaling_factor: Optional[float] = None,
+                  max_trained_positions: int = 2048):
+    """cos/sin (seqlen, dim/2): modeling_hf_nomic_bert.py:1148-1183 (fp32 positions and inverse frequencies).
+    With `scaling_factor` (config.rotary_scaling_factor) the Dynamic-NTK rule of :1215-1235 applies on a fresh module:
+    for seqlen > max_trained_positions the base grows by (f*seqlen/max - (f-1))^(dim/(dim-2))."""
+    if scaling_factor and seqlen > max_trained_positions:
+        base = base * ((scaling_factor * seqlen / max_trained_positions) - (scaling_factor - 1)) ** (dim / (dim - 2))
     inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
     freqs = torch.outer(torch.arange(seqlen, dtype=torch.float32), inv_freq)
     return torch.cos(freqs).to(dtype), torch.sin(freqs).to(dtype)
@@ -54,7 +59,8 @@ def encoder_hidden_states(sd: Dict[str, torch.Tensor], cfg, input_ids: torch.Ten
     key_bias = key_bias.masked_fill(attention_mask.view(B, 1, 1, S) == 0, torch.finfo(x.dtype).min)
     cos = sin = None
     if cfg.rotary_emb_fraction > 0:
-        cos, sin = rotary_tables(S, int(dh * cfg.rotary_emb_fraction), cfg.rotary_emb_base, x.dtype)
+        cos, sin = rotary_tables(S, int(dh * cfg.rotary_emb_fraction), cfg.rotary_emb_base, x.dtype,
+                                 getattr(cfg, "rotary_scaling_factor", None), getattr(cfg, "max_trained_positions", 2048))
         cos, sin = cos.to(x.device), sin.to(x.device)
     for l in range(cfg.n_layer):
         p = f"encoder.layers.{l}."

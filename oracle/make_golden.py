@@ -10,6 +10,7 @@ import os
 import sys
 import warnings
 from pathlib import Path
+from collections import OrderedDict
 from types import SimpleNamespace
 
 import numpy as np
@@ -46,6 +47,7 @@ def ref_model(cfgd, sd):
         layer_norm_epsilon=cfgd["layer_norm_epsilon"], type_vocab_size=cfgd["type_vocab_size"],
         pad_token_id=cfgd["pad_token_id"], resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
         max_position_embeddings=cfgd["max_position_embeddings"], prenorm=False, use_flash_attn=False,
+        rotary_scaling_factor=cfgd.get("rotary_scaling_factor"), max_trained_positions=cfgd.get("max_trained_positions", 2048),
     )
     m = rmod.NomicBertModel(c, add_pooling_layer=False)
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -149,6 +151,70 @@ def gen_vit(name, cfgd, seed):
     np.savez_compressed(GOLD / f"{name}.npz", seed=seed, pixels=pixels.numpy(), hidden=hid.detach().numpy(),
                         weight_checksum=checksum(sd), **out, **{"cfg/" + k: np.array(v) for k, v in cfgd.items()})
     print(name, "hidden", tuple(hid.shape))
+
+
+def hf_bert_state_dict(L=2, d=8, inter=16, vocab=10, types=2, pos=12, seed=11, gamma_beta=False, roberta=False):
+    """A BertForPreTraining-shaped state dict with HF key names (random values): the input of the remap goldens."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    ln_w, ln_b = ("gamma", "beta") if gamma_beta else ("weight", "bias")
+    top = "roberta" if roberta else "bert"
+    sd = OrderedDict()
+    sd[f"{top}.embeddings.position_ids"] = torch.arange(pos).unsqueeze(0)
+    sd[f"{top}.embeddings.word_embeddings.weight"] = r(vocab, d)
+    sd[f"{top}.embeddings.position_embeddings.weight"] = r(pos, d)
+    sd[f"{top}.embeddings.token_type_embeddings.weight"] = r(types, d)
+    sd[f"{top}.embeddings.LayerNorm.{ln_w}"], sd[f"{top}.embeddings.LayerNorm.{ln_b}"] = r(d), r(d)
+    for l in range(L):
+        p = f"{top}.encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            sd[p + f"attention.self.{n}.weight"], sd[p + f"attention.self.{n}.bias"] = r(d, d), r(d)
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = r(d, d), r(d)
+        sd[p + f"attention.output.LayerNorm.{ln_w}"], sd[p + f"attention.output.LayerNorm.{ln_b}"] = r(d), r(d)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = r(inter, d), r(inter)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = r(d, inter), r(d)
+        sd[p + f"output.LayerNorm.{ln_w}"], sd[p + f"output.LayerNorm.{ln_b}"] = r(d), r(d)
+    sd[f"{top}.pooler.dense.weight"], sd[f"{top}.pooler.dense.bias"] = r(d, d), r(d)
+    sd["cls.predictions.bias"] = r(vocab)
+    sd["cls.predictions.transform.dense.weight"], sd["cls.predictions.transform.dense.bias"] = r(d, d), r(d)
+    sd[f"cls.predictions.transform.LayerNorm.{ln_w}"], sd[f"cls.predictions.transform.LayerNorm.{ln_b}"] = r(d), r(d)
+    sd["cls.predictions.decoder.weight"] = sd[f"{top}.embeddings.word_embeddings.weight"].clone()
+    sd["cls.seq_relationship.weight"], sd["cls.seq_relationship.bias"] = r(2, d), r(2)
+    return sd
+
+
+HF_REMAP_CASES = {
+    # name: (state-dict kwargs, config extras, remap kwargs)
+    "plain": (dict(), dict(), dict()),
+    "biencoder": (dict(gamma_beta=True), dict(), dict(remove_bert=True, remove_cls_weights=True, add_pooling_layer=False)),
+    "padded": (dict(), dict(vocab_size=16, pad_vocab_size_multiple=8, orig_vocab_size=10), dict(add_pooling_layer=True)),
+    "roberta_subset_rotary": (dict(roberta=True), dict(last_layer_subset=True, rotary_emb_fraction=1.0), dict()),
+}
+
+
+def gen_hf_remap():
+    """tests/golden/hf_remap.npz: outputs of the reference's remap_bert_state_dict / inv_remap_state_dict
+    (sc/models/encoder/bert.py:75-366) on small HF-named state dicts; keys are stored in order."""
+    from transformers import BertConfig
+
+    rb = ref_import.load_bert_remap()
+    out = {}
+    for case, (sdkw, cfgkw, kw) in HF_REMAP_CASES.items():
+        cfg = BertConfig(vocab_size=10, hidden_size=8, num_hidden_layers=2, num_attention_heads=2, intermediate_size=16,
+                         max_position_embeddings=12, type_vocab_size=2)
+        for k, v in cfgkw.items():
+            setattr(cfg, k, v)
+        fwd = rb.remap_bert_state_dict(hf_bert_state_dict(**sdkw), cfg, **kw)
+        out[f"{case}/fwd_keys"] = np.array(list(fwd.keys()))
+        for k, v in fwd.items():
+            out[f"{case}/fwd/{k}"] = v.numpy()
+        if not kw.get("remove_bert") and not kw.get("remove_cls_weights"):
+            inv = rb.inv_remap_state_dict(OrderedDict((k, v.clone()) for k, v in fwd.items()), cfg)
+            out[f"{case}/inv_keys"] = np.array(list(inv.keys()))
+            for k, v in inv.items():
+                out[f"{case}/inv/{k}"] = v.numpy()
+    np.savez_compressed(GOLD / "hf_remap.npz", **out)
+    print("hf_remap", {c: len(out[f"{c}/fwd_keys"]) for c in HF_REMAP_CASES})
 
 
 class _Scale(torch.nn.Module):
@@ -255,8 +321,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixture
         gen_vit("vit_tiny", TINY_VIT, 5)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "hf_remap":
+        gen_hf_remap()
+        sys.exit(0)
     gen_encoder("encoder_nomic_tiny", TINY_NOMIC, 1)
     gen_encoder("encoder_bert_tiny", TINY_BERT, 2)
+    # Dynamic-NTK rotary (modeling_hf_nomic_bert.py:1215-1235): sequences (32) longer than max_trained_positions (16)
+    gen_encoder("encoder_nomic_ntk_tiny", dict(TINY_NOMIC, rotary_scaling_factor=2.0, max_trained_positions=16), 5)
     gen_clip_loss_single()
     gen_multirank()
     gen_vit("vit_tiny", TINY_VIT, 5)
+    gen_hf_remap()

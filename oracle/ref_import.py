@@ -112,3 +112,16 @@ def load_vit():
 
     ratt.flash_attn_qkvpacked_func = exact_qkvpacked
     return vit
+
+
+def load_bert_remap():
+    """-> the reference's sc/models/encoder/bert.py (config conversion + HF <-> flash state-dict remapping), loaded by
+    file path so that the package __init__ (which wants flash_attn) never runs."""
+    load()
+    for name, path in (("contrastors.models", REF_ROOT / "models"),
+                       ("contrastors.models.encoder", REF_ROOT / "models" / "encoder")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [str(path)]
+            sys.modules[name] = m
+    return importlib.import_module("contrastors.models.encoder.bert")

@@ -53,4 +53,4 @@ def rel_err(a, b):
 
 
 def max_err(a, b):
-    return float((a.double() - b.double()).abs().max())
+    return float((a.detach().double() - b.detach().double()).abs().max())

@@ -33,7 +33,7 @@ def encoder_ref_on_device(sd, cfg, ids, mask):
     return encoder_ref.biencoder_embedding(sd, cfg, ids, mask)
 
 
-@pytest.mark.parametrize("name", ["encoder_nomic_tiny", "encoder_bert_tiny"])
+@pytest.mark.parametrize("name", ["encoder_nomic_tiny", "encoder_bert_tiny", "encoder_nomic_ntk_tiny"])
 def test_engine_matches_reference_golden(gold, name):
     g = gold(name)
     cfg, ns = _cfg_from_gold(g)
@@ -125,3 +125,22 @@ def test_engine_full_architecture_vs_oracle(arch):
            worst_grad_ratio=worst_ratio, worst_grad_name=worst_name)
     # reference rule only: with these random (std 0.05, un-trained) weights bf16 eager itself is ~4e-2 off fp32
     assert e_hip <= 3 * e_b + 1e-4 and m_hip <= 3 * m_b + 1e-5
+
+
+def test_hf_bert_checkpoint_round_trip():
+    """export_hf_bert -> HF key layout -> load_hf_bert restores every trunk parameter bit for bit (hf_bert.py)."""
+    from transformers import BertConfig
+
+    from contrastors_amd.hf_bert import export_hf_bert, load_hf_bert
+    from oracle.make_golden import TINY_BERT
+
+    cfg = NomicBertConfig(**{k: v for k, v in TINY_BERT.items() if k in NomicBertConfig.__dataclass_fields__})
+    a, b = NomicBertEngine(cfg, device=DEV, seed=1), NomicBertEngine(cfg, device=DEV, seed=2)
+    assert not torch.equal(a.flat_param, b.flat_param)
+    hf = export_hf_bert(a)
+    assert "bert.encoder.layer.1.attention.self.key.weight" in hf and "bert.embeddings.LayerNorm.weight" in hf
+    assert not any(".attn.Wqkv." in k or ".mlp.fc1." in k for k in hf)
+    hc = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.n_embd, num_hidden_layers=cfg.n_layer,
+                    num_attention_heads=cfg.n_head, intermediate_size=cfg.n_inner)
+    load_hf_bert(b, hf, hc)
+    assert torch.equal(a.flat_param, b.flat_param)

@@ -18,7 +18,7 @@ def _cfg(g):
     return SimpleNamespace(**{k: (str(v) if isinstance(v, (str, np.str_)) else v) for k, v in d.items()})
 
 
-@pytest.mark.parametrize("name", ["encoder_nomic_tiny", "encoder_bert_tiny"])
+@pytest.mark.parametrize("name", ["encoder_nomic_tiny", "encoder_bert_tiny", "encoder_nomic_ntk_tiny"])
 def test_encoder_restatement_matches_reference(gold, name):
     g = gold(name)
     cfg = _cfg(g)
