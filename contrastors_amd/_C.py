@@ -119,6 +119,10 @@ _SIGS = {
     "cx_transpose_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "cx_encoder_forward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
                                  i32, i32, vp, vp]),
+    "cx_encoder_forward_hidden": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
+                                        i32, i32, vp, vp]),
+    "cx_encoder_backward_hidden": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
+                                         i32, vp, vp]),
     "cx_encoder_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
                                   i32, vp, vp, vp]),
     "cx_probe_mfma_layout": (i32, [vp, vp]),

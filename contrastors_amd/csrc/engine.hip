@@ -335,6 +335,46 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
                            enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);
 }
 
+// ---- token-level outputs (MLM head, sc/models/encoder/modeling_nomic_bert.py:590-669): same trunk, no pooling ------
+int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
+                              const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
+                              int save_for_backward, uint16_t* hidden_out, void* stream) {
+    if (Bc <= 0 || T <= 0) return CX_OK;
+    CX_TRY(check_desc(enc, buf, T));
+    if (!hidden_out) return CX_ERR_ARG;
+    (void)hipGetLastError();
+    const int d = enc->d, I = enc->d_inner;
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+                           enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
+    const uint16_t* h_final = nullptr;
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, save_for_backward, &h_final, stream));
+    return hipMemcpyAsync(hidden_out, h_final, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
+                               const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
+                               const uint16_t* dhidden, void* stream) {
+    if (Bc <= 0 || T <= 0) return CX_OK;
+    CX_TRY(check_desc(enc, buf, T));
+    if (!dhidden) return CX_ERR_ARG;
+    CX_TRY(check_bwd_buffers(buf));
+    (void)hipGetLastError();
+    const int d = enc->d, I = enc->d_inner;
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
+    if (hipMemcpyAsync(buf->g_a, dhidden, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess)
+        return CX_ERR_LAUNCH;
+    const uint16_t* da = nullptr;
+    const uint16_t* db = nullptr;
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    return cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+                           buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
+                           enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);
+}
+
 // ---- ViT image tower -------------------------------------------------------------------------------------------------
 int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
                    const int32_t* cu_seqlens, int Bc, int Cc, int H, int W, int patch, int save_for_backward,

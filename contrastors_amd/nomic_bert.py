@@ -544,6 +544,39 @@ class NomicBertEngine(torch.nn.Module):
         _C.check(rc, "cx_encoder_backward")
         self.release_arena(arena)
 
+    # ---- token-level outputs (MLM head): (T, d) bf16 hidden states in unpadded order -----------------------------
+    def _rotary_or_bounds(self, vb: VarlenBatch):
+        if self.config.rotary_emb_fraction > 0 and self.config.rotary_scaling_factor:
+            self._update_rotary(vb.max_seqlen)
+        elif vb.S > (self.config.n_positions if self.rot_cos is not None else self.config.max_position_embeddings):
+            raise ValueError("sequence longer than the position table")
+
+    def forward_hidden_chunk(self, vb: VarlenBatch, save_for_backward: bool):
+        self._rotary_or_bounds(vb)
+        hidden = torch.empty(vb.T, self.config.n_embd, dtype=torch.bfloat16, device=self.device_)
+        arena = self._get_arena(vb.T, vb.B, save_for_backward)
+        rc = self.lib.cx_encoder_forward_hidden(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
+                                                vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
+                                                vb.max_seqlen, int(save_for_backward), hidden.data_ptr(),
+                                                _C.cur_stream())
+        _C.check(rc, "cx_encoder_forward_hidden")
+        return hidden, (arena if save_for_backward else None)
+
+    def backward_hidden_chunk(self, vb: VarlenBatch, arena: _ChunkArena, dhidden: torch.Tensor):
+        dh = dhidden.to(torch.bfloat16).contiguous()
+        assert dh.shape == (vb.T, self.config.n_embd)
+        rc = self.lib.cx_encoder_backward_hidden(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
+                                                 vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
+                                                 vb.max_seqlen, dh.data_ptr(), _C.cur_stream())
+        _C.check(rc, "cx_encoder_backward_hidden")
+        self.release_arena(arena)
+
+    def hidden_states(self, vb: VarlenBatch) -> torch.Tensor:
+        """(T, d) bf16 last hidden state of the unpadded tokens; differentiable w.r.t. the engine's parameters."""
+        if torch.is_grad_enabled() and self.training:
+            return _HiddenFn.apply(self.flat_decay, self, vb)
+        return self.forward_hidden_chunk(vb, False)[0]
+
     # nn.Module-style call used by BiEncoder: differentiable w.r.t. the engine's own parameters
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 normalize: Optional[bool] = None) -> torch.Tensor:
@@ -568,3 +601,18 @@ class _EncodeFn(torch.autograd.Function):
     def backward(ctx, demb):
         ctx.engine.backward_chunk(ctx.vb, ctx.arena, demb)
         return None, None, None, None
+
+
+class _HiddenFn(torch.autograd.Function):
+    """Token-level twin of _EncodeFn: hidden states out, d(hidden) in, parameter gradients into the flat buffer."""
+
+    @staticmethod
+    def forward(ctx, _anchor, engine: NomicBertEngine, vb: VarlenBatch):
+        hidden, arena = engine.forward_hidden_chunk(vb, True)
+        ctx.engine, ctx.vb, ctx.arena = engine, vb, arena
+        return hidden
+
+    @staticmethod
+    def backward(ctx, dhidden):
+        ctx.engine.backward_hidden_chunk(ctx.vb, ctx.arena, dhidden)
+        return None, None, None

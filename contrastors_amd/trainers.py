@@ -276,8 +276,15 @@ class ImageTextTrainer(TextTextTrainer):
         return out["loss"].detach()
 
 
-# sc/trainers/__init__.py:9-17 (the contrastive entries; mlm / glue / distill trainers are outside the hot path)
-TRAINER_REGISTRY = {"encoder": TextTextTrainer, "image_text": ImageTextTrainer, "locked_text": ImageTextTrainer}
+# sc/trainers/__init__.py:9-17 (the contrastive entries + MLM pretraining; glue / distill trainers are outside the hot path)
+def _mlm_trainer(*a, **k):
+    from .mlm import MLMTrainer  # imported lazily: mlm.py imports this module's schedule helper
+
+    return MLMTrainer(*a, **k)
+
+
+TRAINER_REGISTRY = {"encoder": TextTextTrainer, "image_text": ImageTextTrainer, "locked_text": ImageTextTrainer,
+                    "mlm": _mlm_trainer}
 
 
 def synthetic_batches(n_steps: int, per_rank_batch: int, seq_len: int, vocab: int = 30522, seed: int = 1234,

@@ -279,6 +279,16 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
                         const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
                         const float* demb, const float* emb_out, void* stream);
 
+/* Token-level variant for heads that read every position (the MLM head of NomicBertForPreTraining,
+ * sc/models/encoder/modeling_nomic_bert.py:590-669): hidden_out / dhidden are (T, d) bf16 in unpadded token order
+ * (row t = token indices[t] of the padded batch).  Same arenas, same contracts as the pooled pair above. */
+int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
+                              const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
+                              int save_for_backward, uint16_t* hidden_out, void* stream);
+int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
+                               const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
+                               const uint16_t* dhidden, void* stream);
+
 /* ---- ViT image tower (sc/models/vit/vit.py:176-276 ViTModel.forward, sc/layers/embedding.py:465-516
  *      PatchEmbedding.forward, sc/models/biencoder/modeling_biencoder.py:287-319 pooling): one call per chunk.
  * pixels: (Bc, C, H, W) fp32 or bf16 (pixels_bf16 != 0) device tensor; n_patch = (H/p)*(W/p); sequences have

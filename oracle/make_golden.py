@@ -217,6 +217,52 @@ def gen_hf_remap():
     print("hf_remap", {c: len(out[f"{c}/fwd_keys"]) for c in HF_REMAP_CASES})
 
 
+def make_mlm_inputs(cfgd, B, S, seed, p=0.3):
+    ids, mask, lens = make_inputs(cfgd, B, S, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    target = (torch.rand(B, S, generator=g) < p) & mask.bool()
+    target[0, 1] = True
+    labels = torch.where(target, ids, torch.full_like(ids, -100))
+    masked = torch.where(target & (torch.rand(B, S, generator=g) < 0.8), torch.full_like(ids, 4), ids)
+    return masked, mask, lens, labels
+
+
+def gen_mlm(name, cfgd, seed):
+    """tests/golden/<name>.npz: the reference's eager NomicBertForPreTraining (modeling_hf_nomic_bert.py:1704-1765),
+    fp32 CPU: loss, logits of the target positions, gradient norms of every parameter (tied embedding included)."""
+    from oracle import mlm_ref
+
+    _, rcfg, rmod = ref_import.load()
+    cfg = cfg_ns(cfgd)
+    trunk = encoder_ref.random_state_dict(cfg, seed)
+    head = mlm_ref.random_head_state_dict(cfg, seed + 100)
+    c = ref_model(cfgd, trunk).config
+    m = rmod.NomicBertForPreTraining(c)
+    sd = {f"bert.{k}": v for k, v in trunk.items()}
+    sd.update(head)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("inv_freq" in k or "norm_factor" in k or k == "cls.predictions.decoder.weight" for k in missing), missing
+    m.tie_weights()
+    m.eval()
+    ids, mask, lens, labels = make_mlm_inputs(cfgd, 6, 32, seed + 1)
+    out = m(ids, attention_mask=mask, labels=labels)
+    out.loss.backward()
+    keep = {}
+    for k, p_ in m.named_parameters():
+        if p_.grad is not None:
+            keep["gnorm/" + k] = np.array(float(p_.grad.norm()))
+    tgt = labels.flatten() >= 0
+    keep["g/cls.predictions.transform.layer_norm.weight"] = m.cls.predictions.transform.layer_norm.weight.grad.numpy()
+    keep["g/word_rows"] = m.bert.embeddings.word_embeddings.weight.grad[labels.flatten()[tgt][:8]].numpy()
+    np.savez_compressed(GOLD / f"{name}.npz", seed=seed, input_ids=ids.numpy(), attention_mask=mask.numpy(),
+                        lens=lens.numpy(), labels=labels.numpy(), loss=np.array(float(out.loss)),
+                        target_logits=out.logits.detach().flatten(0, 1)[tgt].numpy().astype(np.float16),
+                        weight_checksum=checksum({**trunk, **head}), **keep,
+                        **{"cfg/" + k: np.array(v) for k, v in cfgd.items()})
+    print(name, "loss", float(out.loss), "targets", int(tgt.sum()))
+
+
 class _Scale(torch.nn.Module):
     """Stand-in for LogitScale with a fixed scale (reference passes a module: sc/loss.py:109)."""
 
@@ -321,6 +367,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixture
         gen_vit("vit_tiny", TINY_VIT, 5)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mlm":
+        gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
+        gen_mlm("mlm_bert_tiny", TINY_BERT, 22)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hf_remap":
         gen_hf_remap()
         sys.exit(0)
@@ -332,3 +382,5 @@ if __name__ == "__main__":
     gen_multirank()
     gen_vit("vit_tiny", TINY_VIT, 5)
     gen_hf_remap()
+    gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
+    gen_mlm("mlm_bert_tiny", TINY_BERT, 22)

@@ -1,0 +1,156 @@
+"""MLM pretraining path (contrastors_amd/mlm.py: hidden-state engine call + head + fused 30k-way cross-entropy) against
+the reference's eager NomicBertForPreTraining goldens, judged by the reference's tolerance rule
+err(new) <= 3 x err(bf16 eager) (tests/test_flash_bert.py:77-82), plus trainer behaviour."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from contrastors_amd.config import Config, DataArgs, ModelArgs, TrainArgs
+from contrastors_amd.mlm import MLMTrainer, NomicBertForPreTraining, mask_tokens, synthetic_mlm_batches
+from contrastors_amd.nomic_bert import NomicBertConfig
+from contrastors_amd.trainers import TRAINER_REGISTRY
+from oracle import encoder_ref, mlm_ref
+from oracle.make_golden import TINY_NOMIC
+from tests.gpu_util import report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cfg_from_gold(g):
+    d = {k[4:]: (g[k].item() if g[k].shape == () else g[k]) for k in g.files if k.startswith("cfg/")}
+    d = {k: (str(v) if isinstance(v, (str, np.str_)) else v) for k, v in d.items()}
+    return NomicBertConfig(**{k: v for k, v in d.items() if k in NomicBertConfig.__dataclass_fields__}), SimpleNamespace(**d)
+
+
+def _load(model, trunk, head):
+    sd = {f"bert.{k}": v for k, v in trunk.items()}
+    sd.update(head)
+    model.load_reference_state_dict(sd)
+
+
+@pytest.mark.parametrize("name", ["mlm_nomic_tiny", "mlm_bert_tiny"])
+@pytest.mark.parametrize("dense", [True, False])
+def test_mlm_matches_reference_golden(gold, name, dense):
+    g = gold(name)
+    cfg, ns = _cfg_from_gold(g)
+    trunk = encoder_ref.random_state_dict(ns, int(g["seed"]))
+    head = mlm_ref.random_head_state_dict(ns, int(g["seed"]) + 100)
+    model = NomicBertForPreTraining(cfg, device=DEV, dense_seq_output=dense).train()
+    _load(model, trunk, head)
+    ids, mask, labels = (torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "attention_mask", "labels"))
+    model.zero_grad()
+    out = model(ids, attention_mask=mask, labels=labels)
+    logits_fwd = out.prediction_logits.detach().float().cpu().numpy()  # inplace_backward overwrites them (as upstream)
+    out.loss.backward()
+    model.fold_tied_grad()
+    # bf16-eager judge: the fp32 restatement under autocast on the same device
+    tr = {k: v.to(DEV).requires_grad_() for k, v in trunk.items()}
+    hd = {k: v.to(DEV).requires_grad_() for k, v in head.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l_bf = mlm_ref.mlm_loss(tr, hd, ns, ids, mask, labels)
+    l_bf.backward()
+    want = float(g["loss"])
+    e_hip, e_bf = abs(float(out.loss.detach()) - want), abs(float(l_bf.detach()) - want)
+    assert e_hip <= 3 * e_bf + 5e-3, (float(out.loss), want, float(l_bf))
+    grads = {f"bert.{k}": v for k, v in model.bert.reference_grad_dict().items()}
+    grads["cls.predictions.transform.dense.weight"] = model.dense_weight.grad
+    grads["cls.predictions.transform.layer_norm.weight"] = model.ln_weight.grad
+    grads["cls.predictions.transform.layer_norm.bias"] = model.ln_bias.grad
+    if model.dense_bias is not None:
+        grads["cls.predictions.transform.dense.bias"] = model.dense_bias.grad
+        grads["cls.predictions.decoder.bias"] = model.decoder_bias.grad
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("gnorm/"):
+            continue
+        n = k[6:]
+        if n == "cls.predictions.decoder.weight" or n not in grads:
+            continue
+        w = float(g[k])
+        got = float(grads[n].norm())
+        src = tr[n[5:]] if n.startswith("bert.") else hd[n]
+        bf = float(src.grad.norm())
+        worst = max(worst, abs(got - w) / max(w, 1e-6))
+        assert abs(got - w) <= 3 * abs(bf - w) + 3e-2 * w + 1e-5, f"{n}: {got} vs {w} (bf16 eager {bf})"
+    tgt = labels.flatten() >= 0
+    rows = labels.flatten()[tgt][:8]
+    got_rows = grads["bert.embeddings.word_embeddings.weight"][rows].cpu().numpy()
+    rel = np.abs(got_rows - g["g/word_rows"]).max() / max(np.abs(g["g/word_rows"]).max(), 1e-9)
+    report("mlm_golden", fixture=name, dense=dense, e_loss_hip=e_hip, e_loss_bf16=e_bf, worst_gnorm_rel=worst,
+           e_word_rows=float(rel))
+    assert rel < 6e-2
+    # logits of the target positions (dense) vs the reference's
+    if dense:
+        lg = logits_fwd
+        assert lg.shape == g["target_logits"].shape
+        assert np.abs(lg - g["target_logits"].astype(np.float32)).max() < 0.15  # bf16 logits of magnitude ~5
+
+
+def test_mlm_inference_logits_shape_and_padding(gold):
+    g = gold("mlm_nomic_tiny")
+    cfg, ns = _cfg_from_gold(g)
+    model = NomicBertForPreTraining(cfg, device=DEV).eval()
+    _load(model, encoder_ref.random_state_dict(ns, int(g["seed"])), mlm_ref.random_head_state_dict(ns, int(g["seed"]) + 100))
+    ids, mask = torch.from_numpy(g["input_ids"]).to(DEV), torch.from_numpy(g["attention_mask"]).to(DEV)
+    with torch.no_grad():
+        out = model(ids, attention_mask=mask)
+    assert out.loss is None and out.prediction_logits.shape == (*ids.shape, cfg.vocab_size)
+    assert float(out.prediction_logits[mask == 0].abs().max()) == 0.0
+    tgt = torch.from_numpy(g["labels"]).to(DEV).flatten() >= 0
+    got = out.prediction_logits.flatten(0, 1)[tgt].float().cpu().numpy()
+    assert np.abs(got - g["target_logits"].astype(np.float32)).max() < 0.15
+
+
+def test_mask_tokens_statistics():
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1000, 30000, (64, 256), generator=g)
+    special = torch.zeros_like(ids, dtype=torch.bool)
+    special[:, 0] = True
+    masked, labels = mask_tokens(ids, special, 0.3, 103, 30522, g)
+    tgt = labels != -100
+    assert not tgt[:, 0].any() and torch.equal(labels[tgt], ids[tgt])
+    frac = float(tgt.float().mean()) * 256 / 255
+    assert 0.28 < frac < 0.32
+    assert 0.77 < float((masked[tgt] == 103).float().mean()) < 0.83
+    changed = (masked[tgt] != ids[tgt]) & (masked[tgt] != 103)
+    assert 0.07 < float(changed.float().mean()) < 0.13
+    assert torch.equal(masked[~tgt], ids[~tgt])
+
+
+def _trainer(accum=1, max_grad_norm=1.0):
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-3, weight_decay=1e-5, warmup_steps=1, schedule_type="linear",
+                                      max_grad_norm=max_grad_norm, gradient_accumulation_steps=accum, adam_beta2=0.98,
+                                      eps=1e-6, clamp_logits=False),
+                 data_args=DataArgs(batch_size=16, seed=3), model_args=ModelArgs(model_type="mlm", seq_len=64))
+    tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
+    return TRAINER_REGISTRY["mlm"](cfg, torch.bfloat16, device=DEV, trunk_config=tc, total_steps=40)
+
+
+def test_mlm_trainer_learns_and_accumulates():
+    batches = list(synthetic_mlm_batches(2, 16, 32, vocab=512, mask_token_id=4))
+    t = _trainer()
+    assert isinstance(t, MLMTrainer)
+    first = float(t.training_step(batches[0]))
+    for _ in range(12):
+        last = float(t.training_step(batches[0]))
+    assert np.isfinite(first) and last < first - 0.3, (first, last)
+    assert abs(float(t.eval_step(batches[0])) - last) < 0.5
+    # accumulation: two micro-batches -> one optimizer step whose gradient is the SUM (base.py:346-351 does not scale)
+    a, b = _trainer(accum=2, max_grad_norm=0.0), _trainer(accum=1, max_grad_norm=0.0)
+    b.model["model"].bert.flat_param.copy_(a.model["model"].bert.flat_param)
+    b.model["model"].bert.sync_shadows()
+    p0 = a.model["model"].bert.flat_param.clone()
+    a.training_step(batches[0])
+    assert torch.equal(a.model["model"].bert.flat_param, p0) and a.scheduler.last_epoch == 0  # no optimizer step yet
+    ga = a.model["model"].bert.flat_grad.clone()
+    a.training_step(batches[1])
+    assert not torch.equal(a.model["model"].bert.flat_param, p0) and a.scheduler.last_epoch == 1
+    # gradient of micro-batch 0 alone, from the accum=1 trainer's first step (same weights): equal up to atomics order
+    m = b.model["model"]
+    m.zero_grad()
+    m(**{k: v for k, v in batches[0].items()}).loss.backward()
+    m.fold_tied_grad()
+    assert float((m.bert.flat_grad - ga).abs().max()) <= 1e-3 * float(ga.abs().max())

@@ -143,3 +143,41 @@ def test_vit_restatement_matches_reference(gold):
             got = sd[n].grad if sl is None else sd[n].grad[:sl, :sl]
             key = f"{pooling}/g/{n}" + ("" if sl is None else "[:16,:16]")
             np.testing.assert_allclose(got.numpy(), g[key], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["mlm_nomic_tiny", "mlm_bert_tiny"])
+def test_mlm_restatement_matches_reference(gold, name):
+    """oracle/mlm_ref.py vs the reference's eager NomicBertForPreTraining (loss, target logits, every gradient norm)."""
+    from oracle import mlm_ref
+
+    g = gold(name)
+    cfg = _cfg(g)
+    trunk = encoder_ref.random_state_dict(cfg, int(g["seed"]))
+    head = mlm_ref.random_head_state_dict(cfg, int(g["seed"]) + 100)
+    allp = {**trunk, **head}
+    cs = np.array([float(sum(v.double().sum() for v in allp.values())),
+                   float(sum((v.double() ** 2).sum() for v in allp.values()))])
+    np.testing.assert_allclose(cs, g["weight_checksum"], rtol=1e-12)
+    for v in allp.values():
+        v.requires_grad_(True)
+    ids, mask, labels = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels"))
+    logits = mlm_ref.mlm_logits(trunk, head, cfg, ids, mask)
+    tgt = labels.flatten() >= 0
+    np.testing.assert_allclose(logits.detach().flatten(0, 1)[tgt].numpy(), g["target_logits"].astype(np.float32),
+                               atol=2e-2, rtol=2e-3)  # fixture stores fp16
+    loss = mlm_ref.mlm_loss(trunk, head, cfg, ids, mask, labels)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    loss.backward()
+    for k in g.files:
+        if not k.startswith("gnorm/"):
+            continue
+        n = k[6:]
+        if n == "cls.predictions.decoder.weight":
+            continue
+        p = allp[n[5:]] if n.startswith("bert.") else allp[n]
+        assert abs(float(p.grad.norm()) - float(g[k])) <= 1e-4 * max(1.0, float(g[k])), n
+    np.testing.assert_allclose(head["cls.predictions.transform.layer_norm.weight"].grad.numpy(),
+                               g["g/cls.predictions.transform.layer_norm.weight"], atol=2e-5, rtol=1e-4)
+    rows = labels.flatten()[tgt][:8]
+    np.testing.assert_allclose(trunk["embeddings.word_embeddings.weight"].grad[rows].numpy(), g["g/word_rows"],
+                               atol=2e-5, rtol=1e-4)
