@@ -68,6 +68,13 @@ class DataArgs(BaseModel):
     input_shards: Optional[str] = None
     download: Optional[bool] = False
     streaming: Optional[bool] = True
+    process_one_shard: Optional[bool] = False
+    weighted_sampling: Optional[bool] = False
+    verbose: Optional[bool] = False
+    sample_negatives: Optional[bool] = False
+    query_max_length: Optional[int] = None
+    document_max_length: Optional[int] = None
+    mlm_prob: Optional[float] = None
 
 
 class ModelArgs(BaseModel):
@@ -81,6 +88,7 @@ class ModelArgs(BaseModel):
     pooling: str = "mean"
     nomic_encoder: bool = True
     add_prefix: bool = False
+    num_negatives: Optional[int] = 7
     pretrained: bool = False
     gradient_checkpointing: bool = False
     projection_dim: Optional[int] = None

@@ -1,9 +1,10 @@
 """`python -m contrastors_amd.train --config X.yaml --dtype bf16 [--key value ...]` (mirror of sc/train.py:51-131).
 
 torchrun / `python -m torch.distributed.run` launches one process per GPU; backend "nccl" is RCCL on ROCm.  CLI flags
-named like fields of train_args / model_args / data_args override the YAML (sc/train.py:87-94).  Data: the streaming
-shard loader is out of scope (no network here) -- `--synthetic-steps N` drives the trainer with synthetic batches of the
-loader's exact key contract.
+named like fields of train_args / model_args / data_args override the YAML (sc/train.py:87-94).  Data: with
+`data_args.input_shards` pointing at a spec YAML of LOCAL shards (contrastors_amd/data.py; S3 transport is not built) and
+`--synthetic-steps 0` the streaming loader feeds the trainer (the tokenizer named by `model_args.tokenizer_name` must be
+available offline); otherwise `--synthetic-steps N` drives it with synthetic batches of the loader's exact key contract.
 """
 from __future__ import annotations
 
@@ -56,7 +57,17 @@ def main():
     config = apply_overrides(read_config(args.config), overrides)
     trainer = TRAINER_REGISTRY[config.model_args.model_type](config, torch.bfloat16, total_steps=args.synthetic_steps)
     per_rank = config.data_args.batch_size // world
-    trainer.train(synthetic_batches(args.synthetic_steps, per_rank, args.seq_len, rank=trainer.rank), log_every=1)
+    if args.synthetic_steps <= 0 and config.data_args.input_shards:
+        from transformers import AutoTokenizer
+
+        from .data import get_streaming_dataset
+
+        tok = AutoTokenizer.from_pretrained(config.model_args.tokenizer_name, local_files_only=True)
+        ds = get_streaming_dataset(config, tok, run_name=getattr(config.train_args, "wandb_run_name", None) or "run")
+        trainer.total_steps = max(1, len(ds) // config.data_args.batch_size)
+        trainer.train(iter(ds), log_every=10)
+    else:
+        trainer.train(synthetic_batches(args.synthetic_steps, per_rank, args.seq_len, rank=trainer.rank), log_every=1)
     if world > 1:
         dist.destroy_process_group()
 

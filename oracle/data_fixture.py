@@ -1,0 +1,109 @@
+"""Deterministic toy corpus + tokenizer for the loader-contract goldens.  TEST INFRASTRUCTURE ONLY.
+
+`build_dataset(root)` writes two datasets of gzip'ed jsonl shards in the reference's record format
+(sc/dataset/text_text_loader.py:575-603: text columns + `metadata.objective.{paired,triplet}` column lists; KD scores)
+together with a spec YAML; the index files (counts.json / offsets.json.gz) are written by the caller with the code
+under test (contrastors_amd.data.build_index) or by `write_index` below (used when generating the goldens).
+`ToyTokenizer` implements the slice of the Hugging Face tokenizer call protocol the loader uses (:646-651).
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import random
+from pathlib import Path
+
+import torch
+import yaml
+
+WORDS = [f"w{i}" for i in range(200)]
+
+
+class ToyTokenizer:
+    """Whitespace / punctuation-free word tokenizer with [PAD]=0, [CLS]=1, [SEP]=2 (= eos), [UNK]=3."""
+
+    eos_token = " [SEP]"
+    eos_token_id = 2
+
+    def __init__(self):
+        self.vocab = {"[PAD]": 0, "[CLS]": 1, "[SEP]": 2, "[UNK]": 3, "query:": 4, "passage:": 5, "search_query:": 6,
+                      "search_document:": 7}
+        for w in WORDS:
+            self.vocab[w] = len(self.vocab)
+
+    def __call__(self, texts, padding="max_length", truncation=True, return_tensors="pt", max_length=32):
+        assert padding == "max_length" and truncation and return_tensors == "pt"
+        ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+        mask = torch.zeros(len(texts), max_length, dtype=torch.long)
+        for i, t in enumerate(texts):
+            toks = [1] + [self.vocab.get(w, 3) for w in t.split()]
+            toks = toks[:max_length]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": mask}
+
+
+def _sentence(rng, lo, hi):
+    return " ".join(rng.choice(WORDS) for _ in range(rng.randint(lo, hi)))
+
+
+def build_dataset(root) -> str:
+    """-> path of the spec YAML.  dsA: paired, 3 shards x 24 records; dsB: triplet with 4 negatives + KD scores, 2 shards x 16 records, custom prefixes."""
+    root = Path(root)
+    rng = random.Random(20240607)
+    (root / "bucket" / "dsA").mkdir(parents=True, exist_ok=True)
+    (root / "bucket" / "dsB").mkdir(parents=True, exist_ok=True)
+    for s, n in enumerate([24, 24, 24]):
+        with gzip.open(root / "bucket" / "dsA" / f"shard-{s:05d}.jsonl.gz", "wt") as f:
+            for i in range(n):
+                rec = {"query": _sentence(rng, 3, 12), "document": _sentence(rng, 10, 60), "id": f"A{s}-{i}",
+                       "metadata": {"objective": {"self": [], "paired": [["query", "document"]], "triplet": []}}}
+                f.write(json.dumps(rec) + "\n")
+    for s in range(2):
+        with gzip.open(root / "bucket" / "dsB" / f"shard-{s:05d}.jsonl.gz", "wt") as f:
+            for i in range(16):
+                rec = {"question": _sentence(rng, 3, 40), "answer": _sentence(rng, 10, 30),
+                       "hard": [_sentence(rng, 5, 30) for _ in range(4)], "document_score": round(rng.random(), 4),
+                       "negatives_scores": [round(rng.random(), 4) for _ in range(4)],
+                       "metadata": {"objective": {"self": [], "paired": [["question", "answer"]],
+                                                  "triplet": [["question", "answer", "hard"]]}}}
+                f.write(json.dumps(rec) + "\n")
+    spec = {"datasets": [
+        {"name": "dsA", "bucket": str(root / "bucket" / "dsA" / "shard-{00000..00002}.jsonl.gz"),
+         "objective": {"type": "paired", "columns": ["query", "document"]}},
+        {"name": "dsB", "bucket": str(root / "bucket" / "dsB" / "shard-{00000..00001}.jsonl.gz"), "kd_loss": True,
+         "query_prefix": "search_query", "document_prefix": "search_document",
+         "objective": {"type": "triplet", "columns": ["question", "answer", "hard"]}}]}
+    path = root / "spec.yaml"
+    with open(path, "w") as f:
+        yaml.safe_dump(spec, f)
+    return str(path)
+
+
+def shard_paths(root, ds):
+    return sorted(str(p) for p in (Path(root) / "bucket" / ds).glob("shard-*.jsonl.gz"))
+
+
+def write_index(root, normalize):
+    """counts.json / offsets.json.gz in the documented format (README.md:102-121), keyed by `normalize(url)`."""
+    for ds in ("dsA", "dsB"):
+        counts, offsets = {}, {}
+        for p in shard_paths(root, ds):
+            per, pos = {}, 0
+            with gzip.open(p, "rb") as f:
+                for i, line in enumerate(f):
+                    per[str(i)] = [pos, pos + len(line)]
+                    pos += len(line)
+            counts[normalize(p)], offsets[normalize(p)] = len(per), per
+        d = Path(root) / "bucket" / ds
+        with open(d / "counts.json", "w") as f:
+            json.dump({"count_per_file": counts}, f)
+        with gzip.open(d / "offsets.json.gz", "wt") as f:
+            json.dump(offsets, f)
+
+
+LOADER_CASES = {
+    # name: StreamingShardDataset kwargs (global batch 8 over 2 ranks)
+    "plain": dict(add_eos=False, add_prefix=False, num_negatives=2),
+    "eos_prefix": dict(add_eos=True, add_prefix=True, num_negatives=3, query_max_length=16, document_max_length=24),
+}

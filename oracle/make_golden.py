@@ -6,6 +6,7 @@ oracle.encoder_ref.random_state_dict and pinned by a checksum stored in the fixt
 """
 from __future__ import annotations
 
+import json
 import os
 import sys
 import warnings
@@ -263,6 +264,61 @@ def gen_mlm(name, cfgd, seed):
     print(name, "loss", float(out.loss), "targets", int(tgt.sum()))
 
 
+class _ForgivingDict(dict):
+    """The reference's non-download path deletes `path2stream[path]` entries it never created when a shard is exhausted
+    (text_text_loader.py:404) -- a KeyError that ends the epoch.  The golden run gets past it with this dict."""
+
+    def __delitem__(self, k):
+        if k in self:
+            super().__delitem__(k)
+
+
+def _rank_loader(rank, world, root, tmp):
+    from oracle import data_fixture as df
+
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29613", rank=rank, world_size=world)
+    tl = ref_import.load_text_loader()
+    spec = str(Path(root) / "spec.yaml")
+    out = {}
+    for case, kw in df.LOADER_CASES.items():
+        d = tl.StreamingShardDataset(spec, 8, df.ToyTokenizer(), seed=5, verbose=False, run_name=f"gold_{case}", **kw)
+        d.path2stream = _ForgivingDict()
+        out[f"{case}/len"] = np.array(len(d))
+        n = 0
+        for b in d:
+            out[f"{case}/{n}/dataset_name"] = np.array(b["dataset_name"])
+            for k, v in b.items():
+                if torch.is_tensor(v):
+                    out[f"{case}/{n}/{k}"] = v.numpy().astype(np.float32 if v.is_floating_point() else np.int16)
+            n += 1
+        out[f"{case}/n_batches"] = np.array(n)
+        processed = json.load(open(d.path))
+        out[f"{case}/processed_keys"] = np.array(["/".join(k.split("/")[-2:]) for k in processed])
+        out[f"{case}/processed_vals"] = np.array(list(processed.values()))
+        dist.barrier()
+    np.savez(f"{tmp}/loader{rank}.npz", **out)
+    dist.destroy_process_group()
+
+
+def gen_loader():
+    """tests/golden/loader_w2.npz: every batch the reference's StreamingShardDataset yields on 2 ranks for the toy
+    shards of oracle/data_fixture.py (global batch 8), for the LOADER_CASES configurations."""
+    import tempfile
+
+    from oracle import data_fixture as df
+
+    tl = ref_import.load_text_loader()
+    with tempfile.TemporaryDirectory(prefix="cxloader_") as root, tempfile.TemporaryDirectory() as tmp:
+        df.build_dataset(root)
+        probe = tl.StreamingShardDataset.__new__(tl.StreamingShardDataset)
+        df.write_index(root, lambda u: probe.normalize_url([u])[0])
+        mp.spawn(_rank_loader, args=(2, root, tmp), nprocs=2, join=True)
+        r = [np.load(f"{tmp}/loader{i}.npz") for i in range(2)]
+        np.savez_compressed(GOLD / "loader_w2.npz", **{f"r{i}/{k}": r[i][k] for i in range(2) for k in r[i].files})
+    print("loader_w2", {c: int(r[0][f"{c}/n_batches"]) for c in df.LOADER_CASES})
+
+
 class _Scale(torch.nn.Module):
     """Stand-in for LogitScale with a fixed scale (reference passes a module: sc/loss.py:109)."""
 
@@ -371,6 +427,9 @@ if __name__ == "__main__":
         gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
         gen_mlm("mlm_bert_tiny", TINY_BERT, 22)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loader":
+        gen_loader()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hf_remap":
         gen_hf_remap()
         sys.exit(0)
@@ -384,3 +443,4 @@ if __name__ == "__main__":
     gen_hf_remap()
     gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
     gen_mlm("mlm_bert_tiny", TINY_BERT, 22)
+    gen_loader()

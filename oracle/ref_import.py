@@ -125,3 +125,45 @@ def load_bert_remap():
             m.__path__ = [str(path)]
             sys.modules[name] = m
     return importlib.import_module("contrastors.models.encoder.bert")
+
+
+def load_text_loader():
+    """-> the reference's sc/dataset/text_text_loader.py.  `webdataset` (absent here) is replaced by the two helpers
+    the loader takes from it, restated from their documented behaviour: `shardlists.expand_urls` = brace expansion,
+    `tariterators.base_plus_ext` = split at the first dot of the last path component."""
+    import re
+
+    load()
+    if "webdataset" not in sys.modules:
+        def expand_urls(url):
+            m = re.search(r"\{(\d+)\.\.(\d+)\}", url)
+            if not m:
+                return [url]
+            a, b = m.group(1), m.group(2)
+            return [url[: m.start()] + str(i).zfill(len(a)) + url[m.end():] for i in range(int(a), int(b) + 1)]
+
+        def base_plus_ext(path):
+            mm = re.match(r"^((?:.*/|)[^.]+)[.]([^/]*)$", path)
+            return (mm.group(1), mm.group(2)) if mm else (None, None)
+
+        w = types.ModuleType("webdataset")
+        w.__spec__ = M.ModuleSpec("webdataset", None)
+        w.shardlists = types.ModuleType("webdataset.shardlists")
+        w.shardlists.expand_urls = expand_urls
+        t = types.ModuleType("webdataset.tariterators")
+        t.base_plus_ext = base_plus_ext
+        w.tariterators = t
+        sys.modules["webdataset"], sys.modules["webdataset.shardlists"], sys.modules["webdataset.tariterators"] = w, w.shardlists, t
+    import fsspec
+    from fsspec.implementations.local import LocalFileSystem
+
+    class _NoS3(LocalFileSystem):  # the loader instantiates an "s3" filesystem before it looks at the spec (:214-215)
+        def __init__(self, *a, config_kwargs=None, **k):
+            super().__init__(*a, **k)
+
+    fsspec.register_implementation("s3", _NoS3, clobber=True)
+    if "contrastors.dataset" not in sys.modules:
+        pkg = types.ModuleType("contrastors.dataset")
+        pkg.__path__ = [str(REF_ROOT / "dataset")]
+        sys.modules["contrastors.dataset"] = pkg
+    return importlib.import_module("contrastors.dataset.text_text_loader")
