@@ -225,7 +225,8 @@ def main():
             "config": {"workload": "configs[1]: nomic-bert-2048 bi-encoder contrastive pretrain step (GradCache, "
                                    "paired InfoNCE scale 50, AdamW, clip 1.0)",
                        "global_batch": G, "pairs_per_gpu": b, "seq_len": S, "grad_cache_chunk": args.chunk_size,
-                       "n_layer": cfg.n_layer, "parallelism": f"dp{world}", "loss_last_step": float(loss.item())},
+                       "n_layer": cfg.n_layer, "parallelism": f"dp{world}", "loss_last_step": float(loss.item()),
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,

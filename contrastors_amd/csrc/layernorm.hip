@@ -24,6 +24,19 @@ CX_DEVICE void load4_f32(const float* p, float (&v)[4]) {
     v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
 }
 
+CX_DEVICE void unpack4_bf16(const uint2 u, float (&v)[4]) {
+    v[0] = bf16lo_to_f32(u.x); v[1] = bf16hi_to_f32(u.x);
+    v[2] = bf16lo_to_f32(u.y); v[3] = bf16hi_to_f32(u.y);
+}
+// Raw (packed bf16) row fetch, issued one row ahead of its use: with one 1.5 KiB row per wave and ~16 waves per CU the
+// kernels had only ~24-36 KiB in flight per CU, well short of what latency x HBM bandwidth asks for (~60 KiB).
+template <int NCH>
+CX_DEVICE void fetch_row(const bf16_t* __restrict__ base, int row, int lane, uint2 (&raw)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        raw[i] = *reinterpret_cast<const uint2*>(base + (size_t)row * (NCH * 256) + (i * 64 + lane) * 4);
+}
+
 template <int NCH>
 CX_DEVICE void row_stats(const float (&z)[NCH][4], int d, float eps, float& mean, float& rstd) {
     float s = 0.f;
@@ -57,18 +70,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
         load4_f32(beta + (i * 64 + lane) * 4, b[i]);
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    uint2 nx[NCH], nr[NCH];
+    if (row < rows) {
+        fetch_row<NCH>(x0, row, lane, nx);
+        if (res) fetch_row<NCH>(res, row, lane, nr);
+    }
+    for (; row < rows; row += stride) {
         float z[NCH][4];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
-            load4_bf16(x0 + off, z[i]);
+            unpack4_bf16(nx[i], z[i]);
             if (res) {
                 float r[4];
-                load4_bf16(res + off, r);
+                unpack4_bf16(nr[i], r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) z[i][e] += r[e];
             }
+        }
+        if (row + stride < rows) {  // next row's loads fly under this row's statistics and stores
+            fetch_row<NCH>(x0, row + stride, lane, nx);
+            if (res) fetch_row<NCH>(res, row + stride, lane, nr);
         }
         float mean, rstd;
         row_stats<NCH>(z, D, eps, mean, rstd);
@@ -175,22 +198,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float mean = mean_i[row], rstd = rstd_i[row];
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    uint2 na[NCH], nb[NCH], nz[NCH];
+    float nmean = 0.f, nrstd = 0.f;
+    if (row < rows) {
+        fetch_row<NCH>(da, row, lane, na);
+        if (dbb) fetch_row<NCH>(dbb, row, lane, nb);
+        fetch_row<NCH>(z, row, lane, nz);
+        nmean = mean_i[row];
+        nrstd = rstd_i[row];
+    }
+    for (; row < rows; row += stride) {
+        const float mean = nmean, rstd = nrstd;
         float dy[NCH][4], xh[NCH][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
-            load4_bf16(da + off, dy[i]);
+            unpack4_bf16(na[i], dy[i]);
             if (dbb) {
                 float t[4];
-                load4_bf16(dbb + off, t);
+                unpack4_bf16(nb[i], t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dy[i][e] += t[e];
             }
             float zz[4];
-            load4_bf16(z + off, zz);
+            unpack4_bf16(nz[i], zz);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xh[i][e] = (zz[e] - mean) * rstd;
@@ -200,6 +233,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 dg[i][e] += dy[i][e] * xh[i][e];
                 db[i][e] += dy[i][e];
             }
+        }
+        if (row + stride < rows) {  // next row's loads fly under this row's reductions and stores
+            fetch_row<NCH>(da, row + stride, lane, na);
+            if (dbb) fetch_row<NCH>(dbb, row + stride, lane, nb);
+            fetch_row<NCH>(z, row + stride, lane, nz);
+            nmean = mean_i[row + stride];
+            nrstd = rstd_i[row + stride];
         }
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
@@ -368,7 +408,7 @@ inline int ln_grid_bwd(int rows) {
 }
 inline int ln_grid(int rows) {
     int g = (rows + 3) / 4;
-    if (g > 256 * 4) g = 256 * 4;
+    if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     return g;
 }
@@ -411,7 +451,7 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
     if (ws && ws_floats >= (long)2 * d * 256) {
         long cap = ws_floats / (2L * d);
         grid = (rows + 3) / 4;
-        if (grid > 768) grid = 768;  // 3 blocks per CU: enough waves in flight for HBM, few enough partials to fold
+        if (grid > 768) grid = 768;  // 3 blocks per CU = the kernel's occupancy (130 VGPRs): one resident round, few partials
         if (grid > cap) grid = (int)cap;
         part = ws;
     }
