@@ -424,6 +424,176 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128_kernel(AttnParams p) {
     }
 }
 
+// Persistent form of attn_fwd_s128_kernel (A/B switch cx_attn_set_fwd_s128(1), not the default): a workgroup walks
+// (sequence, head) problems with stride gridDim.x and issues the NEXT problem's global loads right after staging the
+// current one, so they fly under its MFMA / softmax / stores; the rotary tables depend only on the row a thread
+// stages, so they are loaded once.  Measured 188-215 us vs 194-204 us for the one-shot form at T = 131072: hiding the
+// load latency buys nothing, the kernel is bound by its VALU work (rotary, exp2, masking, V transpose: ~5 k VALU
+// cycles per problem and SIMD against ~1 k MFMA cycles), not by bytes in flight.
+struct Fwd128Raw {
+    uint4 qlo[2], qhi[2], klo[2], khi[2], v0[2], v1[2];
+};
+
+CX_DEVICE void fwd128_issue(const AttnParams& p, int h, int t0, int len, int tid, Fwd128Raw& w) {
+    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const int cp = tid & 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int r = it * 64 + (tid >> 2);
+        r = r < len ? r : len - 1;
+        const bf16_t* qrow = qbase + (size_t)(t0 + r) * tok_stride;
+        const bf16_t* krow = kbase + (size_t)(t0 + r) * tok_stride;
+        w.qlo[it] = *reinterpret_cast<const uint4*>(qrow + cp * 8);
+        w.qhi[it] = *reinterpret_cast<const uint4*>(qrow + 32 + cp * 8);
+        w.klo[it] = *reinterpret_cast<const uint4*>(krow + cp * 8);
+        w.khi[it] = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
+        int ka = it * 64 + 2 * (tid >> 3), kb2 = ka + 1;
+        ka = ka < len ? ka : len - 1;
+        kb2 = kb2 < len ? kb2 : len - 1;
+        w.v0[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + ka) * tok_stride + (tid & 7) * 8);
+        w.v1[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + kb2) * tok_stride + (tid & 7) * 8);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_s128p_kernel(AttnParams p, int B, int max_seqlen) {
+    __shared__ __attribute__((aligned(16))) char smem[16384 + 16384 + 64 * VT128_STRIDE];
+    char* Qs = smem;
+    char* Ks = smem + 16384;
+    char* Vt = smem + 32768;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int cp = tid & 3;
+    const int n_units = B * p.H;
+    // rotary rows of the two token rows this thread stages; rows >= len are staged but never used, so clamping the
+    // table row to max_seqlen - 1 (the table is at least that long) changes nothing that is read
+    float4 cs[2][2], sn[2][2];
+    if (p.cosv) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int r = it * 64 + (tid >> 2);
+            r = r < max_seqlen ? r : max_seqlen - 1;
+            const float* c = p.cosv + (size_t)r * 32 + cp * 8;
+            const float* sp = p.sinv + (size_t)r * 32 + cp * 8;
+            cs[it][0] = *reinterpret_cast<const float4*>(c);
+            cs[it][1] = *reinterpret_cast<const float4*>(c + 4);
+            sn[it][0] = *reinterpret_cast<const float4*>(sp);
+            sn[it][1] = *reinterpret_cast<const float4*>(sp + 4);
+        }
+    }
+    int unit = blockIdx.x;
+    int t0 = 0, len = 0;
+    Fwd128Raw w;
+    while (unit < n_units) {  // first problem with tokens
+        const int b = unit / p.H;
+        t0 = p.cu[b];
+        len = p.cu[b + 1] - t0;
+        if (len > 0) break;
+        unit += gridDim.x;
+    }
+    if (unit >= n_units) return;
+    fwd128_issue(p, unit % p.H, t0, len, tid, w);
+    const float sc2 = p.scale * LOG2E;
+    while (true) {
+        const int h = unit % p.H;
+        // ---- rotate, stage -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = it * 64 + (tid >> 2);
+            uint4 a_lo = w.qlo[it], a_hi = w.qhi[it], b_lo = w.klo[it], b_hi = w.khi[it];
+            if (p.cosv) {
+                rot8(w.qlo[it], w.qhi[it], cs[it], sn[it], a_lo, a_hi);
+                rot8(w.klo[it], w.khi[it], cs[it], sn[it], b_lo, b_hi);
+            }
+            *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = a_lo;
+            *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = a_hi;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = b_lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = b_hi;
+            const int kp = it * 32 + (tid >> 3), c8 = (tid & 7) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t ww = (uint32_t)elem16(w.v0[it], e) | ((uint32_t)elem16(w.v1[it], e) << 16);
+                *reinterpret_cast<uint32_t*>(Vt + (c8 + e) * VT128_STRIDE + kp * 4) = ww;
+            }
+        }
+        __syncthreads();
+        // ---- next problem's loads, under this problem's compute ----------------------------------------------------
+        int nunit = unit + gridDim.x, nt0 = 0, nlen = 0;
+        while (nunit < n_units) {
+            const int nb = nunit / p.H;
+            nt0 = p.cu[nb];
+            nlen = p.cu[nb + 1] - nt0;
+            if (nlen > 0) break;
+            nunit += gridDim.x;
+        }
+        if (nunit < n_units) fwd128_issue(p, nunit % p.H, nt0, nlen, tid, w);
+        // ---- S^T = K Q^T, softmax over the lane-resident row, O = P V -----------------------------------------------
+        bf16x8_t qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
+        float s[4][16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x16_t a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, hi);
+                s[kb][r] = key < len ? a[r] * sc2 : -INFINITY;
+                mx = fmaxf(mx, s[kb][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[kb][r] = fast_exp2(s[kb][r] - mx);
+                psum += s[kb][r];
+            }
+        f32x16_t acc_o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8_t pf = pack_frag(s[kb], half);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    acc_o[db] = mfma_bf16_32x32x16(read_vt128_frag(Vt, db * 32 + l31, kb * 2 + half, hi), pf, acc_o[db]);
+            }
+        const float l_tot = psum + __shfl_xor(psum, 32, 64);
+        const float inv = 1.f / l_tot;
+        const int q = wave * 32 + l31;
+        if (q < len) {
+            bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
+                    pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
+                }
+            if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mx + log2f(l_tot)) * LN2;
+        }
+        if (nunit >= n_units) break;
+        unit = nunit; t0 = nt0; len = nlen;
+        __syncthreads();  // every wave is done with this problem's LDS tiles before they are restaged
+    }
+}
+
 // ------------------------------------------------------------------------------------- delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     const long total = (long)p.T * p.H * 8;
@@ -1440,6 +1610,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
 
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
 
+int g_fwd_s128 = 0;  // cx_attn_set_fwd_s128: 0 one problem per workgroup (default), 1 persistent with next-problem prefetch
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
 
 }  // namespace
@@ -1447,6 +1618,7 @@ int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 wo
 extern "C" {
 
 void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 3) ? mode : 3; }
+void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = mode == 1 ? 1 : 0; }
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
@@ -1457,7 +1629,11 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     AttnParams p = {};
     p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
-    if (max_seqlen <= 128) {
+    if (max_seqlen <= 128 && g_fwd_s128 == 1) {
+        const int n_units = B * H;
+        hipLaunchKernelGGL(attn_fwd_s128p_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), 0,
+                           (hipStream_t)stream, p, B, max_seqlen);
+    } else if (max_seqlen <= 128) {
         hipLaunchKernelGGL(attn_fwd_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);

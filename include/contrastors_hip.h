@@ -150,6 +150,9 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
  * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
  * 0 = the general kernels */
 void cx_attn_set_bwd_s128(int mode);
+/* forward kernel for max_seqlen <= 128: 0 (default) one problem per workgroup, 1 persistent workgroups that prefetch
+ * the next (sequence, head) problem under the current one; bit-identical results (A/B switch for benchmarks). */
+void cx_attn_set_fwd_s128(int mode);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                           int B, int H, int T, int max_seqlen, int sign, void* stream);
