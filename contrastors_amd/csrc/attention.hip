@@ -1610,7 +1610,155 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
 
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
 
-int g_fwd_s128 = 0;  // cx_attn_set_fwd_s128: 0 one problem per workgroup (default), 1 persistent with next-problem prefetch
+// ------------------------------------------------------------------------ forward, sequences <= 128, lean-VALU form
+// attn_fwd_s128_kernel issues ~950 VALU instructions per problem and wave against 32 MFMAs.  Same data flow with the
+// avoidable VALU work (~37 %) removed (A/B switch cx_attn_set_fwd_s128(2), not the default; results differ by <= 1 bf16
+// ulp).  Measured 195-202 us vs 202-204 us at T = 131072: neither this nor the prefetching form (mode 1) moves the
+// kernel, so its ~4 TB/s is bound by neither load latency nor VALU issue -- see DESIGN.md section 5.
+//  * V is staged row-major ([key][64 d], 16-B stores, XOR-swizzled so that both the 16-B writers and the transposing
+//    readers are bank-conflict free) and its fragments come from ds_read_b64_tr_b16 in the accumulator-register key
+//    order pack_frag produces -- no per-element repacking into a transposed tile;
+//  * full-length sequences (len == 128, the metric) skip the key mask;
+//  * the softmax scale is folded into the exponent: p = exp2(fma(s, c, -max(s) * c)).
+CX_DEVICE int v128_off(int key, int d) { return key * 128 + ((((d >> 3) ^ (((key >> 1) & 1) << 2)) << 4)) + (d & 7) * 2; }
+// A[i = d0 + (lane&31)][k]: keys kbase + 4*hi + {0..3}, kbase + 8 + 4*hi + {0..3}  (pairs with pack_frag(s, half),
+// kbase = 32*kb + 16*half)
+CX_DEVICE bf16x8_t v128_tr_frag(const char* tile, int d0, int kbase, int lane) {
+    const int g = lane >> 4, pp = lane & 15;
+    const int t = kbase + 4 * (g >> 1) + (pp >> 2);
+    const int f = d0 + 16 * (g & 1) + 4 * (pp & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + v128_off(t, f)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + v128_off(t + 8, f)));
+    return u.v;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[16384 * 3];
+    char* Qs = smem;
+    char* Ks = smem + 16384;
+    char* Vs = smem + 32768;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    if (len <= 0) return;
+    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const bf16_t* qbase = p.qkv + (size_t)h * DH;
+    const bf16_t* kbase = qbase + (size_t)p.H * DH;
+    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    uint4 qlo[2], qhi[2], klo[2], khi[2], vv[4];
+    float4 cs[2][2], sn[2][2];
+    const int cp = tid & 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int r = it * 64 + (tid >> 2);
+        r = r < len ? r : len - 1;
+        const bf16_t* qrow = qbase + (size_t)(t0 + r) * tok_stride;
+        const bf16_t* krow = kbase + (size_t)(t0 + r) * tok_stride;
+        qlo[it] = *reinterpret_cast<const uint4*>(qrow + cp * 8);
+        qhi[it] = *reinterpret_cast<const uint4*>(qrow + 32 + cp * 8);
+        klo[it] = *reinterpret_cast<const uint4*>(krow + cp * 8);
+        khi[it] = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
+        if (p.cosv) {
+            const float* c = p.cosv + (size_t)r * 32 + cp * 8;
+            const float* sp = p.sinv + (size_t)r * 32 + cp * 8;
+            cs[it][0] = *reinterpret_cast<const float4*>(c);
+            cs[it][1] = *reinterpret_cast<const float4*>(c + 4);
+            sn[it][0] = *reinterpret_cast<const float4*>(sp);
+            sn[it][1] = *reinterpret_cast<const float4*>(sp + 4);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // V: key row it*32 + tid/8, 16-B chunk tid%8
+        int key = it * 32 + (tid >> 3);
+        key = key < len ? key : len - 1;
+        vv[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + key) * tok_stride + (tid & 7) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = it * 64 + (tid >> 2);
+        uint4 a_lo = qlo[it], a_hi = qhi[it], b_lo = klo[it], b_hi = khi[it];
+        if (p.cosv) {
+            rot8(qlo[it], qhi[it], cs[it], sn[it], a_lo, a_hi);
+            rot8(klo[it], khi[it], cs[it], sn[it], b_lo, b_hi);
+        }
+        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = a_lo;
+        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = a_hi;
+        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = b_lo;
+        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = b_hi;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        *reinterpret_cast<uint4*>(Vs + v128_off(it * 32 + (tid >> 3), (tid & 7) * 8)) = vv[it];
+    __syncthreads();
+
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
+    const float sc2 = p.scale * LOG2E;
+    float s[4][16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        f32x16_t a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
+        if (len < 128) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = kb * 32 + acc_row(r, hi) < len ? a[r] : -INFINITY;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = a[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * sc2;  // softmax_scale > 0: the maximum commutes with the scale
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], sc2, -mxs));
+            psum += s[kb][r];
+        }
+    f32x16_t acc_o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16x8_t pf = pack_frag(s[kb], half);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                acc_o[db] = mfma_bf16_32x32x16(v128_tr_frag(Vs, db * 32, kb * 32 + 16 * half, lane), pf, acc_o[db]);
+        }
+    const float l_tot = psum + __shfl_xor(psum, 32, 64);
+    const float inv = 1.f / l_tot;
+    const int q = wave * 32 + l31;
+    if (q < len) {
+        bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
+                pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
+            }
+        if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mxs + log2f(l_tot)) * LN2;
+    }
+}
+
+int g_fwd_s128 = 0;  // cx_attn_set_fwd_s128: 0 one problem per workgroup (default), 1 persistent + next-problem prefetch, 2 lean-VALU
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
 
 }  // namespace
@@ -1618,7 +1766,7 @@ int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 wo
 extern "C" {
 
 void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 3) ? mode : 3; }
-void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = mode == 1 ? 1 : 0; }
+void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 0; }
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
@@ -1633,6 +1781,8 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
         const int n_units = B * H;
         hipLaunchKernelGGL(attn_fwd_s128p_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), 0,
                            (hipStream_t)stream, p, B, max_seqlen);
+    } else if (max_seqlen <= 128 && g_fwd_s128 == 2) {
+        hipLaunchKernelGGL(attn_fwd_s128v_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
     } else if (max_seqlen <= 128) {
         hipLaunchKernelGGL(attn_fwd_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
     } else {

@@ -151,7 +151,9 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
  * 0 = the general kernels */
 void cx_attn_set_bwd_s128(int mode);
 /* forward kernel for max_seqlen <= 128: 0 (default) one problem per workgroup, 1 persistent workgroups that prefetch
- * the next (sequence, head) problem under the current one; bit-identical results (A/B switch for benchmarks). */
+ * the next (sequence, head) problem under the current one (bit-identical), 2 lean-VALU form (V fragments through the
+ * transposing LDS read, mask skipped for full sequences, scale folded into the exponent; <= 1 bf16 ulp apart).
+ * A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
 void cx_attn_set_fwd_s128(int mode);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
