@@ -142,3 +142,83 @@ def test_matryoshka_prefix_views_and_dual_encoder_loss():
     want = (torch.nn.functional.cross_entropy(v @ t.T * 30.0, lab) + torch.nn.functional.cross_entropy(t @ v.T * 30.0, lab)) / 2
     assert abs(out.item() - want.item()) < 1e-5 * abs(want.item()) + 1e-6
     assert torch.isfinite(de.text.w.grad).all() and torch.isfinite(de.vision.w.grad).all()
+
+
+def test_full_architecture_step_properties_at_metric_shapes():
+    """Size-independent properties of the whole GradCache step at the BASELINE architecture (12-layer nomic-bert-2048,
+    seq 128, T = 8192 / 32768 tokens per chunk so every persistent GEMM / fused-epilogue path of the metric runs):
+    (1) the GradCache chunk is a pure memory knob: loss and gradients do not depend on it;
+    (2) the step is deterministic up to fp32 atomics: repeating it reproduces the loss bit for bit;
+    (3) the encoder backward is a sum over sequences: permuting the sequences of a chunk together with their embedding
+        gradients leaves every parameter gradient unchanged (fp32 summation order only);
+    (4) the loss is equivariant: permuting (query, document) pairs permutes the embedding gradients."""
+    from contrastors_amd.nomic_bert import VarlenBatch
+
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=8192)
+    tower = BiEncoder(BiEncoderConfig(model_name="nomic", pooling="mean", logit_scale=50.0, trunk_config=cfg), device=DEV,
+                      seed=11).train()
+    scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(DEV)
+    B, S = 256, 128
+    g = torch.Generator().manual_seed(5)
+    q = torch.randint(1000, 8192, (B, S), generator=g).to(DEV)
+    d = torch.randint(1000, 8192, (B, S), generator=g).to(DEV)
+    lens = [S] * B
+
+    def step(qi, di, chunk):
+        tower.trunk.zero_grad()
+        loss = grad_cache_loss(tower, {"input_ids": qi, "seqlens": lens}, tower, {"input_ids": di, "seqlens": lens},
+                               chunk, scale)
+        torch.cuda.synchronize()
+        return float(loss), tower.trunk.flat_grad.clone()
+
+    l64, g64 = step(q, d, 64)
+    l256, g256 = step(q, d, 256)
+    l64b, g64b = step(q, d, 64)
+    assert l64 == l64b  # (2)
+    gn = float(g64.norm())
+    assert np.isfinite(l64) and gn > 0
+    assert abs(l64 - l256) <= 1e-6 * max(1.0, abs(l64))  # (1) same embeddings -> same fp32 loss
+    rel = float((g64 - g256).norm()) / gn
+    rel_rep = float((g64 - g64b).norm()) / gn
+    assert rel_rep <= 1e-5 and rel <= 1e-4  # fp32 summation order (atomics, split-K extents) only
+
+    # (3) engine level, exact embedding gradients
+    eng = tower.trunk
+    demb = (torch.randn(64, cfg.n_embd, generator=g) * 1e-3).to(DEV)
+    perm = torch.arange(64)
+    perm[[3, 40]] = perm[[40, 3]]
+    perm = perm.to(DEV)
+
+    def bwd(ids_, demb_):
+        eng.zero_grad()
+        vb = VarlenBatch.from_lengths(ids_, [S] * 64)
+        emb, arena = eng.forward_chunk(vb, True, normalize=True)
+        eng.backward_chunk(vb, arena, demb_)
+        torch.cuda.synchronize()
+        return emb.clone(), eng.flat_grad.clone()
+
+    e0, p0 = bwd(q[:64], demb)
+    e1, p1 = bwd(q[:64][perm], demb[perm])
+    assert torch.equal(e1[perm], e0)  # a sequence's embedding does not depend on its slot in the batch
+    rel_perm = float((p1 - p0).norm()) / float(p0.norm())
+    assert rel_perm <= 1e-5
+
+    # (4) loss level, well-conditioned unit vectors
+    qe = torch.nn.functional.normalize(torch.randn(B, cfg.n_embd, generator=g), dim=-1).to(DEV)
+    de = torch.nn.functional.normalize(torch.randn(B, cfg.n_embd, generator=g), dim=-1).to(DEV)
+    pb = torch.randperm(B, generator=g).to(DEV)
+
+    def lossgrad(a, b):
+        a, b = a.clone().requires_grad_(), b.clone().requires_grad_()
+        loss = clip_loss(a, b, scale)
+        loss.backward()
+        return float(loss.detach()), a.grad, b.grad
+
+    l_a, dq_a, dd_a = lossgrad(qe, de)
+    l_b, dq_b, dd_b = lossgrad(qe[pb], de[pb])
+    assert abs(l_a - l_b) <= 1e-6 * max(1.0, abs(l_a))
+    e_q = float((dq_b - dq_a[pb]).norm()) / float(dq_a.norm())
+    e_d = float((dd_b - dd_a[pb]).norm()) / float(dd_a.norm())
+    report("full_arch_step", loss=l64, grad_norm=gn, rel_chunk64_vs_256=rel, rel_repeat=rel_rep, rel_seq_perm=rel_perm,
+           rel_loss_perm_dq=e_q, rel_loss_perm_dd=e_d)
+    assert e_q <= 1e-5 and e_d <= 1e-5
