@@ -651,6 +651,50 @@ CX_DEVICE void store_unrotated(bf16_t* row, const f32x16_t (&acc)[2], float scal
 }
 
 
+// store_unrotated for a wave's 32 consecutive rows with full-row global stores: the accumulator layout gives a lane
+// 4 consecutive d of ONE row, so direct stores are 16-byte pieces of 32 different rows per instruction (partial-line
+// writes; they cost the S <= 128 forward 17 %).  Staged in `stage` (4 KiB private to the wave, tile64 swizzle) the rows
+// leave as 16 B per lane, 8 lanes per 128-B row.  g0 = row 0 of the wave's rows, rows_valid = how many of them exist.
+CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, int rows_valid, const f32x16_t (&acc)[2],
+                                    float scale, const float* cosv, const float* sinv, int pos, int hi, int lane) {
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const int d = 8 * qd + 4 * hi;
+        float lo[4], hh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = acc[0][4 * qd + e] * scale;
+            hh[e] = acc[1][4 * qd + e] * scale;
+        }
+        if (cosv) {
+            const float4 c = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + d);
+            const float4 s = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + d);
+            const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gl = lo[e], gh = hh[e];
+                lo[e] = gl * cc[e] + gh * ss[e];
+                hh[e] = gh * cc[e] - gl * ss[e];
+            }
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(lo[0], lo[1]);
+        pk.y = pack_bf16x2(lo[2], lo[3]);
+        *reinterpret_cast<uint2*>(stage + tile64_off(l31, qd) + hi * 8) = pk;
+        pk.x = pack_bf16x2(hh[0], hh[1]);
+        pk.y = pack_bf16x2(hh[2], hh[3]);
+        *reinterpret_cast<uint2*>(stage + tile64_off(l31, 4 + qd) + hi * 8) = pk;
+        __builtin_amdgcn_sched_barrier(0);  // one qd at a time: hoisting all four cos/sin fetches costs 32 registers
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + tile64_off(r, c));
+        if (r < rows_valid) *reinterpret_cast<uint4*>(g0 + (size_t)r * row_stride + c * 8) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- dQ
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     // Qs/dOs are only needed to build the loop-invariant register fragments; the K/V/Kt tiles alias them.
@@ -1578,12 +1622,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 }
             }
         }
-        if (row_ok) {
-            bf16_t* krow = p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)(p.H + h) * DH;
-            store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, row, hi);
-            store_unrotated(krow + (size_t)p.H * DH, acc_dv, 1.f, nullptr, nullptr, 0, hi);
+        __syncthreads();  // the dS tile is complete; lse / delta, Q^T and dO^T are dead: R2 becomes Kt
+        {   // dK, dV of this wave's 32 keys leave as full rows through the wave's slices of the dead Q^T / dO^T tiles
+            bf16_t* k0 = p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)(p.H + h) * DH;
+            const int pos = row_ok ? row : len - 1;
+            store_unrotated_rows(Qt + wave * 4096, k0, tok_stride, len - wave * 32, acc_dk, p.scale, p.cosv, p.sinv, pos,
+                                 hi, lane);
+            store_unrotated_rows(dOt + wave * 4096, k0 + (size_t)p.H * DH, tok_stride, len - wave * 32, acc_dv, 1.f,
+                                 nullptr, nullptr, 0, hi, lane);
         }
-        __syncthreads();  // the dS tile is complete, lse / delta are dead: R2 becomes Kt
         stage_transposed_sw(R2, kp, cp, k);
         __syncthreads();
 
@@ -1600,9 +1647,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             for (int db = 0; db < 2; ++db)
                 acc_dq[db] = mfma_bf16_32x32x16(sw_linear_frag(R2, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
         }
-        if (row_ok)
-            store_unrotated(p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, row,
-                            hi);
+        store_unrotated_rows(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
+                             len - wave * 32, acc_dq, p.scale, p.cosv, p.sinv, row_ok ? row : len - 1, hi, lane);
         __syncthreads();  // LDS is restaged by the next problem
     }
     if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
@@ -1611,10 +1657,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
 
 // ------------------------------------------------------------------------ forward, sequences <= 128, lean-VALU form
-// attn_fwd_s128_kernel issues ~950 VALU instructions per problem and wave against 32 MFMAs.  Same data flow with the
-// avoidable VALU work (~37 %) removed (A/B switch cx_attn_set_fwd_s128(2), not the default; results differ by <= 1 bf16
-// ulp).  Measured 195-202 us vs 202-204 us at T = 131072: neither this nor the prefetching form (mode 1) moves the
-// kernel, so its ~4 TB/s is bound by neither load latency nor VALU issue -- see DESIGN.md section 5.
+// attn_fwd_s128_kernel issues ~950 VALU instructions per problem and wave against 32 MFMAs and stores its output as
+// 16-byte pieces of 32 different rows per instruction.  Same data flow (default, cx_attn_set_fwd_s128(2); results
+// within 1 bf16 ulp of mode 0) with the avoidable VALU work (~37 %) removed and the output staged through LDS so that
+// it leaves as full 128-byte rows.  At T = 131072: the VALU diet alone 195-202 us vs 202-204 us (nothing), with the
+// full-row stores 167-173 us -- the partial-line writes were the bound, not load latency (mode 1) or VALU issue.
 //  * V is staged row-major ([key][64 d], 16-B stores, XOR-swizzled so that both the 16-B writers and the transposing
 //    readers are bank-conflict free) and its fragments come from ds_read_b64_tr_b16 in the accumulator-register key
 //    order pack_frag produces -- no per-element repacking into a transposed tile;
@@ -1742,9 +1789,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
         }
     const float l_tot = psum + __shfl_xor(psum, 32, 64);
     const float inv = 1.f / l_tot;
-    const int q = wave * 32 + l31;
-    if (q < len) {
-        bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
+    // Output through LDS: the accumulator layout gives a lane 4 consecutive d of ONE query row (8 B), so direct stores
+    // touch 32 rows x 16 B per instruction; staged in this wave's own (now dead) Q rows they leave as 16 B per lane,
+    // 8 lanes per 128-B row.  Only own-wave rows are touched: no barrier, the write -> read order is the wave's own.
+    {
+        const int qrow = wave * 32 + l31;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1752,13 +1801,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
                 uint2 pk;
                 pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
                 pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
+                *reinterpret_cast<uint2*>(Qs + tile64_off(qrow, db * 4 + qd) + hi * 8) = pk;
             }
-        if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mxs + log2f(l_tot)) * LN2;
+        if (qrow < len && hi == 0) p.lse[(size_t)h * p.T + t0 + qrow] = (mxs + log2f(l_tot)) * LN2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = wave * 32 + it * 8 + (lane >> 3), chunk = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(Qs + tile64_off(q, chunk));
+            if (q < len) *reinterpret_cast<uint4*>(p.out + ((size_t)(t0 + q) * p.H + h) * DH + chunk * 8) = v;
+        }
     }
 }
 
-int g_fwd_s128 = 0;  // cx_attn_set_fwd_s128: 0 one problem per workgroup (default), 1 persistent + next-problem prefetch, 2 lean-VALU
+int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
 
 }  // namespace
@@ -1766,7 +1821,7 @@ int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 wo
 extern "C" {
 
 void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 3) ? mode : 3; }
-void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 0; }
+void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,

@@ -150,10 +150,10 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
  * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
  * 0 = the general kernels */
 void cx_attn_set_bwd_s128(int mode);
-/* forward kernel for max_seqlen <= 128: 0 (default) one problem per workgroup, 1 persistent workgroups that prefetch
- * the next (sequence, head) problem under the current one (bit-identical), 2 lean-VALU form (V fragments through the
- * transposing LDS read, mask skipped for full sequences, scale folded into the exponent; <= 1 bf16 ulp apart).
- * A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
+/* forward kernel for max_seqlen <= 128: 2 (default) lean-VALU form with full-row output stores (V fragments through
+ * the transposing LDS read, mask skipped for full sequences, scale folded into the exponent, output staged in LDS),
+ * 0 the first one-problem-per-workgroup form (<= 1 bf16 ulp apart), 1 persistent workgroups that prefetch the next
+ * problem (bit-identical to 0).  A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
 void cx_attn_set_fwd_s128(int mode);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
