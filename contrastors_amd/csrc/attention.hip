@@ -252,18 +252,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     const int q = q0 + wave * 32 + l31;
-    if (q < len) {
-        bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
+    // full-row stores through this wave's own Q rows (dead since the fragments were read; see store_unrotated_rows)
+    char* stage = Qs + wave * 4096;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 pk;
-                pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
-                pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
-            }
-        if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (m_run + log2f(l_tot)) * LN2;
+        for (int qd = 0; qd < 4; ++qd) {
+            uint2 pk;
+            pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
+            pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
+            *reinterpret_cast<uint2*>(stage + tile64_off(l31, db * 4 + qd) + hi * 8) = pk;
+        }
+    if (q < len && hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (m_run + log2f(l_tot)) * LN2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const int qq = q0 + wave * 32 + r;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + tile64_off(r, c));
+        if (qq < len) *reinterpret_cast<uint4*>(p.out + ((size_t)(t0 + qq) * p.H + h) * DH + c * 8) = v;
     }
 }
 
@@ -807,9 +813,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
         }
         __syncthreads();
     }
-    if (q < len)
-        store_unrotated(p.dqkv + (size_t)(t0 + q) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, q,
-                        hi);
+    // (the loop ends with a barrier: all of LDS is dead, every wave stages its 32 rows in its own 4 KiB)
+    store_unrotated_rows(smem + wave * 4096, p.dqkv + (size_t)(t0 + q0 + wave * 32) * tok_stride + (size_t)h * DH,
+                         tok_stride, len - (q0 + wave * 32), acc_dq, p.scale, p.cosv, p.sinv, q < len ? q : len - 1, hi,
+                         lane);
 }
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
@@ -949,11 +956,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
         }
         __syncthreads();
     }
-    if (key_ok) {
-        bf16_t* krow = p.dqkv + (size_t)(t0 + key) * tok_stride + (size_t)(p.H + h) * DH;
-        bf16_t* vrow = krow + (size_t)p.H * DH;
-        store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, key, hi);
-        store_unrotated(vrow, acc_dv, 1.f, nullptr, nullptr, 0, hi);
+    {
+        bf16_t* kr0 = p.dqkv + (size_t)(t0 + k0 + wave * 32) * tok_stride + (size_t)(p.H + h) * DH;
+        const int valid = len - (k0 + wave * 32);
+        store_unrotated_rows(smem + wave * 4096, kr0, tok_stride, valid, acc_dk, p.scale, p.cosv, p.sinv,
+                             key_ok ? key : len - 1, hi, lane);
+        store_unrotated_rows(smem + 16384 + wave * 4096, kr0 + (size_t)p.H * DH, tok_stride, valid, acc_dv, 1.f, nullptr,
+                             nullptr, 0, hi, lane);
     }
 }
 
