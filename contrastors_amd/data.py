@@ -317,6 +317,122 @@ class StreamingShardDataset(IterableDataset):
         return out
 
 
+class LocalShardDataset(torch.utils.data.Dataset):
+    """Map-style twin for small corpora (sc/dataset/text_text_loader.py:660-760): every record of every shard is read
+    into memory; `__getitem__` folds `num_negatives` sampled negatives into `document` the first time a record is
+    touched (the reference pops `negative` from the stored record, so later epochs see the same sample -- kept)."""
+
+    def __init__(self, ds_spec: str, num_negatives: int = 0, seed: int = 42):
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        else:
+            self.rank, self.world_size = 0, 1
+        self.path2objective: Dict[str, dict] = {}
+        self.path2prefix: Dict[str, Dict[str, str]] = {}
+        self.query_only = set()
+        self.num_negatives = num_negatives
+        self.rng = random.Random(seed)
+        self.local_paths = self.parse_spec(ds_spec)
+        self.examples = self.load_examples(self.local_paths)
+
+    def parse_spec(self, fname: str) -> List[str]:
+        with open(fname) as f:
+            spec = yaml.safe_load(f)
+        paths: List[str] = []
+        for ds in spec["datasets"]:
+            if not set(ds.keys()) <= _SPEC_KEYS:
+                raise AssertionError(list(ds.keys()))
+            urls = expand_urls(ds["bucket"])
+            if any(u.startswith("s3://") for u in urls):
+                raise NotImplementedError("s3:// shards: mount the bucket and point `bucket` at the local path")
+            paths.extend(urls)
+            self.path2objective.update({u: ds["objective"] for u in urls})
+            ds_name = Path(ds["bucket"]).parent.name
+            if ds.get("query_only", False):
+                self.query_only.add(ds_name)
+            if ds.get("query_prefix"):
+                doc = ds.get("document_prefix", ds["query_prefix"])
+                self.path2prefix[ds_name] = {"query": ds["query_prefix"], "document": doc}
+                if self.num_negatives > 0:
+                    self.path2prefix[ds_name]["negative"] = doc
+        return paths
+
+    def load_examples(self, paths: List[str]) -> List[dict]:
+        examples = []
+        for path in paths:
+            ds_name = Path(path).parent.name
+            objective = self.path2objective[path]
+            ctype, columns = objective["type"], objective["columns"]
+            opener = gzip.open if str(path).endswith(".gz") else open
+            with opener(path, "rt") as f:
+                for line in f:
+                    if not line.strip():
+                        continue
+                    rec = json.loads(line)
+                    valid = rec["metadata"]["objective"][ctype]
+                    if columns not in valid:
+                        raise AssertionError(f"Invalid columns {columns} for contrastive type {ctype}. Valid columns "
+                                             f"are {valid}")
+                    mapped = {name: rec[col] for name, col in zip(MAPPED_NAMES[ctype], columns)}
+                    mapped["dataset_name"] = ds_name
+                    examples.append(mapped)
+        return examples
+
+    def __len__(self):
+        return len(self.examples)
+
+    def __getitem__(self, index):
+        data = self.examples[index]
+        if "negative" in data:
+            negatives = data.pop("negative")
+            data["document"] = [data["document"]] + random.sample(negatives, self.num_negatives)
+        return data
+
+
+def collate_local_ds(batch, tokenizer, add_prefix: bool = False, query_only=None, path2prefix=None) -> dict:
+    """sc/dataset/text_text_loader.py:763-800: one tokenizer call per column (`padding="max_length"`, the tokenizer's
+    own maximum), list columns flattened in record order, prefix chosen per record by its dataset."""
+    batch = [dict(sample) for sample in batch]  # the reference pops `dataset_name` from the stored records themselves;
+    ds_names = [sample.pop("dataset_name") for sample in batch]  # a copy keeps later epochs usable
+    out = {}
+    for col in batch[0].keys():
+        collected = [sample[col] for sample in batch]
+        if isinstance(collected[0], list):
+            ds_names = sum([[n] * len(sample[col]) for n, sample in zip(ds_names, batch)], [])
+            collected = sum(collected, [])
+        if add_prefix:
+            if path2prefix:
+                prefixes = [path2prefix[n][col] for n in ds_names]
+            elif query_only and col != "query":
+                prefixes = ["query" if n in query_only else KEY2PREFIX[col] for n in ds_names]
+            else:
+                prefixes = [KEY2PREFIX[col]] * len(collected)
+            collected = [f"{pre}: {text}" for pre, text in zip(prefixes, collected)]
+        tok = tokenizer(collected, padding="max_length", truncation=True, return_tensors="pt")
+        out.update({f"{col}_{k}": v for k, v in tok.items()})
+    return out
+
+
+def get_local_dataloader(ds_spec: str, batch_size: int, tokenizer, num_negatives: int, seed: int, add_prefix: bool,
+                         num_workers: int = 0, epoch: int = 0):
+    """sc/dataset/text_text_loader.py:803-823: per-rank batches through a seeded DistributedSampler, drop_last."""
+    from torch.utils.data import DataLoader, DistributedSampler
+
+    dataset = LocalShardDataset(ds_spec, num_negatives=num_negatives, seed=seed)
+    sampler = None
+    if dist.is_available() and dist.is_initialized():
+        sampler = DistributedSampler(dataset, shuffle=True, num_replicas=dist.get_world_size(), rank=dist.get_rank(),
+                                     seed=seed)
+        sampler.set_epoch(epoch)
+
+    def collate(x):
+        return collate_local_ds(x, tokenizer, add_prefix=add_prefix, query_only=dataset.query_only,
+                                path2prefix=dataset.path2prefix)
+
+    return DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate, drop_last=True,
+                      num_workers=num_workers)
+
+
 def get_streaming_dataset(config, tokenizer, run_name: Optional[str] = None) -> StreamingShardDataset:
     """The construction sc/trainers/text_text.py:191-209 does from the YAML sections."""
     da, ma = config.data_args, config.model_args

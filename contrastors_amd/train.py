@@ -63,9 +63,18 @@ def main():
         from .data import get_streaming_dataset
 
         tok = AutoTokenizer.from_pretrained(config.model_args.tokenizer_name, local_files_only=True)
-        ds = get_streaming_dataset(config, tok, run_name=getattr(config.train_args, "wandb_run_name", None) or "run")
-        trainer.total_steps = max(1, len(ds) // config.data_args.batch_size)
-        trainer.train(iter(ds), log_every=10)
+        if config.data_args.streaming:
+            ds = get_streaming_dataset(config, tok, run_name=getattr(config.train_args, "wandb_run_name", None) or "run")
+            trainer.total_steps = max(1, len(ds) // config.data_args.batch_size)
+            trainer.train(iter(ds), log_every=10)
+        else:  # sc/trainers/text_text.py:228-244: map-style dataset + DistributedSampler, per-rank batch
+            from .data import get_local_dataloader
+
+            dl = get_local_dataloader(config.data_args.input_shards, per_rank, tok, seed=config.data_args.seed,
+                                      num_negatives=config.model_args.num_negatives,
+                                      add_prefix=config.model_args.add_prefix, num_workers=config.data_args.workers)
+            trainer.total_steps = max(1, len(dl.dataset) // config.data_args.batch_size)
+            trainer.train(iter(dl), log_every=10)
     else:
         trainer.train(synthetic_batches(args.synthetic_steps, per_rank, args.seq_len, rank=trainer.rank), log_every=1)
     if world > 1:

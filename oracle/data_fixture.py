@@ -107,3 +107,36 @@ LOADER_CASES = {
     "plain": dict(add_eos=False, add_prefix=False, num_negatives=2),
     "eos_prefix": dict(add_eos=True, add_prefix=True, num_negatives=3, query_max_length=16, document_max_length=24),
 }
+
+
+LOCAL_CASES = {
+    # name: (spec variant, get_local_dataloader kwargs)   -- per-rank batch 4, ToyTokenizer default max_length.
+    # One objective per spec: the reference's collate cannot mix string and list columns in a batch (:775).
+    "triplet": ("b_plain", dict(num_negatives=2, add_prefix=False)),
+    "paired_query_only": ("a_query_only", dict(num_negatives=0, add_prefix=True)),
+    "triplet_custom_prefix": ("b_custom", dict(num_negatives=3, add_prefix=True)),
+}
+
+
+def write_local_spec(root, variant: str, scheme: str = "") -> str:
+    """Spec variants for the map-style loader.  `scheme` = "s3:/" gives the URL form the reference's LocalShardDataset
+    needs (its objective lookup only resolves s3-style URLs, sc/dataset/text_text_loader.py:730-735)."""
+    root = Path(root)
+    a = {"name": "dsA", "bucket": scheme + str(root / "bucket" / "dsA" / "shard-{00000..00002}.jsonl.gz"),
+         "objective": {"type": "paired", "columns": ["query", "document"]}}
+    b = {"name": "dsB", "bucket": scheme + str(root / "bucket" / "dsB" / "shard-{00000..00001}.jsonl.gz"),
+         "objective": {"type": "triplet", "columns": ["question", "answer", "hard"]}}
+    if variant == "b_plain":
+        sets = [b]
+    elif variant == "a_query_only":
+        a.update(query_only=True)
+        sets = [a]
+    elif variant == "b_custom":
+        b.update(query_prefix="search_query", document_prefix="search_document")
+        sets = [b]
+    else:
+        raise ValueError(variant)
+    path = root / f"spec_local_{variant}{'_s3' if scheme else ''}.yaml"
+    with open(path, "w") as f:
+        yaml.safe_dump({"datasets": sets}, f)
+    return str(path)

@@ -301,6 +301,52 @@ def _rank_loader(rank, world, root, tmp):
     dist.destroy_process_group()
 
 
+def _rank_local_loader(rank, world, root, tmp):
+    import random
+
+    from oracle import data_fixture as df
+
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29614", rank=rank, world_size=world)
+    tl = ref_import.load_text_loader()
+    out = {}
+    for case, (variant, kw) in df.LOCAL_CASES.items():
+        spec = str(Path(root) / f"spec_local_{variant}_s3.yaml")
+        random.seed(1234 + rank)  # LocalShardDataset.__getitem__ samples negatives from the global RNG (:757)
+        dl = tl.get_local_dataloader(spec, 4, df.ToyTokenizer(), seed=3, **kw)
+        n = 0
+        for b in dl:
+            for k, v in b.items():
+                out[f"{case}/{n}/{k}"] = v.numpy().astype(np.int16)
+            n += 1
+        out[f"{case}/n_batches"] = np.array(n)
+        out[f"{case}/len"] = np.array(len(dl.dataset))
+        dist.barrier()
+    np.savez(f"{tmp}/local{rank}.npz", **out)
+    dist.destroy_process_group()
+
+
+def gen_local_loader():
+    """tests/golden/local_loader_w2.npz: every batch of the reference's get_local_dataloader (map-style dataset,
+    DistributedSampler, collate_local_ds) on 2 ranks over the toy shards, for the LOCAL_CASES configurations."""
+    import shutil
+    import tempfile
+
+    from oracle import data_fixture as df
+
+    with tempfile.TemporaryDirectory(prefix="cxlocal_", dir="/tmp") as root, tempfile.TemporaryDirectory() as tmp:
+        df.build_dataset(root)
+        for variant in {v for v, _ in df.LOCAL_CASES.values()}:
+            df.write_local_spec(root, variant, scheme="s3:/")
+        try:
+            mp.spawn(_rank_local_loader, args=(2, root, tmp), nprocs=2, join=True)
+        finally:
+            shutil.rmtree("/tmp" + root, ignore_errors=True)  # the reference "downloads" into /tmp/<url path>
+        r = [np.load(f"{tmp}/local{i}.npz") for i in range(2)]
+        np.savez_compressed(GOLD / "local_loader_w2.npz", **{f"r{i}/{k}": r[i][k] for i in range(2) for k in r[i].files})
+    print("local_loader_w2", {c: int(r[0][f"{c}/n_batches"]) for c in df.LOCAL_CASES})
+
+
 def gen_loader():
     """tests/golden/loader_w2.npz: every batch the reference's StreamingShardDataset yields on 2 ranks for the toy
     shards of oracle/data_fixture.py (global batch 8), for the LOADER_CASES configurations."""
@@ -430,6 +476,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "loader":
         gen_loader()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "local_loader":
+        gen_local_loader()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hf_remap":
         gen_hf_remap()
         sys.exit(0)
@@ -444,3 +493,4 @@ if __name__ == "__main__":
     gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
     gen_mlm("mlm_bert_tiny", TINY_BERT, 22)
     gen_loader()
+    gen_local_loader()

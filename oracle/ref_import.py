@@ -161,6 +161,12 @@ def load_text_loader():
         def __init__(self, *a, config_kwargs=None, **k):
             super().__init__(*a, **k)
 
+        @classmethod
+        def _strip_protocol(cls, path):  # "s3://tmp/x" -> "/tmp/x": lets LocalShardDataset "download" local shards
+            if isinstance(path, str) and path.startswith("s3://"):
+                path = "/" + path[5:]
+            return super()._strip_protocol(path)
+
     fsspec.register_implementation("s3", _NoS3, clobber=True)
     if "contrastors.dataset" not in sys.modules:
         pkg = types.ModuleType("contrastors.dataset")
