@@ -204,14 +204,30 @@ class DualEncoder(torch.nn.Module):
     Each direction is one fused similarity+CE kernel (cx_infonce_fwd/bwd); logits are never materialised.  Towers are
     any modules returning {"embedding": ...}: the native BiEncoder over a NomicBertEngine (text) or a ViTEngine (image)."""
 
-    def __init__(self, text: torch.nn.Module, vision: torch.nn.Module, logit_scale: LogitScale):
+    def __init__(self, text: torch.nn.Module, vision: torch.nn.Module, logit_scale: LogitScale,
+                 precomputed_text: bool = False):
         super().__init__()
+        if precomputed_text and not getattr(text, "frozen_trunk", False):
+            raise AssertionError("Precomputed text model must be frozen")  # modeling_dual_encoder.py:16-18
         self.text, self.vision, self.logit_scale = text, vision, logit_scale
+        self.precomputed_text = precomputed_text
+
+    def encode_text(self, text, normalize=True):  # modeling_dual_encoder.py:26-29
+        return self.text(**text, normalize=normalize)["embedding"]
+
+    def encode_image(self, vision, normalize=True):  # :31-34 (the pixel tensor is passed positionally)
+        return self.vision(vision, normalize=normalize)["embedding"]
 
     def forward(self, text_inputs, vision_inputs):
         from .loss import _FusedInfoNCE, _scale_of
 
-        text_emb = F.normalize(self.text(**text_inputs, normalize=False)["embedding"], dim=-1, p=2)
+        if self.precomputed_text:  # LiT with text embeddings computed offline (:37-41): the text tower is not run
+            if "text_embs" not in text_inputs:
+                raise AssertionError("Precomputed text inputs must have text_embs")
+            raw_text = text_inputs["text_embs"].to(self.logit_scale.logit_scale.device, torch.float32)
+        else:
+            raw_text = self.text(**text_inputs, normalize=False)["embedding"]
+        text_emb = F.normalize(raw_text, dim=-1, p=2)
         vision_emb = F.normalize(self.vision(**vision_inputs, normalize=False)["embedding"], dim=-1, p=2)
         all_text, all_vis = gather_with_grad(text_emb), gather_with_grad(vision_emb)
         inited = dist.is_available() and dist.is_initialized()

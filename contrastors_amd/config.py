@@ -89,6 +89,7 @@ class ModelArgs(BaseModel):
     nomic_encoder: bool = True
     add_prefix: bool = False
     num_negatives: Optional[int] = 7
+    precomputed: Optional[bool] = False  # LiT: the batch carries `text_embs`, the (frozen) text tower is not run
     pretrained: bool = False
     gradient_checkpointing: bool = False
     projection_dim: Optional[int] = None

@@ -220,7 +220,8 @@ class ImageTextTrainer(TextTextTrainer):
             towers.append(tower)
         va = config.vision_model_args  # the reference takes the logit scale from the image tower's args
         scale = LogitScale(SimpleNamespace(logit_scale=va.logit_scale, trainable_logit_scale=va.trainable_logit_scale))
-        model = DualEncoder(towers[0], towers[1], scale.to(self.device)).train()
+        model = DualEncoder(towers[0], towers[1], scale.to(self.device),
+                            precomputed_text=bool(config.text_model_args.precomputed)).train()
         return {"model": model}
 
     def _trainable_towers(self):

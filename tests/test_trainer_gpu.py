@@ -89,3 +89,31 @@ def test_checkpoint_resume_is_exact(tmp_path):
     assert float((a.model["model"].trunk.flat_param - b.model["model"].trunk.flat_param).abs().max()) < 1e-6
     keys = set(load_file(str(tmp_path / "ckpt" / "model" / "model.safetensors")).keys())
     assert "trunk.encoder.layers.0.attn.Wqkv.weight" in keys and "trunk.encoder.layers.1.mlp.fc11.weight" in keys
+
+
+def test_train_cli_runs_reference_recipe_shape(tmp_path):
+    """`python -m contrastors_amd.train --config <yaml> [--key value ...]` (sc/train.py:51-131): the reference recipe's
+    YAML schema, CLI overrides, registry dispatch and the full nomic-bert-2048 architecture, two synthetic steps."""
+    import subprocess
+    import sys
+
+    import numpy as np
+    import yaml
+
+    cfg = {"train_args": {"num_epochs": 1, "learning_rate": 2.0e-4, "weight_decay": 0.01, "warmup_steps": 1,
+                          "chunk_size": 64, "schedule_type": "cosine", "max_grad_norm": 1.0, "adam_beta1": 0.9,
+                          "adam_beta2": 0.999, "grad_cache": True, "loss_fn": "clip", "clamp_logits": False,
+                          "logit_max": 100, "wandb": False},
+           "model_args": {"logit_scale": 50, "trainable_logit_scale": False, "model_type": "encoder", "seq_len": 2048,
+                          "pooling": "mean", "nomic_encoder": True, "add_prefix": True,
+                          "tokenizer_name": "bert-base-uncased", "model_name": "nomic-ai/nomic-bert-2048"},
+           "data_args": {"workers": 0, "batch_size": 16384, "seed": 42, "shuffle": False}}
+    path = tmp_path / "recipe.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    root = str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    out = subprocess.run([sys.executable, "-m", "contrastors_amd.train", "--config", str(path), "--synthetic-steps", "2",
+                          "--seq-len", "32", "--batch_size", "32", "--chunk_size", "16"], cwd=root, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    losses = [float(ln.split("loss")[1].split()[0].strip(":=")) for ln in out.stdout.splitlines() if "loss" in ln]
+    assert len(losses) >= 2 and all(np.isfinite(losses))

@@ -140,9 +140,49 @@ def test_dual_encoder_native_towers_clip_step():
     ref = 0.5 * (torch.nn.functional.cross_entropy(20.0 * ve @ te.T, labels)
                  + torch.nn.functional.cross_entropy(20.0 * te @ ve.T, labels))
     ref.backward()
-    e_loss = abs(float(out["loss"]) - float(ref))
+    e_loss = abs(float(out["loss"].detach()) - float(ref.detach()))
     gv, gt = vision.trunk.reference_grad_dict(), text.trunk.reference_grad_dict()
     e_v = rel_err(gv["embeddings.proj.weight"], vs["embeddings.proj.weight"].grad)
     e_t = rel_err(gt["encoder.layers.0.attn.Wqkv.weight"], ts["encoder.layers.0.attn.Wqkv.weight"].grad)
     report("dual_encoder_native", loss=float(out["loss"]), ref=float(ref), e_loss=e_loss, e_vproj=e_v, e_tqkv=e_t)
     assert e_loss < 2e-2 and e_v < 5e-2 and e_t < 5e-2
+
+
+def test_dual_encoder_precomputed_text_lit():
+    """LiT with offline text embeddings (modeling_dual_encoder.py:13-18,37-41): the frozen text tower is never run, the
+    batch's `text_embs` are used; same loss / image-tower gradient as running the frozen tower on the same texts."""
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
+    from contrastors_amd.nomic_bert import NomicBertConfig
+
+    vcfg = ViTConfig(n_embd=256, n_layer=2, n_head=4, n_inner=512, img_size=32, patch_size=8, layer_norm_epsilon=1e-6)
+    tcfg = NomicBertConfig.bert_base_uncased(vocab_size=512, n_embd=256, n_layer=2, n_head=4, n_inner=512,
+                                             max_position_embeddings=64)
+    vision = BiEncoder(BiEncoderConfig(pooling="cls", trunk_config=vcfg), device=DEV, seed=1).train()
+    text = BiEncoder(BiEncoderConfig(pooling="mean", trunk_config=tcfg, freeze=True), device=DEV, seed=2)
+    scale = LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=False)).to(DEV)
+    with pytest.raises(AssertionError):
+        DualEncoder(BiEncoder(BiEncoderConfig(pooling="mean", trunk_config=tcfg), device=DEV), vision, scale,
+                    precomputed_text=True)
+    g = torch.Generator().manual_seed(5)
+    n = 8
+    pix = torch.randn(n, 3, 32, 32, generator=g).to(DEV)
+    ids = torch.randint(3, 512, (n, 16), generator=g).to(DEV)
+    mask = torch.ones(n, 16, dtype=torch.long, device=DEV)
+    live = DualEncoder(text, vision, scale).train()
+    vision.trunk.zero_grad()
+    a = live({"input_ids": ids, "attention_mask": mask}, {"input_ids": pix})
+    a["loss"].backward()
+    g_live = vision.trunk.flat_grad.clone()
+    with torch.no_grad():
+        embs = live.encode_text({"input_ids": ids, "attention_mask": mask}, normalize=False)
+    pre = DualEncoder(text, vision, scale, precomputed_text=True).train()
+    with pytest.raises(AssertionError):
+        pre({"input_ids": ids}, {"input_ids": pix})
+    vision.trunk.zero_grad()
+    b = pre({"text_embs": embs.cpu()}, {"input_ids": pix})
+    b["loss"].backward()
+    assert abs(float(a["loss"].detach()) - float(b["loss"].detach())) < 1e-5
+    assert float((vision.trunk.flat_grad - g_live).norm()) <= 1e-4 * float(g_live.norm())
+    assert float(text.trunk.flat_grad.abs().max()) == 0.0
+    assert live.encode_image(pix).shape == (n, 256)
+
