@@ -144,3 +144,59 @@ def test_hf_bert_checkpoint_round_trip():
                     num_attention_heads=cfg.n_head, intermediate_size=cfg.n_inner)
     load_hf_bert(b, hf, hc)
     assert torch.equal(a.flat_param, b.flat_param)
+
+
+@pytest.mark.parametrize("case", ["max_trained_2048", "ntk_4096", "empty_chunk"])
+def test_engine_maximum_sizes_and_empty(case):
+    """Edge sizes of the path at the 12-layer nomic architecture: the maximum trained length (cfg 3: seq 2048, ragged),
+    Dynamic-NTK inference beyond it (4096 tokens, rotary_scaling_factor 2: the table is re-based on the fly), and an
+    empty chunk (a rank whose GradCache split is shorter than the others must be a no-op, not an error)."""
+    kw = dict(vocab_size=4096)
+    if case == "ntk_4096":
+        kw.update(rotary_scaling_factor=2.0, max_trained_positions=2048, n_positions=8192)
+    cfg = NomicBertConfig.nomic_bert_2048(**kw)
+    ns = SimpleNamespace(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    sd = encoder_ref.random_state_dict(ns, 9)
+    eng = NomicBertEngine(cfg, device=DEV)
+    eng.load_reference_state_dict(sd)
+    eng.train()
+    if case == "empty_chunk":
+        ids = torch.zeros(0, 16, dtype=torch.long, device=DEV)
+        vb = VarlenBatch.from_lengths(ids, [])
+        emb, arena = eng.forward_chunk(vb, True)
+        assert emb.shape == (0, cfg.n_embd)
+        eng.zero_grad()
+        eng.backward_chunk(vb, arena, torch.zeros(0, cfg.n_embd, device=DEV))
+        torch.cuda.synchronize()
+        assert float(eng.flat_grad.abs().max()) == 0.0
+        return
+    S = 2048 if case == "max_trained_2048" else 4096
+    B = 2
+    g = torch.Generator().manual_seed(10)
+    lens = torch.tensor([S, S - 517])
+    ids = torch.randint(3, 4096, (B, S), generator=g)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    ids = (ids * mask).to(DEV)
+    mask = mask.to(DEV)
+    vb = VarlenBatch.from_lengths(ids, lens.numpy())
+    emb, arena = eng.forward_chunk(vb, True)
+    ref, sd32 = _oracle(sd, ns, ids, mask, False)
+    ref16, sd16 = _oracle(sd, ns, ids, mask, True)
+    e_hip, e_b = max_err(emb, ref), max_err(ref16, ref)
+    probe = torch.randn(B, cfg.n_embd, generator=g).to(DEV)
+    eng.zero_grad()
+    eng.backward_chunk(vb, arena, probe)
+    (ref * probe).sum().backward()
+    (ref16 * probe).sum().backward()
+    grads = eng.reference_grad_dict()
+    rep = {}
+    for n in ("encoder.layers.0.attn.Wqkv.weight", "encoder.layers.11.mlp.fc2.weight", "emb_ln.weight"):
+        eh, eb = rel_err(grads[n], sd32[n].grad), rel_err(sd16[n].grad.float(), sd32[n].grad)
+        rep[n.replace(".", "_")] = (eh, eb)
+    report("engine_edge", case=case, e_emb_hip=e_hip, e_emb_bf16=e_b,
+           **{k + "_hip": v[0] for k, v in rep.items()}, **{k + "_bf16": v[1] for k, v in rep.items()})
+    assert e_hip <= 3 * e_b + 1e-4
+    for k, (eh, eb) in rep.items():  # the reference's rule (tests/test_flash_bert.py:77-82), as in the S = 128 test
+        assert eh <= 3 * eb + 2e-2, f"{k}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    if case == "ntk_4096":  # the table was re-based: plain rotary at these positions gives a different answer
+        assert eng._rot_len == S and eng.rot_cos.shape[0] == S

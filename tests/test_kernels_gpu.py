@@ -312,7 +312,7 @@ def _attn_ref(qkv, lens, cos, sin, scale):
 
 
 @pytest.mark.parametrize("rotary", [True, False])
-@pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8])
+@pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8, [2048, 1531]])
 def test_attention_fwd_bwd(rotary, lens):
     H, D = 3, 64
     T, B, mx = sum(lens), len(lens), max(lens)
@@ -321,7 +321,7 @@ def test_attention_fwd_bwd(rotary, lens):
     cos = sin = None
     if rotary:
         inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2).float() / D))
-        fr = torch.outer(torch.arange(512).float(), inv)
+        fr = torch.outer(torch.arange(max(512, mx)).float(), inv)
         cos, sin = torch.cos(fr).to(DEV).contiguous(), torch.sin(fr).to(DEV).contiguous()
     scale = 1 / math.sqrt(D)
     out = torch.empty(T, H, D, dtype=torch.bfloat16, device=DEV)
