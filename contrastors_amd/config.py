@@ -90,6 +90,16 @@ class ModelArgs(BaseModel):
     add_prefix: bool = False
     num_negatives: Optional[int] = 7
     precomputed: Optional[bool] = False  # LiT: the batch carries `text_embs`, the (frozen) text tower is not run
+    # architecture overrides of the MLM recipe (sc/config.py:152-170, configs/train/mlm.yaml); None = not given
+    rotary_emb_fraction: Optional[float] = None
+    rotary_emb_base: Optional[int] = 10_000
+    pad_vocab_to_multiple_of: Optional[int] = None
+    use_rms_norm: Optional[bool] = None
+    activation_function: Optional[str] = "gelu"
+    qkv_proj_bias: Optional[bool] = True
+    mlp_fc1_bias: Optional[bool] = True
+    mlp_fc2_bias: Optional[bool] = True
+    attn_pdrop: Optional[float] = 0.0
     pretrained: bool = False
     gradient_checkpointing: bool = False
     projection_dim: Optional[int] = None

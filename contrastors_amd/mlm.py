@@ -189,13 +189,18 @@ class MLMTrainer:
         ta, ma = config.train_args, config.model_args
         torch.manual_seed(config.data_args.seed)
         if trunk_config is None:
-            # sc/trainers/mlm.py:20-40: bert-base-uncased geometry with the recipe's overrides
+            # sc/trainers/mlm.py:20-40: bert-base-uncased geometry (no hub access: its config constants are spelled out)
+            # with the recipe's overrides, then bert_config_to_nomic_config (sc/models/encoder/bert.py:11-50)
+            mult = ma.pad_vocab_to_multiple_of or 1
+            vocab = (30522 + mult - 1) // mult * mult  # modeling_nomic_bert.py:488-490 pads the vocabulary
+            if ma.use_rms_norm:
+                raise NotImplementedError("RMSNorm trunks")
             trunk_config = NomicBertConfig(
-                vocab_size=30528, n_positions=ma.seq_len, max_position_embeddings=ma.seq_len,
-                activation_function=getattr(ma, "activation_function", "swiglu"),
-                rotary_emb_fraction=getattr(ma, "rotary_emb_fraction", 1.0),
-                rotary_emb_base=getattr(ma, "rotary_emb_base", 10000), qkv_proj_bias=getattr(ma, "qkv_proj_bias", False),
-                mlp_fc1_bias=getattr(ma, "mlp_fc1_bias", False), mlp_fc2_bias=getattr(ma, "mlp_fc2_bias", False))
+                vocab_size=vocab, n_positions=ma.seq_len, max_position_embeddings=ma.seq_len,
+                activation_function=ma.activation_function or "gelu", rotary_emb_fraction=ma.rotary_emb_fraction or 0.0,
+                rotary_emb_base=ma.rotary_emb_base or 10_000, qkv_proj_bias=bool(ma.qkv_proj_bias),
+                mlp_fc1_bias=bool(ma.mlp_fc1_bias), mlp_fc2_bias=bool(ma.mlp_fc2_bias), attn_pdrop=ma.attn_pdrop or 0.0,
+                layer_norm_epsilon=1e-12, type_vocab_size=2, pad_token_id=0)
         model = NomicBertForPreTraining(trunk_config, device=self.device, seed=config.data_args.seed).train()
         if self.world > 1:
             dist.broadcast(model.bert.flat_param, 0)
@@ -240,6 +245,19 @@ class MLMTrainer:
             model.zero_grad(set_to_none=False)
         self.step += 1
         return loss.detach()
+
+    def train(self, batches: Iterable[dict], max_steps: Optional[int] = None, log_every: int = 0):
+        """Same driver loop as TextTextTrainer.train (one call = one micro-batch)."""
+        losses = []
+        rank = dist.get_rank() if self.distributed else 0
+        for i, batch in enumerate(batches):
+            if max_steps is not None and i >= max_steps:
+                break
+            loss = self.training_step(batch)
+            losses.append(loss)
+            if log_every and (i + 1) % log_every == 0 and rank == 0:
+                print(f"step {self.step} loss {float(loss):.4f} lr {self.scheduler.get_last_lr()[0]:.3e}", flush=True)
+        return losses
 
     @torch.no_grad()
     def eval_step(self, batch) -> torch.Tensor:

@@ -75,6 +75,13 @@ def main():
                                       add_prefix=config.model_args.add_prefix, num_workers=config.data_args.workers)
             trainer.total_steps = max(1, len(dl.dataset) // config.data_args.batch_size)
             trainer.train(iter(dl), log_every=10)
+    elif config.model_args.model_type == "mlm":
+        from .mlm import synthetic_mlm_batches
+
+        prob = config.data_args.mlm_prob if config.data_args.mlm_prob is not None else 0.3  # mlm.yaml: 0.30
+        rank = dist.get_rank() if world > 1 else 0
+        trainer.train(synthetic_mlm_batches(args.synthetic_steps, per_rank, args.seq_len, mlm_probability=prob,
+                                            seed=1234 + rank), log_every=1)
     else:
         trainer.train(synthetic_batches(args.synthetic_steps, per_rank, args.seq_len, rank=trainer.rank), log_every=1)
     if world > 1:

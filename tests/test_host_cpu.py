@@ -64,3 +64,18 @@ def test_synthetic_batches_follow_loader_contract():
         assert k in b
     assert b["query_input_ids"].dtype == torch.int64 and b["query_input_ids"].shape == (4, 16)
     assert (b["query_input_ids"][b["query_attention_mask"] == 0] == 0).all()  # right padding with pad id 0
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_reference_mlm_recipe_yaml_loads_unchanged():
+    """configs/train/mlm.yaml: the architecture overrides the MLM trainer reads (sc/trainers/mlm.py:20-40) survive."""
+    cfg = read_config(str(REF_YAML.parent / "mlm.yaml"))
+    ma, ta = cfg.model_args, cfg.train_args
+    assert ma.model_type == "mlm" and ma.seq_len == 2048 and ma.rotary_emb_base == 500000
+    assert ma.activation_function == "swiglu" and ma.rotary_emb_fraction == 1.0 and ma.pad_vocab_to_multiple_of == 64
+    assert ma.qkv_proj_bias is False and ma.mlp_fc1_bias is False and ma.mlp_fc2_bias is False
+    assert ta.gradient_accumulation_steps == 4 and ta.max_grad_norm == 0.0 and ta.warmup_pct == 0.06
+    assert cfg.data_args.mlm_prob == 0.30
+    from contrastors_amd.trainers import TRAINER_REGISTRY
+
+    assert set(TRAINER_REGISTRY) >= {"encoder", "image_text", "locked_text", "mlm"}
