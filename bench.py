@@ -1,7 +1,11 @@
 """bench.py -- query-doc pairs/sec of the contrastive GradCache training step (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 without a torch.distributed environment re-launches ITSELF as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(one rank per GPU over RCCL); launched by the driver under torch.distributed.run it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.  Either way rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): nomic-bert-2048 architecture (random init, no hub), bi-encoder with mean pooling,
 paired InfoNCE at logit scale 50, seq_len 128, GLOBAL batch 16384 (fixed; each of the N ranks owns 16384/N pairs ->
@@ -10,8 +14,12 @@ cosine schedule.  A step = everything in the reference's training_step (sc/train
 embedding all-gather, fused loss fwd/bwd, pass 2 (re-forward + backward), gradient all-reduce, clip, AdamW, scheduler,
 bf16 shadow refresh.  Synthetic token ids are staged in HBM before the timed region.
 
-One JSON line on rank 0 with `roofline` (dominant kernel = bf16 MFMA GEMM, timed live with HIP events on its own
-stream, sampled every 8th launch) and `cpu_baseline` (oracle = CPU restatement of the reference, bounded sample).
+The JSON line carries, besides the contract fields:
+  roofline      dominant kernel family (bf16 MFMA GEMMs) timed live with HIP events on its own stream (every 7th launch)
+  weak          the same step at 2048 pairs per GPU (global batch 2048 x N: SURVEY.md §8(d) asks for both curves)
+  dropin_chunk64  (N = 1) the same step at the reference recipe's GradCache chunk_size 64 (contrastive_pretrain.yaml:15)
+  xgmi_allgather  (N > 1) the embedding all-gather of the loss timed on its own, against 7 x 153 GB/s of xGMI per GPU
+  cpu_baseline  (N = 1) oracle = CPU restatement of the reference, one 64-pair chunk forward + backward, min of 3
 """
 from __future__ import annotations
 
@@ -20,6 +28,8 @@ import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -30,11 +40,10 @@ sys.path.insert(0, str(ROOT))
 # the host driver only supports dmabuf IPC: must be in the environment before the HIP runtime starts (RCCL, N > 1)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 GFLOP_PER_PAIR = 236.84       # 2 seqs x 4 fwd-equivalents x 29.595 GFLOP + loss
+XGMI_PEAK_GBS = 7 * 153.0     # per GPU, each direction
+WEAK_PAIRS_PER_GPU = 2048     # per-GPU b = 2048 fixed
 
 
 def parse():
@@ -50,6 +59,7 @@ def parse():
                          "GEMM (512 whole 256-row tile panels per launch) and needs ~50 GB of the MI355X's 288 GB")
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the metric
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the weak-scaling and chunk-64 records")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     # every 7th GEMM launch is timed with HIP events: a stride coprime to the launch pattern's periods (4 GEMMs per layer
     # forward, 8 per layer backward) so that the sample walks through every shape; a stride of 8 always lands on the
@@ -71,10 +81,8 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline_subprocess(seq_len: int, timeout_s: int = 240) -> dict:
+def cpu_baseline_subprocess(seq_len: int, timeout_s: int = 300) -> dict:
     """Run the CPU leg in a child process with a hard time bound so the GPU line is never lost to a slow host."""
-    import subprocess
-
     try:
         r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-only", "--seq-len",
                             str(seq_len)], capture_output=True, text=True, timeout=timeout_s)
@@ -90,7 +98,11 @@ def cpu_baseline_subprocess(seq_len: int, timeout_s: int = 240) -> dict:
 
 def cpu_baseline(seq_len: int) -> dict:
     """Reference algorithm (oracle restatement, fp32, torch CPU kernels) on a bounded sample of the same workload:
-    direct forward+backward of 8 query-document pairs through the 12-layer encoder + InfoNCE."""
+    ONE GradCache chunk of the reference recipe -- 64 query-document pairs, direct forward + backward through the
+    12-layer encoder + InfoNCE -- min of 3 repetitions after an 8-pair warm-up.  A port, not the
+    reference itself: /root/reference does not exist on the GPU box (the oracle is pinned to it by tests/golden)."""
+    import torch
+
     from contrastors_amd.nomic_bert import NomicBertConfig
     from oracle import encoder_ref, infonce_ref
 
@@ -101,26 +113,43 @@ def cpu_baseline(seq_len: int) -> dict:
     sd = encoder_ref.random_state_dict(ns, 0)
     for v in sd.values():
         v.requires_grad_(True)
-    pairs = 8
+    pairs = 64
     g = torch.Generator().manual_seed(1234)
     q = torch.randint(1000, 30522, (pairs, seq_len), generator=g)
     d = torch.randint(1000, 30522, (pairs, seq_len), generator=g)
     mask = torch.ones(pairs, seq_len, dtype=torch.long)
 
-    def step():
-        loss = infonce_ref.clip_loss_ref(encoder_ref.biencoder_embedding(sd, ns, q, mask),
-                                         encoder_ref.biencoder_embedding(sd, ns, d, mask), 50.0)
+    def step(n):
+        loss = infonce_ref.clip_loss_ref(encoder_ref.biencoder_embedding(sd, ns, q[:n], mask[:n]),
+                                         encoder_ref.biencoder_embedding(sd, ns, d[:n], mask[:n]), 50.0)
         loss.backward()
 
-    step()  # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    reps = 2
+    step(8)  # warm-up (allocator, thread pool)
+    reps, times = 3, []
     for _ in range(reps):
-        step()
-    dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        step(pairs)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{pairs} pairs x seq {seq_len}, direct fwd+bwd+InfoNCE (3x fwd FLOPs, no GradCache re-forward), "
-                      f"fp32 torch-CPU, {reps} reps, {dt:.2f} s/step"}
+            "sample": f"one {pairs}-pair chunk x seq {seq_len}, direct fwd+bwd+InfoNCE (3x fwd FLOPs, no GradCache "
+                      f"re-forward), fp32 torch-CPU oracle port (the reference tree is absent on the GPU box), min of "
+                      f"{reps} reps = {dt:.2f} s (all: {', '.join(f'{t:.2f}' for t in times)})"}
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: spawn the N ranks ourselves (same command line the
+    driver would use) and pass their output through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CX_BENCH_SELF_LAUNCHED="1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -128,11 +157,17 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.seq_len)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # test hook (tests/test_distributed_gpu.py): several ranks may share one GPU with gloo carrying the device tensors;
     # the product launch is always one rank per GPU over RCCL ("nccl").
     backend = os.environ.get("CX_BENCH_BACKEND", "nccl")
@@ -148,6 +183,7 @@ def main():
 
     from contrastors_amd import _C
     from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
+    from contrastors_amd.distributed import gather_with_grad
     from contrastors_amd.loss import grad_cache_loss
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.optimizer import FusedAdamW
@@ -155,7 +191,6 @@ def main():
     lib = _C.lib()
     G, S = args.global_batch, args.seq_len
     assert G % world == 0
-    b = G // world
     cfg = NomicBertConfig.nomic_bert_2048(n_layer=args.layers)
     tower = BiEncoder(BiEncoderConfig(model_name="nomic-ai/nomic-bert-2048", pooling="mean", logit_scale=50.0,
                                       trunk_config=cfg), device=dev, seed=0).train()
@@ -166,58 +201,107 @@ def main():
     sched = torch.optim.lr_scheduler.LambdaLR(
         opt, lambda s: (s + 1) / warm if s < warm else 0.5 * (1 + math.cos(math.pi * (s - warm) / (total_steps - warm))))
 
-    # synthetic (query, document) token ids, SURVEY.md §8(d): staged on the device before timing
-    g = torch.Generator().manual_seed(1234 + rank)
-    q_ids = torch.randint(1000, 30522, (b, S), generator=g)
-    d_ids = torch.randint(1000, 30522, (b, S), generator=g)
-    q_ids[:, 0] = 101
-    d_ids[:, 0] = 101
-    lens = [S] * b
-    q_in = {"input_ids": q_ids.to(dev), "seqlens": lens}
-    d_in = {"input_ids": d_ids.to(dev), "seqlens": lens}
-
-    def step():
-        tower.trunk.zero_grad()
-        loss = grad_cache_loss(tower, q_in, tower, d_in, args.chunk_size, scale)
-        opt.step(max_grad_norm=1.0)  # global-norm clip + AdamW fused (cx_grad_sq_norm + cx_adamw_clip_step)
-        sched.step()
-        tower.trunk.sync_shadows()
-        return loss
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    lib.cx_prof_gemm_config(1, args.prof_stride)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    def run_leg(pairs_per_gpu: int, chunk: int, steps: int, warmup: int, prof: bool):
+        """W untimed + K timed steps at `pairs_per_gpu` pairs on every rank; returns the max-over-ranks wall time."""
+        # synthetic (query, document) token ids, SURVEY.md §8(d): staged on the device before timing
+        g = torch.Generator().manual_seed(1234 + rank)
+        q_ids = torch.randint(1000, 30522, (pairs_per_gpu, S), generator=g)
+        d_ids = torch.randint(1000, 30522, (pairs_per_gpu, S), generator=g)
+        q_ids[:, 0] = 101
+        d_ids[:, 0] = 101
+        lens = [S] * pairs_per_gpu
+        q_in = {"input_ids": q_ids.to(dev), "seqlens": lens}
+        d_in = {"input_ids": d_ids.to(dev), "seqlens": lens}
 
+        def step():
+            tower.trunk.zero_grad()
+            loss = grad_cache_loss(tower, q_in, tower, d_in, chunk, scale)
+            opt.step(max_grad_norm=1.0)  # global-norm clip + AdamW fused (cx_grad_sq_norm + cx_adamw_clip_step)
+            sched.step()
+            tower.trunk.sync_shadows()
+            return loss
+
+        for _ in range(warmup):
+            step()
+        fence()
+        if prof:
+            lib.cx_prof_gemm_config(1, args.prof_stride)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), float(loss.item())
+
+    # ---- the metric: global batch 16384 (strong scaling) -------------------------------------------------------------
+    b = G // world
+    dt, loss_last = run_leg(b, args.chunk_size, args.steps, args.warmup, prof=True)
     ms, fl = C.c_double(), C.c_double()
     n_t, n_all = C.c_long(), C.c_long()
     lib.cx_prof_gemm_collect(C.byref(ms), C.byref(fl), C.byref(n_t), C.byref(n_all))
     lib.cx_prof_gemm_config(0, 1)
+    peak_hbm = torch.cuda.max_memory_allocated(dev)
+
+    extra = {}
+    if not args.no_extra_legs:
+        few = max(2, args.steps // 4)
+        # weak-scaling curve: 2048 pairs per GPU whatever N is (coincides with the strong point at N = 8)
+        if b != WEAK_PAIRS_PER_GPU and G >= WEAK_PAIRS_PER_GPU:
+            wdt, _ = run_leg(WEAK_PAIRS_PER_GPU, args.chunk_size, args.steps, 1, prof=False)
+            extra["weak"] = {"value": WEAK_PAIRS_PER_GPU * world * args.steps / wdt, "unit": "pairs/s",
+                             "pairs_per_gpu": WEAK_PAIRS_PER_GPU, "global_batch": WEAK_PAIRS_PER_GPU * world,
+                             "ms_per_step": 1e3 * wdt / args.steps, "steps": args.steps, "scaling": "weak"}
+        elif b == WEAK_PAIRS_PER_GPU:
+            extra["weak"] = "same point as the headline (2048 pairs per GPU)"
+        # what an unmodified reference YAML gets: GradCache chunk_size 64 (8192 token rows per GEMM launch)
+        if world == 1 and args.chunk_size != 64:
+            cdt, _ = run_leg(min(b, 2048), 64, few, 1, prof=False)
+            extra["dropin_chunk64"] = {"value": min(b, 2048) * few / cdt, "unit": "pairs/s", "grad_cache_chunk": 64,
+                                       "global_batch": min(b, 2048), "ms_per_step": 1e3 * cdt / few, "steps": few,
+                                       "note": "reference recipe chunk_size (contrastive_pretrain.yaml:15); loss rows x "
+                                               "2048 documents, encoder work per pair unchanged"}
+        # the loss path's one exchange step on its own: all-gather of (2048 x N / N, 768) fp32 embeddings per rank
+        if world > 1 and backend == "nccl":
+            emb = torch.randn(b, cfg.n_embd, device=dev)
+            for _ in range(5):
+                gather_with_grad(emb)
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record()
+            for _ in range(reps):
+                gather_with_grad(emb)
+            e1.record()
+            torch.cuda.synchronize()
+            t_ag = torch.tensor([e0.elapsed_time(e1) / reps * 1e-3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_ag, op=dist.ReduceOp.MAX)
+            recv = (world - 1) * emb.numel() * 4
+            extra["xgmi_allgather"] = {"bytes_received_per_gpu": recv, "seconds": float(t_ag.item()),
+                                       "achieved": recv / float(t_ag.item()) / 1e9, "peak": XGMI_PEAK_GBS, "unit": "GB/s",
+                                       "frac": recv / float(t_ag.item()) / 1e9 / XGMI_PEAK_GBS,
+                                       "collective": "RCCL all_gather_into_tensor, one fused buffer in rank order"}
+
     if rank == 0:
         # HBM bytes per GEMM launch: not measurable from inside the process; taken from the committed rocprofv3 PMC
         # passes of this same command line (scripts/gpu_round.sh PMC=1 -> scripts/pmc_traffic.py) when they were
         # collected at the same launch sizes (same GradCache chunk), else null.
         traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_gemm_traffic.json")))
-            if tj.get("grad_cache_chunk") == min(args.chunk_size, b):
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1_pmc_gemm_traffic.json"
-        except (OSError, ValueError, KeyError):
-            pass
+        for name in ("r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
+            try:
+                tj = json.load(open(ROOT / "profiles" / name))
+                if tj.get("grad_cache_chunk") == min(args.chunk_size, b):
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{name}"
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         pairs_per_s = G * args.steps / dt
         achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
         out = {
@@ -228,8 +312,10 @@ def main():
             "config": {"workload": "configs[1]: nomic-bert-2048 bi-encoder contrastive pretrain step (GradCache, "
                                    "paired InfoNCE scale 50, AdamW, clip 1.0)",
                        "global_batch": G, "pairs_per_gpu": b, "seq_len": S, "grad_cache_chunk": args.chunk_size,
-                       "n_layer": cfg.n_layer, "parallelism": f"dp{world}", "loss_last_step": float(loss.item()),
-                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
+                       "n_layer": cfg.n_layer, "parallelism": f"dp{world}", "loss_last_step": loss_last,
+                       "peak_hbm_gb": round(peak_hbm / 2**30, 1),
+                       "launch": "self (torch.distributed.run)" if os.environ.get("CX_BENCH_SELF_LAUNCHED") else
+                                 ("torch.distributed.run" if world > 1 else "single process")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
@@ -240,6 +326,7 @@ def main():
                          "algorithmic_flop_per_launch": fl.value / max(1, n_t.value),
                          "whole_step_frac_of_mfma_peak": pairs_per_s / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS},
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(S)
         print(json.dumps(out), flush=True)

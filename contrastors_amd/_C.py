@@ -74,6 +74,9 @@ _SIGS = {
     "cx_gemm_get_variant": (i32, []),
     "cx_gemm_set_debug": (None, [i32]),
     "cx_gemm_set_trace": (None, [vp]),
+    "cx_gemm_v6_ablate": (None, [i32]),
+    "cx_gemm_v6_stagger": (None, [i32, i32]),
+    "cx_gemm_v6_trace": (None, [vp]),
     "cx_prof_gemm_config": (i32, [i32, i32]),
     "cx_prof_gemm_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "cx_gemm_set_glds": (None, [i32]),

@@ -36,9 +36,14 @@ struct Frags6 {
 
 #include "gemm_v6_acc.inc"
 
-template <int EPI>
+// DBG (ablation builds only, scripts/gemm_ablate.py; results are garbage, timing is the point): bit0 no DMA in the main
+// loop, bit1 no barrier, bit2 no fragment reads, bit3 no MFMA, bit4 no epilogue, bit5 no vmcnt wait.  With p.trace set,
+// wave 0 of every workgroup stores its s_memtime span and K-tile count.
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
+    long long t_begin = 0, n_ktiles = 0;
+    if constexpr (DBG != 0) t_begin = (long long)__builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,6 +57,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // slice of W, which then stays L2-resident across rounds instead of being re-streamed for every M-panel.
     const int per_xcd = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    // De-phasing.  Every workgroup does the same work per tile, so all 256 CUs run their MFMA phases together and then
+    // all stream their epilogues together: HBM idles during the former and the matrix pipes during the latter.
+    // p.sup_m (> 0) = cycles by which workgroup phase k of `p.split_k` phases starts late (k = idx % phases), paid once per launch.
+    if (p.sup_m > 0) {
+        const int phases = p.split_k > 1 ? p.split_k : 2;
+        const long long wait = (long long)p.sup_m * (idx % phases);
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     const int gn = p.sup_n > 0 ? p.sup_n : 1, gm = 8 / gn;
     const int xi = xcd / gn, xj = xcd - xi * gn;
     const int m_lo = p.tiles_m * xi / gm, m_hi = p.tiles_m * (xi + 1) / gm;
@@ -64,32 +78,37 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         return (m_lo + q) * p.tiles_n + n_lo + (l - q * n_wd);
     };
 
-    // ---- DMA cursors.  A K-tile of one operand = 32 instructions of 1 KiB (8 rows x 128 B), 8 per wave ---------------
-    const bf16_t* xsrc[8];
-    const bf16_t* wsrc[8];
+    // ---- DMA cursors.  A K-tile of one operand = 32 instructions of 1 KiB (8 rows x 128 B), 8 per wave.  A cursor is a
+    // wave-uniform 64-bit panel base (SGPR pair, set when the cursor enters an output tile) + one 32-bit byte offset per
+    // instruction (VGPR): half the address registers of 64-bit pointers and one VALU add per instruction and K-tile.
+    uint32_t xoff[8], woff[8];
+    const bf16_t* xbase = p.X;
+    const bf16_t* wbase = p.W;
     int lx_round = 0, lx_kt = 0, lx_slot = 0;
     int lw_round = 0, lw_kt = 0, lw_slot = 0;
     bool lx_live, lw_live;
     auto x_setup = [&](int tile) {
         const int tm = tile / p.tiles_n;
+        xbase = p.X + (size_t)tm * BM6 * p.ldx;
+        const int rows = p.M - tm * BM6;  // >= 1: rows of this panel that exist (others re-read the last one)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = (j * 4 + wave) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int gx = tm * BM6 + r;
-            gx = gx < p.M ? gx : p.M - 1;
-            xsrc[j] = p.X + (size_t)gx * p.ldx + c * 8;
+            const int rr = r < rows ? r : rows - 1;
+            xoff[j] = (uint32_t)rr * (uint32_t)p.ldx * 2u + c * 16;
         }
     };
     auto w_setup = [&](int tile) {
         const int tn = tile % p.tiles_n;
+        wbase = p.W + (size_t)tn * BN6 * p.ldw;
+        const int rows = p.N - tn * BN6;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = (j * 4 + wave) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int gw = tn * BN6 + r;
-            gw = gw < p.N ? gw : p.N - 1;
-            wsrc[j] = p.W + (size_t)gw * p.ldw + c * 8;
+            const int rr = r < rows ? r : rows - 1;
+            woff[j] = (uint32_t)rr * (uint32_t)p.ldw * 2u + c * 16;
         }
     };
     // one DMA instruction of the next X / W K-tile (j = 0..7); the cursor advances with the last one
@@ -98,12 +117,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // DMA round trip per tile), in front of every transposing read in the TN kernel below.  All DMA waits in this file
     // are explicit counted s_waitcnt + barrier.  (M0 = the wave's LDS destination; nothing else here uses M0.)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)dsm;
-    auto dma1 = [&](const bf16_t* src, uint32_t lds_byte) {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory");
+    auto dma1 = [&](uint32_t off, const bf16_t* base, uint32_t lds_byte) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
     };
     auto issue_x1 = [&](int j) {
-        dma1(xsrc[j], lds0 + lx_slot * XS6 + (j * 4 + wave) * 1024);
-        xsrc[j] += BK6;
+        dma1(xoff[j], xbase, lds0 + lx_slot * XS6 + (j * 4 + wave) * 1024);
+        xoff[j] += BK6 * 2;
     };
     auto x_advance = [&]() {
         lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
@@ -115,8 +134,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
     };
     auto issue_w1 = [&](int j) {
-        dma1(wsrc[j], lds0 + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024);
-        wsrc[j] += BK6;
+        dma1(woff[j], wbase, lds0 + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024);
+        woff[j] += BK6 * 2;
     };
     auto w_advance = [&]() {
         lw_slot ^= 1;
@@ -157,14 +176,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     Frags6 F0, F1;
     // fragment i of k-step ks: i = 0..3 -> W n-blocks, 4..7 -> X m-blocks
     auto read_one = [&](Frags6& f, const char* xs, const char* ws, int ks, int i) {
+        if constexpr ((DBG & 4) != 0) return;
         if (i < 4)
             f.w[i] = lds_read_frag(ws, tile64_off(wn * 128 + i * 32 + l31, ks * 2 + hi));
         else
             f.x[i - 4] = lds_read_frag(xs, tile64_off(wm * 128 + (i - 4) * 32 + l31, ks * 2 + hi));
     };
     // i-th MFMA of a k-step: a = i & 3, b = i >> 2 (block index == i)
-    auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 3], f.x[i >> 2]); };
-    auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]); };
+    auto mma1 = [&](const Frags6& f, int i) {
+        if constexpr ((DBG & 8) != 0) return;
+        v6_mfma(i, f.w[i & 3], f.x[i >> 2]);
+    };
+    auto mma1z = [&](const Frags6& f, int i) {
+        if constexpr ((DBG & 8) != 0) return;
+        v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]);
+    };
     // One k-step: 16 MFMAs on `cur`; after the first one, the 8 reads of the next k-step (into `nxt`) and up to 4 DMA
     // instructions are interleaved one per MFMA, the rest of the MFMAs follow back to back.
     // dma_kind: 0 none, 1 W instructions j0..j0+3, 2 X instructions j0..j0+3
@@ -207,7 +233,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     auto kt_body = [&](auto first) {
         // DMA of this iteration: W of iteration +1 (k-steps 0,1), X of iteration +2 (k-steps 2,3); both target slots
         // consumed in iteration -1.
-        const bool w_go = lw_live, x_go = lx_live;
+        const bool w_go = lw_live && !(DBG & 1), x_go = lx_live && !(DBG & 1);
+        if constexpr (DBG != 0) ++n_ktiles;
         const char* xs = dsm + xs_slot * XS6;
         const char* ws = dsm + (3 + ws_slot) * XS6;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
@@ -225,12 +252,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // k-step 2 (the other 4 of that K-tile follow below).  "All but the newest 4" stays correct across a tile end:
         // the epilogue's global stores are older than the next iteration's newest 4 and retire in order with them (gfx9
         // has one in-order vmcnt for loads and stores), so they can only make that wait stronger, never weaker.
-        if (x_go) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((DBG & 32) == 0) {
+            if (x_go) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
-        __builtin_amdgcn_s_barrier();
+        if constexpr ((DBG & 2) == 0) __builtin_amdgcn_s_barrier();
         const char* nxs = dsm + nxs_slot * XS6;
         const char* nws = dsm + (3 + nws_slot) * XS6;
         // (at a tile end these reads fetch the first fragments of the next tile: its operands have landed too)
@@ -259,7 +288,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const int m0 = tm * BM6 + wm * 128, n0 = tn * BN6 + wn * 128;
             char* my = ((wave < 2) ? dsm + pxs_slot * XS6 : dsm + (3 + pws_slot) * XS6) + (wave & 1) * 16384;
             constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
-            if constexpr (EPI == GEMM_EPI_NONE) {
+            if constexpr ((DBG & 16) != 0) {
+                // ablation: no epilogue
+            } else if constexpr (EPI == GEMM_EPI_NONE) {
                 const bool add_bias = p.bias != nullptr;
                 // `plain` (compile time): alpha == 1 and no bias -- the forward / dgrad launches of bias-free models;
                 // saves 256 multiplies per lane per tile in an epilogue that is VALU-issue-bound (one wave per SIMD)
@@ -267,6 +298,104 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 // the `x0 + residual` of dropout_add_layer_norm (sc/layers/block.py:422-431) moves from the HBM-bound
                 // LayerNorm kernel into this epilogue, where it overlaps other workgroups' MFMA phases.
                 const bf16_t* resid = reinterpret_cast<const bf16_t*>(p.Out2);
+                // ---- fast path: interior tile, alpha == 1, no bias (every launch of the bias-free trunk).  What the
+                // first version lost (13 k cycles per tile = 29 % of a K = 768 tile, scripts/gemm_ablate.py): each
+                // 16-byte row piece went LDS read -> wait -> predicated store one at a time (8 LDS round trips per pass),
+                // and the residual loads of pass b + 1, issued after the stores of pass b, could only be waited for
+                // together with those stores (gfx9 counts loads and stores on one in-order vmcnt) -- the wave sat
+                // through a store round trip per pass.  Here a pass is software-pipelined: all 8 row reads are issued
+                // at once, the accumulator read + convert of the NEXT pass runs under their latency, the residual loads
+                // of the next pass are issued BEFORE this pass's stores, and nothing is predicated.
+                auto fast_tile = [&](auto with_resid) {
+                    constexpr bool RES = decltype(with_resid)::value;
+                    const int rrow = lane >> 4, rch = lane & 15;
+                    bf16_t* outp = reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8;
+                    const bf16_t* resp = RES ? resid + (size_t)(m0 + rrow) * p.ldo2 + n0 + rch * 8 : nullptr;
+                    const char* rd = my + rrow * ROWB + rch * 16;
+                    char* wr = my + l31 * ROWB + hi * 8;
+                    uint2 pk[16];
+                    auto pack_pass = [&](int b) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            float blk[16];
+                            v6_read_block(4 * b + a, blk);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                pk[a * 4 + q].x = pack_bf16x2(blk[4 * q], blk[4 * q + 1]);
+                                pk[a * 4 + q].y = pack_bf16x2(blk[4 * q + 2], blk[4 * q + 3]);
+                            }
+                        }
+                    };
+                    auto stage = [&]() {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wr + (a * 32 + 8 * q) * 2) = pk[a * 4 + q];
+                    };
+                    // (named registers and explicit pass constants: a `uint4 rr[8]` carried across the passes of an
+                    // unrolled loop is left in scratch memory by the compiler)
+                    uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {}, r4 = {}, r5 = {}, r6 = {}, r7 = {};
+#define CX_RES_ROWS(b_)                                                                                   \
+    r0 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 0) * p.ldo2);                          \
+    r1 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 4) * p.ldo2);                          \
+    r2 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 8) * p.ldo2);                          \
+    r3 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 12) * p.ldo2);                         \
+    r4 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 16) * p.ldo2);                         \
+    r5 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 20) * p.ldo2);                         \
+    r6 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 24) * p.ldo2);                         \
+    r7 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 28) * p.ldo2);
+                    auto add_res = [&](uint4& v, const uint4& r) {
+                        v.x = pack_bf16x2(bf16lo_to_f32(v.x) + bf16lo_to_f32(r.x), bf16hi_to_f32(v.x) + bf16hi_to_f32(r.x));
+                        v.y = pack_bf16x2(bf16lo_to_f32(v.y) + bf16lo_to_f32(r.y), bf16hi_to_f32(v.y) + bf16hi_to_f32(r.y));
+                        v.z = pack_bf16x2(bf16lo_to_f32(v.z) + bf16lo_to_f32(r.z), bf16hi_to_f32(v.z) + bf16hi_to_f32(r.z));
+                        v.w = pack_bf16x2(bf16lo_to_f32(v.w) + bf16lo_to_f32(r.w), bf16hi_to_f32(v.w) + bf16hi_to_f32(r.w));
+                    };
+                    auto one_pass = [&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        uint4 v0 = *reinterpret_cast<const uint4*>(rd + 0 * ROWB), v1 = *reinterpret_cast<const uint4*>(rd + 4 * ROWB),
+                              v2 = *reinterpret_cast<const uint4*>(rd + 8 * ROWB), v3 = *reinterpret_cast<const uint4*>(rd + 12 * ROWB),
+                              v4 = *reinterpret_cast<const uint4*>(rd + 16 * ROWB), v5 = *reinterpret_cast<const uint4*>(rd + 20 * ROWB),
+                              v6 = *reinterpret_cast<const uint4*>(rd + 24 * ROWB), v7 = *reinterpret_cast<const uint4*>(rd + 28 * ROWB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (b < 3) pack_pass(b + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (RES) {
+                            add_res(v0, r0); add_res(v1, r1); add_res(v2, r2); add_res(v3, r3);
+                            add_res(v4, r4); add_res(v5, r5); add_res(v6, r6); add_res(v7, r7);
+                            if constexpr (b < 3) {  // next pass's residual rows: issued BEFORE this pass's stores (one in-order vmcnt)
+                                __builtin_amdgcn_sched_barrier(0);
+                                CX_RES_ROWS(b + 1)
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        if constexpr (b < 3) stage();  // the LDS executes a wave's operations in order: these follow the row reads
+                        bf16_t* o = outp + (size_t)(b * 32) * p.ldo;
+                        if constexpr ((DBG & 64) != 0) {  // ablation: everything but the stores
+                            const uint4 vs[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(vs[i].x), "v"(vs[i].y), "v"(vs[i].z), "v"(vs[i].w));
+                            asm volatile("" ::"v"(o));
+                            return;
+                        }
+                        *reinterpret_cast<uint4*>(o) = v0;
+                        *reinterpret_cast<uint4*>(o + (size_t)4 * p.ldo) = v1;
+                        *reinterpret_cast<uint4*>(o + (size_t)8 * p.ldo) = v2;
+                        *reinterpret_cast<uint4*>(o + (size_t)12 * p.ldo) = v3;
+                        *reinterpret_cast<uint4*>(o + (size_t)16 * p.ldo) = v4;
+                        *reinterpret_cast<uint4*>(o + (size_t)20 * p.ldo) = v5;
+                        *reinterpret_cast<uint4*>(o + (size_t)24 * p.ldo) = v6;
+                        *reinterpret_cast<uint4*>(o + (size_t)28 * p.ldo) = v7;
+                    };
+                    if constexpr (RES) { CX_RES_ROWS(0) }
+                    pack_pass(0);
+                    stage();
+                    one_pass(std::integral_constant<int, 0>{});
+                    one_pass(std::integral_constant<int, 1>{});
+                    one_pass(std::integral_constant<int, 2>{});
+                    one_pass(std::integral_constant<int, 3>{});
+#undef CX_RES_ROWS
+                };
+                const bool fast = p.alpha == 1.f && !add_bias && m0 + 128 <= p.M && n0 + 128 <= p.N && !(p.dbg & 0x10000);  // bit 16: A/B switch back to the first epilogue
                 auto store_tile = [&](auto plain) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
@@ -329,7 +458,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         }
                     }
                 };
-                if (p.alpha == 1.f && !add_bias) {
+                if (fast) {
+                    if (resid) {
+                        fast_tile(std::true_type{});
+                    } else {
+                        fast_tile(std::false_type{});
+                    }
+                } else if (p.alpha == 1.f && !add_bias) {
                     store_tile(std::true_type{});
                 } else {
                     store_tile(std::false_type{});
@@ -345,6 +480,86 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 bf16_t* dyg = reinterpret_cast<bf16_t*>(p.Out);
                 const int c0 = 2 * n0;  // first pre-activation column of this wave
                 auto cell = [&](int row, int colbyte) { return my + row * 512 + ((((colbyte >> 4) ^ row) & 31) << 4) + (colbyte & 15); };
+                // ---- fast path (interior tiles).  The first version ran its four 32-row passes strictly one after the
+                // other: the (y, gate) loads of pass b + 1 were issued after the dYG stores of pass b, and on gfx9 a load
+                // can only be waited for together with every older store (one in-order vmcnt) -- each pass sat through a
+                // full store round trip before its data was even requested.  Here the 16 row loads of pass b + 1 are
+                // issued right after pass b's rows have been staged (their registers are free from then on) and BEFORE
+                // pass b's stores; they land while the wave does the pass's sigmoid arithmetic.
+                const bool fast_bwd = m0 + 128 <= p.M && n0 + 128 <= p.N && !(p.dbg & 0x10000);
+                if (fast_bwd) {
+                    const int lrow = lane >> 5, lch = lane & 31;
+                    const bf16_t* src = yg_in + (size_t)(m0 + lrow) * p.ldo2 + c0 + lch * 8;
+                    bf16_t* dst = dyg + (size_t)(m0 + lrow) * p.ldo + c0 + lch * 8;
+                    uint4 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
+#define CX_L(i, b_) t##i = *reinterpret_cast<const uint4*>(src + (size_t)((b_) * 32 + (i) * 2) * p.ldo2);
+#define CX_LOAD_LO(b_) CX_L(0, b_) CX_L(1, b_) CX_L(2, b_) CX_L(3, b_) CX_L(4, b_) CX_L(5, b_) CX_L(6, b_) CX_L(7, b_)
+#define CX_LOAD_HI(b_) CX_L(8, b_) CX_L(9, b_) CX_L(10, b_) CX_L(11, b_) CX_L(12, b_) CX_L(13, b_) CX_L(14, b_) CX_L(15, b_)
+#define CX_S(i) *reinterpret_cast<uint4*>(cell((i) * 2 + lrow, lch * 16)) = t##i;
+#define CX_STAGE_ALL CX_S(0) CX_S(1) CX_S(2) CX_S(3) CX_S(4) CX_S(5) CX_S(6) CX_S(7) CX_S(8) CX_S(9) CX_S(10) CX_S(11) CX_S(12) CX_S(13) CX_S(14) CX_S(15)
+                    auto one_pass = [&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        CX_STAGE_ALL
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (b < 3) { CX_LOAD_LO(b + 1) }  // rows 0..15 of the next pass fly under the arithmetic
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            float da[16];
+                            v6_read_block(4 * b + a, da);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                char* py = cell(l31, (a * 64 + 8 * q + 4 * hi) * 2);
+                                char* pg = cell(l31, (a * 64 + 32 + 8 * q + 4 * hi) * 2);
+                                const uint2 yy = *reinterpret_cast<const uint2*>(py);
+                                const uint2 gg = *reinterpret_cast<const uint2*>(pg);
+                                const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
+                                const float g[4] = {bf16lo_to_f32(gg.x), bf16hi_to_f32(gg.x), bf16lo_to_f32(gg.y), bf16hi_to_f32(gg.y)};
+                                // the standalone op sees bf16 d(act): round pairwise with the hardware convert
+                                const uint32_t d01 = pack_bf16x2(da[4 * q], da[4 * q + 1]), d23 = pack_bf16x2(da[4 * q + 2], da[4 * q + 3]);
+                                const float d[4] = {bf16lo_to_f32(d01), bf16hi_to_f32(d01), bf16lo_to_f32(d23), bf16hi_to_f32(d23)};
+                                float dy[4], dg[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
+                                    const float gs = g[e] * sg;
+                                    dy[e] = gs * d[e];
+                                    dg[e] = (sg + gs * (1.f - sg)) * d[e] * y[e];
+                                }
+                                uint2 o;
+                                o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);
+                                *reinterpret_cast<uint2*>(py) = o;
+                                o.x = pack_bf16x2(dg[0], dg[1]); o.y = pack_bf16x2(dg[2], dg[3]);
+                                *reinterpret_cast<uint2*>(pg) = o;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);  // one accumulator block at a time (register pressure)
+                        }
+                        if constexpr (b < 3) { CX_LOAD_HI(b + 1) }  // rows 16..31: still ahead of this pass's stores
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {  // (named registers: a small uint4 array lands in scratch memory here)
+                            const uint4 v0 = *reinterpret_cast<const uint4*>(cell((h * 4 + 0) * 2 + lrow, lch * 16));
+                            const uint4 v1 = *reinterpret_cast<const uint4*>(cell((h * 4 + 1) * 2 + lrow, lch * 16));
+                            const uint4 v2 = *reinterpret_cast<const uint4*>(cell((h * 4 + 2) * 2 + lrow, lch * 16));
+                            const uint4 v3 = *reinterpret_cast<const uint4*>(cell((h * 4 + 3) * 2 + lrow, lch * 16));
+                            bf16_t* o = dst + (size_t)(b * 32 + h * 8) * p.ldo;
+                            *reinterpret_cast<uint4*>(o) = v0;
+                            *reinterpret_cast<uint4*>(o + (size_t)2 * p.ldo) = v1;
+                            *reinterpret_cast<uint4*>(o + (size_t)4 * p.ldo) = v2;
+                            *reinterpret_cast<uint4*>(o + (size_t)6 * p.ldo) = v3;
+                        }
+                    };
+                    CX_LOAD_LO(0) CX_LOAD_HI(0)
+                    one_pass(std::integral_constant<int, 0>{});
+                    one_pass(std::integral_constant<int, 1>{});
+                    one_pass(std::integral_constant<int, 2>{});
+                    one_pass(std::integral_constant<int, 3>{});
+#undef CX_L
+#undef CX_LOAD_LO
+#undef CX_LOAD_HI
+#undef CX_S
+#undef CX_STAGE_ALL
+                } else
 #pragma unroll 1
                 for (int b = 0; b < 4; ++b) {
                     // 2 x 8 loads in flight, held in NAMED registers (an L2 prefetch during the last K-tile and 4 x 4 groups measured slower) (a `uint4 in[16]` array lands in scratch memory here)
@@ -465,6 +680,106 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 // = one 256-B run per row of the (M, 2I) pre-activation tensor and 64 activation columns.
                 constexpr int AROWB = 144;      // 32 staged rows x 64 bf16 (+16 B pad) = 4608 B
                 char* mya = my + 32 * ROWB;     // separate region: no hazard against the pre-activation staging
+                // ---- fast path (interior tiles): the passes are software-pipelined as in the plain epilogue -- all row
+                // reads of a pass issued together, the accumulator read + SiLU arithmetic of the next pass under their
+                // latency, unpredicated 16-byte stores -- instead of 12 serial LDS-read -> wait -> predicated-store steps.
+                auto fast_swiglu = [&](auto save_c) {
+                    constexpr bool SAVE = decltype(save_c)::value;
+                    const int rrow = lane >> 4, rch = lane & 15;     // pre-activation rows: 16 lanes x 16 B
+                    const int arow = lane >> 3, ach = lane & 7;      // activation rows: 8 lanes x 16 B
+                    bf16_t* ygp = SAVE ? reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8 : nullptr;
+                    bf16_t* actp = reinterpret_cast<bf16_t*>(p.Out2) + (size_t)(m0 + arow) * p.ldo2 + (n0 >> 1) + ach * 8;
+                    const char* rdy = my + rrow * ROWB + rch * 16;
+                    const char* rda = mya + arow * AROWB + ach * 16;
+                    char* wry = my + l31 * ROWB + hi * 8;
+                    char* wra = mya + l31 * AROWB + hi * 8;
+                    uint2 pky[16], pka[8];
+                    auto compute_pass = [&](int b) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            float yb[16], gb[16];
+                            v6_read_block(4 * b + 2 * pr, yb);
+                            v6_read_block(4 * b + 2 * pr + 1, gb);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                // the standalone op sees bf16 y / gate (FusedDense outputs): round pairwise, reuse the packed words
+                                uint2 py, pg;
+                                py.x = pack_bf16x2(yb[4 * q], yb[4 * q + 1]);
+                                py.y = pack_bf16x2(yb[4 * q + 2], yb[4 * q + 3]);
+                                pg.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
+                                pg.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
+                                if constexpr (SAVE) {
+                                    pky[(2 * pr) * 4 + q] = py;
+                                    pky[(2 * pr + 1) * 4 + q] = pg;
+                                }
+                                const float yy[4] = {bf16lo_to_f32(py.x), bf16hi_to_f32(py.x), bf16lo_to_f32(py.y), bf16hi_to_f32(py.y)};
+                                const float gg[4] = {bf16lo_to_f32(pg.x), bf16hi_to_f32(pg.x), bf16lo_to_f32(pg.y), bf16hi_to_f32(pg.y)};
+                                float o[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = gg[e] * yy[e] * __builtin_amdgcn_rcpf(1.f + __expf(-gg[e]));
+                                pka[pr * 4 + q].x = pack_bf16x2(o[0], o[1]);
+                                pka[pr * 4 + q].y = pack_bf16x2(o[2], o[3]);
+                            }
+                        }
+                    };
+                    auto stage = [&]() {
+                        if constexpr (SAVE) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wry + (a * 32 + 8 * q) * 2) = pky[a * 4 + q];
+                        }
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wra + (pr * 32 + 8 * q) * 2) = pka[pr * 4 + q];
+                    };
+                    auto one_pass = [&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        uint4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {};
+                        if constexpr (SAVE) {
+                            v0 = *reinterpret_cast<const uint4*>(rdy + 0 * ROWB); v1 = *reinterpret_cast<const uint4*>(rdy + 4 * ROWB);
+                            v2 = *reinterpret_cast<const uint4*>(rdy + 8 * ROWB); v3 = *reinterpret_cast<const uint4*>(rdy + 12 * ROWB);
+                            v4 = *reinterpret_cast<const uint4*>(rdy + 16 * ROWB); v5 = *reinterpret_cast<const uint4*>(rdy + 20 * ROWB);
+                            v6 = *reinterpret_cast<const uint4*>(rdy + 24 * ROWB); v7 = *reinterpret_cast<const uint4*>(rdy + 28 * ROWB);
+                        }
+                        const uint4 a0 = *reinterpret_cast<const uint4*>(rda + 0 * AROWB), a1 = *reinterpret_cast<const uint4*>(rda + 8 * AROWB),
+                                    a2 = *reinterpret_cast<const uint4*>(rda + 16 * AROWB), a3 = *reinterpret_cast<const uint4*>(rda + 24 * AROWB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (b < 3) compute_pass(b + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (b < 3) stage();  // the LDS executes a wave's operations in order: these follow the row reads
+                        if constexpr (SAVE) {
+                            bf16_t* o = ygp + (size_t)(b * 32) * p.ldo;
+                            *reinterpret_cast<uint4*>(o) = v0;
+                            *reinterpret_cast<uint4*>(o + (size_t)4 * p.ldo) = v1;
+                            *reinterpret_cast<uint4*>(o + (size_t)8 * p.ldo) = v2;
+                            *reinterpret_cast<uint4*>(o + (size_t)12 * p.ldo) = v3;
+                            *reinterpret_cast<uint4*>(o + (size_t)16 * p.ldo) = v4;
+                            *reinterpret_cast<uint4*>(o + (size_t)20 * p.ldo) = v5;
+                            *reinterpret_cast<uint4*>(o + (size_t)24 * p.ldo) = v6;
+                            *reinterpret_cast<uint4*>(o + (size_t)28 * p.ldo) = v7;
+                        }
+                        bf16_t* oa = actp + (size_t)(b * 32) * p.ldo2;
+                        *reinterpret_cast<uint4*>(oa) = a0;
+                        *reinterpret_cast<uint4*>(oa + (size_t)8 * p.ldo2) = a1;
+                        *reinterpret_cast<uint4*>(oa + (size_t)16 * p.ldo2) = a2;
+                        *reinterpret_cast<uint4*>(oa + (size_t)24 * p.ldo2) = a3;
+                    };
+                    compute_pass(0);
+                    stage();
+                    one_pass(std::integral_constant<int, 0>{});
+                    one_pass(std::integral_constant<int, 1>{});
+                    one_pass(std::integral_constant<int, 2>{});
+                    one_pass(std::integral_constant<int, 3>{});
+                };
+                if (m0 + 128 <= p.M && n0 + 128 <= p.N && !(p.dbg & 0x10000)) {
+                    if (p.Out) {
+                        fast_swiglu(std::true_type{});
+                    } else {
+                        fast_swiglu(std::false_type{});
+                    }
+                } else
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -520,25 +835,41 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
             }
             cp_tile = tile_of(++cp_round);
+            if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
+                // This epilogue needs the registers: the first fragments of the next tile (read into F0 during the last
+                // k-step above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead
+                // across the epilogue (~200 cycles of exposed LDS latency per tile against 32 registers).
+                asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
+                if (cp_tile < ntiles) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) read_one(F0, dsm + xs_slot * XS6, dsm + (3 + ws_slot) * XS6, 0, i);
+                }
+            }
             // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
             __builtin_amdgcn_s_barrier();
         }
     }
 #undef CX_KSTEP
+    if constexpr (DBG != 0) {
+        if (p.trace && tid == 0) {
+            p.trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+            p.trace[2 * blockIdx.x + 1] = n_ktiles;
+        }
+    }
 }
 
-template <int EPI>
+template <int EPI, int DBG = 0>
 hipError_t launch6(const GemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int ntiles = p.tiles_m * p.tiles_n;
     const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI>), dim3(grid), dim3(256), LDS6, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, DBG>), dim3(grid), dim3(256), LDS6, stream, p);
     return hipGetLastError();
 }
 
@@ -755,6 +1086,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
+int g_v6_dbg = 0;              // ablation mask (cx_gemm_v6_ablate)
+int g_v6_stagger = 0, g_v6_phases = 2;  // experiments: start-time skew between workgroup phases (cycles), phase count
+long long* g_v6_trace = nullptr;  // ablation builds only: 2 x int64 per workgroup {cycles, K-tiles}
 int g_v6_force_gn = 0;  // experiments: 1, 2, 4 or 8 forces the N-group count; 0 = heuristic
 
 // N-groups of the XCD grid: the estimated L2-miss traffic is gn * |X| (every X panel is fetched by the gn XCDs of its
@@ -779,6 +1113,9 @@ int cx_gemm_v6_groups(int tiles_m, int tiles_n, int K) {
 
 }  // namespace
 
+void cx_gemm_v6_set_trace(long long* buf) { g_v6_trace = buf; }
+void cx_gemm_v6_set_ablate(int mask) { g_v6_dbg = mask; }
+void cx_gemm_v6_set_stagger(int cycles, int phases) { g_v6_stagger = cycles; g_v6_phases = phases < 2 ? 2 : phases; }
 void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
 
 // TN wgrad form: p.X = dY (T, M), p.W = A (T, N), p.K = tokens, p.Out = fp32 partial slabs [split_k][M][ldo];
@@ -802,6 +1139,26 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     p.tiles_m = (p.M + BM6 - 1) / BM6;
     p.tiles_n = (p.N + BN6 - 1) / BN6;
     p.sup_n = cx_gemm_v6_groups(p.tiles_m, p.tiles_n, p.K);
+    p.sup_m = g_v6_stagger;
+    p.split_k = g_v6_phases;
+    if (epi == GEMM_EPI_NONE && g_v6_dbg) {  // ablation builds (scripts/gemm_ablate.py)
+        p.trace = g_v6_trace;
+        switch (g_v6_dbg) {
+            case 1: return launch6<GEMM_EPI_NONE, 1>(p, stream);
+            case 2: return launch6<GEMM_EPI_NONE, 2>(p, stream);
+            case 4: return launch6<GEMM_EPI_NONE, 4>(p, stream);
+            case 16: return launch6<GEMM_EPI_NONE, 16>(p, stream);
+            case 32: return launch6<GEMM_EPI_NONE, 32>(p, stream);
+            case 33: return launch6<GEMM_EPI_NONE, 33>(p, stream);
+            case 35: return launch6<GEMM_EPI_NONE, 35>(p, stream);
+            case 39: return launch6<GEMM_EPI_NONE, 39>(p, stream);
+            case 55: return launch6<GEMM_EPI_NONE, 55>(p, stream);
+            case 59: return launch6<GEMM_EPI_NONE, 59>(p, stream);  // everything but the fragment reads
+            case 64: return launch6<GEMM_EPI_NONE, 64>(p, stream);    // epilogue without its global stores
+            case 128: return launch6<GEMM_EPI_NONE, 128>(p, stream);  // trace only
+            default: break;
+        }
+    }
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
            : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD ? launch6<GEMM_EPI_SWIGLU_BWD>(p, stream)

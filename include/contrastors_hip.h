@@ -53,6 +53,14 @@ void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0/bit1 ab
 /* in-kernel phase timers of the persistent 256x256x64 kernel: buf = int64[grid*8 waves*8] {wait, compute, epilogue
    cycles, iterations, epilogue DMA-wait cycles, -, -, -} per wave, or NULL to disable (scripts/gemm_trace.py) */
 void cx_gemm_set_trace(void* buf);
+/* one-wave-per-SIMD kernel: ablation builds (mask bits: 1 no DMA, 2 no barrier, 4 no fragment reads, 8 no MFMA, 16 no
+   epilogue, 32 no DMA wait, 128 trace only; results are garbage, timing is the point) and their per-workgroup trace
+   buffer int64[grid][2] = {s_memtime span, K-tiles} (scripts/gemm_ablate.py) */
+void cx_gemm_v6_ablate(int mask);
+/* experiment: workgroup phase k (of `phases`) starts k * cycles late, so that epilogue streaming and MFMA phases of
+   different CUs overlap in time instead of running in lock-step */
+void cx_gemm_v6_stagger(int cycles, int phases);
+void cx_gemm_v6_trace(void* buf);
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
  * (2*M*N*K) of exactly the sampled launches. */

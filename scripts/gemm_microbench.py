@@ -17,6 +17,8 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", type=str, default="")
 ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--tn", type=int, default=1)
+ap.add_argument("--stagger", type=int, default=0)
+ap.add_argument("--phases", type=int, default=2)
 ap.add_argument("--zeros", type=int, default=0, help="all-zero operands: no switching power, clocks stay high")
 ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
 a = ap.parse_args()
@@ -24,6 +26,8 @@ lib = _C.lib()
 lib.cx_gemm_set_variant(a.variant)
 lib.cx_gemm_set_glds(a.glds)
 lib.cx_gemm_set_debug(a.dbg)
+lib.cx_gemm_v6_ablate(0)
+lib.cx_gemm_v6_stagger(a.stagger, a.phases)
 T = a.chunk * 128
 shapes = {  # name: (M, N, K)
     "qkv_fwd": (T, 2304, 768), "out_fwd": (T, 768, 768), "fc1_fwd": (T, 6144, 768), "fc2_fwd": (T, 768, 3072),
@@ -72,3 +76,35 @@ for name, (M, N, K) in shapes.items():
     tot_t += us
     print(f"{name:10s} M={M:6d} N={N:5d} K={K:6d}  {us:8.1f} us  {fl/us/1e6:7.1f} TF")
 print(f"sum: {tot_t:.1f} us  {tot_f/tot_t/1e6:.1f} TF  (variant {a.variant}, chunk {a.chunk})")
+
+# ---- the fused epilogue forms the engine actually launches (nomic-bert-2048 block) ----------------------------------
+if not a.shape and not a.only:
+    d, I = 768, 3072
+    x = torch.randn(T, d, device=dev).bfloat16()
+    res = torch.randn(T, d, device=dev).bfloat16()
+    w1 = (torch.randn(2 * I, d, device=dev) * 0.05).bfloat16()
+    w2 = (torch.randn(d, I, device=dev) * 0.05).bfloat16()
+    w2t = w2.T.contiguous()
+    wo = (torch.randn(d, d, device=dev) * 0.05).bfloat16()
+    yg = torch.randn(T, 2 * I, device=dev).bfloat16()
+    dyg = torch.empty_like(yg)
+    act = torch.randn(T, I, device=dev).bfloat16()
+    out = torch.empty(T, d, device=dev, dtype=torch.bfloat16)
+    fused = {
+        "fc1+swiglu (save yg)": (2.0 * T * 2 * I * d, lambda: lib.cx_gemm_bf16_swiglu(x.data_ptr(), w1.data_ptr(), yg.data_ptr(), act.data_ptr(), T, I, d, d, d, 2 * I, I, s)),
+        "fc1+swiglu (no save)": (2.0 * T * 2 * I * d, lambda: lib.cx_gemm_bf16_swiglu(x.data_ptr(), w1.data_ptr(), None, act.data_ptr(), T, I, d, d, d, 2 * I, I, s)),
+        "fc2 dgrad+swiglu bwd": (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_swiglu_bwd(x.data_ptr(), w2t.data_ptr(), yg.data_ptr(), dyg.data_ptr(), T, I, d, d, d, 2 * I, s)),
+        "fc2 fwd + residual": (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_nt_residual(act.data_ptr(), w2.data_ptr(), out.data_ptr(), None, res.data_ptr(), T, d, I, I, I, d, d, s)),
+        "out_proj fwd + residual": (2.0 * T * d * d, lambda: lib.cx_gemm_bf16_nt_residual(x.data_ptr(), wo.data_ptr(), out.data_ptr(), None, res.data_ptr(), T, d, d, d, d, d, d, s)),
+    }
+    for name, (fl, run) in fused.items():
+        for _ in range(3):
+            assert run() == 0, name
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.reps
+        print(f"{name:26s} {us:8.1f} us  {fl/us/1e6:7.1f} TF")
