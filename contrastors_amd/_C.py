@@ -59,7 +59,7 @@ class CxChunkBuffers(C.Structure):
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
             "ws_f32",
         )
-    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")]
+    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32)]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.

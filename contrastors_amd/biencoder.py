@@ -80,6 +80,8 @@ class BiEncoder(torch.nn.Module):
         self.is_vision = isinstance(trunk_cfg, ViTConfig)  # image tower: `input_ids` carries the pixel tensor
         engine_cls = ViTEngine if self.is_vision else NomicBertEngine
         self.trunk = engine_cls(trunk_cfg, device=device, pooling=config.pooling, normalize=True, seed=seed)
+        if config.gradient_checkpointing:  # modeling_biencoder.py:261-262
+            self.trunk.gradient_checkpointing_enable()
         self.frozen_trunk = bool(config.freeze)
         if self.frozen_trunk:
             self.trunk.eval()

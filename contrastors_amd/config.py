@@ -100,7 +100,8 @@ class ModelArgs(BaseModel):
     mlp_fc1_bias: Optional[bool] = True
     mlp_fc2_bias: Optional[bool] = True
     attn_pdrop: Optional[float] = 0.0
-    pretrained: bool = False
+    pretrained: Optional[bool] = True       # sc/config.py:161 (the reference default)
+    checkpoint: Optional[str] = None         # sc/config.py:162: a BiEncoder.save_pretrained directory
     gradient_checkpointing: bool = False
     projection_dim: Optional[int] = None
     freeze: bool = False

@@ -22,24 +22,32 @@ namespace {
 
 inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
+// Slot mapping.  mode 0: every layer shares slot 0 (no-grad pass); 1: one slot per layer (saved for backward);
+// 2 (activation checkpointing, sc/models/encoder/modeling_nomic_bert.py:339-365, sc/models/vit/vit.py:200-231): only the
+// tensor that carries a block's INPUT keeps one slot per layer -- h2 (the previous block's output) for post-norm trunks,
+// z1 (the complete residual stream at LN1) for pre-norm trunks -- everything else lives in slot 0 and is recomputed
+// block by block during backward.
 struct Slots {
     const CxChunkBuffers* b;
     const CxEncoderDesc* e;
     long T_cap;
     int d, I, wfc1;  // wfc1 = width of the fc1 output (2I gated, I plain)
-    uint16_t* qkv(int s) const { return b->qkv + (size_t)s * T_cap * 3 * d; }
-    uint16_t* ctx(int s) const { return b->ctx + (size_t)s * T_cap * d; }
-    float* lse(int s) const { return b->lse + (size_t)s * T_cap * e->n_head; }
-    uint16_t* z1(int s) const { return b->z1 + (size_t)s * T_cap * d; }
-    uint16_t* h1(int s) const { return b->h1 + (size_t)s * T_cap * d; }
-    float* mean1(int s) const { return b->mean1 + (size_t)s * T_cap; }
-    float* rstd1(int s) const { return b->rstd1 + (size_t)s * T_cap; }
-    uint16_t* yg(int s) const { return b->yg + (size_t)s * T_cap * wfc1; }
-    uint16_t* act(int s) const { return b->act + (size_t)s * T_cap * I; }
-    uint16_t* z2(int s) const { return b->z2 + (size_t)s * T_cap * d; }
-    uint16_t* h2(int s) const { return b->h2 + (size_t)s * T_cap * d; }
-    float* mean2(int s) const { return b->mean2 + (size_t)s * T_cap; }
-    float* rstd2(int s) const { return b->rstd2 + (size_t)s * T_cap; }
+    int mode;
+    int sl(int s) const { return mode == 1 ? s : 0; }
+    int sl_in(int s) const { return mode == 0 ? 0 : s; }   // the per-layer tensor of the checkpointing mode
+    uint16_t* qkv(int s) const { return b->qkv + (size_t)sl(s) * T_cap * 3 * d; }
+    uint16_t* ctx(int s) const { return b->ctx + (size_t)sl(s) * T_cap * d; }
+    float* lse(int s) const { return b->lse + (size_t)sl(s) * T_cap * e->n_head; }
+    uint16_t* z1(int s) const { return b->z1 + (size_t)(e->prenorm ? sl_in(s) : sl(s)) * T_cap * d; }
+    uint16_t* h1(int s) const { return b->h1 + (size_t)sl(s) * T_cap * d; }
+    float* mean1(int s) const { return b->mean1 + (size_t)sl(s) * T_cap; }
+    float* rstd1(int s) const { return b->rstd1 + (size_t)sl(s) * T_cap; }
+    uint16_t* yg(int s) const { return b->yg + (size_t)sl(s) * T_cap * wfc1; }
+    uint16_t* act(int s) const { return b->act + (size_t)sl(s) * T_cap * I; }
+    uint16_t* z2(int s) const { return b->z2 + (size_t)sl(s) * T_cap * d; }
+    uint16_t* h2(int s) const { return b->h2 + (size_t)(e->prenorm ? sl(s) : sl_in(s)) * T_cap * d; }
+    float* mean2(int s) const { return b->mean2 + (size_t)sl(s) * T_cap; }
+    float* rstd2(int s) const { return b->rstd2 + (size_t)sl(s) * T_cap; }
 };
 
 int check_desc(const CxEncoderDesc* e, const CxChunkBuffers* b, int T) {
@@ -100,53 +108,93 @@ bool gelu_fused_shape(int T, int N, int K) {
 //           after the last block  h = ln_f(x + r)  (sc/models/vit/vit.py:253-263).
 // Buffers in pre-norm mode: z1/z2 hold the residual stream r at the two LayerNorms (the GEMM producing x writes into
 // the slot the LayerNorm then completes in place), h1/h2 the normalised inputs of attention / MLP.
+struct BlockRunner {
+    const CxEncoderDesc* enc;
+    const CxChunkBuffers* buf;
+    const Slots& s;
+    const int32_t* cu_seqlens;
+    int Bc, T, max_seqlen;
+    void* stream;
+
+    // (`residual`: added to the fc2 / out_proj output in the GEMM epilogue when possible; *folded reports it)
+    int mlp_up(const CxLayerWeights& w, const uint16_t* x, int l, bool keep) const {
+        const int d = enc->d, I = enc->d_inner;
+        if (enc->gated) {
+            // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
+            return cx_gemm_bf16_swiglu(x, w.Wfc1, keep ? s.yg(l) : nullptr, s.act(l), T, I, d, d, d, s.wfc1, I, stream);
+        }
+        // bias + erf-GELU in the GEMM epilogue; yg then holds the biased pre-activation, which backward reads with a
+        // NULL bias.  Shapes the fused kernel does not cover take the two-kernel route (yg without the bias).
+        const int rc = cx_gemm_bf16_bias_gelu(x, w.Wfc1, w.bfc1, keep ? s.yg(l) : nullptr, s.act(l), T, s.wfc1, d, d, d, s.wfc1,
+                                              I, stream);
+        if (rc != CX_ERR_SHAPE) return rc;
+        CX_TRY(cx_gemm_bf16_nt(x, w.Wfc1, s.yg(l), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
+        return cx_bias_gelu_fwd(s.yg(l), w.bfc1, s.act(l), T, I, stream);
+    }
+    int mlp(const CxLayerWeights& w, const uint16_t* x, int l, uint16_t* out, const uint16_t* residual, bool keep,
+            bool* folded) const {
+        CX_TRY(mlp_up(w, x, l, keep));
+        return proj_residual(s.act(l), w.Wfc2, w.bfc2, residual, out, T, enc->d, enc->d_inner, folded, stream);
+    }
+    int attn(const CxLayerWeights& w, const uint16_t* x, int l, uint16_t* out, const uint16_t* residual, bool* folded) const {
+        const int d = enc->d;
+        CX_TRY(cx_gemm_bf16_nt(x, w.Wqkv, s.qkv(l), w.bqkv, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.f, stream));
+        CX_TRY(cx_attn_varlen_fwd(s.qkv(l), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(l), s.lse(l), Bc, enc->n_head, T,
+                                  max_seqlen, enc->softmax_scale, stream));
+        return proj_residual(s.ctx(l), w.Wout, w.bout, residual, out, T, d, d, folded, stream);
+    }
+    // one post-norm block: h_in -> h2(l).  keep = backward will read this block's intermediates
+    int post_block(int l, const uint16_t* h_in, bool keep) const {
+        const CxLayerWeights& w = enc->layers[l];
+        const int d = enc->d;
+        // z = sublayer output + residual: added in the projection's epilogue when the fused kernel covers the shape
+        // (then z is complete in place and the LayerNorm reads one stream), else by the LayerNorm kernel, which
+        // writes z only when backward needs it.
+        bool f1 = false, f2 = false;
+        CX_TRY(attn(w, h_in, l, s.z1(l), h_in, &f1));
+        CX_TRY(cx_layernorm_fwd(s.z1(l), f1 ? nullptr : h_in, w.ln1_g, w.ln1_b, s.h1(l), (keep && !f1) ? s.z1(l) : nullptr,
+                                s.mean1(l), s.rstd1(l), T, d, enc->ln_eps, stream));
+        CX_TRY(mlp(w, s.h1(l), l, s.z2(l), s.h1(l), keep, &f2));
+        return cx_layernorm_fwd(s.z2(l), f2 ? nullptr : s.h1(l), w.ln2_g, w.ln2_b, s.h2(l), (keep && !f2) ? s.z2(l) : nullptr,
+                                s.mean2(l), s.rstd2(l), T, d, enc->ln_eps, stream);
+    }
+    // one pre-norm block.  In: x = output of the previous sub-layer, r = residual stream (NULL once folded into x).
+    // Out: *x_out (= z1(l+1) or zf), *r_out, *folded_out.  up_only: stop after the MLP's first projection (the
+    // recomputation of a checkpointed block needs nothing beyond `act`).
+    int pre_block(int l, const uint16_t* x, const uint16_t* r, bool r_folded, bool keep, bool up_only, const uint16_t** x_out,
+                  const uint16_t** r_out, bool* folded_out) const {
+        const CxLayerWeights& w = enc->layers[l];
+        const int d = enc->d, L = enc->n_layer;
+        // (when the previous fc2 folded the residual in, x == z1(l) already holds the complete residual stream; for the
+        // first block x = h0 is copied into z1 by the kernel)
+        CX_TRY(cx_layernorm_fwd(x, r, w.ln1_g, w.ln1_b, s.h1(l), (r_folded && x == s.z1(l)) ? nullptr : s.z1(l), s.mean1(l),
+                                s.rstd1(l), T, d, enc->ln_eps, stream));
+        bool f1 = false, f2 = false;
+        CX_TRY(attn(w, s.h1(l), l, s.z2(l), s.z1(l), &f1));
+        CX_TRY(cx_layernorm_fwd(s.z2(l), f1 ? nullptr : s.z1(l), w.ln2_g, w.ln2_b, s.h2(l), f1 ? nullptr : s.z2(l), s.mean2(l),
+                                s.rstd2(l), T, d, enc->ln_eps, stream));
+        if (up_only) return mlp_up(w, s.h2(l), l, keep);
+        // the MLP output lands where the next LayerNorm completes it in place: the next block's z1 slot, or zf
+        uint16_t* nxt = (l + 1 < L) ? s.z1(l + 1) : buf->zf;
+        CX_TRY(mlp(w, s.h2(l), l, nxt, s.z2(l), keep, &f2));
+        *x_out = nxt;
+        *r_out = f2 ? nullptr : s.z2(l);   // already folded into x by the fc2 epilogue
+        *folded_out = f2;
+        return CX_OK;
+    }
+};
+
 int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Slots& s, const uint16_t* h0,
                    const int32_t* cu_seqlens, int Bc, int T, int max_seqlen, int save, const uint16_t** h_final,
                    void* stream) {
-    const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
-    // (`residual`: added to the fc2 / out_proj output in the GEMM epilogue when possible; *folded reports it)
-    auto mlp = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out, const uint16_t* residual,
-                   bool* folded) -> int {
-        if (enc->gated) {
-            // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
-            CX_TRY(cx_gemm_bf16_swiglu(x, w.Wfc1, save ? s.yg(sl) : nullptr, s.act(sl), T, I, d, d, d, s.wfc1, I, stream));
-        } else {
-            // bias + erf-GELU in the GEMM epilogue; yg then holds the biased pre-activation, which backward reads with a
-            // NULL bias.  Shapes the fused kernel does not cover take the two-kernel route (yg without the bias).
-            const int rc = cx_gemm_bf16_bias_gelu(x, w.Wfc1, w.bfc1, save ? s.yg(sl) : nullptr, s.act(sl), T, s.wfc1, d, d, d,
-                                                  s.wfc1, I, stream);
-            if (rc == CX_ERR_SHAPE) {
-                CX_TRY(cx_gemm_bf16_nt(x, w.Wfc1, s.yg(sl), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
-                CX_TRY(cx_bias_gelu_fwd(s.yg(sl), w.bfc1, s.act(sl), T, I, stream));
-            } else {
-                CX_TRY(rc);
-            }
-        }
-        return proj_residual(s.act(sl), w.Wfc2, w.bfc2, residual, out, T, d, I, folded, stream);
-    };
-    auto attn = [&](const CxLayerWeights& w, const uint16_t* x, int sl, uint16_t* out, const uint16_t* residual,
-                    bool* folded) -> int {
-        CX_TRY(cx_gemm_bf16_nt(x, w.Wqkv, s.qkv(sl), w.bqkv, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.f, stream));
-        CX_TRY(cx_attn_varlen_fwd(s.qkv(sl), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(sl), s.lse(sl), Bc, H, T,
-                                  max_seqlen, enc->softmax_scale, stream));
-        return proj_residual(s.ctx(sl), w.Wout, w.bout, residual, out, T, d, d, folded, stream);
-    };
+    const int d = enc->d, L = enc->n_layer;
+    const BlockRunner run{enc, buf, s, cu_seqlens, Bc, T, max_seqlen, stream};
+    const bool keep = save == 1;  // save == 2 (checkpointing): only the block inputs are kept, by the slot mapping
     if (!enc->prenorm) {
         const uint16_t* h_in = h0;
         for (int l = 0; l < L; ++l) {
-            const CxLayerWeights& w = enc->layers[l];
-            const int sl = save ? l : 0;
-            // z = sublayer output + residual: added in the projection's epilogue when the fused kernel covers the shape
-            // (then z is complete in place and the LayerNorm reads one stream), else by the LayerNorm kernel, which
-            // writes z only when backward needs it.
-            bool f1 = false, f2 = false;
-            CX_TRY(attn(w, h_in, sl, s.z1(sl), h_in, &f1));
-            CX_TRY(cx_layernorm_fwd(s.z1(sl), f1 ? nullptr : h_in, w.ln1_g, w.ln1_b, s.h1(sl),
-                                    (save && !f1) ? s.z1(sl) : nullptr, s.mean1(sl), s.rstd1(sl), T, d, enc->ln_eps, stream));
-            CX_TRY(mlp(w, s.h1(sl), sl, s.z2(sl), s.h1(sl), &f2));
-            CX_TRY(cx_layernorm_fwd(s.z2(sl), f2 ? nullptr : s.h1(sl), w.ln2_g, w.ln2_b, s.h2(sl),
-                                    (save && !f2) ? s.z2(sl) : nullptr, s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
-            h_in = s.h2(sl);
+            CX_TRY(run.post_block(l, h_in, keep));
+            h_in = s.h2(l);
         }
         *h_final = h_in;
         return CX_OK;
@@ -156,22 +204,9 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
     const uint16_t* r = nullptr;   // residual stream
     bool r_folded = false;         // the residual stream was already added into x by a GEMM epilogue
     for (int l = 0; l < L; ++l) {
-        const CxLayerWeights& w = enc->layers[l];
-        const int sl = save ? l : 0;
-        // (when the previous fc2 folded the residual in, x == z1(sl) already holds the complete residual stream; for the
-        // first block x = h0 is copied into z1 by the kernel)
-        CX_TRY(cx_layernorm_fwd(x, r, w.ln1_g, w.ln1_b, s.h1(sl), (r_folded && x == s.z1(sl)) ? nullptr : s.z1(sl), s.mean1(sl),
-                                s.rstd1(sl), T, d, enc->ln_eps, stream));
-        bool f1 = false, f2 = false;
-        CX_TRY(attn(w, s.h1(sl), sl, s.z2(sl), s.z1(sl), &f1));
-        CX_TRY(cx_layernorm_fwd(s.z2(sl), f1 ? nullptr : s.z1(sl), w.ln2_g, w.ln2_b, s.h2(sl), f1 ? nullptr : s.z2(sl),
-                                s.mean2(sl), s.rstd2(sl), T, d, enc->ln_eps, stream));
-        // the MLP output lands where the next LayerNorm completes it in place: the next block's z1 slot, or zf
-        uint16_t* nxt = (l + 1 < L) ? s.z1(save ? l + 1 : 0) : buf->zf;
-        CX_TRY(mlp(w, s.h2(sl), sl, nxt, s.z2(sl), &f2));
-        x = nxt;
-        r = f2 ? nullptr : s.z2(sl);   // already folded into x by the fc2 epilogue
-        r_folded = f2;
+        CX_TRY(run.pre_block(l, x, r, r_folded, keep, false, &x, &r, &r_folded));
+        // checkpointing keeps ONE tensor per block, the complete residual stream z1(l): needs the fc2 epilogue fold
+        if (save == 2 && !r_folded) return CX_ERR_SHAPE;
     }
     CX_TRY(cx_layernorm_fwd(x, r, enc->lnf_g, enc->lnf_b, buf->hf, r_folded ? nullptr : buf->zf, buf->meanf, buf->rstdf, T,
                             d, enc->ln_eps, stream));
@@ -253,12 +288,16 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         CX_TRY(wgrad(buf->g_wide, 3 * d, attn_in, d, w.gWqkv, buf, T, stream));
         return proj_residual(buf->g_wide, w.WqkvT, nullptr, add, buf->g_b, T, d, 3 * d, folded, stream);
     };
+    // activation checkpointing (slot mode 2): the block's intermediates are recomputed from its saved input into slot 0
+    // right before its backward (bit-identical: every kernel on the path is deterministic)
+    const BlockRunner run{enc, buf, s, cu_seqlens, Bc, T, max_seqlen, stream};
     if (!enc->prenorm) {
         const uint16_t* da = buf->g_a;
         const uint16_t* db = nullptr;
         for (int l = L - 1; l >= 0; --l) {
             const CxLayerWeights& w = enc->layers[l];
             const uint16_t* h_in = (l == 0) ? buf->h0 : s.h2(l - 1);
+            if (s.mode == 2) CX_TRY(run.post_block(l, h_in, true));
             // LN2: dz2 = grad of (mlp_out + h1)
             CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
                                     w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
@@ -282,6 +321,12 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
     for (int l = L - 1; l >= 0; --l) {   // invariant: buf->g_c = d(x_l + r_l) = gradient of both the MLP output and r
         const CxLayerWeights& w = enc->layers[l];
         bool unused = false;
+        if (s.mode == 2) {
+            const uint16_t* xo = nullptr;
+            const uint16_t* ro = nullptr;
+            bool fo = false;
+            CX_TRY(run.pre_block(l, s.z1(l), nullptr, true, true, /*up_only*/ true, &xo, &ro, &fo));
+        }
         CX_TRY(mlp_bwd(w, l, buf->g_c, s.h2(l), nullptr, &unused));    // -> g_b = d h2
         CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), /*dz_extra*/ buf->g_c,
                                 buf->g_a, w.gln2_g, w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
@@ -305,11 +350,11 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
     CX_TRY(check_desc(enc, buf, T));
     (void)hipGetLastError();  // a stale error of some earlier, unrelated runtime call must not fail this launch train
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
     const uint16_t* h_final = nullptr;
-    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, save_for_backward, &h_final, stream));
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, s.mode, &h_final, stream));
     return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
                                  stream);
 }
@@ -323,7 +368,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
                                  enc->normalize, stream));
@@ -344,11 +389,11 @@ int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* bu
     if (!hidden_out) return CX_ERR_ARG;
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
     const uint16_t* h_final = nullptr;
-    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, save_for_backward, &h_final, stream));
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, s.mode, &h_final, stream));
     return hipMemcpyAsync(hidden_out, h_final, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
                           (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
@@ -362,7 +407,7 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
     CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     if (hipMemcpyAsync(buf->g_a, dhidden, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
                        (hipStream_t)stream) != hipSuccess)
@@ -387,13 +432,13 @@ int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const vo
     if (enc->patch_dim != Cc * patch * patch || (enc->patch_dim % 64) != 0) return CX_ERR_SHAPE;
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
     CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
     CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
                            enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
     CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
     const uint16_t* h_final = nullptr;
-    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, save_for_backward, &h_final, stream));
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, s.mode, &h_final, stream));
     return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
                                  stream);
 }
@@ -408,7 +453,7 @@ int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const i
     CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I};
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
                                  enc->normalize, stream));
@@ -430,7 +475,7 @@ int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const i
     return wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream);
 }
 
-int cx_abi_version(void) { return 1; }
+int cx_abi_version(void) { return 2; }  // 2: CxChunkBuffers.checkpoint
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

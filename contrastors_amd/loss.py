@@ -54,6 +54,10 @@ class _FusedInfoNCE(torch.autograd.Function):
             d = d.contiguous()
         N, dim = q.shape
         G = d.shape[0]
+        if labels.shape[0] != N:
+            raise ValueError(f"labels has {labels.shape[0]} entries for {N} query rows")  # F.cross_entropy raises too
+        if (N % 4) or (G % 4) or (dim % 4):
+            raise ValueError(f"fused InfoNCE needs N, G and dim to be multiples of 4 (got {N}, {G}, {dim})")
         ws = torch.empty(lib.cx_infonce_ws_floats(N, G), dtype=torch.float32, device=q.device)
         lse = torch.empty(N, dtype=torch.float32, device=q.device)
         rows = torch.empty(N, dtype=torch.float32, device=q.device)
@@ -109,8 +113,16 @@ def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tra
     rank = dist.get_rank() if inited else 0
     world = dist.get_world_size() if inited else 1  # the reference requires an initialised group (quirk 3)
     n = query.shape[0]
-    labels = make_labels(n, document.shape[0], rank, world, query.device)
+    G = document.shape[0]
+    # the label vector is a host formula: check its range here (a label outside [0, G) would read a garbage logit;
+    # F.cross_entropy in the reference raises) -- no device sync needed
+    if n * world > G or (n - 1 + rank * n) * (G // (n * world)) >= G:
+        raise ValueError(f"labels out of range: {n} queries on rank {rank}/{world} against {G} gathered documents")
+    labels = make_labels(n, G, rank, world, query.device)
     scale, scale_param = _scale_of(logit_scale)
+    if bidirectional and G != n:
+        raise ValueError("bidirectional clip_loss needs as many documents as queries (sc/loss.py:119-123 only "
+                         "type-checks for one process without negatives)")
     if bidirectional:
         # sc/loss.py:119-123: CE(q->d) + CE(d->q) with the same labels, no world-size factor
         l_qd = _FusedInfoNCE.apply(query, document, labels, scale, 1.0 / n, scale_param)

@@ -101,12 +101,18 @@ class _ChunkArena:
     """Device memory for one in-flight chunk (CxChunkBuffers).  `n_slots` = 1 for no-grad forwards, n_layer else."""
 
     def __init__(self, cfg: NomicBertConfig, T_cap: int, n_slots: int, with_backward: bool, B_cap: int,
-                 device: torch.device):
+                 device: torch.device, checkpoint: bool = False):
         d, I, H = cfg.n_embd, cfg.n_inner, cfg.n_head
         wfc1 = 2 * I if cfg.gated else I
         bf = dict(dtype=torch.bfloat16, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         self.T_cap, self.n_slots, self.with_backward, self.B_cap = T_cap, n_slots, with_backward, B_cap
+        self.checkpoint = bool(checkpoint and with_backward)
+        # activation checkpointing: only the tensor carrying a block's input keeps one slot per layer (CxChunkBuffers)
+        kept = ("z1" if getattr(cfg, "prenorm", False) else "h2") if self.checkpoint else None
+        n_layer_slots = n_slots
+        if self.checkpoint:
+            n_slots = 1
         t: Dict[str, torch.Tensor] = {}
         t["h0"] = torch.empty(T_cap, d, **bf)
         t["emb_mean"] = torch.empty(T_cap, **f32)
@@ -115,7 +121,7 @@ class _ChunkArena:
         t["ctx"] = torch.empty(n_slots, T_cap, d, **bf)
         t["lse"] = torch.empty(n_slots, T_cap * H, **f32)
         for n in ("z1", "h1", "z2", "h2"):
-            t[n] = torch.empty(n_slots, T_cap, d, **bf)
+            t[n] = torch.empty(n_layer_slots if n == kept else n_slots, T_cap, d, **bf)
         for n in ("mean1", "rstd1", "mean2", "rstd2"):
             t[n] = torch.empty(n_slots, T_cap, **f32)
         t["yg"] = torch.empty(n_slots, T_cap, wfc1, **bf)
@@ -147,6 +153,8 @@ class _ChunkArena:
         for name, _ in _C.CxChunkBuffers._fields_[1:]:
             if name == "ws_floats":
                 self.desc.ws_floats = t["ws_f32"].numel() if "ws_f32" in t else 0
+            elif name == "checkpoint":
+                self.desc.checkpoint = int(self.checkpoint)
             else:
                 setattr(self.desc, name, t[name].data_ptr() if name in t else None)
         self.emb_out: Optional[torch.Tensor] = None  # set by a saving forward, consumed by backward
@@ -256,6 +264,9 @@ class NomicBertEngine(torch.nn.Module):
         self._build_desc()
         self._arena_nograd: Optional[_ChunkArena] = None
         self._arena_free: List[_ChunkArena] = []
+        # BiEncoderConfig.gradient_checkpointing (sc/models/biencoder/modeling_biencoder.py:261-262): a saving forward
+        # keeps one (T, d) tensor per block and backward recomputes the rest block by block (engine.hip, slot mode 2)
+        self.gradient_checkpointing = False
         self.sync_shadows()
 
     # ------------------------------------------------------------------------------------------------ parameters
@@ -501,14 +512,19 @@ class NomicBertEngine(torch.nn.Module):
                 a = _ChunkArena(self.config, T_cap, 1, False, max(B, 1), self.device_)
                 self._arena_nograd = a
             return a
+        ck = bool(self.gradient_checkpointing)
         for i, a in enumerate(self._arena_free):
-            if a.T_cap >= T_cap and a.B_cap >= B:
+            if a.T_cap >= T_cap and a.B_cap >= B and a.checkpoint == ck:
                 return self._arena_free.pop(i)
-        return _ChunkArena(self.config, T_cap, self.config.n_layer, True, max(B, 1), self.device_)
+        return _ChunkArena(self.config, T_cap, self.config.n_layer, True, max(B, 1), self.device_, checkpoint=ck)
 
     def release_arena(self, arena: _ChunkArena):
         arena.emb_out = None
         self._arena_free.append(arena)
+
+    def gradient_checkpointing_enable(self, enabled: bool = True):
+        self.gradient_checkpointing = bool(enabled)
+        self._arena_free = [a for a in self._arena_free if a.checkpoint == self.gradient_checkpointing]
 
     # ------------------------------------------------------------------------------------------------ compute
     def forward_chunk(self, vb: VarlenBatch, save_for_backward: bool, normalize: Optional[bool] = None,

@@ -65,7 +65,7 @@ def main():
         tok = AutoTokenizer.from_pretrained(config.model_args.tokenizer_name, local_files_only=True)
         if config.data_args.streaming:
             ds = get_streaming_dataset(config, tok, run_name=getattr(config.train_args, "wandb_run_name", None) or "run")
-            trainer.total_steps = max(1, len(ds) // config.data_args.batch_size)
+            trainer.set_total_steps(len(ds) // config.data_args.batch_size)  # before the first step: the LR horizon
             trainer.train(iter(ds), log_every=10)
         else:  # sc/trainers/text_text.py:228-244: map-style dataset + DistributedSampler, per-rank batch
             from .data import get_local_dataloader
@@ -73,7 +73,7 @@ def main():
             dl = get_local_dataloader(config.data_args.input_shards, per_rank, tok, seed=config.data_args.seed,
                                       num_negatives=config.model_args.num_negatives,
                                       add_prefix=config.model_args.add_prefix, num_workers=config.data_args.workers)
-            trainer.total_steps = max(1, len(dl.dataset) // config.data_args.batch_size)
+            trainer.set_total_steps(len(dl.dataset) // config.data_args.batch_size)
             trainer.train(iter(dl), log_every=10)
     elif config.model_args.model_type == "mlm":
         from .mlm import synthetic_mlm_batches

@@ -41,6 +41,48 @@ def _lr_lambda(schedule: str, warmup: int, total: int):
     return f
 
 
+def _load_initial_weights(model: BiEncoder, ma, explicit_arch: bool):
+    """sc/trainers/text_text.py:139-160 + sc/models/biencoder/modeling_biencoder.py:160-250: `checkpoint` = a
+    BiEncoder.save_pretrained directory, `pretrained` = hub weights of `model_name`.  There is no hub here: a local
+    directory in `model_name` is loaded (native safetensors layout, or a HuggingFace BERT checkpoint through the
+    reference's remap, hf_bert.py); otherwise `pretrained: true` RAISES instead of silently training from a random init.
+    An explicitly passed trunk architecture (tests, benchmarks) is a declared random init."""
+    import os
+
+    ckpt = getattr(ma, "checkpoint", None)
+    if ckpt:
+        model.load_pretrained(ckpt)
+        return
+    if not getattr(ma, "pretrained", False) or explicit_arch:
+        return
+    name = ma.model_name or ""
+    if os.path.isdir(name):
+        if os.path.exists(os.path.join(name, "model.safetensors")) and os.path.exists(os.path.join(name, "config.json")):
+            import json
+
+            cfg = json.load(open(os.path.join(name, "config.json")))
+            if "trunk_config" in cfg:  # written by BiEncoder.save_pretrained
+                model.load_pretrained(name)
+                return
+        from transformers import BertConfig
+
+        from .hf_bert import load_hf_bert
+
+        hf_cfg = BertConfig.from_pretrained(name, local_files_only=True)
+        st = os.path.join(name, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(name, "pytorch_model.bin"), map_location="cpu")
+        load_hf_bert(model.trunk, sd, hf_cfg)
+        return
+    raise FileNotFoundError(
+        f"model_args.pretrained is true but {name!r} is not a local directory (no hub access): point model_name / "
+        "checkpoint at local weights, or set pretrained: false to train from a random init")
+
+
 class TextTextTrainer:
     def __init__(self, config: Config, dtype=torch.bfloat16, device=None, trunk_config: Optional[NomicBertConfig] = None,
                  total_steps: Optional[int] = None):
@@ -58,17 +100,35 @@ class TextTextTrainer:
         self.scheduler = self.get_scheduler(config, self.optimizer)
         self.step = 0
 
+    def set_total_steps(self, total_steps: int):
+        """The schedule horizon is baked into the LR lambda: derive it from the dataloader BEFORE training starts
+        (sc/trainers/base.py:228-243 computes it from len(dataloader)); this rebuilds the scheduler for a new horizon."""
+        if self.step != 0:
+            raise RuntimeError("set_total_steps after training started")
+        self.total_steps = max(1, int(total_steps))
+        self.scheduler = self.get_scheduler(self.config, self.optimizer)
+
     # sc/trainers/text_text.py:139-182
     def get_model(self, config: Config, trunk_config=None) -> Dict[str, torch.nn.Module]:
         ma = config.model_args
         bc = BiEncoderConfig(model_name=ma.model_name or "", pooling=ma.pooling, logit_scale=ma.logit_scale,
                              trainable_logit_scale=ma.trainable_logit_scale, projection_dim=ma.projection_dim,
-                             freeze=ma.freeze, hamming=ma.hamming, nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
+                             freeze=ma.freeze, hamming=ma.hamming, gradient_checkpointing=ma.gradient_checkpointing,
+                                 nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
                              trunk_config=trunk_config)
         model = BiEncoder(bc, device=self.device).train()
+        _load_initial_weights(model, ma, explicit_arch=trunk_config is not None)
         model.broadcast_parameters(0)  # what DDP's constructor does
         scale = LogitScale(SimpleNamespace(logit_scale=ma.logit_scale, trainable_logit_scale=ma.trainable_logit_scale))
         return {"model": model, "logit_scale": scale.to(self.device)}
+
+    def _sync_logit_scale_grad(self):
+        """A trainable LogitScale is DDP-wrapped in the reference (sc/trainers/text_text.py:172-178): average its
+        gradient over ranks like every other parameter."""
+        ls = self.model["logit_scale"].logit_scale if "logit_scale" in self.model else None
+        if ls is not None and ls.grad is not None and self.distributed and self.world > 1:
+            dist.all_reduce(ls.grad)
+            ls.grad.div_(self.world)
 
     # sc/optimizer.py:7-47 (decay / no-decay groups, torch AdamW)
     def get_optimizer(self, config: Config):
@@ -107,7 +167,9 @@ class TextTextTrainer:
             raise ValueError("negatives must be folded into document_* (sc/trainers/text_text.py:346-347)")
         q, d = self._inputs(batch, "query"), self._inputs(batch, "document")
         if ta.grad_cache:
-            return grad_cache_loss(model, q, model, d, ta.chunk_size, scale)
+            loss = grad_cache_loss(model, q, model, d, ta.chunk_size, scale)
+            self._sync_logit_scale_grad()
+            return loss
         dims = ta.matryoshka_dims
         normalize = dims is None  # sc/trainers/text_text.py:325
         queries = model(**q, normalize=normalize)["embedding"]
@@ -129,6 +191,7 @@ class TextTextTrainer:
             return  # gradients were accumulated inside grad_cache_loss (text_text.py:292-302)
         loss.backward()
         self.model["model"].sync_gradients()
+        self._sync_logit_scale_grad()
 
     # sc/trainers/base.py:366-393
     def training_step(self, batch) -> torch.Tensor:
@@ -150,6 +213,12 @@ class TextTextTrainer:
         m = self.model["model"]
         return {"model": m} if hasattr(m, "trunk") else {"text": m.text, "vision": m.vision}
 
+    def _logit_scale_param(self):
+        if "logit_scale" in self.model:
+            return self.model["logit_scale"].logit_scale
+        m = self.model["model"]
+        return m.logit_scale.logit_scale if hasattr(m, "logit_scale") else None
+
     def save_state(self, output_dir: str):
         import os
         import random
@@ -158,9 +227,14 @@ class TextTextTrainer:
         if self.rank == 0:
             for name, tower in self._towers().items():
                 tower.save_pretrained(os.path.join(output_dir, name))
+            ls = self._logit_scale_param()
+            if ls is not None and ls.requires_grad:  # sc/trainers/text_text.py:247-255: saved next to the towers
+                torch.save({"logit_scale": ls.detach().cpu()}, os.path.join(output_dir, "logit_scale.pt"))
             torch.save(self.optimizer.state_dict(), os.path.join(output_dir, "optimizer.pt"))
-            torch.save({"scheduler": self.scheduler.state_dict(), "step": self.step},
-                       os.path.join(output_dir, "scheduler.pt"))
+            # reference layout (sc/trainers/base.py:275-344): scheduler.pt IS the scheduler's state_dict; the step counter
+            # travels in its own file
+            torch.save(self.scheduler.state_dict(), os.path.join(output_dir, "scheduler.pt"))
+            torch.save({"step": self.step}, os.path.join(output_dir, "trainer_state.pt"))
         torch.save({"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "random": random.getstate(),
                     "cuda": torch.cuda.get_rng_state_all()}, os.path.join(output_dir, f"random_states_{self.rank}.pt"))
 
@@ -171,9 +245,19 @@ class TextTextTrainer:
         for name, tower in self._towers().items():
             tower.load_pretrained(os.path.join(input_dir, name))
         self.optimizer.load_state_dict(torch.load(os.path.join(input_dir, "optimizer.pt"), map_location=self.device))
+        ls = self._logit_scale_param()
+        ls_path = os.path.join(input_dir, "logit_scale.pt")
+        if ls is not None and os.path.exists(ls_path):
+            with torch.no_grad():
+                ls.copy_(torch.load(ls_path)["logit_scale"].to(ls.device))
         sch = torch.load(os.path.join(input_dir, "scheduler.pt"))
-        self.scheduler.load_state_dict(sch["scheduler"])
-        self.step = int(sch["step"])
+        if "scheduler" in sch and "step" in sch:  # round-1 layout
+            self.scheduler.load_state_dict(sch["scheduler"])
+            self.step = int(sch["step"])
+        else:
+            self.scheduler.load_state_dict(sch)
+            st = os.path.join(input_dir, "trainer_state.pt")
+            self.step = int(torch.load(st)["step"]) if os.path.exists(st) else int(sch.get("last_epoch", 0))
         rs = torch.load(os.path.join(input_dir, f"random_states_{self.rank}.pt"), weights_only=False)
         torch.set_rng_state(rs["torch"])
         np.random.set_state(rs["numpy"])
@@ -213,9 +297,11 @@ class ImageTextTrainer(TextTextTrainer):
         for ma, trunk in zip((config.text_model_args, config.vision_model_args), self._trunks):
             bc = BiEncoderConfig(model_name=ma.model_name or "", pooling=ma.pooling, logit_scale=ma.logit_scale,
                                  trainable_logit_scale=ma.trainable_logit_scale, projection_dim=ma.projection_dim,
-                                 freeze=ma.freeze, hamming=ma.hamming, nomic_encoder=ma.nomic_encoder,
+                                 freeze=ma.freeze, hamming=ma.hamming, gradient_checkpointing=ma.gradient_checkpointing,
+                                 nomic_encoder=ma.nomic_encoder,
                                  seq_len=ma.seq_len, trunk_config=trunk)
             tower = BiEncoder(bc, device=self.device).train()
+            _load_initial_weights(tower, ma, explicit_arch=trunk is not None)
             tower.broadcast_parameters(0)
             towers.append(tower)
         va = config.vision_model_args  # the reference takes the logit scale from the image tower's args

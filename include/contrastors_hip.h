@@ -279,6 +279,12 @@ typedef struct CxChunkBuffers {
     /* ViT front end: patchified pixels (Bc*n_patch rounded up to 64 rows, patch_dim) and their projection (.., d);
      * patch_proj doubles as the gradient of the projection in backward */
     uint16_t* patch_in; uint16_t* patch_proj;
+    /* activation checkpointing (sc/models/encoder/modeling_nomic_bert.py:339-365 gradient_checkpointing,
+     * sc/models/vit/vit.py:200-231): != 0 -> a saving forward keeps ONE (T,d) tensor per block -- `h2` (post-norm: the
+     * block's output = the next block's input) or `z1` (pre-norm: the residual stream at LN1) has n_layer slots, every
+     * other per-layer buffer has a single slot -- and backward recomputes each block from it before differentiating
+     * it.  Results are bit-identical to checkpoint = 0; the arena shrinks from ~31 KB to ~1.5 KB per token and layer. */
+    int checkpoint;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.

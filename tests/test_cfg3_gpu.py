@@ -1,0 +1,144 @@
+"""BASELINE configs[2] end to end: nomic-embed-text-v1 finetune -- triplets with hard negatives
+folded into the document side (1 positive + 7 negatives per query, sc/dataset/text_text_loader.py:575-586), sequences up
+to 2048 tokens, `hamming: true` (LayerNorm without affine on the pooled vector), Matryoshka prefixes {768,512,256,128},
+NO GradCache -- driven through TextTextTrainer.forward_step / backward (sc/trainers/text_text.py:324-378) and judged
+against the fp32 oracle (oracle/encoder_ref.py + oracle/infonce_ref.py) with the reference's own rule
+err <= 3 x err(bf16 eager) (tests/test_flash_bert.py:77-82)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from contrastors_amd.config import Config, DataArgs, ModelArgs, TrainArgs
+from contrastors_amd.nomic_bert import NomicBertConfig
+from contrastors_amd.trainers import TextTextTrainer
+from oracle import encoder_ref, infonce_ref
+from tests.gpu_util import rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DIMS = [768, 512, 256, 128]
+
+
+def _trainer(n_layer, vocab, checkpointing=False, batch=4):
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=1, grad_cache=False,
+                                      schedule_type="linear", max_grad_norm=1.0, clamp_logits=False,
+                                      matryoshka_dims=DIMS),
+                 data_args=DataArgs(batch_size=batch, seed=3),
+                 model_args=ModelArgs(logit_scale=50.0, pooling="mean", model_name="cfg3", hamming=True, num_negatives=7,
+                                      gradient_checkpointing=checkpointing, seq_len=2048))
+    tc = NomicBertConfig.nomic_bert_2048(vocab_size=vocab, n_layer=n_layer)
+    return TextTextTrainer(cfg, torch.bfloat16, device=DEV, trunk_config=tc, total_steps=10), tc
+
+
+def _triplet_batch(n_query, S, vocab, seed, full_len_first=True):
+    """Loader contract with folded negatives: document rows [pos_0, neg_0_1..7, pos_1, ...]."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for side, n in (("query", n_query), ("document", 8 * n_query)):
+        lens = torch.randint(48, S + 1, (n,), generator=g)
+        if full_len_first:
+            lens[0] = S
+        ids = torch.randint(5, vocab, (n, S), generator=g)
+        ids[:, 0] = 101
+        mask = (torch.arange(S)[None] < lens[:, None]).long()
+        out[f"{side}_input_ids"] = ids * mask
+        out[f"{side}_attention_mask"] = mask
+        out[f"{side}_seqlens"] = lens.numpy()
+    return out
+
+
+def _oracle_loss(sd, ns, batch, scale, bf16):
+    """fp32 (or bf16-autocast eager) restatement of the step: one sequence at a time (no padding waste at S = 2048)."""
+    sdd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd.items()}
+
+    def embed(prefix):
+        rows = []
+        ids, mask = batch[f"{prefix}_input_ids"].to(DEV), batch[f"{prefix}_attention_mask"].to(DEV)
+        for i in range(ids.shape[0]):
+            n = int(mask[i].sum())
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                rows.append(encoder_ref.biencoder_embedding(sdd, ns, ids[i: i + 1, :n], mask[i: i + 1, :n], normalize=False,
+                                                            hamming=True).float())
+        return torch.cat(rows)
+
+    q, d = embed("query"), embed("document")
+    loss = 0.0
+    labels = torch.from_numpy(infonce_ref.labels_for(q.shape[0], d.shape[0], 0, 1)).to(DEV)   # stride 8: 1 pos + 7 neg
+    for dim in DIMS:  # sc/trainers/text_text.py:352-369, unit weights; sc/loss.py:108-125 at world size 1
+        sim = F.normalize(q[:, :dim], dim=-1) @ F.normalize(d[:, :dim], dim=-1).T * scale
+        loss = loss + F.cross_entropy(sim, labels)
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in sdd.items()}
+
+
+def test_cfg3_direct_matryoshka_hamming_triplet_step_vs_oracle():
+    tr, tc = _trainer(n_layer=12, vocab=4096)
+    ns = SimpleNamespace(**{k: getattr(tc, k) for k in tc.__dataclass_fields__})
+    sd = encoder_ref.random_state_dict(ns, 17)
+    model = tr.model["model"]
+    model.trunk.load_reference_state_dict(sd)
+    batch = _triplet_batch(n_query=4, S=2048, vocab=4096, seed=23)
+    model.trunk.zero_grad()
+    loss = tr.forward_step(batch)
+    tr.backward(loss)
+    torch.cuda.synchronize()
+    ref, g32 = _oracle_loss(sd, ns, batch, 50.0, bf16=False)
+    ref16, g16 = _oracle_loss(sd, ns, batch, 50.0, bf16=True)
+    e_loss, e_loss16 = abs(float(loss) - float(ref)), abs(float(ref16) - float(ref))
+    grads = model.trunk.reference_grad_dict()
+    worst, worst_name = 0.0, ""
+    for n, gh in grads.items():
+        eh, eb = rel_err(gh, g32[n]), rel_err(g16[n].float(), g32[n])
+        ratio = eh / max(eb, 1e-9)
+        if ratio > worst:
+            worst, worst_name = ratio, n
+        assert eh <= 3 * eb + 2e-2, f"{n}: rel err {eh:.4f} vs bf16 eager {eb:.4f}"
+    report("cfg3_direct_step", loss=float(loss), loss_ref=float(ref), e_loss=e_loss, e_loss_bf16=e_loss16,
+           worst_grad_ratio=worst, worst_name=worst_name)
+    assert e_loss <= 3 * e_loss16 + 2e-3 * abs(float(ref)), (float(loss), float(ref), float(ref16))
+
+
+def test_cfg3_checkpointed_step_matches_plain_step():
+    """gradient_checkpointing through the trainer: identical loss, identical gradients (up to embedding atomics)."""
+    batch = _triplet_batch(n_query=4, S=512, vocab=2048, seed=5)
+    res = {}
+    for ck in (False, True):
+        tr, _ = _trainer(n_layer=3, vocab=2048, checkpointing=ck, batch=4)
+        assert tr.model["model"].trunk.gradient_checkpointing == ck
+        if res:
+            tr.model["model"].trunk.flat_param.copy_(res[False][2])
+            tr.model["model"].trunk.sync_shadows()
+        p0 = tr.model["model"].trunk.flat_param.clone()
+        tr.model["model"].trunk.zero_grad()
+        loss = tr.forward_step(batch)
+        tr.backward(loss)
+        torch.cuda.synchronize()
+        res[ck] = (float(loss), tr.model["model"].trunk.flat_grad.clone(), p0)
+    assert res[False][0] == res[True][0]
+    assert float((res[False][1] - res[True][1]).abs().max()) <= 1e-4 * float(res[False][1].abs().max())  # embedding atomics order
+
+
+def test_cfg3_baseline_per_gpu_shape_fits_with_checkpointing():
+    """configs[2] per-GPU shape: 32 queries + 256 documents x 2048 tokens (590 k tokens), direct step, Matryoshka, hamming.
+    Saved activations without checkpointing would be ~369 KB/token = 217 GB; with it the step has to fit comfortably."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    tr, tc = _trainer(n_layer=12, vocab=30528, checkpointing=True, batch=32)
+    g = torch.Generator().manual_seed(1)
+    S = 2048
+    batch = {}
+    for side, n in (("query", 32), ("document", 256)):
+        batch[f"{side}_input_ids"] = torch.randint(1000, 30522, (n, S), generator=g)
+        batch[f"{side}_seqlens"] = np.full(n, S)
+    loss = tr.training_step(batch)
+    torch.cuda.synchronize()
+    peak = (torch.cuda.max_memory_allocated() - base) / 2**30
+    report("cfg3_baseline_shape", loss=float(loss), peak_hbm_gb=peak, tokens=288 * S)
+    assert np.isfinite(float(loss)) and peak < 120.0

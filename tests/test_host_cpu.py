@@ -79,3 +79,37 @@ def test_reference_mlm_recipe_yaml_loads_unchanged():
     from contrastors_amd.trainers import TRAINER_REGISTRY
 
     assert set(TRAINER_REGISTRY) >= {"encoder", "image_text", "locked_text", "mlm"}
+
+
+def test_pretrained_without_local_weights_raises():
+    """`pretrained: true` (the reference default, sc/config.py:161) must not silently train from scratch."""
+    from contrastors_amd.config import ModelArgs
+    from contrastors_amd.trainers import _load_initial_weights
+
+    ma = ModelArgs(model_name="nomic-ai/nomic-bert-2048")
+    assert ma.pretrained is True and ma.checkpoint is None
+    with pytest.raises(FileNotFoundError):
+        _load_initial_weights(object(), ma, explicit_arch=False)
+    _load_initial_weights(object(), ma, explicit_arch=True)          # explicit architecture = declared random init
+    _load_initial_weights(object(), ModelArgs(pretrained=False), explicit_arch=False)
+
+
+def test_lr_horizon_follows_set_total_steps():
+    """the schedule horizon must come from the dataset length, before the scheduler is built."""
+    from contrastors_amd.trainers import TextTextTrainer
+
+    class _T(TextTextTrainer):  # scheduler plumbing only: no device, no model
+        def __init__(self, cfg):
+            self.config, self.step, self.total_steps = cfg, 0, 10_000
+            self.optimizer = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+            self.scheduler = self.get_scheduler(cfg, self.optimizer)
+
+    cfg = Config(train_args=TrainArgs(warmup_pct=0.1, schedule_type="linear", learning_rate=1.0))
+    t = _T(cfg)
+    t.set_total_steps(100)
+    lrs = []
+    for _ in range(100):
+        lrs.append(t.scheduler.get_last_lr()[0])
+        t.optimizer.step()
+        t.scheduler.step()
+    assert abs(lrs[9] - 1.0) < 1e-6 and lrs[0] == pytest.approx(0.1) and lrs[99] < 0.02

@@ -13,11 +13,12 @@ from oracle.make_golden import TINY_NOMIC
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(grad_cache: bool):
+def _trainer(grad_cache: bool, trainable_scale: bool = False):
     cfg = Config(train_args=TrainArgs(learning_rate=1e-3, weight_decay=0.01, warmup_steps=1, grad_cache=grad_cache,
                                       chunk_size=4, schedule_type="linear", max_grad_norm=1.0, clamp_logits=False),
                  data_args=DataArgs(batch_size=16, seed=7),
-                 model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny"))
+                 model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny",
+                                      trainable_logit_scale=trainable_scale))
     tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
     return TextTextTrainer(cfg, torch.bfloat16, device="cuda", trunk_config=tc, total_steps=20)
 
@@ -74,14 +75,18 @@ def test_checkpoint_resume_is_exact(tmp_path):
     from safetensors.torch import load_file
 
     batches = list(synthetic_batches(4, 16, 32, vocab=512, ragged=True))
-    a = _trainer(True)
+    a = _trainer(True, trainable_scale=True)
     a.training_step(batches[0])
     a.training_step(batches[1])
     a.save_state(str(tmp_path / "ckpt"))
     la = a.training_step(batches[2])
-    b = _trainer(True)
+    b = _trainer(True, trainable_scale=True)
     b.load_state(str(tmp_path / "ckpt"))
     assert b.step == 2
+    # a trainable logit scale travels with the checkpoint (sc/trainers/text_text.py:247-255), and scheduler.pt is the bare
+    # scheduler state_dict of the reference layout (sc/trainers/base.py:275-344)
+    assert float(b.model["logit_scale"].logit_scale) != float(torch.log(torch.tensor(20.0)))
+    assert "last_epoch" in torch.load(str(tmp_path / "ckpt" / "scheduler.pt"))
     lb = b.training_step(batches[2])
     assert float(la) == float(lb)
     # the word-embedding gradient is scattered with fp32 atomics (order-dependent in the last bits); everything else in
@@ -106,7 +111,8 @@ def test_train_cli_runs_reference_recipe_shape(tmp_path):
                           "logit_max": 100, "wandb": False},
            "model_args": {"logit_scale": 50, "trainable_logit_scale": False, "model_type": "encoder", "seq_len": 2048,
                           "pooling": "mean", "nomic_encoder": True, "add_prefix": True,
-                          "tokenizer_name": "bert-base-uncased", "model_name": "nomic-ai/nomic-bert-2048"},
+                          "tokenizer_name": "bert-base-uncased", "model_name": "nomic-ai/nomic-bert-2048",
+                          "pretrained": False},  # declared random init: `pretrained: true` without local weights raises
            "data_args": {"workers": 0, "batch_size": 16384, "seed": 42, "shuffle": False}}
     path = tmp_path / "recipe.yaml"
     path.write_text(yaml.safe_dump(cfg))
