@@ -119,6 +119,10 @@ _SIGS = {
     "cx_infonce_ws_floats": (i64, [i32, i32]),
     "cx_infonce_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_infonce_bwd": (i32, [vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_infonce_fp8_ws_floats": (i64, [i32, i32]),
+    "cx_infonce_fp8_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_infonce_fp8_bwd": (i32, [vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32,
+                                 i32, i32, vp]),
     "cx_sgemm_nt": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "cx_transpose_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "cx_encoder_forward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,

@@ -207,12 +207,13 @@ class DualEncoder(torch.nn.Module):
     any modules returning {"embedding": ...}: the native BiEncoder over a NomicBertEngine (text) or a ViTEngine (image)."""
 
     def __init__(self, text: torch.nn.Module, vision: torch.nn.Module, logit_scale: LogitScale,
-                 precomputed_text: bool = False):
+                 precomputed_text: bool = False, use_fp8: Optional[bool] = None):
         super().__init__()
         if precomputed_text and not getattr(text, "frozen_trunk", False):
             raise AssertionError("Precomputed text model must be frozen")  # modeling_dual_encoder.py:16-18
         self.text, self.vision, self.logit_scale = text, vision, logit_scale
         self.precomputed_text = precomputed_text
+        self.use_fp8 = use_fp8  # None: the process default (loss.set_similarity_fp8); cfg 5 sets `use_fp8: true`
 
     def encode_text(self, text, normalize=True):  # modeling_dual_encoder.py:26-29
         return self.text(**text, normalize=normalize)["embedding"]
@@ -221,7 +222,7 @@ class DualEncoder(torch.nn.Module):
         return self.vision(vision, normalize=normalize)["embedding"]
 
     def forward(self, text_inputs, vision_inputs):
-        from .loss import _FusedInfoNCE, _scale_of
+        from .loss import _infonce, _scale_of
 
         if self.precomputed_text:  # LiT with text embeddings computed offline (:37-41): the text tower is not run
             if "text_embs" not in text_inputs:
@@ -239,6 +240,6 @@ class DualEncoder(torch.nn.Module):
         labels = torch.arange(n, device=vision_emb.device) + n * rank
         scale, sp = _scale_of(self.logit_scale)
         coef = 0.5 * world / n
-        loss = (_FusedInfoNCE.apply(vision_emb, all_text, labels, scale, coef, sp)
-                + _FusedInfoNCE.apply(text_emb, all_vis, labels, scale, coef, sp))
+        loss = (_infonce(vision_emb, all_text, labels, scale, coef, sp, self.use_fp8)
+                + _infonce(text_emb, all_vis, labels, scale, coef, sp, self.use_fp8))
         return {"loss": loss, "image_text_loss": loss}

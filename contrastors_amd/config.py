@@ -47,6 +47,9 @@ class TrainArgs(BaseModel):
     matryoshka_dims: Optional[List[int]] = None
     matryoshka_loss_weights: Optional[List[float]] = None
     profile: Optional[bool] = False
+    # the reference YAMLs carry this key (contrastive_pretrain.yaml:24) without a TrainArgs field or any code behind it;
+    # here it selects the fp8 matrix-core similarity GEMM of the fused InfoNCE (BASELINE configs[4])
+    use_fp8: Optional[bool] = False
 
     @model_validator(mode="after")
     def _checks(self):

@@ -35,6 +35,79 @@ def _scale_of(logit_scale) -> tuple:
     return float(p.detach().exp().item()), (p if p.requires_grad else None)
 
 
+class _FusedInfoNCEFp8(torch.autograd.Function):
+    """Same loss with the similarity GEMM on the fp8 matrix cores (cx_infonce_fp8_fwd / _bwd; BASELINE configs[4],
+    `use_fp8: true`).  Shapes the fp8 backward does not cover raise (no silent switch of numerics)."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, d: torch.Tensor, labels: torch.Tensor, scale: float, coef: float,
+                scale_param: Optional[torch.Tensor]):
+        if not q.is_cuda:
+            raise RuntimeError("fused InfoNCE needs the HIP device path (no CPU fallback)")
+        lib = _C.lib()
+        q = q.float() if q.dtype != torch.float32 else q
+        d = d.float() if d.dtype != torch.float32 else d
+        q = q if q.stride(-1) == 1 else q.contiguous()
+        d = d if d.stride(-1) == 1 else d.contiguous()
+        N, dim = q.shape
+        G = d.shape[0]
+        if labels.shape[0] != N:
+            raise ValueError(f"labels has {labels.shape[0]} entries for {N} query rows")
+        if (N % 256) or (G % 64) or dim not in (256, 512, 768, 1024):
+            raise ValueError(f"fp8 InfoNCE needs N % 256 == 0, G % 64 == 0, dim in (256, 512, 768, 1024); got {N}, {G}, {dim}")
+        dev = q.device
+        ws = torch.empty(lib.cx_infonce_fp8_ws_floats(N, G), dtype=torch.float32, device=dev)
+        q8 = torch.empty(N, dim, dtype=torch.uint8, device=dev)
+        d8 = torch.empty(G, dim, dtype=torch.uint8, device=dev)
+        sq = torch.empty(N, dtype=torch.float32, device=dev)
+        sd = torch.empty(G, dtype=torch.float32, device=dev)
+        lse = torch.empty(N, dtype=torch.float32, device=dev)
+        rows = torch.empty(N, dtype=torch.float32, device=dev)
+        _C.check(lib.cx_infonce_fp8_fwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), scale, ws.data_ptr(), q8.data_ptr(),
+                                        d8.data_ptr(), sq.data_ptr(), sd.data_ptr(), lse.data_ptr(), rows.data_ptr(), N, G,
+                                        dim, q.stride(0), d.stride(0), _C.cur_stream()), "cx_infonce_fp8_fwd")
+        ctx.save_for_backward(q, d, labels, lse, q8, d8, sq, sd)
+        ctx.scale, ctx.coef, ctx.has_scale_param = scale, coef, scale_param is not None
+        return rows.sum() * coef
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, d, labels, lse, q8, d8, sq, sd = ctx.saved_tensors
+        lib = _C.lib()
+        N, dim = q.shape
+        G = d.shape[0]
+        dev = q.device
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        gmt = torch.empty(G, N, **bf)
+        qb, qbt, db = torch.empty(N, dim, **bf), torch.empty(dim, N, **bf), torch.empty(G, dim, **bf)
+        gws = torch.empty(max(N * dim, 8 * N * dim), dtype=torch.float32, device=dev)
+        dq = torch.empty(N, dim, dtype=torch.float32, device=dev)
+        dd = torch.empty(G, dim, dtype=torch.float32, device=dev)
+        dscale = torch.zeros(1, dtype=torch.float32, device=dev) if ctx.has_scale_param else None
+        _C.check(lib.cx_infonce_fp8_bwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), lse.data_ptr(), ctx.scale, ctx.coef,
+                                        q8.data_ptr(), d8.data_ptr(), sq.data_ptr(), sd.data_ptr(), gmt.data_ptr(),
+                                        qb.data_ptr(), qbt.data_ptr(), db.data_ptr(), gws.data_ptr(), gws.numel(),
+                                        dq.data_ptr(), dd.data_ptr(), _C.ptr(dscale), N, G, dim, q.stride(0), d.stride(0),
+                                        _C.cur_stream()), "cx_infonce_fp8_bwd")
+        gparam = (dscale[0] * ctx.scale * gout).reshape(()) if ctx.has_scale_param else None
+        return dq * gout, dd * gout, None, None, None, gparam
+
+
+_USE_FP8 = False
+
+
+def set_similarity_fp8(enabled: bool):
+    """Process-wide default of the `use_fp8` recipe flag (configs/train/contrastive_pretrain.yaml:24): route every fused
+    InfoNCE through the fp8 similarity GEMM.  `clip_loss(..., use_fp8=...)` overrides it per call."""
+    global _USE_FP8
+    _USE_FP8 = bool(enabled)
+
+
+def _infonce(q, d, labels, scale, coef, scale_param, use_fp8=None):
+    fp8 = _USE_FP8 if use_fp8 is None else bool(use_fp8)
+    return (_FusedInfoNCEFp8 if fp8 else _FusedInfoNCE).apply(q, d, labels, scale, coef, scale_param)
+
+
 class _FusedInfoNCE(torch.autograd.Function):
     """sum_i (lse_i - logit_{i,label_i}) * coef  for logits = scale * Q D^T, without materialising the logits."""
 
@@ -56,8 +129,11 @@ class _FusedInfoNCE(torch.autograd.Function):
         G = d.shape[0]
         if labels.shape[0] != N:
             raise ValueError(f"labels has {labels.shape[0]} entries for {N} query rows")  # F.cross_entropy raises too
-        if (N % 4) or (G % 4) or (dim % 4):
-            raise ValueError(f"fused InfoNCE needs N, G and dim to be multiples of 4 (got {N}, {G}, {dim})")
+        if dim % 4:
+            raise ValueError(f"fused InfoNCE needs dim % 4 == 0 (got {dim})")
+        if ((N % 4) or (G % 4)) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            # the backward's two output GEMMs contract over N and G: fail here, not in the middle of loss.backward()
+            raise ValueError(f"fused InfoNCE backward needs N and G to be multiples of 4 (got {N}, {G})")
         ws = torch.empty(lib.cx_infonce_ws_floats(N, G), dtype=torch.float32, device=q.device)
         lse = torch.empty(N, dtype=torch.float32, device=q.device)
         rows = torch.empty(N, dtype=torch.float32, device=q.device)
@@ -103,7 +179,7 @@ def make_labels(n_query: int, n_docs_all: int, rank: int, world: int, device) ->
 
 
 def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tracker=None, dataset="",
-              bidirectional=False):
+              bidirectional=False, *, use_fp8=None):
     """InfoNCE over (local queries) x (all gathered documents); see sc/loss.py:76-132 for the contract."""
     if gather_enabled:
         document = gather_with_grad(document)
@@ -125,11 +201,11 @@ def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tra
                          "type-checks for one process without negatives)")
     if bidirectional:
         # sc/loss.py:119-123: CE(q->d) + CE(d->q) with the same labels, no world-size factor
-        l_qd = _FusedInfoNCE.apply(query, document, labels, scale, 1.0 / n, scale_param)
-        l_dq = _FusedInfoNCE.apply(document, query, labels, scale, 1.0 / document.shape[0], scale_param)
+        l_qd = _infonce(query, document, labels, scale, 1.0 / n, scale_param, use_fp8)
+        l_dq = _infonce(document, query, labels, scale, 1.0 / document.shape[0], scale_param, use_fp8)
         loss = l_qd + l_dq
     else:
-        loss = _FusedInfoNCE.apply(query, document, labels, scale, float(world) / n, scale_param)
+        loss = _infonce(query, document, labels, scale, float(world) / n, scale_param, use_fp8)
     if tracker is not None:
         with torch.no_grad():
             sim = (query.float() @ document.float().T) * scale

@@ -94,6 +94,10 @@ class TextTextTrainer:
         self.world = dist.get_world_size() if self.distributed else 1
         self.rank = dist.get_rank() if self.distributed else 0
         torch.manual_seed(config.data_args.seed)
+        if config.train_args.use_fp8:  # the GradCache path reaches clip_loss through the reference's fixed signature
+            from .loss import set_similarity_fp8
+
+            set_similarity_fp8(True)
         self.model = self.get_model(config, trunk_config)
         self.total_steps = total_steps or config.train_args.num_train_steps or 10_000
         self.optimizer = self.get_optimizer(config)
@@ -175,7 +179,7 @@ class TextTextTrainer:
         queries = model(**q, normalize=normalize)["embedding"]
         all_documents = gather_with_grad(model(**d, normalize=normalize)["embedding"])
         if not dims:
-            return clip_loss(queries, all_documents, scale)
+            return clip_loss(queries, all_documents, scale, use_fp8=bool(ta.use_fp8))
         # Matryoshka (text_text.py:352-369): one InfoNCE per prefix width on re-normalised prefixes, weighted sum.
         # The fused loss kernel reads the (N, dim) prefix views in place (leading dimension 768).
         weights = ta.matryoshka_loss_weights or [1.0] * len(dims)
@@ -307,7 +311,8 @@ class ImageTextTrainer(TextTextTrainer):
         va = config.vision_model_args  # the reference takes the logit scale from the image tower's args
         scale = LogitScale(SimpleNamespace(logit_scale=va.logit_scale, trainable_logit_scale=va.trainable_logit_scale))
         model = DualEncoder(towers[0], towers[1], scale.to(self.device),
-                            precomputed_text=bool(config.text_model_args.precomputed)).train()
+                            precomputed_text=bool(config.text_model_args.precomputed),
+                            use_fp8=bool(config.train_args.use_fp8)).train()
         return {"model": model}
 
     def _trainable_towers(self):

@@ -196,6 +196,23 @@ int cx_infonce_fwd(const float* Q, const float* D, const int64_t* labels, float 
 int cx_infonce_bwd(const float* Q, const float* D, const int64_t* labels, const float* lse, float scale, float coef,
                    float* Gmat, float* GmatT, float* QT, float* DT, float* dQ, float* dD, float* dscale_accum,
                    int N, int G, int dim, int ldq, int ldd, void* stream);
+/* ---- the same loss on the fp8 matrix-core path (BASELINE.json configs[4] "fp8 MFMA similarity GEMM"; the reference
+ * only carries the `use_fp8` flag, configs/train/contrastive_pretrain.yaml:24).  Rows are quantised to OCP e4m3 with
+ * one scale per row, the contraction is v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 accumulate, online fp32 log-sum-exp);
+ * the logits are never written.  dim in {256,512,768,1024}.  Scratch, all caller-owned: ws = fp32
+ * [cx_infonce_fp8_ws_floats(N,G)]; Q8 (N,dim) / D8 (G,dim) bytes and sq (N) / sd (G) row scales are WRITTEN by fwd and
+ * read again by bwd.  bwd writes GmT (G,N) bf16 = coef*scale*(softmax - onehot)^T once and forms dD = GmT Q, dQ = GmT^T D
+ * on the bf16 GEMM family (Qb (N,dim), QbT (dim,N), Db (G,dim) bf16 scratch; gws / gws_floats = split-K workspace as for
+ * cx_gemm_bf16_tn_accum, >= N*dim floats).  bwd needs N % 256 == 0, G % 64 == 0, dim % 128 == 0 (else CX_ERR_SHAPE:
+ * use the exact path).  Tolerance against the fp32 oracle (tests/test_infonce_fp8_gpu.py): e4m3 has 3 mantissa bits. */
+long cx_infonce_fp8_ws_floats(int N, int G);
+int cx_infonce_fp8_fwd(const float* Q, const float* D, const int64_t* labels, float scale, float* ws, uint8_t* Q8,
+                       uint8_t* D8, float* sq, float* sd, float* lse, float* loss_rows, int N, int G, int dim, int ldq,
+                       int ldd, void* stream);
+int cx_infonce_fp8_bwd(const float* Q, const float* D, const int64_t* labels, const float* lse, float scale, float coef,
+                       const uint8_t* Q8, const uint8_t* D8, const float* sq, const float* sd, uint16_t* GmT, uint16_t* Qb,
+                       uint16_t* QbT, uint16_t* Db, float* gws, long gws_floats, float* dQ, float* dD,
+                       float* dscale_accum, int N, int G, int dim, int ldq, int ldd, void* stream);
 /* plain exact-fp32 MFMA GEMM  C[m][n] = sum_k A[m][k] B[n][k]  (K % 4 == 0; lda, ldb % 4 == 0). */
 int cx_sgemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 void* stream);
