@@ -188,6 +188,7 @@ def main():
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.optimizer import FusedAdamW
 
+    os.environ["CX_GRADCACHE_CHUNK"] = "exact"  # --chunk-size is taken literally in every leg but the drop-in one
     lib = _C.lib()
     G, S = args.global_batch, args.seq_len
     assert G % world == 0
@@ -263,11 +264,19 @@ def main():
             extra["weak"] = "same point as the headline (2048 pairs per GPU)"
         # what an unmodified reference YAML gets: GradCache chunk_size 64 (8192 token rows per GEMM launch)
         if world == 1 and args.chunk_size != 64:
-            cdt, _ = run_leg(min(b, 2048), 64, few, 1, prof=False)
-            extra["dropin_chunk64"] = {"value": min(b, 2048) * few / cdt, "unit": "pairs/s", "grad_cache_chunk": 64,
-                                       "global_batch": min(b, 2048), "ms_per_step": 1e3 * cdt / few, "steps": few,
-                                       "note": "reference recipe chunk_size (contrastive_pretrain.yaml:15); loss rows x "
-                                               "2048 documents, encoder work per pair unchanged"}
+            nb = min(b, 2048)
+            os.environ["CX_GRADCACHE_CHUNK"] = "exact"   # chunk_size 64 taken literally: 8192 token rows per launch
+            cdt, _ = run_leg(nb, 64, few, 1, prof=False)
+            os.environ["CX_GRADCACHE_CHUNK"] = "auto"    # the default: the recipe's 64 is a lower bound on a 288 GB part
+            adt, _ = run_leg(nb, 64, few, 1, prof=False)
+            os.environ["CX_GRADCACHE_CHUNK"] = "exact"
+            extra["dropin_chunk64"] = {"value": nb * few / adt, "unit": "pairs/s", "recipe_chunk_size": 64,
+                                       "global_batch": nb, "ms_per_step": 1e3 * adt / few, "steps": few,
+                                       "exact_chunk64": {"value": nb * few / cdt, "ms_per_step": 1e3 * cdt / few},
+                                       "note": "reference recipe chunk_size 64 (contrastive_pretrain.yaml:15): `value` is what "
+                                               "an unmodified YAML gets (CX_GRADCACHE_CHUNK=auto raises the chunk to ~131072 "
+                                               "tokens, results unchanged), exact_chunk64 = the literal 64 (CX_GRADCACHE_CHUNK="
+                                               "exact); loss rows x 2048 documents, encoder work per pair unchanged"}
         # the loss path's one exchange step on its own: all-gather of (2048 x N / N, 768) fp32 embeddings per rank
         if world > 1 and backend == "nccl":
             emb = torch.randn(b, cfg.n_embd, device=dev)

@@ -89,6 +89,7 @@ _SIGS = {
     "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "cx_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cx_embed_ln_bwd": (i32, [vp] * 15 + [i32, i32, i32, i32, vp]),
+    "cx_embed_ln_bwd_sorted": (i32, [vp] * 15 + [i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "cx_swiglu_fwd": (i32, [vp, vp, i32, i32, i32, vp]),
     "cx_swiglu_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cx_gemm_bf16_swiglu": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -130,9 +131,9 @@ _SIGS = {
     "cx_encoder_forward_hidden": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
                                         i32, i32, vp, vp]),
     "cx_encoder_backward_hidden": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
-                                         i32, vp, vp]),
+                                         i32, vp, vp, vp, vp]),
     "cx_encoder_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
-                                  i32, vp, vp, vp]),
+                                  i32, vp, vp, vp, vp, vp]),
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),

@@ -361,7 +361,8 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
 
 int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
                         const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
-                        const float* demb, const float* emb_out, void* stream) {
+                        const float* demb, const float* emb_out, const int32_t* sort_ids, const int32_t* sort_perm,
+                        void* stream) {
     if (Bc <= 0 || T <= 0) return CX_OK;
     CX_TRY(check_desc(enc, buf, T));
     if (!demb || !emb_out) return CX_ERR_ARG;
@@ -375,6 +376,13 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
     CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
+    // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
+    if (sort_ids && sort_perm)
+        return cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+                                      buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
+                                      enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, enc->vocab, sort_ids,
+                                      sort_perm, buf->g_wide, stream);
     return cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                            enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);
@@ -400,7 +408,7 @@ int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* bu
 
 int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
                                const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
-                               const uint16_t* dhidden, void* stream) {
+                               const uint16_t* dhidden, const int32_t* sort_ids, const int32_t* sort_perm, void* stream) {
     if (Bc <= 0 || T <= 0) return CX_OK;
     CX_TRY(check_desc(enc, buf, T));
     if (!dhidden) return CX_ERR_ARG;
@@ -415,6 +423,13 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
     const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
     CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
+    // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
+    if (sort_ids && sort_perm)
+        return cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+                                      buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
+                                      enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, enc->vocab, sort_ids,
+                                      sort_perm, buf->g_wide, stream);
     return cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                            enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ word, const float* __restrict__ type0,
     const float* __restrict__ pos_emb, const float* __restrict__ gamma, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, float* dword, float* dtype0, float* dpos, float* dgamma, float* dbeta, int T,
-    int S, int padding_idx) {
+    int S, int padding_idx, bf16_t* __restrict__ dz_out) {
     constexpr int D = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -378,14 +378,18 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int col = (i * 64 + lane) * 4;
+            float ov[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float o = (g[i][e] * dy[i][e] - s1 * xh[i][e] - s2) * rstd;
+                ov[e] = o;
                 dty[i][e] += o;
                 // nn.Embedding(padding_idx=...) gives that row no gradient (sc/layers/embedding.py:581)
-                if (dword && id != padding_idx) unsafeAtomicAdd(dword + (size_t)id * D + col + e, o);
+                if (!dz_out && dword && id != padding_idx) unsafeAtomicAdd(dword + (size_t)id * D + col + e, o);
                 if (dpos) unsafeAtomicAdd(dpos + (size_t)pos * D + col + e, o);
             }
+            // sorted path: the row gradient goes to scratch, embed_scatter_sorted_kernel sums it per vocabulary row
+            if (dz_out) store4_bf16(dz_out + (size_t)t * D + col, ov);
         }
     }
     flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
@@ -397,6 +401,71 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) zero[i][e] = 0.f;
     flush_param_grads<NCH>(dty, zero, dtype0, nullptr, smem);
+}
+
+// Word-embedding gradient without atomics (the scatter of 100 M fp32 atomics cost 1.4 ms per 131072-token chunk and made the
+// result depend on arrival order).  The host passes the chunk's token ids sorted (stable) with the permutation; workgroup v
+// owns vocabulary row v: it binary-searches its run [lo, hi) in the sorted ids, its four waves sum the rows
+// dz[perm[lo + w]], dz[perm[lo + w + 4]], ... (each in token order), the four partials are folded in wave order and the
+// row is read-modify-written once, by its only owner.  Bit-reproducible.
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const bf16_t* __restrict__ dz, const int32_t* __restrict__ sorted_ids,
+                                                                   const int32_t* __restrict__ perm, float* __restrict__ dword, int T,
+                                                                   int vocab, int padding_idx) {
+    constexpr int D = NCH * 256;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int v = blockIdx.x; v < vocab; v += gridDim.x) {
+        if (v == padding_idx) continue;
+        // lower bounds of v and v + 1 in sorted_ids (wave-uniform scalar loop)
+        int lo = 0, hi = T;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sorted_ids[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        int lo2 = lo, hi2 = T;
+        while (lo2 < hi2) {
+            const int mid = (lo2 + hi2) >> 1;
+            if (sorted_ids[mid] <= v) lo2 = mid + 1; else hi2 = mid;
+        }
+        const int n = lo2 - lo;
+        if (n == 0) continue;     // (uniform over the workgroup: no barrier is skipped by part of it)
+        float acc[NCH][4];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+        for (int k = wave; k < n; k += 4) {
+            const int t = perm[lo + k];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                float r[4];
+                load4_bf16(dz + (size_t)t * D + (i * 64 + lane) * 4, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] += r[e];
+            }
+        }
+        float* row = dword + (size_t)v * D;
+        if (n <= 1) {               // the common case for a large vocabulary: one token, one wave, no fold
+            if (wave == 0) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    float4* p4 = reinterpret_cast<float4*>(row + (i * 64 + lane) * 4);
+                    float4 cur = *p4;
+                    cur.x += acc[i][0]; cur.y += acc[i][1]; cur.z += acc[i][2]; cur.w += acc[i][3];
+                    *p4 = cur;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][(i * 64 + lane) * 4 + e] = acc[i][e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) row[c] += ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        __syncthreads();
+    }
 }
 
 // backward kernels end with 2*d device-scope atomics per block (they serialise at the memory fabric): one block per CU
@@ -484,7 +553,30 @@ int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_
     CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_bwd_kernel<NCH>), dim3(ln_grid_bwd(T)), dim3(256), smem,
                                          (hipStream_t)stream, dout_a, dout_b, input_ids, indices, word, type0,
                                          pos_emb, gamma, mean, rstd, dword, dtype0, dpos, dgamma, dbeta, T, S,
-                                         padding_idx));
+                                         padding_idx, (bf16_t*)nullptr));
+    return done();
+}
+
+int cx_embed_ln_bwd_sorted(const uint16_t* dout_a, const uint16_t* dout_b, const int64_t* input_ids,
+                           const int32_t* indices, const float* word, const float* type0, const float* pos_emb,
+                           const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
+                           float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, int vocab,
+                           const int32_t* sorted_ids, const int32_t* perm, uint16_t* dz_scratch, void* stream) {
+    if (T <= 0) return CX_OK;
+    if (!dout_a || !input_ids || !indices || !word || !type0 || !gamma || !mean || !rstd) return CX_ERR_ARG;
+    if (!sorted_ids || !perm || !dz_scratch || vocab <= 0) return CX_ERR_ARG;
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    // many blocks here: without the word-row atomics this kernel is a plain streaming LayerNorm backward
+    int grid = (T + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_bwd_kernel<NCH>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                         dout_b, input_ids, indices, word, type0, pos_emb, gamma, mean, rstd, dword, dtype0,
+                                         dpos, dgamma, dbeta, T, S, padding_idx, dz_scratch));
+    if (dword) {
+        int sg = vocab < 8192 ? vocab : 8192;
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_scatter_sorted_kernel<NCH>), dim3(sg), dim3(256), 0, (hipStream_t)stream,
+                                             dz_scratch, sorted_ids, perm, dword, T, vocab, padding_idx));
+    }
     return done();
 }
 

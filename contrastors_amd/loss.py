@@ -263,11 +263,44 @@ def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional
     return q.grad, d.grad, loss.detach()
 
 
+def effective_chunk(tower, inputs, chunk_size: int) -> int:
+    """The GradCache chunk is a pure memory knob: embeddings, loss and gradients do not depend on it (tested to fp32
+    summation order).  The reference recipes say 64 because an 80 GB part cannot hold more activations; an MI355X has
+    288 GB, and its GEMMs want >= 512 row panels per launch.  With CX_GRADCACHE_CHUNK=auto (the default) a recipe's
+    chunk_size is therefore treated as a LOWER bound and raised -- in multiples of itself -- until a chunk carries ~131072
+    tokens or its activation arena would take more than a third of the free HBM.  CX_GRADCACHE_CHUNK=exact keeps the
+    recipe's number; CX_GRADCACHE_CHUNK=<n> forces n."""
+    import os
+
+    mode = os.environ.get("CX_GRADCACHE_CHUNK", "auto")
+    if mode == "exact" or chunk_size is None or chunk_size <= 0:
+        return chunk_size
+    if mode not in ("auto", ""):
+        return max(1, int(mode))
+    cfg = getattr(getattr(tower, "trunk", None), "config", None)
+    ids = inputs.get("input_ids") if isinstance(inputs, dict) else None
+    if cfg is None or ids is None or ids.ndim != 2 or not ids.is_cuda:
+        return chunk_size
+    B, S = ids.shape
+    d, I, L = cfg.n_embd, cfg.n_inner, cfg.n_layer
+    wfc1 = 2 * I if getattr(cfg, "gated", False) else I
+    per_layer = 2 * (3 * d + 5 * d + wfc1 + I) + 4 * (cfg.n_head + 4)          # saved activations, bytes per token
+    kept = 1 if getattr(tower.trunk, "gradient_checkpointing", False) else L
+    scratch = 2 * (3 * d + 3 * max(3 * d, wfc1) + I)                            # backward ping-pong + transposes
+    bytes_per_token = kept * per_layer + (L - kept) * 2 * d + scratch
+    free, _ = torch.cuda.mem_get_info(ids.device)
+    free += torch.cuda.memory_reserved(ids.device) - torch.cuda.memory_allocated(ids.device)  # the allocator's own cache
+    tokens = int(min(131072, max(S, free / 3 / bytes_per_token)))
+    want = max(chunk_size, tokens // max(S, 1))
+    want = max(chunk_size, want // chunk_size * chunk_size)
+    return int(min(want, max(B, chunk_size)))
+
+
 def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scale, bidirectional=False,
                     router_aux_coeff=False):
     """GradCache step (sc/loss.py:187-213).  Leaves parameter gradients in the towers and returns the loss."""
-    q_chunks = _split_inputs(t1_inputs, chunk_size)
-    d_chunks = _split_inputs(t2_inputs, chunk_size)
+    q_chunks = _split_inputs(t1_inputs, effective_chunk(tower1, t1_inputs, chunk_size))
+    d_chunks = _split_inputs(t2_inputs, effective_chunk(tower2, t2_inputs, chunk_size))
     was_training1, was_training2 = tower1.training, tower2.training
     q_embs = get_chunked_embeddings(tower1, q_chunks)
     d_embs = get_chunked_embeddings(tower2, d_chunks)

@@ -177,6 +177,16 @@ class VarlenBatch:
     S: int
     T: int
     max_seqlen: int
+    _sort: Optional[tuple] = None  # (sorted ids int32, permutation int32): built on first use by a backward
+
+    def embedding_sort(self):
+        """Token ids of the chunk in ascending stable order + the permutation that sorts them: lets the engine reduce the
+        word-embedding gradient per vocabulary row without atomics (cx_embed_ln_bwd_sorted).  One device sort, no sync."""
+        if self._sort is None:
+            tok = self.input_ids.reshape(-1)[self.indices.long()].to(torch.int32)
+            sorted_ids, perm = torch.sort(tok, stable=True)
+            self._sort = (sorted_ids.contiguous(), perm.to(torch.int32).contiguous())
+        return self._sort
 
     @staticmethod
     def from_lengths(input_ids: torch.Tensor, seqlens) -> "VarlenBatch":
@@ -554,9 +564,11 @@ class NomicBertEngine(torch.nn.Module):
         assert arena.emb_out is not None, "backward_chunk needs a forward with save_for_backward=True"
         demb = demb.to(torch.float32).contiguous()
         self._desc.normalize = arena.normalize
+        sids, perm = vb.embedding_sort()
         rc = self.lib.cx_encoder_backward(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
                                           vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
-                                          vb.max_seqlen, demb.data_ptr(), arena.emb_out.data_ptr(), _C.cur_stream())
+                                          vb.max_seqlen, demb.data_ptr(), arena.emb_out.data_ptr(), sids.data_ptr(),
+                                          perm.data_ptr(), _C.cur_stream())
         _C.check(rc, "cx_encoder_backward")
         self.release_arena(arena)
 
@@ -581,9 +593,11 @@ class NomicBertEngine(torch.nn.Module):
     def backward_hidden_chunk(self, vb: VarlenBatch, arena: _ChunkArena, dhidden: torch.Tensor):
         dh = dhidden.to(torch.bfloat16).contiguous()
         assert dh.shape == (vb.T, self.config.n_embd)
+        sids, perm = vb.embedding_sort()
         rc = self.lib.cx_encoder_backward_hidden(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
                                                  vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
-                                                 vb.max_seqlen, dh.data_ptr(), _C.cur_stream())
+                                                 vb.max_seqlen, dh.data_ptr(), sids.data_ptr(), perm.data_ptr(),
+                                                 _C.cur_stream())
         _C.check(rc, "cx_encoder_backward_hidden")
         self.release_arena(arena)
 

@@ -107,6 +107,17 @@ int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_
                     const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
                     float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, void* stream);
 
+/* The same backward with the word-embedding rows reduced WITHOUT atomics: `sorted_ids` = the chunk's T token ids in
+ * ascending order (stable), `perm` = the token index each sorted entry came from (both int32[T], prepared by the host
+ * with one device sort per chunk), dz_scratch = (T, d) bf16.  One workgroup per vocabulary row sums its tokens in token
+ * order: deterministic, and ~10x faster than 100 M fp32 atomics per 131072-token chunk.  dpos / dtype0 / dgamma / dbeta as
+ * above. */
+int cx_embed_ln_bwd_sorted(const uint16_t* dout_a, const uint16_t* dout_b, const int64_t* input_ids,
+                           const int32_t* indices, const float* word, const float* type0, const float* pos_emb,
+                           const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
+                           float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, int vocab,
+                           const int32_t* sorted_ids, const int32_t* perm, uint16_t* dz_scratch, void* stream);
+
 /* ---- K10 swiglu (flash_attn.ops.activations.swiglu; sc/layers/mlp.py:75) and GELU(erf) (mlp.py:30-34) ----
  * yg:(T, 2*I) holds y = fc11(x) and gate = fc12(x);  act = silu(gate) * y, fp32 math, one rounding.
  * layout 0: yg = [y | gate] concatenated; layout 1: interleaved in groups of 32 columns
@@ -313,7 +324,11 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
  * parameter gradient in enc->g* / layers[i].g*.  Must follow a forward with save_for_backward = 1 on `buf`. */
 int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
                         const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
-                        const float* demb, const float* emb_out, void* stream);
+                        const float* demb, const float* emb_out, const int32_t* sort_ids, const int32_t* sort_perm,
+                        void* stream);
+/* sort_ids / sort_perm (both int32[T], or both NULL): the chunk's token ids in ascending stable order and the permutation
+ * that sorts them -- with them the word-embedding gradient is a deterministic segmented reduction
+ * (cx_embed_ln_bwd_sorted), without them fp32 atomics. */
 
 /* Token-level variant for heads that read every position (the MLM head of NomicBertForPreTraining,
  * sc/models/encoder/modeling_nomic_bert.py:590-669): hidden_out / dhidden are (T, d) bf16 in unpadded token order
@@ -323,7 +338,7 @@ int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* bu
                               int save_for_backward, uint16_t* hidden_out, void* stream);
 int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int64_t* input_ids,
                                const int32_t* indices, const int32_t* cu_seqlens, int Bc, int S, int T, int max_seqlen,
-                               const uint16_t* dhidden, void* stream);
+                               const uint16_t* dhidden, const int32_t* sort_ids, const int32_t* sort_perm, void* stream);
 
 /* ---- ViT image tower (sc/models/vit/vit.py:176-276 ViTModel.forward, sc/layers/embedding.py:465-516
  *      PatchEmbedding.forward, sc/models/biencoder/modeling_biencoder.py:287-319 pooling): one call per chunk.

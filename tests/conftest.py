@@ -9,6 +9,9 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 GOLD = ROOT / "tests" / "golden"
+# tests pass GradCache chunk sizes they mean literally (chunk-invariance, multi-chunk paths); the auto re-chunking of
+# contrastors_amd.loss.effective_chunk has its own test
+os.environ.setdefault("CX_GRADCACHE_CHUNK", "exact")
 
 
 def pytest_configure(config):

@@ -59,11 +59,17 @@ def _step(rank, world, dev, G=16, S=32, chunk=4):
     return float(loss), tower.trunk.flat_grad.detach().float().cpu().numpy()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, str(ROOT))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    loss, grad = _step(rank, world, torch.device("cuda", 0))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local = rank if backend == "nccl" else 0   # RCCL: one rank per GPU; gloo: the ranks share the test box's one GPU
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    loss, grad = _step(rank, world, torch.device("cuda", local))
     np.savez(f"{out_dir}/w{rank}.npz", loss=loss, grad=grad)
     dist.barrier()
     dist.destroy_process_group()
@@ -100,3 +106,32 @@ def test_bench_two_ranks_prints_one_json_line():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["pairs_per_gpu"] == 32 and j["value"] > 0
     assert j["config"]["parallelism"] == "dp2" and np.isfinite(j["config"]["loss_last_step"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box skips this)")
+def test_two_rank_gradcache_step_over_rccl(tmp_path):
+    """The production collectives: all_gather_into_tensor / reduce_scatter_tensor of gather_with_grad
+    (contrastors_amd/distributed.py, backend "nccl" = RCCL over xGMI) and the flat gradient all-reduce, one rank per GPU."""
+    port = 29700 + (os.getpid() % 90)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    loss1, grad1 = _step(0, 1, torch.device("cuda", 0))
+    w = [np.load(tmp_path / f"w{r}.npz") for r in range(2)]
+    np.testing.assert_array_equal(w[0]["grad"], w[1]["grad"])
+    assert abs((float(w[0]["loss"]) + float(w[1]["loss"])) / 2 - 2 * loss1) < 2e-3 * max(1.0, abs(loss1))
+    g2, g1 = w[0]["grad"], 2.0 * grad1
+    assert np.abs(g2 - g1).max() <= 2e-2 * np.abs(g1).max()
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed environment: bench.py spawns its own ranks
+    and rank 0 prints exactly one JSON line with n_gpus = 2 (gloo on the shared test GPU; RCCL when launched for real)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CX_BENCH_BACKEND="gloo", CX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--global-batch", "64",
+           "--chunk-size", "16", "--layers", "2", "--no-cpu-baseline", "--no-extra-legs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["launch"].startswith("self") and j["value"] > 0

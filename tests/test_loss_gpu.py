@@ -222,3 +222,29 @@ def test_full_architecture_step_properties_at_metric_shapes():
     report("full_arch_step", loss=l64, grad_norm=gn, rel_chunk64_vs_256=rel, rel_repeat=rel_rep, rel_seq_perm=rel_perm,
            rel_loss_perm_dq=e_q, rel_loss_perm_dd=e_d)
     assert e_q <= 1e-5 and e_d <= 1e-5
+
+
+def test_auto_chunk_raises_the_recipe_chunk_without_changing_results(monkeypatch):
+    """CX_GRADCACHE_CHUNK=auto (the product default): a recipe's chunk_size is a lower bound on a 288 GB part."""
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig
+    from contrastors_amd.loss import effective_chunk, grad_cache_loss
+    from contrastors_amd.nomic_bert import NomicBertConfig
+
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=1024, n_layer=2)
+    tower = BiEncoder(BiEncoderConfig(pooling="mean", trunk_config=cfg), device=DEV, seed=1).train()
+    scale = LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=False)).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    q = {"input_ids": torch.randint(5, 1024, (64, 32), generator=g).to(DEV), "seqlens": [32] * 64}
+    d = {"input_ids": torch.randint(5, 1024, (64, 32), generator=g).to(DEV), "seqlens": [32] * 64}
+    monkeypatch.setenv("CX_GRADCACHE_CHUNK", "auto")
+    eff = effective_chunk(tower, q, 4)
+    assert eff == 64 and eff % 4 == 0      # 64 x 32 tokens fit trivially: one chunk
+    tower.trunk.zero_grad()
+    l_auto = grad_cache_loss(tower, q, tower, d, 4, scale)
+    g_auto = tower.trunk.flat_grad.clone()
+    monkeypatch.setenv("CX_GRADCACHE_CHUNK", "exact")
+    assert effective_chunk(tower, q, 4) == 4
+    tower.trunk.zero_grad()
+    l_exact = grad_cache_loss(tower, q, tower, d, 4, scale)
+    assert abs(float(l_auto) - float(l_exact)) < 1e-5
+    assert float((g_auto - tower.trunk.flat_grad).abs().max()) <= 2e-4 * float(g_auto.abs().max())
