@@ -53,10 +53,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--global-batch", type=int, default=16384)
     ap.add_argument("--seq-len", type=int, default=128)
-    ap.add_argument("--chunk-size", type=int, default=int(os.environ.get("CX_BENCH_CHUNK", 1024)),
+    ap.add_argument("--chunk-size", type=int, default=int(os.environ.get("CX_BENCH_CHUNK", 2048)),
                     help="GradCache chunk = sequences per encoder call.  A pure memory knob (results are identical); the "
-                         "reference recipe uses 64 on 80 GB parts (contrastive_pretrain.yaml:15); 1024 = 131072 token rows per "
-                         "GEMM (512 whole 256-row tile panels per launch) and needs ~50 GB of the MI355X's 288 GB")
+                         "reference recipe uses 64 on 80 GB parts (contrastive_pretrain.yaml:15); 2048 = 262144 token rows per "
+                         "GEMM launch (1024 whole 256-row tile panels) and peaks at ~115 GB of the MI355X's 288 GB")
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the metric
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the weak-scaling and chunk-64 records")

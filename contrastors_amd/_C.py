@@ -70,17 +70,8 @@ _SIGS = {
     "cx_gemm_bf16_nt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "cx_gemm_bf16_nt_accum": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_tn_accum": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
-    "cx_gemm_set_variant": (None, [i32]),
-    "cx_gemm_get_variant": (i32, []),
-    "cx_gemm_set_debug": (None, [i32]),
-    "cx_gemm_set_trace": (None, [vp]),
-    "cx_gemm_v6_ablate": (None, [i32]),
-    "cx_gemm_v6_stagger": (None, [i32, i32]),
-    "cx_gemm_v6_trace": (None, [vp]),
     "cx_prof_gemm_config": (i32, [i32, i32]),
     "cx_prof_gemm_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
-    "cx_gemm_set_glds": (None, [i32]),
-    "cx_gemm_get_glds": (i32, []),
     "cx_transpose_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "cx_cast_transpose_f32_to_bf16": (i32, [vp, vp, i32, i32, vp]),
@@ -101,8 +92,6 @@ _SIGS = {
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
-    "cx_attn_set_bwd_s128": (None, [i32]),
-    "cx_attn_set_fwd_s128": (None, [i32]),
     "cx_rotary_qkv_inplace": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_rotary_apply": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_pool_normalize_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -134,6 +123,21 @@ _SIGS = {
                                          i32, vp, vp, vp, vp]),
     "cx_encoder_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, vp, vp, i32, i32, i32,
                                   i32, vp, vp, vp, vp, vp]),
+}
+
+# development-only entry points (include/contrastors_hip_dev.h): exported by libcontrastors_hip_dev.so, which is the same
+# code built without -DCX_PRODUCT (+ the earlier GEMM generations, A/B attention kernels, probes)
+_DEV_SIGS = {
+    "cx_gemm_set_variant": (None, [i32]),
+    "cx_gemm_get_variant": (i32, []),
+    "cx_gemm_set_debug": (None, [i32]),
+    "cx_gemm_set_trace": (None, [vp]),
+    "cx_gemm_v6_ablate": (None, [i32]),
+    "cx_gemm_v6_trace": (None, [vp]),
+    "cx_gemm_set_glds": (None, [i32]),
+    "cx_gemm_get_glds": (i32, []),
+    "cx_attn_set_bwd_s128": (None, [i32]),
+    "cx_attn_set_fwd_s128": (None, [i32]),
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),
@@ -141,8 +145,11 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
+DEV_EXPORTED_SYMBOLS = tuple(_DEV_SIGS)
+DEV_LIB_PATH = Path(os.environ.get("CONTRASTORS_HIP_DEV_LIB", _PKG / "lib" / "libcontrastors_hip_dev.so"))
 
 _lib = None
+_dev_lib = None
 
 
 def lib() -> C.CDLL:
@@ -165,6 +172,23 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def dev_lib() -> C.CDLL:
+    """The development library (scripts/, A/B parity tests): product entry points + the switches of _DEV_SIGS."""
+    global _dev_lib
+    if _dev_lib is None:
+        if not DEV_LIB_PATH.exists():
+            raise ImportError(f"{DEV_LIB_PATH} not found: build it with `python -m contrastors_amd.build`")
+        import torch  # noqa: F401
+
+        h = C.CDLL(str(DEV_LIB_PATH))
+        for name, (res, args) in {**_SIGS, **_DEV_SIGS}.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _dev_lib = h
+    return _dev_lib
 
 
 def check(rc: int, what: str = "") -> None:

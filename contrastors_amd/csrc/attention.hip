@@ -304,6 +304,7 @@ CX_DEVICE bf16x8_t read_vt128_frag(const char* tile, int d, int blk16, int hi) {
     return x.v;
 }
 
+#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
 __global__ __launch_bounds__(256, 2) void attn_fwd_s128_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[16384 + 16384 + 64 * VT128_STRIDE];
     char* Qs = smem;
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128_kernel(AttnParams p) {
         if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mx + log2f(l_tot)) * LN2;
     }
 }
+#endif  // !CX_PRODUCT
 
 // Persistent form of attn_fwd_s128_kernel (A/B switch cx_attn_set_fwd_s128(1), not the default): a workgroup walks
 // (sequence, head) problems with stride gridDim.x and issues the NEXT problem's global loads right after staging the
@@ -464,6 +466,7 @@ CX_DEVICE void fwd128_issue(const AttnParams& p, int h, int t0, int len, int tid
     }
 }
 
+#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
 __global__ __launch_bounds__(256, 2) void attn_fwd_s128p_kernel(AttnParams p, int B, int max_seqlen) {
     __shared__ __attribute__((aligned(16))) char smem[16384 + 16384 + 64 * VT128_STRIDE];
     char* Qs = smem;
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128p_kernel(AttnParams p, in
         __syncthreads();  // every wave is done with this problem's LDS tiles before they are restaged
     }
 }
+#endif  // !CX_PRODUCT
 
 // ------------------------------------------------------------------------------------- delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
@@ -1022,6 +1026,7 @@ CX_DEVICE void stage_transposed128(char* tile, int kp, int cp, const RowPairLoad
     }
 }
 
+#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_s128_kernel(AttnParams p) {
     // phase 1: Qs | dOs (only to build the register fragments);  phase 2: Ks | Vs alias them, Kt is separate
     __shared__ __attribute__((aligned(16))) char smem[32768 + 64 * VT128_STRIDE];
@@ -1107,7 +1112,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_s128_kernel(AttnParams p) 
         store_unrotated(p.dqkv + (size_t)(t0 + qrow) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, qrow,
                         hi);
 }
+#endif  // !CX_PRODUCT
 
+#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p) {
     // phase 1: Ks | Vs (register fragments);  phase 2: Qs | dOs alias them, Qt | dOt | lse | delta are separate
     __shared__ __attribute__((aligned(16))) char smem[32768 + 2 * 64 * VT128_STRIDE + 1024];
@@ -1220,6 +1227,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p)
         store_unrotated(vrow, acc_dv, 1.f, nullptr, nullptr, 0, hi);
     }
 }
+#endif  // !CX_PRODUCT
 
 // ----------------------------------------------------------------- backward, sequences <= 128, ONE fused kernel
 // dQ, dK, dV (and delta) of a whole (sequence, head) problem in one workgroup, reading Q, K, V, dO, O from HBM once
@@ -1260,6 +1268,7 @@ CX_DEVICE bf16x8_t read_vt128_linear(const char* tile, int d, int k0, int hi) {
 
 constexpr int FUSED_LDS = 32768 + 3 * 64 * VT128_STRIDE + 32768 + 1024;
 
+#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_fused_s128_kernel(AttnParams p,
                                                                                                                int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1452,6 +1461,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
     if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
 }
+#endif  // !CX_PRODUCT
 
 // ------------------------------------------------ backward, sequences <= 128, fused, TWO workgroups per CU (80 KiB)
 // Same algorithm as attn_bwd_fused_s128_kernel with an LDS diet so that two workgroups share a CU (two waves per SIMD:
@@ -1822,15 +1832,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
     }
 }
 
+#ifndef CX_PRODUCT
 int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
+#endif
 
 }  // namespace
 
 extern "C" {
 
+#ifndef CX_PRODUCT
 void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 3) ? mode : 3; }
 void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
+#endif
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                        uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
@@ -1841,14 +1855,20 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     AttnParams p = {};
     p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
+#ifndef CX_PRODUCT
     if (max_seqlen <= 128 && g_fwd_s128 == 1) {
         const int n_units = B * H;
         hipLaunchKernelGGL(attn_fwd_s128p_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), 0,
                            (hipStream_t)stream, p, B, max_seqlen);
-    } else if (max_seqlen <= 128 && g_fwd_s128 == 2) {
-        hipLaunchKernelGGL(attn_fwd_s128v_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (max_seqlen <= 128) {
+        return done();
+    }
+    if (max_seqlen <= 128 && g_fwd_s128 == 0) {
         hipLaunchKernelGGL(attn_fwd_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+        return done();
+    }
+#endif
+    if (max_seqlen <= 128) {  // one workgroup per (sequence, head) problem, single pass
+        hipLaunchKernelGGL(attn_fwd_s128v_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
         hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -1867,41 +1887,40 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
-    if (max_seqlen <= 128 && g_bwd_s128 == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
-        static bool attr_set2 = false;
-        if (!attr_set2) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, FUSED2_LDS) != hipSuccess)
-                return CX_ERR_LAUNCH;
-            attr_set2 = true;
-        }
+#ifndef CX_PRODUCT
+    const int bwd_mode = g_bwd_s128;
+#else
+    constexpr int bwd_mode = 3;
+#endif
+    if (max_seqlen <= 128 && bwd_mode == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
+        static CxLdsOptIn lds2;
+        if (!lds2.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel), FUSED2_LDS)) return CX_ERR_LAUNCH;
         const int n_units = B * H;
         hipLaunchKernelGGL(attn_bwd_fused2_s128_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
                            (hipStream_t)stream, p, B);
         return done();
     }
-    if (max_seqlen <= 128 && g_bwd_s128 == 2) {  // one fused persistent kernel (computes delta itself)
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_s128_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) != hipSuccess)
-                return CX_ERR_LAUNCH;
-            attr_set = true;
-        }
+#ifndef CX_PRODUCT
+    if (max_seqlen <= 128 && bwd_mode == 2) {  // one fused persistent kernel (computes delta itself)
+        static CxLdsOptIn lds1;
+        if (!lds1.ensure(reinterpret_cast<const void*>(&attn_bwd_fused_s128_kernel), FUSED_LDS)) return CX_ERR_LAUNCH;
         const int n_units = B * H;
         hipLaunchKernelGGL(attn_bwd_fused_s128_kernel, dim3(n_units < 256 ? n_units : 256), dim3(256), FUSED_LDS,
                            (hipStream_t)stream, p, B);
         return done();
     }
+#endif
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
-    if (max_seqlen <= 128 && g_bwd_s128) {
+#ifndef CX_PRODUCT
+    if (max_seqlen <= 128 && bwd_mode) {
         hipLaunchKernelGGL(attn_bwd_dq_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
         hipLaunchKernelGGL(attn_bwd_dkv_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
         return done();
     }
+#endif
     dim3 grid((max_seqlen + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);

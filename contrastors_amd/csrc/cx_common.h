@@ -94,3 +94,20 @@ CX_DEVICE int xcd_remap(int bid, int nwg) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// host side: opt a kernel into > 64 KiB of dynamic LDS.  The attribute is per device, so it is remembered per device
+// index (the deployment is one process per GPU, but nothing in the library may silently depend on that).
+// ---------------------------------------------------------------------------------------------
+struct CxLdsOptIn {
+    bool done[32] = {};
+    bool ensure(const void* fn, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+        if (done[dev]) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        done[dev] = true;
+        return true;
+    }
+};

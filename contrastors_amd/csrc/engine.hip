@@ -74,8 +74,8 @@ int wgrad_split(int out_f, int in_f, long Tp) {
 int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW, const CxChunkBuffers* b, int T,
           void* stream) {
     if (!gW) return CX_OK;
-    if ((out_f % 256) == 0 && (in_f % 128) == 0)
-        return cx_gemm_bf16_tn_accum(dY, X, gW, b->ws_f32, b->ws_floats, T, out_f, in_f, out_f, in_f, stream);
+    const int rc = cx_gemm_bf16_tn_accum(dY, X, gW, b->ws_f32, b->ws_floats, T, out_f, in_f, out_f, in_f, stream);
+    if (rc != CX_ERR_SHAPE) return rc;
     const int Tp = (int)round_up(T, 64);
     CX_TRY(cx_transpose_bf16(dY, b->tr_a, T, out_f, out_f, Tp, Tp, stream));
     CX_TRY(cx_transpose_bf16(X, b->tr_b, T, in_f, in_f, Tp, Tp, stream));
@@ -99,7 +99,7 @@ int proj_residual(const uint16_t* x, const uint16_t* W, const float* bias, const
 
 // true when cx_gemm_bf16_bias_gelu covers the fc1 shape (keep in sync with its checks)
 bool gelu_fused_shape(int T, int N, int K) {
-    return T > 0 && (K % 64) == 0 && (N % 8) == 0 && cx_gemm_get_variant() == 6;
+    return T > 0 && (K % 64) == 0 && (N % 8) == 0;
 }
 
 // ---- transformer blocks, forward.  h0: (T,d) input embeddings.  Returns the final hidden states in *h_final. ------

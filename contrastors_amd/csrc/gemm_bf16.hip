@@ -645,7 +645,6 @@ extern "C" {
 void cx_gemm_set_trace(void* buf) { cx_gemm_v5_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_v6_trace(void* buf) { cx_gemm_v6_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_v6_ablate(int mask) { cx_gemm_v6_set_ablate(mask); }
-void cx_gemm_v6_stagger(int cycles, int phases) { cx_gemm_v6_set_stagger(cycles, phases); }
 void cx_gemm_set_debug(int d) {
     g_dbg = d;
     cx_gemm_v5_set_persistent((d & 4) == 0);

@@ -337,19 +337,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmParams p) {
 
 template <int FORM, int OUT_MODE, int EPI>
 hipError_t launch5(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v5_kernel<FORM, OUT_MODE, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NST5 * ST5);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static CxLdsOptIn lds;
+    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v5_kernel<FORM, OUT_MODE, EPI>), NST5 * ST5)) return hipErrorInvalidValue;
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
     hipLaunchKernelGGL((gemm_bf16_v5_kernel<FORM, OUT_MODE, EPI>), dim3(nwg), dim3(512), NST5 * ST5, stream, p);
     return hipGetLastError();
 }
 
 
+#ifndef CX_PRODUCT  // the 8-wave persistent kernel (superseded by gemm_bf16_v6.hip) and its switches: dev library only
 // =====================================================================================================================
 // Persistent walk of the same 256x256x64 tile (NT forms with bf16 output): 256 workgroups, each loops over its tiles
 // and keeps the two-stage DMA pipeline running ACROSS tile boundaries -- the first K-tile of the next output tile is
@@ -708,14 +704,17 @@ hipError_t launch5p(const GemmParams& p, hipStream_t stream) {
 
 bool g_v5_persistent = true;
 bool g_v5_use_v6 = true;  // default: persistent NT forms run on the one-wave-per-SIMD kernel (gemm_bf16_v6.hip)
+#endif  // !CX_PRODUCT
 
 }  // namespace
 
+#ifndef CX_PRODUCT
 void cx_gemm_v5_set_use_v6(bool on) { g_v5_use_v6 = on; }
 bool cx_gemm_v5_get_use_v6(void) { return g_v5_use_v6; }
 
 void cx_gemm_v5_set_persistent(bool on) { g_v5_persistent = on; }
 void cx_gemm_v5_set_trace(long long* buf) { g_v5_trace = buf; }
+#endif
 
 // form 0 = NT, 1 = TN (p.X = dY (T,M), p.W = A (T,N), p.K = tokens; M % 256 == 0 and N % 256 == 0 required).
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream) {
@@ -724,6 +723,13 @@ hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipS
     p.tiles_n = (p.N + BN5 - 1) / BN5;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > p.K / BK5) p.split_k = p.K / BK5;
+#ifdef CX_PRODUCT
+    // product library: the persistent forms are gemm_bf16_v6.hip's (called directly by gemm_api.hip); what is left here is
+    // the one-tile-per-workgroup kernel for fp32 / fp32-partial outputs and bf16 shapes with N or ldo not a multiple of 8
+    if (form == 1) return hipErrorInvalidValue;
+    if (epi == GEMM_EPI_SWIGLU)
+        return out_mode == GEMM_OUT_BF16 ? launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_SWIGLU>(p, stream) : hipErrorInvalidValue;
+#else
     if (form == 1) {
         if ((p.M % BM5) != 0 || (p.N % BN5) != 0 || out_mode != GEMM_OUT_F32_PARTIAL) return hipErrorInvalidValue;
         if (g_v5_use_v6) return cx_launch_gemm_v6_tn(p, stream);
@@ -738,6 +744,7 @@ hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipS
     }
     if (out_mode == GEMM_OUT_BF16 && pers && (p.ldo % 8) == 0)
         return (g_v5_use_v6 && !g_v5_trace) ? cx_launch_gemm_v6(p, GEMM_EPI_NONE, stream) : launch5p<GEMM_EPI_NONE>(p, stream);
+#endif
     switch (out_mode) {
         case GEMM_OUT_BF16: return launch5<FORM_NT, GEMM_OUT_BF16, GEMM_EPI_NONE>(p, stream);
         case GEMM_OUT_F32: return launch5<FORM_NT, GEMM_OUT_F32, GEMM_EPI_NONE>(p, stream);

@@ -57,15 +57,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // slice of W, which then stays L2-resident across rounds instead of being re-streamed for every M-panel.
     const int per_xcd = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    // De-phasing.  Every workgroup does the same work per tile, so all 256 CUs run their MFMA phases together and then
-    // all stream their epilogues together: HBM idles during the former and the matrix pipes during the latter.
-    // p.sup_m (> 0) = cycles by which workgroup phase k of `p.split_k` phases starts late (k = idx % phases), paid once per launch.
-    if (p.sup_m > 0) {
-        const int phases = p.split_k > 1 ? p.split_k : 2;
-        const long long wait = (long long)p.sup_m * (idx % phases);
-        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     const int gn = p.sup_n > 0 ? p.sup_n : 1, gm = 8 / gn;
     const int xi = xcd / gn, xj = xcd - xi * gn;
     const int m_lo = p.tiles_m * xi / gm, m_hi = p.tiles_m * (xi + 1) / gm;
@@ -395,7 +386,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     one_pass(std::integral_constant<int, 3>{});
 #undef CX_RES_ROWS
                 };
-                const bool fast = p.alpha == 1.f && !add_bias && m0 + 128 <= p.M && n0 + 128 <= p.N && !(p.dbg & 0x10000);  // bit 16: A/B switch back to the first epilogue
+                const bool fast = p.alpha == 1.f && !add_bias && m0 + 128 <= p.M && n0 + 128 <= p.N;
                 auto store_tile = [&](auto plain) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {  // 32 rows of the wave's 128 per pass
@@ -486,7 +477,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 // full store round trip before its data was even requested.  Here the 16 row loads of pass b + 1 are
                 // issued right after pass b's rows have been staged (their registers are free from then on) and BEFORE
                 // pass b's stores; they land while the wave does the pass's sigmoid arithmetic.
-                const bool fast_bwd = m0 + 128 <= p.M && n0 + 128 <= p.N && !(p.dbg & 0x10000);
+                const bool fast_bwd = m0 + 128 <= p.M && n0 + 128 <= p.N;
                 if (fast_bwd) {
                     const int lrow = lane >> 5, lch = lane & 31;
                     const bf16_t* src = yg_in + (size_t)(m0 + lrow) * p.ldo2 + c0 + lch * 8;
@@ -773,7 +764,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     one_pass(std::integral_constant<int, 2>{});
                     one_pass(std::integral_constant<int, 3>{});
                 };
-                if (m0 + 128 <= p.M && n0 + 128 <= p.N && !(p.dbg & 0x10000)) {
+                if (m0 + 128 <= p.M && n0 + 128 <= p.N) {
                     if (p.Out) {
                         fast_swiglu(std::true_type{});
                     } else {
@@ -835,11 +826,28 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
             }
             cp_tile = tile_of(++cp_round);
-            if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
-                // This epilogue needs the registers: the first fragments of the next tile (read into F0 during the last
-                // k-step above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead
-                // across the epilogue (~200 cycles of exposed LDS latency per tile against 32 registers).
+            // Register relief for the two epilogues that need it (the plain / residual one sat at 256 VGPRs and the compiler
+            // parked live values in a0..a3, i.e. INSIDE accumulator block 0, which it cannot see; build.py audits the
+            // generated code for exactly that).  The first fragments of the next tile (read into F0 during the last k-step
+            // above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead across the epilogue
+            // (~150 cycles of exposed LDS latency per tile against 32 registers); the SwiGLU backward additionally rebuilds
+            // its 16 DMA cursor offsets from (round, K-tile).
+            if constexpr (EPI == GEMM_EPI_NONE || EPI == GEMM_EPI_SWIGLU_BWD) {
                 asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
+                if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
+                    asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
+                    asm volatile("" : "=v"(woff[0]), "=v"(woff[1]), "=v"(woff[2]), "=v"(woff[3]), "=v"(woff[4]), "=v"(woff[5]), "=v"(woff[6]), "=v"(woff[7]));
+                    if (lx_live) {
+                        x_setup(tile_of(lx_round));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xoff[j] += lx_kt * (BK6 * 2);
+                    }
+                    if (lw_live) {
+                        w_setup(tile_of(lw_round));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) woff[j] += lw_kt * (BK6 * 2);
+                    }
+                }
                 if (cp_tile < ntiles) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) read_one(F0, dsm + xs_slot * XS6, dsm + (3 + ws_slot) * XS6, 0, i);
@@ -860,13 +868,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
 template <int EPI, int DBG = 0>
 hipError_t launch6(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static CxLdsOptIn lds;
+    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG>), LDS6)) return hipErrorInvalidValue;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
     hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, DBG>), dim3(grid), dim3(256), LDS6, stream, p);
@@ -1086,10 +1089,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
+#ifndef CX_PRODUCT
 int g_v6_dbg = 0;              // ablation mask (cx_gemm_v6_ablate)
-int g_v6_stagger = 0, g_v6_phases = 2;  // experiments: start-time skew between workgroup phases (cycles), phase count
 long long* g_v6_trace = nullptr;  // ablation builds only: 2 x int64 per workgroup {cycles, K-tiles}
 int g_v6_force_gn = 0;  // experiments: 1, 2, 4 or 8 forces the N-group count; 0 = heuristic
+#else
+constexpr int g_v6_force_gn = 0;
+#endif
 
 // N-groups of the XCD grid: the estimated L2-miss traffic is gn * |X| (every X panel is fetched by the gn XCDs of its
 // grid row) + (8 / gn) * |W| when an XCD's W slice (tiles_n / gn row-blocks of 256 x K) can stay L2-resident, and
@@ -1113,21 +1119,17 @@ int cx_gemm_v6_groups(int tiles_m, int tiles_n, int K) {
 
 }  // namespace
 
+#ifndef CX_PRODUCT
 void cx_gemm_v6_set_trace(long long* buf) { g_v6_trace = buf; }
 void cx_gemm_v6_set_ablate(int mask) { g_v6_dbg = mask; }
-void cx_gemm_v6_set_stagger(int cycles, int phases) { g_v6_stagger = cycles; g_v6_phases = phases < 2 ? 2 : phases; }
 void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
+#endif
 
 // TN wgrad form: p.X = dY (T, M), p.W = A (T, N), p.K = tokens, p.Out = fp32 partial slabs [split_k][M][ldo];
 // M % 256 == 0, N % 256 == 0, K % 64 == 0, 1 <= split_k <= K / 64 (checked by the caller).
 hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v6tn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static CxLdsOptIn lds;
+    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v6tn_kernel), LDS6)) return hipErrorInvalidValue;
     p.tiles_m = p.M / BM6;
     p.tiles_n = p.N / BN6;
     hipLaunchKernelGGL(gemm_bf16_v6tn_kernel, dim3(p.tiles_m * p.tiles_n * p.split_k), dim3(256), LDS6, stream, p);
@@ -1139,8 +1141,7 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     p.tiles_m = (p.M + BM6 - 1) / BM6;
     p.tiles_n = (p.N + BN6 - 1) / BN6;
     p.sup_n = cx_gemm_v6_groups(p.tiles_m, p.tiles_n, p.K);
-    p.sup_m = g_v6_stagger;
-    p.split_k = g_v6_phases;
+#ifndef CX_PRODUCT
     if (epi == GEMM_EPI_NONE && g_v6_dbg) {  // ablation builds (scripts/gemm_ablate.py)
         p.trace = g_v6_trace;
         switch (g_v6_dbg) {
@@ -1159,6 +1160,7 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
             default: break;
         }
     }
+#endif
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
            : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD ? launch6<GEMM_EPI_SWIGLU_BWD>(p, stream)

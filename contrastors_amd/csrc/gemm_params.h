@@ -30,7 +30,6 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream);
 void cx_gemm_v6_force_groups(int gn);
 void cx_gemm_v6_set_trace(long long* buf);
 void cx_gemm_v6_set_ablate(int mask);
-void cx_gemm_v6_set_stagger(int cycles, int phases);
 hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream);
 void cx_gemm_v5_set_persistent(bool on);
 void cx_gemm_v5_set_use_v6(bool on);

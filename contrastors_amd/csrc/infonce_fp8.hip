@@ -313,13 +313,8 @@ int quantize(const float* X, int ldx, uint8_t* X8, float* sc, uint16_t* Xb, int 
 template <int KS>
 int launch_main(const Fp8Params& p, int mode, hipStream_t s) {
     constexpr int LDS = 2 * TD * (KS * 64 + 16) + 2 * TD * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&infonce_fp8_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS) != hipSuccess)
-            return CX_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static CxLdsOptIn lds;
+    if (!lds.ensure(reinterpret_cast<const void*>(&infonce_fp8_kernel<KS>), LDS)) return CX_ERR_LAUNCH;
     hipLaunchKernelGGL((infonce_fp8_kernel<KS>), dim3((p.N + QB - 1) / QB, p.nsplit), dim3(256), LDS, s, p, mode);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
@@ -376,8 +371,8 @@ int cx_infonce_fp8_bwd(const float* Q, const float* D, const int64_t* labels, co
     if (!Q || !D || !labels || !lse || !Q8 || !D8 || !sq || !sd || !GmT || !Qb || !QbT || !Db || !ws || !dQ || !dD)
         return CX_ERR_ARG;
     // the two output products run on the bf16 GEMM family: dD = GmT Q needs K = N % 64 == 0; dQ = GmT^T D is the
-    // natural-layout wgrad form (O = N % 256 == 0, I = dim % 128 == 0, K = G rows zero-padded to a multiple of 64)
-    if ((N % 256) != 0 || (dim % 128) != 0 || (G % 64) != 0) return CX_ERR_SHAPE;
+    // natural-layout wgrad form (O = N % 256 == 0, I = dim % 256 == 0, K = G rows zero-padded to a multiple of 64)
+    if ((N % 256) != 0 || (dim % 256) != 0 || (G % 64) != 0) return CX_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     Fp8Params p = {};
     p.Q8 = Q8; p.D8 = D8; p.sq = sq; p.sd = sd; p.labels = labels; p.N = N; p.G = G; p.dim = dim; p.scale = scale;

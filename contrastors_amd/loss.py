@@ -267,7 +267,7 @@ def effective_chunk(tower, inputs, chunk_size: int) -> int:
     """The GradCache chunk is a pure memory knob: embeddings, loss and gradients do not depend on it (tested to fp32
     summation order).  The reference recipes say 64 because an 80 GB part cannot hold more activations; an MI355X has
     288 GB, and its GEMMs want >= 512 row panels per launch.  With CX_GRADCACHE_CHUNK=auto (the default) a recipe's
-    chunk_size is therefore treated as a LOWER bound and raised -- in multiples of itself -- until a chunk carries ~131072
+    chunk_size is therefore treated as a LOWER bound and raised -- in multiples of itself -- until a chunk carries ~262144
     tokens or its activation arena would take more than a third of the free HBM.  CX_GRADCACHE_CHUNK=exact keeps the
     recipe's number; CX_GRADCACHE_CHUNK=<n> forces n."""
     import os
@@ -290,7 +290,7 @@ def effective_chunk(tower, inputs, chunk_size: int) -> int:
     bytes_per_token = kept * per_layer + (L - kept) * 2 * d + scratch
     free, _ = torch.cuda.mem_get_info(ids.device)
     free += torch.cuda.memory_reserved(ids.device) - torch.cuda.memory_allocated(ids.device)  # the allocator's own cache
-    tokens = int(min(131072, max(S, free / 3 / bytes_per_token)))
+    tokens = int(min(262144, max(S, free / 3 / bytes_per_token)))
     want = max(chunk_size, tokens // max(S, 1))
     want = max(chunk_size, want // chunk_size * chunk_size)
     return int(min(want, max(B, chunk_size)))

@@ -183,6 +183,11 @@ class VarlenBatch:
         """Token ids of the chunk in ascending stable order + the permutation that sorts them: lets the engine reduce the
         word-embedding gradient per vocabulary row without atomics (cx_embed_ln_bwd_sorted).  One device sort, no sync."""
         if self._sort is None:
+            import os
+
+            if os.environ.get("CX_EMBED_ATOMICS"):  # debugging aid: fall back to the fp32-atomics scatter
+                self._sort = (None, None)
+                return self._sort
             tok = self.input_ids.reshape(-1)[self.indices.long()].to(torch.int32)
             sorted_ids, perm = torch.sort(tok, stable=True)
             self._sort = (sorted_ids.contiguous(), perm.to(torch.int32).contiguous())
@@ -567,8 +572,8 @@ class NomicBertEngine(torch.nn.Module):
         sids, perm = vb.embedding_sort()
         rc = self.lib.cx_encoder_backward(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
                                           vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
-                                          vb.max_seqlen, demb.data_ptr(), arena.emb_out.data_ptr(), sids.data_ptr(),
-                                          perm.data_ptr(), _C.cur_stream())
+                                          vb.max_seqlen, demb.data_ptr(), arena.emb_out.data_ptr(), _C.ptr(sids),
+                                          _C.ptr(perm), _C.cur_stream())
         _C.check(rc, "cx_encoder_backward")
         self.release_arena(arena)
 
@@ -596,7 +601,7 @@ class NomicBertEngine(torch.nn.Module):
         sids, perm = vb.embedding_sort()
         rc = self.lib.cx_encoder_backward_hidden(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
                                                  vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
-                                                 vb.max_seqlen, dh.data_ptr(), sids.data_ptr(), perm.data_ptr(),
+                                                 vb.max_seqlen, dh.data_ptr(), _C.ptr(sids), _C.ptr(perm),
                                                  _C.cur_stream())
         _C.check(rc, "cx_encoder_backward_hidden")
         self.release_arena(arena)

@@ -33,8 +33,8 @@ const char* cx_error_string(int code);
 /* ---- K9  FusedDense  (flash_attn.ops.fused_dense.FusedDense; sc/layers/attention.py:82-85,112-114,243,
  *          sc/layers/mlp.py:24-28,61-83) ----------------------------------------------------------------
  * Out[m][n] = alpha * sum_k X[m][k] * W[n][k] (+ bias[n])          X:(M,K) ldx   W:(N,K) ldw   Out:(M,N) ldo
- * out_mode 0: Out is bf16;  1: Out is fp32 (overwrite);  2: Out is fp32, atomically ACCUMULATED (wgrad; the
- * only mode that honours split_k > 1).  Requirements: K % 64 == 0, N % 4 == 0, ldx/ldw % 8 == 0, ldo % 4 == 0.
+ * out_mode 0: Out is bf16;  1: Out is fp32 (overwrite).  Accumulating forms: cx_gemm_bf16_nt_accum / _tn_accum
+ * (deterministic split-K); `split_k` is ignored here.  Requirements: K % 64 == 0, N % 4 == 0, ldx/ldw % 8 == 0, ldo % 4 == 0.
  * forward: X=act, W=weight.  dgrad: X=dY, W=W^T.  wgrad: X=dY^T, W=act^T (both via cx_transpose_bf16). */
 int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float* bias, int M, int N, int K, int ldx,
                     int ldw, int ldo, int out_mode, int split_k, float alpha, void* stream);
@@ -44,30 +44,15 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
 int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, float* ws, long ws_floats, int M, int N,
                           int K, int ldx, int ldw, void* stream);
 /* wgrad in its natural layout, no transposes: G:(O,I) fp32 (ld = I) += dY:(T,O)^T A:(T,I).  The kernel reads
- * round_up(T,64) token rows of both operands: rows T.. of that range must be ZERO.  O % 256 == 0, I % 128 == 0. */
+ * round_up(T,64) token rows of both operands: rows T.. of that range must be ZERO.  O % 256 == 0, I % 256 == 0 (else
+ * CX_ERR_SHAPE: transpose both operands with cx_transpose_bf16 and use cx_gemm_bf16_nt_accum). */
 int cx_gemm_bf16_tn_accum(const uint16_t* dY, const uint16_t* A, float* G, float* ws, long ws_floats, int T, int O, int I,
                           int ld_dy, int ld_a, void* stream);
-void cx_gemm_set_variant(int v); /* 5 (default): 256x256x64 2-stage; 2: 256x128x64 3-stage ring; 3/4: persistent experiments; 1: 128x128 */
-int cx_gemm_get_variant(void);
-void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0/bit1 ablate the v2 main loop; bit2 = non-persistent v5 */
-/* in-kernel phase timers of the persistent 256x256x64 kernel: buf = int64[grid*8 waves*8] {wait, compute, epilogue
-   cycles, iterations, epilogue DMA-wait cycles, -, -, -} per wave, or NULL to disable (scripts/gemm_trace.py) */
-void cx_gemm_set_trace(void* buf);
-/* one-wave-per-SIMD kernel: ablation builds (mask bits: 1 no DMA, 2 no barrier, 4 no fragment reads, 8 no MFMA, 16 no
-   epilogue, 32 no DMA wait, 128 trace only; results are garbage, timing is the point) and their per-workgroup trace
-   buffer int64[grid][2] = {s_memtime span, K-tiles} (scripts/gemm_ablate.py) */
-void cx_gemm_v6_ablate(int mask);
-/* experiment: workgroup phase k (of `phases`) starts k * cycles late, so that epilogue streaming and MFMA phases of
-   different CUs overlap in time instead of running in lock-step */
-void cx_gemm_v6_stagger(int cycles, int phases);
-void cx_gemm_v6_trace(void* buf);
 /* Sampled per-launch timing of this (dominant) kernel for bench.py's roofline: every `stride`-th launch is bracketed by
  * HIP events on its own stream; collect() synchronises them and returns the summed duration (ms) and algorithmic FLOPs
  * (2*M*N*K) of exactly the sampled launches. */
 int cx_prof_gemm_config(int enable, int stride);
 int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_timed, long* launches_total);
-void cx_gemm_set_glds(int enable); /* 1 (default): operand tiles via global_load_lds DMA; 0: register staging */
-int cx_gemm_get_glds(void);
 
 /* Out[c][r] = In[r][c] for r < rows, zero for rows <= r < rows_pad (token padding for the wgrad reduction).
  * In:(rows,cols) ld_in, Out:(cols,rows_pad) ld_out.  cols % 8 == 0. */
@@ -165,15 +150,6 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
                        const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
                        uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
-/* backward kernel choice for max_seqlen <= 128: 3 = fused persistent kernel with an 80 KiB LDS layout, two workgroups
- * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
- * 0 = the general kernels */
-void cx_attn_set_bwd_s128(int mode);
-/* forward kernel for max_seqlen <= 128: 2 (default) lean-VALU form with full-row output stores (V fragments through
- * the transposing LDS read, mask skipped for full sequences, scale folded into the exponent, output staged in LDS),
- * 0 the first one-problem-per-workgroup form (<= 1 bf16 ulp apart), 1 persistent workgroups that prefetch the next
- * problem (bit-identical to 0).  A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
-void cx_attn_set_fwd_s128(int mode);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                           int B, int H, int T, int max_seqlen, int sign, void* stream);
@@ -378,15 +354,6 @@ int cx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* e
                        float beta2, float eps, float weight_decay, long step, const double* sq_norm, float max_norm,
                        void* stream);
 
-/* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
-int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
-int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);
-/* MFMA issue-rate probe (scripts/mfma_probe.py): see probe.hip */
-int cx_probe_mfma_rate(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
-                       void* stream);
-/* global->LDS DMA throughput probe (scripts/dma_probe.py): see probe.hip */
-int cx_probe_dma_bw(const void* src, long wg_stride, long span, long row_stride, int per_wave, int iters, int depth,
-                    int nwg, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,59 @@
+/* contrastors_hip_dev.h -- DEVELOPMENT-ONLY entry points of libcontrastors_hip_dev.so (gfx950).
+ *
+ * The product library (libcontrastors_hip.so, include/contrastors_hip.h) carries ONE kernel per op and no mutable
+ * switches.  This library is the same code built WITHOUT -DCX_PRODUCT: it additionally contains the earlier GEMM
+ * generations (gemm_bf16.hip v1/v2, gemm_bf16_v3.hip, gemm_bf16_v4.hip, the 8-wave persistent v5p), the A/B attention
+ * kernels, the hardware probes and the process-global switches below.  Used by scripts/ (microbenchmarks, ablations) and
+ * by the A/B parity tests; never by contrastors_amd's product path.  Everything in contrastors_hip.h is exported here too. */
+#ifndef CONTRASTORS_HIP_DEV_H
+#define CONTRASTORS_HIP_DEV_H
+
+#include "contrastors_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void cx_gemm_set_variant(int v); /* 5 (default): 256x256x64 2-stage; 2: 256x128x64 3-stage ring; 3/4: persistent experiments; 1: 128x128 */
+int cx_gemm_get_variant(void);
+
+void cx_gemm_set_debug(int bits); /* experiments only (0 = normal): bit0/bit1 ablate the v2 main loop; bit2 = non-persistent v5 */
+
+/* in-kernel phase timers of the persistent 256x256x64 kernel: buf = int64[grid*8 waves*8] {wait, compute, epilogue
+   cycles, iterations, epilogue DMA-wait cycles, -, -, -} per wave, or NULL to disable (scripts/gemm_trace.py) */
+void cx_gemm_set_trace(void* buf);
+
+/* one-wave-per-SIMD kernel: ablation builds (mask bits: 1 no DMA, 2 no barrier, 4 no fragment reads, 8 no MFMA, 16 no
+   epilogue, 32 no DMA wait, 128 trace only; results are garbage, timing is the point) and their per-workgroup trace
+   buffer int64[grid][2] = {s_memtime span, K-tiles} (scripts/gemm_ablate.py) */
+void cx_gemm_v6_ablate(int mask);
+void cx_gemm_v6_trace(void* buf);
+
+void cx_gemm_set_glds(int enable); /* 1 (default): operand tiles via global_load_lds DMA; 0: register staging */
+int cx_gemm_get_glds(void);
+
+/* backward kernel choice for max_seqlen <= 128: 3 = fused persistent kernel with an 80 KiB LDS layout, two workgroups
+ * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
+ * 0 = the general kernels */
+void cx_attn_set_bwd_s128(int mode);
+
+/* forward kernel for max_seqlen <= 128: 2 (default) lean-VALU form with full-row output stores (V fragments through
+ * the transposing LDS read, mask skipped for full sequences, scale folded into the exponent, output staged in LDS),
+ * 0 the first one-problem-per-workgroup form (<= 1 bf16 ulp apart), 1 persistent workgroups that prefetch the next
+ * problem (bit-identical to 0).  A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
+void cx_attn_set_fwd_s128(int mode);
+
+/* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
+int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
+int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);
+/* MFMA issue-rate probe (scripts/mfma_probe.py): see probe.hip */
+int cx_probe_mfma_rate(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
+                       void* stream);
+/* global->LDS DMA throughput probe (scripts/dma_probe.py): see probe.hip */
+int cx_probe_dma_bw(const void* src, long wg_stride, long span, long row_stride, int per_wave, int iters, int depth,
+                    int nwg, float* sink, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTRASTORS_HIP_DEV_H */

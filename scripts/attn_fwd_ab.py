@@ -9,7 +9,7 @@ import torch  # noqa: E402
 from contrastors_amd import _C  # noqa: E402
 
 modes = [int(m) for m in sys.argv[1:]] or [0, 1, 2]
-lib = _C.lib()
+lib = _C.dev_lib()
 s = torch.cuda.current_stream().cuda_stream
 H, D, S = 12, 64, 128
 inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))

@@ -14,7 +14,7 @@ ap.add_argument("--tokens", type=int, default=131072)
 ap.add_argument("--heads", type=int, default=12)
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
-lib = _C.lib()
+lib = _C.dev_lib()
 s = torch.cuda.current_stream().cuda_stream
 H, D = a.heads, 64
 print("S      B     fwd us   fwd TF    bwd us   bwd TF   (FLOP: fwd 4*S*S*D per seq-head, bwd 2.5x)")

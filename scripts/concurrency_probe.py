@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from contrastors_amd import _C  # noqa: E402
 
-lib = _C.lib()
+lib = _C.dev_lib()
 dev = "cuda"
 T, d, I = 131072, 768, 3072
 reps = 6

@@ -7,7 +7,7 @@ import torch  # noqa: E402
 
 from contrastors_amd import _C  # noqa: E402
 
-lib = _C.lib()
+lib = _C.dev_lib()
 buf = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
 sink = torch.zeros(256, device="cuda")
 s = torch.cuda.current_stream().cuda_stream

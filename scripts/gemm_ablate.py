@@ -13,11 +13,9 @@ from contrastors_amd import _C  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunk", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--old-epilogue", type=int, default=0)
 a = ap.parse_args()
-lib = _C.lib()
+lib = _C.dev_lib()
 lib.cx_gemm_set_variant(6)
-lib.cx_gemm_set_debug(0x10000 if a.old_epilogue else 0)
 T = a.chunk * 128
 shapes = {"fc1_dgrad K=6144": (T, 768, 6144), "fc1_fwd K=768": (T, 6144, 768), "out_fwd K=768": (T, 768, 768)}
 masks = [(128, "full kernel (trace only)"), (128, "full kernel again"), (64, "epilogue without global stores"), (16, "no epilogue"), (1, "no DMA"), (2, "no barrier"), (4, "no fragment reads"),

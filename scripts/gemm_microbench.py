@@ -17,17 +17,14 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", type=str, default="")
 ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--tn", type=int, default=1)
-ap.add_argument("--stagger", type=int, default=0)
-ap.add_argument("--phases", type=int, default=2)
 ap.add_argument("--zeros", type=int, default=0, help="all-zero operands: no switching power, clocks stay high")
 ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
 a = ap.parse_args()
-lib = _C.lib()
+lib = _C.dev_lib()  # variant / ablation switches live in the dev library
 lib.cx_gemm_set_variant(a.variant)
 lib.cx_gemm_set_glds(a.glds)
 lib.cx_gemm_set_debug(a.dbg)
 lib.cx_gemm_v6_ablate(0)
-lib.cx_gemm_v6_stagger(a.stagger, a.phases)
 T = a.chunk * 128
 shapes = {  # name: (M, N, K)
     "qkv_fwd": (T, 2304, 768), "out_fwd": (T, 768, 768), "fc1_fwd": (T, 6144, 768), "fc2_fwd": (T, 768, 3072),

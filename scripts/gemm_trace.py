@@ -15,7 +15,7 @@ ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--zeros", type=int, default=0)
 ap.add_argument("--shape", type=str, action="append", default=[], help="M,N,K (repeatable)")
 a = ap.parse_args()
-lib = _C.lib()
+lib = _C.dev_lib()
 lib.cx_gemm_set_debug(a.dbg)
 T = a.chunk * 128
 shapes = {"qkv_fwd": (T, 2304, 768), "out_fwd": (T, 768, 768), "fc1_fwd": (T, 6144, 768), "fc2_fwd": (T, 768, 3072),

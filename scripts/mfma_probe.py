@@ -7,7 +7,7 @@ import torch  # noqa: E402
 
 from contrastors_amd import _C  # noqa: E402
 
-lib = _C.lib()
+lib = _C.dev_lib()
 s = torch.cuda.current_stream().cuda_stream
 cyc = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
 sink = torch.zeros(4, device="cuda")

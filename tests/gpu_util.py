@@ -31,18 +31,23 @@ def L():
     return _C.lib()
 
 
+def LD():
+    """Development library: earlier GEMM generations, A/B attention kernels, probes, process-global switches."""
+    return _C.dev_lib()
+
+
 def bf(x):
     return x.to(torch.bfloat16).contiguous()
 
 
-def gemm(x, w, bias=None, out_mode=0, split_k=1, out=None, alpha=1.0):
+def gemm(x, w, bias=None, out_mode=0, split_k=1, out=None, alpha=1.0, lib=None):
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16 if out_mode == 0 else torch.float32, device=x.device)
         if out_mode == 2:
             out.zero_()
-    _C.check(L().cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), out.data_ptr(), _C.ptr(bias), M, N, K, x.stride(0),
+    _C.check((lib or L()).cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), out.data_ptr(), _C.ptr(bias), M, N, K, x.stride(0),
                                  w.stride(0), out.stride(0), out_mode, split_k, alpha, S()), "gemm")
     return out
 

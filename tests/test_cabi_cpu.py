@@ -33,6 +33,20 @@ def test_header_symbols_exported(built):
     assert b"gfx950" in lib.cx_build_info()
     assert lib.cx_error_string(-1) == b"unsupported shape"
     assert lib.cx_infonce_ws_floats(2048, 16384) == 2048 * (2 * 2 * 128 + 1)
+    # the product library carries no debug switch, probe or superseded kernel generation
+    for name in _C.DEV_EXPORTED_SYMBOLS:
+        assert not hasattr(lib, name), f"{name} must live in the dev library only"
+
+
+def test_dev_header_symbols_exported(built):
+    from contrastors_amd import _C
+
+    text = (ROOT / "include" / "contrastors_hip_dev.h").read_text()
+    declared = set(re.findall(r"\b(cx_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(_C.DEV_EXPORTED_SYMBOLS), declared ^ set(_C.DEV_EXPORTED_SYMBOLS)
+    dev = _C.dev_lib()
+    for name in sorted(declared | set(_C.EXPORTED_SYMBOLS)):
+        assert hasattr(dev, name), f"{name} missing from the dev library"
 
 
 def test_ctypes_struct_layout_matches_c(tmp_path, built):

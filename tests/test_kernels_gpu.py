@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from contrastors_amd import _C
-from tests.gpu_util import L, S, bf, gemm, max_err, rel_err, report
+from tests.gpu_util import LD, L, S, bf, gemm, max_err, rel_err, report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -21,7 +21,7 @@ def _randn(*s, seed=0, std=1.0):
 # ------------------------------------------------------------------------------------------------- hardware probes
 def test_probe_mfma_accumulator_layout():
     out = torch.zeros(32, 32, device=DEV)
-    _C.check(L().cx_probe_mfma_layout(out.data_ptr(), S()))
+    _C.check(LD().cx_probe_mfma_layout(out.data_ptr(), S()))
     i = torch.arange(32, device=DEV).float()
     want = (i[:, None] + 1) + 64 * (i[None, :] + 1)  # asymmetric: catches a transposed C mapping
     assert torch.equal(out, want)
@@ -30,7 +30,7 @@ def test_probe_mfma_accumulator_layout():
 def test_probe_ds_read_tr16_pattern():
     src = torch.arange(256, dtype=torch.int16, device=DEV)
     out = torch.zeros(256, dtype=torch.int16, device=DEV)
-    _C.check(L().cx_probe_ds_read_tr16(src.data_ptr(), out.data_ptr(), S()))
+    _C.check(LD().cx_probe_ds_read_tr16(src.data_ptr(), out.data_ptr(), S()))
     got = out.cpu().numpy().reshape(64, 4)
     want = np.zeros((64, 4), dtype=np.int16)
     for lane in range(64):
@@ -44,28 +44,47 @@ def test_probe_ds_read_tr16_pattern():
 
 
 # ------------------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", ["v6", "v5", "v4", "v3", "v2", "v1_glds", "v1_reg"])
+def _gemm_lib(variant):
+    """"product" -> libcontrastors_hip.so (one kernel family, no switches); anything else -> the dev library with its
+    process-global variant switch (earlier GEMM generations kept for A/B)."""
+    if variant in ("product", 6):
+        return L()
+    lib = LD()
+    lib.cx_gemm_set_variant({"v6": 6, "v5": 5, "v4": 4, "v3": 3, "v2": 2}.get(variant, variant if isinstance(variant, int) else 1))
+    lib.cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
+    return lib
+
+
+def _gemm_lib_reset():
+    LD().cx_gemm_set_variant(6)
+    LD().cx_gemm_set_glds(1)
+
+
+@pytest.mark.parametrize("variant", ["product", "v6", "v5", "v4", "v3", "v2", "v1_glds", "v1_reg"])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
                                    (257, 6144, 768), (300, 768, 128)])
 def test_gemm_bf16_nt(variant, M, N, K):
-    L().cx_gemm_set_variant({"v6": 6, "v5": 5, "v4": 4, "v3": 3, "v2": 2}.get(variant, 1))
-    L().cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
+    lib = _gemm_lib(variant)
     try:
         x, w = bf(_randn(M, K, seed=1)), bf(_randn(N, K, seed=2, std=0.05))
         bias = _randn(N, seed=3)
         ref = x.float() @ w.float().T
-        out32 = gemm(x, w, out_mode=1)
+        out32 = gemm(x, w, out_mode=1, lib=lib)
         e32 = rel_err(out32, ref)
-        out16 = gemm(x, w, bias=bias, out_mode=0)
+        out16 = gemm(x, w, bias=bias, out_mode=0, lib=lib)
         e16 = rel_err(out16.float(), ref + bias)
         acc = torch.ones(M, N, device=DEV)
-        gemm(x, w, out_mode=2, split_k=min(4, K // 64), out=acc)
-        eacc = rel_err(acc - 1.0, ref)
+        if variant == "product":  # no atomically-accumulating mode in the product library: the caller is told so
+            assert lib.cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), acc.data_ptr(), None, M, N, K, K, K, N, 2, 4, 1.0, S()) == -3
+            eacc = 0.0
+        else:
+            gemm(x, w, out_mode=2, split_k=min(4, K // 64), out=acc, lib=lib)
+            eacc = rel_err(acc - 1.0, ref)
         # workspace split-K accumulate (the wgrad form): Out += X W^T, twice, deterministic
         acc2 = torch.ones(M, N, device=DEV)
         ws = torch.empty(3 * M * N + 5, device=DEV)
         for _ in range(2):
-            _C.check(L().cx_gemm_bf16_nt_accum(x.data_ptr(), w.data_ptr(), acc2.data_ptr(), ws.data_ptr(), ws.numel(),
+            _C.check(lib.cx_gemm_bf16_nt_accum(x.data_ptr(), w.data_ptr(), acc2.data_ptr(), ws.data_ptr(), ws.numel(),
                                                M, N, K, K, K, S()))
         eacc2 = rel_err(acc2 - 1.0, 2 * ref)
         report("gemm", variant=variant, M=M, N=N, K=K, e32=e32, e16=e16, eacc=eacc, eacc2=eacc2)
@@ -73,21 +92,20 @@ def test_gemm_bf16_nt(variant, M, N, K):
         assert e16 < 4e-3, "bf16-out GEMM: one bf16 rounding (2^-9 rel) of the fp32 result"
         assert eacc < 1e-5 and eacc2 < 1e-5
     finally:
-        L().cx_gemm_set_variant(6)
-        L().cx_gemm_set_glds(1)
+        _gemm_lib_reset()
 
 
 @pytest.mark.parametrize("variant", [2, 4, 5, 6])
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
 def test_gemm_swiglu_fused(M, I, K, variant):
     """fc11 || fc12 GEMM with SwiGLU in the epilogue == standalone GEMM + swiglu (interleaved-by-32 weight rows)."""
-    L().cx_gemm_set_variant(variant)  # 2 -> fused epilogue runs on the v3 kernel, 4 -> on the v4 kernel
+    lib = _gemm_lib(variant)  # 6 -> product library; 2 -> fused epilogue on the v3 kernel, 4 -> v4, 5 -> v5/v6 (dev library)
     x = bf(_randn(M, K, seed=90))
     w11, w12 = bf(_randn(I, K, seed=91, std=0.05)), bf(_randn(I, K, seed=92, std=0.05))
     wi = torch.stack([w11.view(I // 32, 32, K), w12.view(I // 32, 32, K)], 1).reshape(2 * I, K).contiguous()
     yg = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV)
     act = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
-    _C.check(L().cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), yg.data_ptr(), act.data_ptr(), M, I, K, K, K, 2 * I, I,
+    _C.check(lib.cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), yg.data_ptr(), act.data_ptr(), M, I, K, K, K, 2 * I, I,
                                      S()))
     y_ref = (x.float() @ w11.float().T).to(torch.bfloat16)
     g_ref = (x.float() @ w12.float().T).to(torch.bfloat16)
@@ -99,19 +117,23 @@ def test_gemm_swiglu_fused(M, I, K, variant):
     want = torch.nn.functional.silu(gg) * yy
     assert rel_err(act.float(), want) < 3e-3
     act2 = torch.empty_like(act)
-    _C.check(L().cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), None, act2.data_ptr(), M, I, K, K, K, 2 * I, I, S()))
+    _C.check(lib.cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), None, act2.data_ptr(), M, I, K, K, K, 2 * I, I, S()))
     assert torch.equal(act, act2), "no-grad variant (no pre-activation store) must give identical activations"
     # interleaved-layout standalone ops agree with the fused epilogue
     act3 = torch.empty_like(act)
-    _C.check(L().cx_swiglu_fwd(yg.data_ptr(), act3.data_ptr(), M, I, 1, S()))
+    _C.check(lib.cx_swiglu_fwd(yg.data_ptr(), act3.data_ptr(), M, I, 1, S()))
     assert rel_err(act3.float(), act.float()) < 2e-3
+    _gemm_lib_reset()
 
 
 @pytest.mark.parametrize("variant", [2, 5, 6])
 @pytest.mark.parametrize("T,O,I", [(8192, 768, 3072), (8192, 2304, 768), (1000, 256, 128), (130, 1024, 256)])
 def test_wgrad_natural_layout_tn(T, O, I, variant):
     """G += dY^T A straight from the (T,features) row-major operands (ds_read_b64_tr_b16 fragments), vs torch."""
-    L().cx_gemm_set_variant(variant)
+    lib = _gemm_lib(variant)
+    if variant == 6 and I % 256:
+        assert lib.cx_gemm_bf16_tn_accum(None, None, None, None, 0, T, O, I, O, I, S()) == -1   # product: CX_ERR_SHAPE
+        return
     Tp = (T + 63) // 64 * 64
     dy = torch.zeros(Tp, O, dtype=torch.bfloat16, device=DEV)
     a = torch.zeros(Tp, I, dtype=torch.bfloat16, device=DEV)
@@ -120,12 +142,12 @@ def test_wgrad_natural_layout_tn(T, O, I, variant):
     ws = torch.empty(max(2 * O * I, 16 * 768 * 768), device=DEV)
     g = torch.ones(O, I, device=DEV)
     for _ in range(2):
-        _C.check(L().cx_gemm_bf16_tn_accum(dy.data_ptr(), a.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), T, O, I,
+        _C.check(lib.cx_gemm_bf16_tn_accum(dy.data_ptr(), a.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), T, O, I,
                                            O, I, S()))
     ref = dy.float().T @ a.float()
     e = rel_err(g - 1.0, 2 * ref)
     report("wgrad_tn", T=T, O=O, I=I, e=e)
-    L().cx_gemm_set_variant(6)
+    _gemm_lib_reset()
     assert e < 1e-5
 
 
@@ -474,7 +496,7 @@ def test_sgemm_nt():
 @pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
 def test_gemm_bias_gelu_fused(M, N, K):
     """fc1 + bias + erf-GELU in the GEMM epilogue == GEMM, then bias + GELU in fp32 (one bf16 rounding each)."""
-    L().cx_gemm_set_variant(6)
+
     x, w = bf(_randn(M, K, seed=70)), bf(_randn(N, K, seed=71, std=0.05))
     bias = _randn(N, seed=72)
     pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
@@ -496,7 +518,7 @@ def test_gemm_bias_gelu_fused(M, N, K):
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (1000, 512, 256), (257, 256, 64)])
 def test_gemm_swiglu_bwd_fused(M, I, K):
     """fc2 dgrad with the SwiGLU backward in the epilogue == dgrad GEMM (bf16 d(act)) followed by cx_swiglu_bwd."""
-    L().cx_gemm_set_variant(6)
+
     dy = bf(_randn(M, K, seed=80))
     w = bf(_randn(I, K, seed=81, std=0.05))          # transposed fc2 weight: (I, d)
     yg = bf(_randn(M, 2 * I, seed=82))               # interleaved-by-32 [y | g] pre-activations
@@ -520,7 +542,7 @@ def test_gemm_swiglu_bwd_fused(M, I, K):
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1000, 768, 3072), (257, 264, 64)])
 def test_gemm_residual_fused(M, N, K, with_bias):
     """Projection + residual add in the GEMM epilogue == bf16 GEMM output, then fp32 add, one more bf16 rounding."""
-    L().cx_gemm_set_variant(6)
+
     x, w = bf(_randn(M, K, seed=60)), bf(_randn(N, K, seed=61, std=0.05))
     res = bf(_randn(M, N, seed=62))
     bias = _randn(N, seed=63) if with_bias else None
