@@ -78,6 +78,8 @@ _SIGS = {
     "cx_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "cx_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cx_layernorm_fwd_mixed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "cx_layernorm_bwd_mixed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "cx_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "cx_embed_ln_bwd": (i32, [vp] * 15 + [i32, i32, i32, i32, vp]),
     "cx_embed_ln_bwd_sorted": (i32, [vp] * 15 + [i32, i32, i32, i32, i32, vp, vp, vp, vp]),

@@ -468,6 +468,119 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const bf16_t*
     }
 }
 
+// ---- mixed-dtype forms for the flash_attn.ops.layer_norm surface: on the reference's BERT path the
+// embedding LayerNorm sees fp32 in / fp32 out and layer 0's residual is fp32 (`residual_in_fp32`, or simply an fp32
+// residual); every operand carries its own dtype flag.  One wave per row, statistics in fp32; not the engine's hot path
+// (the engine keeps the bf16 kernels above), so no prefetch pipelining here.
+CX_DEVICE void load4_any(const void* base, bool f32, size_t off, float (&v)[4]) {
+    if (f32) load4_f32(reinterpret_cast<const float*>(base) + off, v);
+    else load4_bf16(reinterpret_cast<const bf16_t*>(base) + off, v);
+}
+CX_DEVICE void store4_any(void* base, bool f32, size_t off, const float (&v)[4]) {
+    if (f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = make_float4(v[0], v[1], v[2], v[3]);
+    else store4_bf16(reinterpret_cast<bf16_t*>(base) + off, v);
+}
+
+enum { LNF_X0_F32 = 1, LNF_RES_F32 = 2, LNF_OUT_F32 = 4, LNF_Z_F32 = 8 };
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_mixed_kernel(const void* __restrict__ x0, const void* __restrict__ res,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           void* __restrict__ out, void* z_out, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int rows, float eps, int flags) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float z[NCH][4];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            load4_any(x0, flags & LNF_X0_F32, off, z[i]);
+            if (res) {
+                float r[4];
+                load4_any(res, flags & LNF_RES_F32, off, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[i][e] += r[e];
+            }
+        }
+        float mean, rstd;
+        row_stats<NCH>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float g[4], b[4], o[4];
+            load4_f32(gamma + (i * 64 + lane) * 4, g);
+            load4_f32(beta + (i * 64 + lane) * 4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (z[i][e] - mean) * rstd * g[e] + b[e];
+            store4_any(out, flags & LNF_OUT_F32, off, o);
+            if (z_out) store4_any(z_out, flags & LNF_Z_F32, off, z[i]);  // statistics use the unrounded fp32 sum (as upstream)
+        }
+        if (lane == 0) {
+            mean_o[row] = mean;
+            rstd_o[row] = rstd;
+        }
+    }
+}
+
+// dz = LN-backward(dout) (+ dz_extra);  dx0 (dtype of x0) and dres (dtype of the residual, may be NULL) both receive dz.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_mixed_kernel(const void* __restrict__ dout, const void* __restrict__ z,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                           const float* __restrict__ rstd_i, const void* __restrict__ dz_extra,
+                                                           void* __restrict__ dx0, void* __restrict__ dres, float* dgamma,
+                                                           float* dbeta, int rows, int flags) {
+    constexpr int D = NCH * 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][4], dg[NCH][4], db[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float dy[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            load4_any(dout, flags & LNF_OUT_F32, off, dy[i]);
+            float zz[4];
+            load4_any(z, flags & LNF_Z_F32, off, zz);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (zz[e] - mean) * rstd;
+                const float wdy = g[i][e] * dy[i][e];
+                s1 += wdy * xh[i][e];
+                s2 += wdy;
+                dg[i][e] += dy[i][e] * xh[i][e];
+                db[i][e] += dy[i][e];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (g[i][e] * dy[i][e] - s1 * xh[i][e] - s2) * rstd;
+            if (dz_extra) {
+                float t[4];
+                load4_any(dz_extra, flags & LNF_Z_F32, off, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += t[e];
+            }
+            store4_any(dx0, flags & LNF_X0_F32, off, o);
+            if (dres) store4_any(dres, flags & LNF_RES_F32, off, o);
+        }
+    }
+    flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
+}
+
 // backward kernels end with 2*d device-scope atomics per block (they serialise at the memory fabric): one block per CU
 inline int ln_grid_bwd(int rows) {
     int g = (rows + 3) / 4;
@@ -529,6 +642,26 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
     if (part && (dgamma || dbeta))
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part,
                            dgamma, dbeta, grid, d);
+    return done();
+}
+
+int cx_layernorm_fwd_mixed(const void* x0, const void* residual, const float* gamma, const float* beta, void* out, void* z_out,
+                           float* mean, float* rstd, int rows, int d, float eps, int flags, void* stream) {
+    if (rows <= 0) return CX_OK;
+    if (!x0 || !gamma || !beta || !out || !mean || !rstd) return CX_ERR_ARG;
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_fwd_mixed_kernel<NCH>), dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x0,
+                                         residual, gamma, beta, out, z_out, mean, rstd, rows, eps, flags));
+    return done();
+}
+
+int cx_layernorm_bwd_mixed(const void* dout, const void* z, const float* gamma, const float* mean, const float* rstd,
+                           const void* dz_extra, void* dx0, void* dres, float* dgamma, float* dbeta, int rows, int d, int flags,
+                           void* stream) {
+    if (rows <= 0) return CX_OK;
+    if (!dout || !z || !gamma || !mean || !rstd || !dx0) return CX_ERR_ARG;
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_mixed_kernel<NCH>), dim3(ln_grid_bwd(rows)), dim3(256), smem, (hipStream_t)stream,
+                                         dout, z, gamma, mean, rstd, dz_extra, dx0, dres, dgamma, dbeta, rows, flags));
     return done();
 }
 

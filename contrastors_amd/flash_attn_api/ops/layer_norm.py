@@ -6,48 +6,60 @@ import torch
 from ... import _C
 
 
+def _as(t, dtype):
+    return t if t.dtype == dtype and t.is_contiguous() else t.to(dtype).contiguous()
+
+
 class _DropoutAddLN(torch.autograd.Function):
+    """dropout_add_layer_norm with p = 0 (SURVEY.md Appendix C): z = x0 + residual; statistics and normalisation in fp32;
+    `out` in x0's dtype; z kept in fp32 when `residual_in_fp32` or the residual is fp32, else in x0's dtype.  Every
+    operand keeps its dtype down to the kernel (cx_layernorm_fwd_mixed / _bwd_mixed): fp32 or bf16 (fp16 is cast to bf16)."""
+
     @staticmethod
-    def forward(ctx, x0, residual, weight, bias, eps, prenorm):
+    def forward(ctx, x0, residual, weight, bias, eps, prenorm, residual_in_fp32):
         shape = x0.shape
         d = shape[-1]
-        in_dtype = x0.dtype
-        x = x0.reshape(-1, d).to(torch.bfloat16).contiguous()
-        r = None if residual is None else residual.reshape(-1, d).to(torch.bfloat16).contiguous()
+        f32 = torch.float32
+        xdt = f32 if x0.dtype == f32 else torch.bfloat16
+        rdt = None if residual is None else (f32 if residual.dtype == f32 else torch.bfloat16)
+        zdt = f32 if (residual_in_fp32 or rdt == f32 or xdt == f32) else torch.bfloat16
+        x = _as(x0.reshape(-1, d), xdt)
+        r = None if residual is None else _as(residual.reshape(-1, d), rdt)
         rows = x.shape[0]
-        out = torch.empty_like(x)
-        z = torch.empty_like(x)
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        out = torch.empty(rows, d, dtype=xdt, device=x.device)
+        z = torch.empty(rows, d, dtype=zdt, device=x.device)
+        mean = torch.empty(rows, dtype=f32, device=x.device)
+        rstd = torch.empty(rows, dtype=f32, device=x.device)
         w, b = weight.float().contiguous(), bias.float().contiguous()
-        _C.check(_C.lib().cx_layernorm_fwd(x.data_ptr(), _C.ptr(r), w.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                           z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps),
-                                           _C.cur_stream()), "layernorm fwd")
+        flags = (1 if xdt == f32 else 0) | (2 if rdt == f32 else 0) | (4 if xdt == f32 else 0) | (8 if zdt == f32 else 0)
+        _C.check(_C.lib().cx_layernorm_fwd_mixed(x.data_ptr(), _C.ptr(r), w.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                                 z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps), flags,
+                                                 _C.cur_stream()), "layernorm fwd")
         ctx.save_for_backward(z, w, mean, rstd)
-        ctx.meta = (shape, in_dtype, None if residual is None else residual.dtype, prenorm, weight.dtype)
+        ctx.meta = (shape, x0.dtype, None if residual is None else residual.dtype, prenorm, weight.dtype, flags, xdt, rdt, zdt)
+        out = out.view(shape).to(x0.dtype)
         if prenorm:
-            return out.view(shape), z.view(shape)
-        return out.view(shape)
+            return out, z.view(shape)
+        return out
 
     @staticmethod
     def backward(ctx, dout, dz_in=None):
         z, w, mean, rstd = ctx.saved_tensors
-        shape, in_dtype, res_dtype, prenorm, wdtype = ctx.meta
+        shape, in_dtype, res_dtype, prenorm, wdtype, flags, xdt, rdt, zdt = ctx.meta
         d = shape[-1]
         rows = z.shape[0]
-        do = dout.reshape(-1, d).to(torch.bfloat16).contiguous()
-        dze = None
-        if prenorm and dz_in is not None:
-            dze = dz_in.reshape(-1, d).to(torch.bfloat16).contiguous()
-        dz = torch.empty_like(z)
+        do = _as(dout.reshape(-1, d), xdt)
+        dze = _as(dz_in.reshape(-1, d), zdt) if (prenorm and dz_in is not None) else None
+        dx = torch.empty(rows, d, dtype=xdt, device=z.device)
+        dr = None if rdt is None else torch.empty(rows, d, dtype=rdt, device=z.device)
         dg = torch.zeros(d, dtype=torch.float32, device=z.device)
         db = torch.zeros(d, dtype=torch.float32, device=z.device)
-        _C.check(_C.lib().cx_layernorm_bwd(do.data_ptr(), None, z.data_ptr(), w.data_ptr(), mean.data_ptr(),
-                                           rstd.data_ptr(), _C.ptr(dze), dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                           None, 0, rows, d, _C.cur_stream()), "layernorm bwd")
-        dx0 = dz.view(shape).to(in_dtype)
-        dres = None if res_dtype is None else dz.view(shape).to(res_dtype)
-        return dx0, dres, dg.to(wdtype), db.to(wdtype), None, None
+        _C.check(_C.lib().cx_layernorm_bwd_mixed(do.data_ptr(), z.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 _C.ptr(dze), dx.data_ptr(), _C.ptr(dr), dg.data_ptr(), db.data_ptr(), rows, d,
+                                                 flags, _C.cur_stream()), "layernorm bwd")
+        dx0 = dx.view(shape).to(in_dtype)
+        dres = None if res_dtype is None else dr.view(shape).to(res_dtype)
+        return dx0, dres, dg.to(wdtype), db.to(wdtype), None, None, None
 
 
 def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None,
@@ -56,11 +68,11 @@ def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowsc
         raise NotImplementedError("residual dropout > 0 is not implemented (BASELINE configs use 0)")
     if rowscale is not None or layerscale is not None or return_dropout_mask:
         raise NotImplementedError("rowscale / layerscale / return_dropout_mask")
-    return _DropoutAddLN.apply(x0, residual, weight, bias, epsilon, prenorm)
+    return _DropoutAddLN.apply(x0, residual, weight, bias, epsilon, prenorm, bool(residual_in_fp32))
 
 
 def layer_norm(x, weight, bias, epsilon):
-    return _DropoutAddLN.apply(x, None, weight, bias, epsilon, False)
+    return _DropoutAddLN.apply(x, None, weight, bias, epsilon, False, False)
 
 
 def dropout_add_layer_norm_parallel_residual(*a, **k):
@@ -70,10 +82,10 @@ def dropout_add_layer_norm_parallel_residual(*a, **k):
 class DropoutAddLayerNorm(torch.nn.Module):
     def __init__(self, hidden_size, prenorm=False, p=0.0, eps=1e-5, residual_in_fp32=False, device=None, dtype=None):
         super().__init__()
-        self.prenorm, self.p, self.eps = prenorm, p, eps
+        self.prenorm, self.p, self.eps, self.residual_in_fp32 = prenorm, p, eps, residual_in_fp32
         self.weight = torch.nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
         self.bias = torch.nn.Parameter(torch.zeros(hidden_size, device=device, dtype=dtype))
 
     def forward(self, x0, residual=None):
         return dropout_add_layer_norm(x0, residual, self.weight, self.bias, self.p if self.training else 0.0, self.eps,
-                                      prenorm=self.prenorm)
+                                      prenorm=self.prenorm, residual_in_fp32=self.residual_in_fp32)

@@ -78,6 +78,17 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
                      const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
                      float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream);
 
+/* The same two ops with a dtype per operand, for the flash_attn.ops.layer_norm python surface (`residual_in_fp32`, fp32
+ * inputs on the reference's BERT path: embedding LayerNorm fp32 in / fp32 out, layer-0 residual fp32).
+ * flags: bit0 x0 is fp32, bit1 residual is fp32, bit2 out is fp32, bit3 z (the saved sum / prenorm residual output) is
+ * fp32; clear = bf16 (statistics always use the unrounded fp32 sum).  bwd writes
+ * dz to dx0 (x0's dtype) and, if not NULL, to dres (the residual's dtype); dout has out's dtype, dz_extra has z's. */
+int cx_layernorm_fwd_mixed(const void* x0, const void* residual, const float* gamma, const float* beta, void* out,
+                           void* z_out, float* mean, float* rstd, int rows, int d, float eps, int flags, void* stream);
+int cx_layernorm_bwd_mixed(const void* dout, const void* z, const float* gamma, const float* mean, const float* rstd,
+                           const void* dz_extra, void* dx0, void* dres, float* dgamma, float* dbeta, int rows, int d,
+                           int flags, void* stream);
+
 /* ---- a11 BertEmbeddings + K6 embedding LayerNorm, on the unpadded token stream
  *          (sc/layers/embedding.py:594-615, sc/models/encoder/modeling_nomic_bert.py:531-535, K4 unpad_input
  *          sc/models/encoder/modeling_nomic_bert.py:332-333) -------------------------------------------------
