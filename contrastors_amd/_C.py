@@ -48,6 +48,7 @@ class CxEncoderDesc(C.Structure):
         ("Wpatch", vp), ("bpatch", vp), ("cls_token", vp), ("vit_pos", vp),
         ("gWpatch", vp), ("gbpatch", vp), ("gcls_token", vp), ("gvit_pos", vp),
         ("patch_dim", i32),
+        ("resid_pdrop", f32), ("embd_pdrop", f32),
     ]
 
 
@@ -59,7 +60,7 @@ class CxChunkBuffers(C.Structure):
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
             "ws_f32",
         )
-    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32)]
+    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp)]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.
@@ -78,6 +79,11 @@ _SIGS = {
     "cx_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "cx_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cx_dropout_add_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, C.c_ulonglong, C.c_ulonglong,
+                                           C.c_uint, vp]),
+    "cx_dropout_add_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, C.c_ulonglong,
+                                           C.c_ulonglong, C.c_uint, vp]),
+    "cx_dropout_scale": (i32, [vp, i64, f32, C.c_ulonglong, C.c_ulonglong, C.c_uint, vp]),
     "cx_layernorm_fwd_mixed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "cx_layernorm_bwd_mixed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "cx_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),

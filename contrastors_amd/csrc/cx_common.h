@@ -97,6 +97,40 @@ CX_DEVICE int xcd_remap(int bid, int nwg) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., the counter-based generator behind torch's CUDA/HIP generator): dropout masks are a pure
+// function of (seed, offset, element index), so the backward -- and a GradCache re-forward under the reference's
+// RandContext (sc/rand_state.py:6-22), which restores the generator's (seed, offset) -- regenerates them bit for bit
+// instead of storing them.
+// ---------------------------------------------------------------------------------------------
+CX_DEVICE uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+// keep-mask of 4 consecutive elements: element group `g` (64-bit) of dropout site `site` under (seed, offset)
+struct CxDropout {
+    float p;                       // drop probability; 0 = off
+    unsigned long long seed, offset;
+};
+CX_DEVICE void dropout_keep4(const CxDropout& d, uint32_t site, unsigned long long g, float (&keep)[4]) {
+    const unsigned long long off = d.offset + site;
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)off, (uint32_t)(off >> 32)),
+                                  make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32)));
+    const uint32_t thr = (uint32_t)fminf(d.p * 4294967296.f, 4294967040.f);
+    const float inv = 1.f / (1.f - d.p);
+    keep[0] = r.x >= thr ? inv : 0.f;
+    keep[1] = r.y >= thr ? inv : 0.f;
+    keep[2] = r.z >= thr ? inv : 0.f;
+    keep[3] = r.w >= thr ? inv : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: opt a kernel into > 64 KiB of dynamic LDS.  The attribute is per device, so it is remembered per device
 // index (the deployment is one process per GPU, but nothing in the library may silently depend on that).
 // ---------------------------------------------------------------------------------------------

@@ -151,6 +151,18 @@ struct BlockRunner {
         // (then z is complete in place and the LayerNorm reads one stream), else by the LayerNorm kernel, which
         // writes z only when backward needs it.
         bool f1 = false, f2 = false;
+        if (drop()) {
+            // resid_pdrop > 0 (training): the mask sits between the projection and the residual add, so nothing is folded
+            // into the GEMM epilogue -- K5 with p > 0 does dropout + add + LayerNorm in one pass (sites 2l, 2l + 1)
+            const float p = enc->resid_pdrop;
+            CX_TRY(attn(w, h_in, l, s.z1(l), nullptr, &f1));
+            CX_TRY(cx_dropout_add_layernorm_fwd(s.z1(l), h_in, w.ln1_g, w.ln1_b, s.h1(l), keep ? s.z1(l) : nullptr, s.mean1(l),
+                                                s.rstd1(l), T, d, enc->ln_eps, p, buf->drop_seed, buf->drop_offset, 2 * l, stream));
+            CX_TRY(mlp(w, s.h1(l), l, s.z2(l), nullptr, keep, &f2));
+            return cx_dropout_add_layernorm_fwd(s.z2(l), s.h1(l), w.ln2_g, w.ln2_b, s.h2(l), keep ? s.z2(l) : nullptr, s.mean2(l),
+                                                s.rstd2(l), T, d, enc->ln_eps, p, buf->drop_seed, buf->drop_offset, 2 * l + 1,
+                                                stream);
+        }
         CX_TRY(attn(w, h_in, l, s.z1(l), h_in, &f1));
         CX_TRY(cx_layernorm_fwd(s.z1(l), f1 ? nullptr : h_in, w.ln1_g, w.ln1_b, s.h1(l), (keep && !f1) ? s.z1(l) : nullptr,
                                 s.mean1(l), s.rstd1(l), T, d, enc->ln_eps, stream));
@@ -158,6 +170,7 @@ struct BlockRunner {
         return cx_layernorm_fwd(s.z2(l), f2 ? nullptr : s.h1(l), w.ln2_g, w.ln2_b, s.h2(l), (keep && !f2) ? s.z2(l) : nullptr,
                                 s.mean2(l), s.rstd2(l), T, d, enc->ln_eps, stream);
     }
+    bool drop() const { return buf->drop_active && enc->resid_pdrop > 0.f; }
     // one pre-norm block.  In: x = output of the previous sub-layer, r = residual stream (NULL once folded into x).
     // Out: *x_out (= z1(l+1) or zf), *r_out, *folded_out.  up_only: stop after the MLP's first projection (the
     // recomputation of a checkpointed block needs nothing beyond `act`).
@@ -200,6 +213,7 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
         return CX_OK;
     }
     if (!buf->zf || !buf->hf || !buf->meanf || !buf->rstdf || !enc->lnf_g || !enc->lnf_b) return CX_ERR_ARG;
+    if (buf->drop_active && enc->resid_pdrop > 0.f) return CX_ERR_ARG;   // dropout: post-norm text trunks only
     const uint16_t* x = h0;        // output of the previous sub-layer (the embeddings for the first block)
     const uint16_t* r = nullptr;   // residual stream
     bool r_folded = false;         // the residual stream was already added into x by a GEMM epilogue
@@ -231,6 +245,7 @@ int clear_pad_rows(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
     CX_TRY(clear(buf->g_a, d));
     CX_TRY(clear(buf->g_b, d));
     CX_TRY(clear(buf->g_c, d));
+    if (buf->g_d) CX_TRY(clear(buf->g_d, d));
     CX_TRY(clear(buf->g_wide, 3 * d));   // used as (T,3d) and as (T,wfc1): clear for both widths
     CX_TRY(clear(buf->g_wide, s.wfc1));
     CX_TRY(clear(buf->h0, d));
@@ -298,6 +313,24 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
             const CxLayerWeights& w = enc->layers[l];
             const uint16_t* h_in = (l == 0) ? buf->h0 : s.h2(l - 1);
             if (s.mode == 2) CX_TRY(run.post_block(l, h_in, true));
+            if (run.drop()) {
+                // dropout between every sub-layer output and the residual add: the LayerNorm backward returns the
+                // residual's gradient (dz) and the masked, rescaled gradient of the sub-layer output (dx0, in g_d)
+                if (!buf->g_d) return CX_ERR_ARG;
+                const float p = enc->resid_pdrop;
+                bool f1 = false, f2 = false;
+                CX_TRY(cx_dropout_add_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, buf->g_d, w.gln2_g,
+                                                    w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, p, buf->drop_seed,
+                                                    buf->drop_offset, 2 * l + 1, stream));
+                CX_TRY(mlp_bwd(w, l, buf->g_d, s.h1(l), buf->g_c, &f1));   // -> g_b = d h1 (+ dz2 when folded)
+                CX_TRY(cx_dropout_add_layernorm_bwd(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l),
+                                                    s.rstd1(l), buf->g_a, buf->g_d, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats,
+                                                    T, d, p, buf->drop_seed, buf->drop_offset, 2 * l, stream));
+                CX_TRY(attn_bwd(w, l, buf->g_d, h_in, buf->g_a, &f2));
+                da = f2 ? buf->g_b : buf->g_a;
+                db = f2 ? nullptr : buf->g_b;
+                continue;
+            }
             // LN2: dz2 = grad of (mlp_out + h1)
             CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
                                     w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
@@ -353,6 +386,8 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
+    if (buf->drop_active && enc->embd_pdrop > 0.f)  // modeling_nomic_bert.py:534-535: dropout on the embedding-LN output
+        CX_TRY(cx_dropout_scale(buf->h0, (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset, 2 * enc->n_layer, stream));
     const uint16_t* h_final = nullptr;
     CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, s.mode, &h_final, stream));
     return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
@@ -376,6 +411,13 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
     CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    if (buf->drop_active && enc->embd_pdrop > 0.f) {  // gradient through the embedding dropout (both branches: linear)
+        CX_TRY(cx_dropout_scale(const_cast<uint16_t*>(da), (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset,
+                                2 * enc->n_layer, stream));
+        if (db)
+            CX_TRY(cx_dropout_scale(const_cast<uint16_t*>(db), (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset,
+                                    2 * enc->n_layer, stream));
+    }
     // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
     // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
     if (sort_ids && sort_perm)
@@ -400,6 +442,8 @@ int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* bu
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
+    if (buf->drop_active && enc->embd_pdrop > 0.f)  // modeling_nomic_bert.py:534-535: dropout on the embedding-LN output
+        CX_TRY(cx_dropout_scale(buf->h0, (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset, 2 * enc->n_layer, stream));
     const uint16_t* h_final = nullptr;
     CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, max_seqlen, s.mode, &h_final, stream));
     return hipMemcpyAsync(hidden_out, h_final, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
@@ -423,6 +467,13 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
     const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
     CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    if (buf->drop_active && enc->embd_pdrop > 0.f) {  // gradient through the embedding dropout (both branches: linear)
+        CX_TRY(cx_dropout_scale(const_cast<uint16_t*>(da), (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset,
+                                2 * enc->n_layer, stream));
+        if (db)
+            CX_TRY(cx_dropout_scale(const_cast<uint16_t*>(db), (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset,
+                                    2 * enc->n_layer, stream));
+    }
     // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
     // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
     if (sort_ids && sort_perm)
@@ -490,7 +541,7 @@ int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const i
     return wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream);
 }
 
-int cx_abi_version(void) { return 2; }  // 2: CxChunkBuffers.checkpoint
+int cx_abi_version(void) { return 3; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

@@ -581,6 +581,125 @@ __global__ __launch_bounds__(256) void ln_bwd_mixed_kernel(const void* __restric
     flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
 }
 
+// ---- dropout > 0 (K5 dropout_add_layer_norm(p > 0), BertEmbeddings dropout): z = dropout_p(x0) + residual.  The mask is
+// regenerated from Philox (cx_common.h), never stored.  Backward returns BOTH gradients: dz (the residual's) and
+// dx0 = dz * mask / (1 - p) (the sub-layer's).  One wave per row.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_drop_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ res,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* __restrict__ out, bf16_t* z_out, float* __restrict__ mean_o,
+                                                          float* __restrict__ rstd_o, int rows, float eps, CxDropout dr,
+                                                          uint32_t site) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float z[NCH][4];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float keep[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+            load4_bf16(x0 + off, z[i]);
+            dropout_keep4(dr, site, off >> 2, keep);
+            if (res) load4_bf16(res + off, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[i][e] = z[i][e] * keep[e] + r[e];
+        }
+        float mean, rstd;
+        row_stats<NCH>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float g[4], b[4], o[4];
+            load4_f32(gamma + (i * 64 + lane) * 4, g);
+            load4_f32(beta + (i * 64 + lane) * 4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (z[i][e] - mean) * rstd * g[e] + b[e];
+            store4_bf16(out + off, o);
+            if (z_out) store4_bf16(z_out + off, z[i]);
+        }
+        if (lane == 0) {
+            mean_o[row] = mean;
+            rstd_o[row] = rstd;
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
+                                                          const bf16_t* __restrict__ z, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          bf16_t* __restrict__ dz, bf16_t* __restrict__ dx0, float* dgamma,
+                                                          float* dbeta, float* part, int rows, CxDropout dr, uint32_t site) {
+    constexpr int D = NCH * 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][4], dg[NCH][4], db[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float dy[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            load4_bf16(da + off, dy[i]);
+            if (dbb) {
+                float t[4];
+                load4_bf16(dbb + off, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dy[i][e] += t[e];
+            }
+            float zz[4];
+            load4_bf16(z + off, zz);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (zz[e] - mean) * rstd;
+                const float wdy = g[i][e] * dy[i][e];
+                s1 += wdy * xh[i][e];
+                s2 += wdy;
+                dg[i][e] += dy[i][e] * xh[i][e];
+                db[i][e] += dy[i][e];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
+            float o[4], keep[4], m[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (g[i][e] * dy[i][e] - s1 * xh[i][e] - s2) * rstd;
+            dropout_keep4(dr, site, off >> 2, keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = o[e] * keep[e];
+            store4_bf16(dz + off, o);
+            store4_bf16(dx0 + off, m);
+        }
+    }
+    if (part) {
+        store_param_partials<NCH>(dg, db, part, smem);
+    } else {
+        flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
+    }
+}
+
+// x <- x * mask / (1 - p) in place (the embedding dropout on the embedding-LayerNorm output, and on its incoming gradient)
+__global__ __launch_bounds__(256) void dropout_scale_kernel(bf16_t* __restrict__ x, long n4, CxDropout dr, uint32_t site) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4], keep[4];
+        load4_bf16(x + i * 4, v);
+        dropout_keep4(dr, site, (unsigned long long)i, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= keep[e];
+        store4_bf16(x + i * 4, v);
+    }
+}
+
 // backward kernels end with 2*d device-scope atomics per block (they serialise at the memory fabric): one block per CU
 inline int ln_grid_bwd(int rows) {
     int g = (rows + 3) / 4;
@@ -642,6 +761,55 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
     if (part && (dgamma || dbeta))
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part,
                            dgamma, dbeta, grid, d);
+    return done();
+}
+
+int cx_dropout_add_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* gamma, const float* beta,
+                                 uint16_t* out, uint16_t* z_out, float* mean, float* rstd, int rows, int d, float eps, float p,
+                                 unsigned long long seed, unsigned long long offset, unsigned int site, void* stream) {
+    if (rows <= 0) return CX_OK;
+    if (!x0 || !gamma || !beta || !out || !mean || !rstd) return CX_ERR_ARG;
+    if (!(p > 0.f) || p >= 1.f) return CX_ERR_ARG;
+    const CxDropout dr{p, seed, offset};
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_fwd_drop_kernel<NCH>), dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x0,
+                                         residual, gamma, beta, out, z_out, mean, rstd, rows, eps, dr, site));
+    return done();
+}
+
+int cx_dropout_add_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                                 const float* mean, const float* rstd, uint16_t* dz, uint16_t* dx0, float* dgamma, float* dbeta,
+                                 float* ws, long ws_floats, int rows, int d, float p, unsigned long long seed,
+                                 unsigned long long offset, unsigned int site, void* stream) {
+    if (rows <= 0) return CX_OK;
+    if (!dout_a || !z || !gamma || !mean || !rstd || !dz || !dx0) return CX_ERR_ARG;
+    if (!(p > 0.f) || p >= 1.f) return CX_ERR_ARG;
+    const CxDropout dr{p, seed, offset};
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    int grid = ln_grid_bwd(rows);
+    float* part = nullptr;
+    if (ws && ws_floats >= (long)2 * d * 256) {
+        long cap = ws_floats / (2L * d);
+        grid = (rows + 3) / 4;
+        if (grid > 768) grid = 768;
+        if (grid > cap) grid = (int)cap;
+        part = ws;
+    }
+    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_drop_kernel<NCH>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                         dout_b, z, gamma, mean, rstd, dz, dx0, dgamma, dbeta, part, rows, dr, site));
+    if (part && (dgamma || dbeta))
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, dgamma, dbeta,
+                           grid, d);
+    return done();
+}
+
+int cx_dropout_scale(uint16_t* x, long n, float p, unsigned long long seed, unsigned long long offset, unsigned int site,
+                     void* stream) {
+    if (n <= 0) return CX_OK;
+    if (!x || (n % 4) != 0) return CX_ERR_ARG;
+    if (!(p > 0.f) || p >= 1.f) return CX_ERR_ARG;
+    long g = (n / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, n / 4, CxDropout{p, seed, offset}, site);
     return done();
 }
 

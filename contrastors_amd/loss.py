@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 from . import _C
 from .distributed import gather_with_grad
+from .rand_state import RandContext
 
 
 def _scale_of(logit_scale) -> tuple:
@@ -237,19 +238,33 @@ def _split_inputs(inputs: Dict[str, torch.Tensor], chunk_size: int) -> List[Dict
     return chunks
 
 
-def get_chunked_embeddings(model, chunks):
-    """Pass 1 (sc/loss.py:135-146): no-grad chunk forwards; returns (N,d) embeddings."""
+def _uses_rng(model) -> bool:
+    """Does a forward of this tower consume random numbers (dropout > 0 in training mode)?  Only then is the RNG snapshot
+    of sc/loss.py:141-145 worth its cost; with p = 0 (every BASELINE config) nothing is drawn and nothing is saved."""
+    trunk = getattr(model, "trunk", None)
+    return bool(getattr(trunk, "uses_rng", False)) if trunk is not None else bool(getattr(model, "training", False))
+
+
+def get_chunked_embeddings(model, chunks, rand_states=None):
+    """Pass 1 (sc/loss.py:135-146): no-grad chunk forwards; returns (N,d) embeddings.  `rand_states` (a list) receives one
+    RandContext snapshot per chunk, taken right before the chunk's forward (loss.py:141-143)."""
     embs = []
+    needed = rand_states is not None and _uses_rng(model)
     with torch.no_grad():
         for c in chunks:
+            if rand_states is not None:
+                rand_states.append(RandContext(c, needed=needed))
             embs.append(model(**c)["embedding"])
     return torch.cat(embs, dim=0)
 
 
-def accumulate_gradients(model, chunks, cache):
-    """Pass 2 (sc/loss.py:149-161): re-forward with grad and back-propagate the cached embedding gradient."""
-    for c, g in zip(chunks, cache):
-        out = model(**c)["embedding"]
+def accumulate_gradients(model, chunks, cache, rand_states=None):
+    """Pass 2 (sc/loss.py:149-161): re-forward under the chunk's saved RNG state, back-propagate the cached embedding
+    gradient through it."""
+    for i, (c, g) in enumerate(zip(chunks, cache)):
+        state = rand_states[i] if rand_states is not None else RandContext(c, needed=False)
+        with state:
+            out = model(**c)["embedding"]
         surrogate = torch.dot(out.flatten(), g.flatten().to(out.dtype))
         surrogate.backward()
 
@@ -302,14 +317,15 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
     q_chunks = _split_inputs(t1_inputs, effective_chunk(tower1, t1_inputs, chunk_size))
     d_chunks = _split_inputs(t2_inputs, effective_chunk(tower2, t2_inputs, chunk_size))
     was_training1, was_training2 = tower1.training, tower2.training
-    q_embs = get_chunked_embeddings(tower1, q_chunks)
-    d_embs = get_chunked_embeddings(tower2, d_chunks)
+    q_rnd, d_rnd = [], []
+    q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd)
+    d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd)
     q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional)
     sizes_q = [c["input_ids"].shape[0] for c in q_chunks]
     sizes_d = [c["input_ids"].shape[0] for c in d_chunks]
-    accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q))
+    accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd)
     if was_training2:
-        accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d))
+        accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd)
     # data-parallel reduction of the accumulated gradients: once per step, one flat buffer per distinct tower
     seen = set()
     for tw, active in ((tower1, was_training1), (tower2, was_training2)):

@@ -200,6 +200,9 @@ class MLMTrainer:
                 activation_function=ma.activation_function or "gelu", rotary_emb_fraction=ma.rotary_emb_fraction or 0.0,
                 rotary_emb_base=ma.rotary_emb_base or 10_000, qkv_proj_bias=bool(ma.qkv_proj_bias),
                 mlp_fc1_bias=bool(ma.mlp_fc1_bias), mlp_fc2_bias=bool(ma.mlp_fc2_bias), attn_pdrop=ma.attn_pdrop or 0.0,
+                # bert-base-uncased's hidden_dropout_prob = 0.1 becomes resid_pdrop and embd_pdrop (bert.py:20-21); the
+                # recipe only overrides the attention dropout (trainers/mlm.py:37)
+                resid_pdrop=0.1, embd_pdrop=0.1,
                 layer_norm_epsilon=1e-12, type_vocab_size=2, pad_token_id=0)
         model = NomicBertForPreTraining(trunk_config, device=self.device, seed=config.data_args.seed).train()
         if self.world > 1:

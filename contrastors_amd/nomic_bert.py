@@ -60,8 +60,11 @@ class NomicBertConfig:
     def __post_init__(self):
         if self.prenorm or self.causal or self.use_rms_norm or self.rotary_emb_interleaved:
             raise NotImplementedError("engine covers the post-norm, non-causal, LayerNorm encoder (cfg 1-3)")
-        if self.resid_pdrop or self.embd_pdrop or self.attn_pdrop:
-            raise NotImplementedError("dropout > 0 is not implemented in the fused kernels (all BASELINE configs use 0)")
+        if self.attn_pdrop:
+            raise NotImplementedError("attention-probability dropout > 0 is not implemented in the fused attention kernels "
+                                      "(every shipped recipe sets attn_pdrop 0.0); resid_pdrop / embd_pdrop are supported")
+        if not (0.0 <= self.resid_pdrop < 1.0 and 0.0 <= self.embd_pdrop < 1.0):
+            raise ValueError("dropout probabilities must be in [0, 1)")
         if self.n_embd != self.n_head * 64:
             raise NotImplementedError("head_dim must be 64")
         if self.rotary_emb_fraction not in (0.0, 1.0):
@@ -147,6 +150,8 @@ class _ChunkArena:
             t["delta"] = torch.empty(T_cap * H, **f32)
             # split-K workspace of the wgrad GEMMs (fp32 partial slabs): 8 slabs of the largest weight, 16 of the smallest
             t["ws_f32"] = torch.empty(max(8 * wide * d, 16 * d * d), **f32)
+            if getattr(cfg, "resid_pdrop", 0.0) > 0:  # dropout: the LayerNorm backward returns a second gradient
+                t["g_d"] = torch.empty(T_cap, d, **bf)
         self.tensors = t
         self.desc = _C.CxChunkBuffers()
         self.desc.T_cap = T_cap
@@ -155,6 +160,8 @@ class _ChunkArena:
                 self.desc.ws_floats = t["ws_f32"].numel() if "ws_f32" in t else 0
             elif name == "checkpoint":
                 self.desc.checkpoint = int(self.checkpoint)
+            elif name in ("drop_active", "drop_seed", "drop_offset"):
+                setattr(self.desc, name, 0)
             else:
                 setattr(self.desc, name, t[name].data_ptr() if name in t else None)
         self.emb_out: Optional[torch.Tensor] = None  # set by a saving forward, consumed by backward
@@ -516,6 +523,7 @@ class NomicBertEngine(torch.nn.Module):
         e.rot_sin = None if self.rot_sin is None else self.rot_sin.data_ptr()
         e.layers = C.cast(self._layers_arr, C.POINTER(_C.CxLayerWeights))
         e.pool_mode, e.normalize = self.pool_mode, 1
+        e.resid_pdrop, e.embd_pdrop = float(getattr(cfg, "resid_pdrop", 0.0)), float(getattr(cfg, "embd_pdrop", 0.0))
         self._desc = e
 
     # ------------------------------------------------------------------------------------------------ arenas
@@ -532,6 +540,25 @@ class NomicBertEngine(torch.nn.Module):
             if a.T_cap >= T_cap and a.B_cap >= B and a.checkpoint == ck:
                 return self._arena_free.pop(i)
         return _ChunkArena(self.config, T_cap, self.config.n_layer, True, max(B, 1), self.device_, checkpoint=ck)
+
+    def _arm_dropout(self, arena: _ChunkArena):
+        """Dropout is active in training mode when the config asks for it.  The Philox (seed, offset) of the chunk comes
+        from torch's generator of this device and advances it, exactly like a torch dropout op would: RandContext
+        (rand_state.py; sc/rand_state.py:6-22) snapshots and restores that state around the GradCache re-forward, so the
+        second forward of a chunk regenerates the first one's masks."""
+        cfg = self.config
+        active = self.training and (getattr(cfg, "resid_pdrop", 0.0) > 0 or getattr(cfg, "embd_pdrop", 0.0) > 0)
+        arena.desc.drop_active = int(active)
+        if active:
+            gen = torch.cuda.default_generators[self.device_.index if self.device_.index is not None else torch.cuda.current_device()]
+            off = gen.get_offset()
+            gen.set_offset(off + 4)  # torch keeps Philox offsets in multiples of 4
+            arena.desc.drop_seed, arena.desc.drop_offset = gen.initial_seed() & (2**64 - 1), off
+
+    @property
+    def uses_rng(self) -> bool:
+        cfg = self.config
+        return self.training and (getattr(cfg, "resid_pdrop", 0.0) > 0 or getattr(cfg, "embd_pdrop", 0.0) > 0)
 
     def release_arena(self, arena: _ChunkArena):
         arena.emb_out = None
@@ -553,6 +580,7 @@ class NomicBertEngine(torch.nn.Module):
         if out is None:
             out = torch.empty(vb.B, d, dtype=torch.float32, device=self.device_)
         arena = self._get_arena(vb.T, vb.B, save_for_backward)
+        self._arm_dropout(arena)
         self._desc.normalize = int(self.normalize_default if normalize is None else normalize)
         rc = self.lib.cx_encoder_forward(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
                                          vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
@@ -588,6 +616,7 @@ class NomicBertEngine(torch.nn.Module):
         self._rotary_or_bounds(vb)
         hidden = torch.empty(vb.T, self.config.n_embd, dtype=torch.bfloat16, device=self.device_)
         arena = self._get_arena(vb.T, vb.B, save_for_backward)
+        self._arm_dropout(arena)
         rc = self.lib.cx_encoder_forward_hidden(C.byref(self._desc), C.byref(arena.desc), vb.input_ids.data_ptr(),
                                                 vb.indices.data_ptr(), vb.cu_seqlens.data_ptr(), vb.B, vb.S, vb.T,
                                                 vb.max_seqlen, int(save_for_backward), hidden.data_ptr(),

@@ -1,10 +1,12 @@
 """RNG snapshot / replay for GradCache re-forwards (role of sc/rand_state.py:6-22 `RandContext`).
 
-The fused kernels implement dropout p = 0 only and consume no random numbers, so `grad_cache_loss` skips the snapshot
-(`needed=False`) and avoids the per-chunk device sync the reference pays.  When a tower does
-use torch-side randomness, the context captures the CPU generator and the generator of every CUDA/HIP device that
-owns one of the chunk's tensors at construction, and replays them inside `with ctx:`, restoring the outer streams
-on exit.
+`grad_cache_loss` takes one snapshot per chunk before the no-grad forward of pass 1 and replays it around the re-forward
+of pass 2 (sc/loss.py:141-145,156-158).  The native engine draws the Philox (seed, offset) of its dropout masks from
+torch's device generator (NomicBertEngine._arm_dropout), so restoring that generator regenerates the masks bit for bit.
+With dropout 0 (every BASELINE config) no random number is consumed and the snapshot is skipped (`needed=False`), which
+also avoids the per-chunk device sync the reference pays.  The context captures the CPU generator
+and the generator of every CUDA/HIP device that owns one of the chunk's tensors at construction, and replays them inside
+`with ctx:`, restoring the outer state on exit.
 """
 from __future__ import annotations
 

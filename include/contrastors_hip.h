@@ -78,6 +78,25 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
                      const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
                      float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream);
 
+/* dropout p > 0 (flash_attn.ops.layer_norm.dropout_add_layer_norm(p > 0), sc/layers/block.py:422-431,453-462 with
+ * resid_pdrop > 0): z = dropout_p(x0) + residual, out = LN(z).  The keep-mask is Philox4x32-10(seed; offset + site,
+ * element group) -- a pure function of the torch generator's (seed, offset) the host drew for this chunk, so backward and
+ * a GradCache re-forward under RandContext (sc/rand_state.py:6-22) regenerate it; nothing is stored.  bwd returns dz
+ * (gradient of the residual) AND dx0 = dz * mask / (1 - p) (gradient of x0).  0 < p < 1.  `site` separates the dropout
+ * sites of one chunk (2 per block + the embeddings). */
+int cx_dropout_add_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* gamma, const float* beta,
+                                 uint16_t* out, uint16_t* z_out, float* mean, float* rstd, int rows, int d, float eps,
+                                 float p, unsigned long long seed, unsigned long long offset, unsigned int site,
+                                 void* stream);
+int cx_dropout_add_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                                 const float* mean, const float* rstd, uint16_t* dz, uint16_t* dx0, float* dgamma,
+                                 float* dbeta, float* ws, long ws_floats, int rows, int d, float p,
+                                 unsigned long long seed, unsigned long long offset, unsigned int site, void* stream);
+/* x <- x * mask / (1 - p) in place, n % 4 == 0 (embedding dropout, sc/models/encoder/modeling_nomic_bert.py:534-535, and
+ * its gradient). */
+int cx_dropout_scale(uint16_t* x, long n, float p, unsigned long long seed, unsigned long long offset, unsigned int site,
+                     void* stream);
+
 /* The same two ops with a dtype per operand, for the flash_attn.ops.layer_norm python surface (`residual_in_fp32`, fp32
  * inputs on the reference's BERT path: embedding LayerNorm fp32 in / fp32 out, layer-0 residual fp32).
  * flags: bit0 x0 is fp32, bit1 residual is fp32, bit2 out is fp32, bit3 z (the saved sum / prenorm residual output) is
@@ -260,6 +279,10 @@ typedef struct CxEncoderDesc {
     const float* vit_pos;                      /* fp32 (n_patch + 1, d) */
     float* gWpatch; float* gbpatch; float* gcls_token; float* gvit_pos;
     int patch_dim;                             /* C * p * p */
+    /* dropout (post-norm text trunks; 0 = off, the BASELINE configs): on every sub-layer output before the residual add
+     * (resid_pdrop, sc/layers/block.py:422-431,453-462) and on the embedding-LayerNorm output (embd_pdrop).  Applied when
+     * CxChunkBuffers.drop_active != 0 (training mode). */
+    float resid_pdrop, embd_pdrop;
 } CxEncoderDesc;
 
 /* Per-chunk activation arena (device memory owned by the caller).  save_for_backward = 0 lets every layer reuse
@@ -300,6 +323,12 @@ typedef struct CxChunkBuffers {
      * other per-layer buffer has a single slot -- and backward recomputes each block from it before differentiating
      * it.  Results are bit-identical to checkpoint = 0; the arena shrinks from ~31 KB to ~1.5 KB per token and layer. */
     int checkpoint;
+    /* dropout state of the chunk, set by the host before the forward and read again by the backward: Philox (seed, offset)
+     * drawn from the torch generator (so RandContext replays it), the on/off switch, and one more (T,d) gradient buffer
+     * (the LayerNorm backward returns two different gradients once a mask sits between x0 and the sum). */
+    int drop_active;
+    unsigned long long drop_seed, drop_offset;
+    uint16_t* g_d;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.
