@@ -22,3 +22,5 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 python scripts/pmc_multi.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_summary.txt 2>&1
 rm -rf $O/pmc_sq
 head -30 $O/kernel_summary.txt
+timeout 300 python scripts/gemm_ablate.py > $O/gemm_ablation.txt 2>&1; tail -3 $O/gemm_ablation.txt
+timeout 300 python scripts/gemm_microbench.py > $O/gemm_microbench.txt 2>&1; tail -3 $O/gemm_microbench.txt
