@@ -17,6 +17,7 @@ bf16 shadow refresh.  Synthetic token ids are staged in HBM before the timed reg
 The JSON line carries, besides the contract fields:
   roofline      dominant kernel family (bf16 MFMA GEMMs) timed live with HIP events on its own stream (every 7th launch)
   weak          the same step at 2048 pairs per GPU (global batch 2048 x N: SURVEY.md §8(d) asks for both curves)
+  resident      2048 pairs per GPU with pass 1's activations kept in HBM (no re-forward; identical results)
   dropin_chunk64  (N = 1) the same step at the reference recipe's GradCache chunk_size 64 (contrastive_pretrain.yaml:15)
   xgmi_allgather  (N > 1) the embedding all-gather of the loss timed on its own, against 7 x 153 GB/s of xGMI per GPU
   cpu_baseline  (N = 1) oracle = CPU restatement of the reference, one 64-pair chunk forward + backward, min of 3
@@ -189,6 +190,7 @@ def main():
     from contrastors_amd.optimizer import FusedAdamW
 
     os.environ["CX_GRADCACHE_CHUNK"] = "exact"  # --chunk-size is taken literally in every leg but the drop-in one
+    os.environ["CX_GRADCACHE_RESIDENT"] = "0"   # the metric is the two-pass GradCache step; the `resident` record is separate
     lib = _C.lib()
     G, S = args.global_batch, args.seq_len
     assert G % world == 0
@@ -262,6 +264,23 @@ def main():
                              "ms_per_step": 1e3 * wdt / args.steps, "steps": args.steps, "scaling": "weak"}
         elif b == WEAK_PAIRS_PER_GPU:
             extra["weak"] = "same point as the headline (2048 pairs per GPU)"
+        # the same 2048 pairs per GPU with the activations of pass 1 kept in HBM (193 GB of 288): nothing to recompute in
+        # pass 2, identical loss and gradients (tests/test_loss_gpu.py), 3 forward-equivalents of FLOPs instead of 4
+        if G >= WEAK_PAIRS_PER_GPU:
+            os.environ["CX_GRADCACHE_RESIDENT"] = "1"
+            try:
+                rdt, _ = run_leg(WEAK_PAIRS_PER_GPU, args.chunk_size, args.steps, 1, prof=False)
+                extra["resident"] = {"value": WEAK_PAIRS_PER_GPU * world * args.steps / rdt, "unit": "pairs/s",
+                                     "pairs_per_gpu": WEAK_PAIRS_PER_GPU, "global_batch": WEAK_PAIRS_PER_GPU * world,
+                                     "ms_per_step": 1e3 * rdt / args.steps, "steps": args.steps,
+                                     "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                                     "note": "GradCache with pass 1's activations resident (CX_GRADCACHE_RESIDENT=auto, the "
+                                             "library default, picks this whenever the per-GPU batch fits: 8 GPUs x 2048 "
+                                             "pairs is the metric's own per-GPU shape); same loss bit for bit, gradients equal up to fp32-atomics order, "
+                                             "encoder FLOPs 3/4 of the two-pass step. NOT the headline: `value` stays two-pass"}
+            except torch.OutOfMemoryError:
+                extra["resident"] = "activations of 2048 pairs per GPU did not fit beside this run's other buffers"
+            os.environ["CX_GRADCACHE_RESIDENT"] = "0"
         # what an unmodified reference YAML gets: GradCache chunk_size 64 (8192 token rows per GEMM launch)
         if world == 1 and args.chunk_size != 64:
             nb = min(b, 2048)

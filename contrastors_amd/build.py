@@ -24,7 +24,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
     "-Wno-unused-function", "-Wno-unused-variable", f"-I{INCLUDE}",
-]
+] + os.environ.get("CX_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DCX_V6_NT=1); the default build has none
 
 
 def _stale(target: Path, deps) -> bool:

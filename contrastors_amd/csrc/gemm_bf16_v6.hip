@@ -23,6 +23,32 @@
 
 namespace {
 
+// Epilogue traffic is touched once: outputs are not re-read by this launch and the streamed epilogue inputs (residual,
+// saved (y, gate)) are read once.  CX_V6_NT (bit 0 stores, bit 1 loads) marks them non-temporal so that they do not evict
+// the operand panels the XCD's other workgroups are about to re-use from L2.
+#ifndef CX_V6_NT
+#define CX_V6_NT 3   // measured on the whole step (scripts/gpu_variant_bench.sh): 0 -> 3861..3873, 1 -> 3895, 3 -> 3907 pairs/s
+#endif
+typedef unsigned int cx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gst_nt(void* ptr, uint4 v) {
+    cx_u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<cx_u32x4*>(ptr));
+}
+__device__ __forceinline__ uint4 gld_nt(const void* ptr) {
+    const cx_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const cx_u32x4*>(ptr));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+#if CX_V6_NT & 1
+#define gst(ptr, v) gst_nt((ptr), (v))
+#else
+#define gst(ptr, v) (*reinterpret_cast<uint4*>(ptr) = (v))
+#endif
+#if CX_V6_NT & 2
+#define gld(ptr) gld_nt(ptr)
+#else
+#define gld(ptr) (*reinterpret_cast<const uint4*>(ptr))
+#endif
+
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
@@ -327,14 +353,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     // unrolled loop is left in scratch memory by the compiler)
                     uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {}, r4 = {}, r5 = {}, r6 = {}, r7 = {};
 #define CX_RES_ROWS(b_)                                                                                   \
-    r0 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 0) * p.ldo2);                          \
-    r1 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 4) * p.ldo2);                          \
-    r2 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 8) * p.ldo2);                          \
-    r3 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 12) * p.ldo2);                         \
-    r4 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 16) * p.ldo2);                         \
-    r5 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 20) * p.ldo2);                         \
-    r6 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 24) * p.ldo2);                         \
-    r7 = *reinterpret_cast<const uint4*>(resp + (size_t)((b_) * 32 + 28) * p.ldo2);
+    r0 = gld(resp + (size_t)((b_) * 32 + 0) * p.ldo2);                          \
+    r1 = gld(resp + (size_t)((b_) * 32 + 4) * p.ldo2);                          \
+    r2 = gld(resp + (size_t)((b_) * 32 + 8) * p.ldo2);                          \
+    r3 = gld(resp + (size_t)((b_) * 32 + 12) * p.ldo2);                         \
+    r4 = gld(resp + (size_t)((b_) * 32 + 16) * p.ldo2);                         \
+    r5 = gld(resp + (size_t)((b_) * 32 + 20) * p.ldo2);                         \
+    r6 = gld(resp + (size_t)((b_) * 32 + 24) * p.ldo2);                         \
+    r7 = gld(resp + (size_t)((b_) * 32 + 28) * p.ldo2);
                     auto add_res = [&](uint4& v, const uint4& r) {
                         v.x = pack_bf16x2(bf16lo_to_f32(v.x) + bf16lo_to_f32(r.x), bf16hi_to_f32(v.x) + bf16hi_to_f32(r.x));
                         v.y = pack_bf16x2(bf16lo_to_f32(v.y) + bf16lo_to_f32(r.y), bf16hi_to_f32(v.y) + bf16hi_to_f32(r.y));
@@ -368,14 +394,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             asm volatile("" ::"v"(o));
                             return;
                         }
-                        *reinterpret_cast<uint4*>(o) = v0;
-                        *reinterpret_cast<uint4*>(o + (size_t)4 * p.ldo) = v1;
-                        *reinterpret_cast<uint4*>(o + (size_t)8 * p.ldo) = v2;
-                        *reinterpret_cast<uint4*>(o + (size_t)12 * p.ldo) = v3;
-                        *reinterpret_cast<uint4*>(o + (size_t)16 * p.ldo) = v4;
-                        *reinterpret_cast<uint4*>(o + (size_t)20 * p.ldo) = v5;
-                        *reinterpret_cast<uint4*>(o + (size_t)24 * p.ldo) = v6;
-                        *reinterpret_cast<uint4*>(o + (size_t)28 * p.ldo) = v7;
+                        gst(o, v0);
+                        gst(o + (size_t)4 * p.ldo, v1);
+                        gst(o + (size_t)8 * p.ldo, v2);
+                        gst(o + (size_t)12 * p.ldo, v3);
+                        gst(o + (size_t)16 * p.ldo, v4);
+                        gst(o + (size_t)20 * p.ldo, v5);
+                        gst(o + (size_t)24 * p.ldo, v6);
+                        gst(o + (size_t)28 * p.ldo, v7);
                     };
                     if constexpr (RES) { CX_RES_ROWS(0) }
                     pack_pass(0);
@@ -398,7 +424,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         m_ = m_ < p.M ? m_ : p.M - 1;                                                                 \
         int n_ = n0 + (lane & 15) * 8;                                                                \
         n_ = n_ + 8 <= p.N ? n_ : 0;                                                                  \
-        dst = *reinterpret_cast<const uint4*>(resid + (size_t)m_ * p.ldo2 + n_);                      \
+        dst = gld(resid + (size_t)m_ * p.ldo2 + n_);                      \
     }
                             CX_RES_LOAD(0, r0) CX_RES_LOAD(1, r1) CX_RES_LOAD(2, r2) CX_RES_LOAD(3, r3)
                             CX_RES_LOAD(4, r4) CX_RES_LOAD(5, r5) CX_RES_LOAD(6, r6) CX_RES_LOAD(7, r7)
@@ -445,7 +471,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 vv.w = pack_bf16x2(bf16lo_to_f32(vv.w) + bf16lo_to_f32(rr.w), bf16hi_to_f32(vv.w) + bf16hi_to_f32(rr.w));
                             }
                             if (m < p.M && n + 8 <= p.N)
-                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                                gst(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n, vv);
                         }
                     }
                 };
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     const bf16_t* src = yg_in + (size_t)(m0 + lrow) * p.ldo2 + c0 + lch * 8;
                     bf16_t* dst = dyg + (size_t)(m0 + lrow) * p.ldo + c0 + lch * 8;
                     uint4 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
-#define CX_L(i, b_) t##i = *reinterpret_cast<const uint4*>(src + (size_t)((b_) * 32 + (i) * 2) * p.ldo2);
+#define CX_L(i, b_) t##i = gld(src + (size_t)((b_) * 32 + (i) * 2) * p.ldo2);
 #define CX_LOAD_LO(b_) CX_L(0, b_) CX_L(1, b_) CX_L(2, b_) CX_L(3, b_) CX_L(4, b_) CX_L(5, b_) CX_L(6, b_) CX_L(7, b_)
 #define CX_LOAD_HI(b_) CX_L(8, b_) CX_L(9, b_) CX_L(10, b_) CX_L(11, b_) CX_L(12, b_) CX_L(13, b_) CX_L(14, b_) CX_L(15, b_)
 #define CX_S(i) *reinterpret_cast<uint4*>(cell((i) * 2 + lrow, lch * 16)) = t##i;
@@ -534,10 +560,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             const uint4 v2 = *reinterpret_cast<const uint4*>(cell((h * 4 + 2) * 2 + lrow, lch * 16));
                             const uint4 v3 = *reinterpret_cast<const uint4*>(cell((h * 4 + 3) * 2 + lrow, lch * 16));
                             bf16_t* o = dst + (size_t)(b * 32 + h * 8) * p.ldo;
-                            *reinterpret_cast<uint4*>(o) = v0;
-                            *reinterpret_cast<uint4*>(o + (size_t)2 * p.ldo) = v1;
-                            *reinterpret_cast<uint4*>(o + (size_t)4 * p.ldo) = v2;
-                            *reinterpret_cast<uint4*>(o + (size_t)6 * p.ldo) = v3;
+                            gst(o, v0);
+                            gst(o + (size_t)2 * p.ldo, v1);
+                            gst(o + (size_t)4 * p.ldo, v2);
+                            gst(o + (size_t)6 * p.ldo, v3);
                         }
                     };
                     CX_LOAD_LO(0) CX_LOAD_HI(0)
@@ -610,7 +636,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         const int row = i * 2 + (lane >> 5), ch = lane & 31;
                         const int m = m0 + b * 32 + row;
                         const uint4 vv = *reinterpret_cast<const uint4*>(cell(row, ch * 16));
-                        if (m < p.M) *reinterpret_cast<uint4*>(dyg + (size_t)m * p.ldo + c0 + ch * 8) = vv;
+                        if (m < p.M) gst(dyg + (size_t)m * p.ldo + c0 + ch * 8, vv);
                     }
                 }
             } else if constexpr (EPI == GEMM_EPI_GELU) {
@@ -662,7 +688,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             const int m = m0 + b * 32 + row, n = n0 + ch * 8;
                             const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
                             if (m < p.M && n + 8 <= p.N)
-                                *reinterpret_cast<uint4*>(outp + (size_t)m * ldo + n) = vv;
+                                gst(outp + (size_t)m * ldo + n, vv);
                         }
                     }
                 }
@@ -742,20 +768,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         if constexpr (b < 3) stage();  // the LDS executes a wave's operations in order: these follow the row reads
                         if constexpr (SAVE) {
                             bf16_t* o = ygp + (size_t)(b * 32) * p.ldo;
-                            *reinterpret_cast<uint4*>(o) = v0;
-                            *reinterpret_cast<uint4*>(o + (size_t)4 * p.ldo) = v1;
-                            *reinterpret_cast<uint4*>(o + (size_t)8 * p.ldo) = v2;
-                            *reinterpret_cast<uint4*>(o + (size_t)12 * p.ldo) = v3;
-                            *reinterpret_cast<uint4*>(o + (size_t)16 * p.ldo) = v4;
-                            *reinterpret_cast<uint4*>(o + (size_t)20 * p.ldo) = v5;
-                            *reinterpret_cast<uint4*>(o + (size_t)24 * p.ldo) = v6;
-                            *reinterpret_cast<uint4*>(o + (size_t)28 * p.ldo) = v7;
+                            gst(o, v0);
+                            gst(o + (size_t)4 * p.ldo, v1);
+                            gst(o + (size_t)8 * p.ldo, v2);
+                            gst(o + (size_t)12 * p.ldo, v3);
+                            gst(o + (size_t)16 * p.ldo, v4);
+                            gst(o + (size_t)20 * p.ldo, v5);
+                            gst(o + (size_t)24 * p.ldo, v6);
+                            gst(o + (size_t)28 * p.ldo, v7);
                         }
                         bf16_t* oa = actp + (size_t)(b * 32) * p.ldo2;
-                        *reinterpret_cast<uint4*>(oa) = a0;
-                        *reinterpret_cast<uint4*>(oa + (size_t)8 * p.ldo2) = a1;
-                        *reinterpret_cast<uint4*>(oa + (size_t)16 * p.ldo2) = a2;
-                        *reinterpret_cast<uint4*>(oa + (size_t)24 * p.ldo2) = a3;
+                        gst(oa, a0);
+                        gst(oa + (size_t)8 * p.ldo2, a1);
+                        gst(oa + (size_t)16 * p.ldo2, a2);
+                        gst(oa + (size_t)24 * p.ldo2, a3);
                     };
                     compute_pass(0);
                     stage();
@@ -811,7 +837,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             const int m = m0 + b * 32 + row, n = n0 + ch * 8;
                             const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
                             if (m < p.M && n < p.N)
-                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n) = vv;
+                                gst(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n, vv);
                         }
                     }
 #pragma unroll
@@ -821,7 +847,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         const int col = (n0 >> 1) + ch * 8;
                         const uint4 vv = *reinterpret_cast<const uint4*>(mya + row * AROWB + ch * 16);
                         if (m < p.M && 2 * col < p.N)
-                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.Out2) + (size_t)m * p.ldo2 + col) = vv;
+                            gst(reinterpret_cast<bf16_t*>(p.Out2) + (size_t)m * p.ldo2 + col, vv);
                     }
                 }
             }

@@ -297,12 +297,7 @@ def effective_chunk(tower, inputs, chunk_size: int) -> int:
     if cfg is None or ids is None or ids.ndim != 2 or not ids.is_cuda:
         return chunk_size
     B, S = ids.shape
-    d, I, L = cfg.n_embd, cfg.n_inner, cfg.n_layer
-    wfc1 = 2 * I if getattr(cfg, "gated", False) else I
-    per_layer = 2 * (3 * d + 5 * d + wfc1 + I) + 4 * (cfg.n_head + 4)          # saved activations, bytes per token
-    kept = 1 if getattr(tower.trunk, "gradient_checkpointing", False) else L
-    scratch = 2 * (3 * d + 3 * max(3 * d, wfc1) + I)                            # backward ping-pong + transposes
-    bytes_per_token = kept * per_layer + (L - kept) * 2 * d + scratch
+    bytes_per_token = _arena_bytes_per_token(tower)
     free, _ = torch.cuda.mem_get_info(ids.device)
     free += torch.cuda.memory_reserved(ids.device) - torch.cuda.memory_allocated(ids.device)  # the allocator's own cache
     tokens = int(min(262144, max(S, free / 3 / bytes_per_token)))
@@ -311,21 +306,95 @@ def effective_chunk(tower, inputs, chunk_size: int) -> int:
     return int(min(want, max(B, chunk_size)))
 
 
+def _arena_bytes_per_token(tower) -> float:
+    """Saved activations + backward scratch of the native encoder, bytes per token (see nomic_bert._ChunkArena)."""
+    cfg = tower.trunk.config
+    d, I, L = cfg.n_embd, cfg.n_inner, cfg.n_layer
+    wfc1 = 2 * I if getattr(cfg, "gated", False) else I
+    per_layer = 2 * (3 * d + 5 * d + wfc1 + I) + 4 * (cfg.n_head + 4)
+    kept = 1 if getattr(tower.trunk, "gradient_checkpointing", False) else L
+    scratch = 2 * (3 * d + 3 * max(3 * d, wfc1) + I)
+    return kept * per_layer + (L - kept) * 2 * d + scratch
+
+
+def resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs) -> bool:
+    """GradCache exists because one pass cannot hold a big batch's activations (sc/loss.py:187-213 was written for 80 GB
+    parts): pass 1 throws them away and pass 2 recomputes them, 4 forward-equivalents of FLOPs instead of 3.  When the
+    WHOLE per-GPU batch of both towers fits in HBM (2048 pairs x 128 tokens of nomic-bert-2048: 193 GB of 288), pass 1
+    can keep them and pass 2 has nothing to recompute: same embeddings, same loss, same gradients (the same kernels in the
+    same order; identical up to the fp32-atomics noise two runs of the two-pass step show), a quarter of the work gone.  CX_GRADCACHE_RESIDENT = auto | 0 | 1; `auto` keeps the
+    activations when they take <= 80 % of the free HBM."""
+    import os
+
+    mode = os.environ.get("CX_GRADCACHE_RESIDENT", "auto")
+    if mode == "0":
+        return False
+    need = 0.0
+    dev = None
+    for tw, inp in ((tower1, t1_inputs), (tower2, t2_inputs)):
+        ids = inp.get("input_ids") if isinstance(inp, dict) else None
+        cfg = getattr(getattr(tw, "trunk", None), "config", None)
+        if ids is None or cfg is None or not ids.is_cuda or ids.ndim != 2 or not hasattr(cfg, "n_inner"):
+            return False
+        if not tw.training or getattr(tw, "frozen_trunk", False):
+            continue  # a frozen / eval tower saves nothing
+        dev = ids.device
+        mask = inp.get("attention_mask")
+        tokens = ids.shape[0] * ids.shape[1] if mask is None else None
+        if tokens is None:
+            lens = inp.get("seqlens")
+            tokens = int(sum(lens)) if lens is not None else ids.shape[0] * ids.shape[1]   # no sync: an upper bound is enough
+        need += tokens * _arena_bytes_per_token(tw) * 1.03
+    if dev is None:
+        return False
+    if mode == "1":
+        return True
+    free, _ = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    for tw in {id(tower1): tower1, id(tower2): tower2}.values():
+        free += sum(a.nbytes() for a in getattr(tw.trunk, "_arena_free", []))   # arenas the engine already holds are reused
+    return need <= 0.8 * free
+
+
+def _resident_forward(model, chunks):
+    """Forward of every chunk with its activations kept (autograd holds the arenas until the chunk's backward)."""
+    if not model.training or getattr(model, "frozen_trunk", False):
+        with torch.no_grad():
+            return [model(**c)["embedding"] for c in chunks]
+    with torch.enable_grad():
+        return [model(**c)["embedding"] for c in chunks]
+
+
+def _resident_backward(outs, cache):
+    for o, g in zip(outs, cache):
+        if o.requires_grad:
+            o.backward(g.to(o.dtype))
+
+
 def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scale, bidirectional=False,
                     router_aux_coeff=False):
     """GradCache step (sc/loss.py:187-213).  Leaves parameter gradients in the towers and returns the loss."""
     q_chunks = _split_inputs(t1_inputs, effective_chunk(tower1, t1_inputs, chunk_size))
     d_chunks = _split_inputs(t2_inputs, effective_chunk(tower2, t2_inputs, chunk_size))
     was_training1, was_training2 = tower1.training, tower2.training
-    q_rnd, d_rnd = [], []
-    q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd)
-    d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd)
-    q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional)
     sizes_q = [c["input_ids"].shape[0] for c in q_chunks]
     sizes_d = [c["input_ids"].shape[0] for c in d_chunks]
-    accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd)
-    if was_training2:
-        accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd)
+    if resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs):
+        q_out = _resident_forward(tower1, q_chunks)
+        d_out = _resident_forward(tower2, d_chunks)
+        q_cache, d_cache, loss = cache_loss(torch.cat([o.detach() for o in q_out]), torch.cat([o.detach() for o in d_out]),
+                                            logit_scale, bidirectional=bidirectional)
+        _resident_backward(q_out, q_cache.split(sizes_q))
+        _resident_backward(d_out, d_cache.split(sizes_d))
+        del q_out, d_out
+    else:
+        q_rnd, d_rnd = [], []
+        q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd)
+        d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd)
+        q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional)
+        accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd)
+        if was_training2:
+            accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd)
     # data-parallel reduction of the accumulated gradients: once per step, one flat buffer per distinct tower
     seen = set()
     for tw, active in ((tower1, was_training1), (tower2, was_training2)):

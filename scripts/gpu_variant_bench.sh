@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B a set of library variants (scripts/build_variant.py) on the whole step: swaps the product .so on the (scratch) GPU
+# box and runs the headline leg.  usage: bash scripts/gpu_variant_bench.sh base nt1 nt3
+set -u
+mkdir -p gpurun_out/variants
+export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
+L=contrastors_amd/lib
+cp $L/libcontrastors_hip.so /tmp/base.so
+for v in "$@"; do
+  if [[ $v == base ]]; then cp /tmp/base.so $L/libcontrastors_hip.so; else cp $L/variants/libcontrastors_hip_$v.so $L/libcontrastors_hip.so; fi
+  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > gpurun_out/variants/bench_$v.log 2>&1
+  echo "$v: $(tail -1 gpurun_out/variants/bench_$v.log | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["roofline"]["achieved"])')"
+done
+cp /tmp/base.so $L/libcontrastors_hip.so

@@ -12,6 +12,8 @@ GOLD = ROOT / "tests" / "golden"
 # tests pass GradCache chunk sizes they mean literally (chunk-invariance, multi-chunk paths); the auto re-chunking of
 # contrastors_amd.loss.effective_chunk has its own test
 os.environ.setdefault("CX_GRADCACHE_CHUNK", "exact")
+# ... and the two-pass GradCache schedule unless a test asks for resident activations (tests/test_loss_gpu.py)
+os.environ.setdefault("CX_GRADCACHE_RESIDENT", "0")
 
 
 def pytest_configure(config):

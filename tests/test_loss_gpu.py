@@ -80,24 +80,34 @@ def test_grad_cache_loss_equals_full_batch_oracle(gold):
     tower.trunk.zero_grad()
     loss = grad_cache_loss(tower, {"input_ids": qi, "attention_mask": qm}, tower,
                            {"input_ids": di, "attention_mask": dm}, chunk_size=2, logit_scale=scale)
-    for v in sd.values():
-        v.requires_grad_(True)
-    qe = encoder_ref.biencoder_embedding(sd, ns, qi.cpu(), qm.cpu())
-    de = encoder_ref.biencoder_embedding(sd, ns, di.cpu(), dm.cpu())
-    ref = infonce_ref.clip_loss_ref(qe, de, 20.0)
-    ref.backward()
+    def oracle_step(bf16):
+        sdd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd.items()}
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            qe = encoder_ref.biencoder_embedding(sdd, ns, qi, qm)
+            de = encoder_ref.biencoder_embedding(sdd, ns, di, dm)
+        labels = torch.from_numpy(infonce_ref.labels_for(qe.shape[0], de.shape[0], 0, 1)).to(DEV)
+        ref = torch.nn.functional.cross_entropy((qe.float() @ de.float().T) * 20.0, labels)   # infonce_ref.clip_loss_ref, W = 1
+        ref.backward()
+        return ref.item(), sdd
+
+    ref, sd32 = oracle_step(False)
+    ref_bf, sd_bf = oracle_step(True)
     grads = tower.trunk.reference_grad_dict()
-    e_loss = abs(loss.item() - ref.item())
-    worst = 0.0
+    e_loss, e_loss_bf = abs(loss.item() - ref), abs(ref_bf - ref)
+    worst = worst_bf = 0.0
     for n, gh in grads.items():
-        r = sd[n].grad
+        r = sd32[n].grad
         if r is None:
             continue
-        e = rel_err(gh.cpu(), r)
-        worst = max(worst, e)
-    report("grad_cache", loss_hip=loss.item(), loss_ref=ref.item(), worst_rel_grad=worst)
-    assert e_loss < 2e-2, "loss through bf16 encoders at logit scale 20"
-    assert worst < 8e-2
+        eh, eb = rel_err(gh, r), rel_err(sd_bf[n].grad, r)
+        worst, worst_bf = max(worst, eh), max(worst_bf, eb)
+        # the reference's own rule (tests/test_flash_bert.py:77-82): err <= 3 x err(bf16 eager), + a floor: the engine's
+        # residual stream is bf16 (flash-attn's residual_in_fp32=False path) while autocast eager keeps LayerNorm in fp32,
+        # which shows on LayerNorm bias gradients summed over the 2 x 8 short sequences of this fixture (3.7 % measured)
+        assert eh <= 3 * eb + 3e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    report("grad_cache", loss_hip=loss.item(), loss_ref=ref, loss_bf16_eager=ref_bf, worst_rel_grad=worst,
+           worst_rel_grad_bf16_eager=worst_bf)
+    assert e_loss <= 3 * e_loss_bf + 2e-3, "loss through bf16 encoders at logit scale 20"
 
 
 def test_matryoshka_prefix_views_and_dual_encoder_loss():
@@ -248,3 +258,41 @@ def test_auto_chunk_raises_the_recipe_chunk_without_changing_results(monkeypatch
     l_exact = grad_cache_loss(tower, q, tower, d, 4, scale)
     assert abs(float(l_auto) - float(l_exact)) < 1e-5
     assert float((g_auto - tower.trunk.flat_grad).abs().max()) <= 2e-4 * float(g_auto.abs().max())
+
+
+def test_resident_activation_gradcache_equals_two_pass(monkeypatch):
+    """CX_GRADCACHE_RESIDENT: when the whole batch's activations fit in HBM pass 1 keeps them and pass 2 has nothing to
+    recompute.  Same kernels in the same order -> the same loss bit for bit and the same gradients up to fp32-atomics
+    summation order, at the BASELINE architecture, several chunks per tower, and also with dropout on (the masks are
+    drawn from the same generator states)."""
+    from contrastors_amd.loss import resident_activations_fit
+
+    scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    B, S = 192, 128
+    q = {"input_ids": torch.randint(1000, 8192, (B, S), generator=g).to(DEV), "seqlens": [S] * B}
+    d = {"input_ids": torch.randint(1000, 8192, (B, S), generator=g).to(DEV), "seqlens": [S - 7] * B}
+    for p_drop in (0.0, 0.1):
+        cfg = NomicBertConfig.nomic_bert_2048(vocab_size=8192, resid_pdrop=p_drop, embd_pdrop=p_drop)
+        tower = BiEncoder(BiEncoderConfig(model_name="nomic", pooling="mean", trunk_config=cfg), device=DEV, seed=11).train()
+        res = {}
+        for mode in ("0", "1", "auto"):
+            monkeypatch.setenv("CX_GRADCACHE_RESIDENT", mode)
+            assert resident_activations_fit(tower, q, tower, d) == (mode != "0")
+            torch.manual_seed(123)
+            tower.trunk.zero_grad()
+            loss = grad_cache_loss(tower, q, tower, d, 64, scale)
+            torch.cuda.synchronize()
+            res[mode] = (float(loss), tower.trunk.flat_grad.clone())
+            if mode != "0":
+                assert len(tower.trunk._arena_free) >= 6   # 3 + 3 chunk arenas came back for re-use
+        assert res["0"][0] == res["1"][0] == res["auto"][0]            # the same embeddings -> the same loss, bit for bit
+        gn = float(res["0"][1].norm())
+        assert gn > 0
+        for mode in ("1", "auto"):   # LayerNorm / bias / type-embedding gradients are reduced with fp32 atomics: the
+            # run-to-run noise of the two-pass step itself (rel_repeat <= 1e-5 above) is the floor
+            assert float((res["0"][1] - res[mode][1]).norm()) <= 1e-5 * gn
+    # a batch that cannot fit is left to the two-pass schedule
+    monkeypatch.setenv("CX_GRADCACHE_RESIDENT", "auto")
+    ids = torch.zeros(1, 1, dtype=torch.long, device=DEV).expand(1 << 20, 128)   # 134 M tokens, no memory behind it
+    assert not resident_activations_fit(tower, {"input_ids": ids}, tower, {"input_ids": ids})
