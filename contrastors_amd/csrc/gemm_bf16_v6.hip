@@ -29,6 +29,20 @@ namespace {
 #ifndef CX_V6_NT
 #define CX_V6_NT 3   // measured on the whole step (scripts/gpu_variant_bench.sh): 0 -> 3861..3873, 1 -> 3895, 3 -> 3907 pairs/s
 #endif
+// LDS-DMA issue (see the cursor comments in the kernels): M0 = slot base + J * 4 KiB, then the load; split in two so that
+// an MFMA can sit between the M0 write and its use (the wait state the hardware asks for), or fused with an s_nop.
+template <int J>
+__device__ __forceinline__ void v6_dma_m0(uint32_t slot_base) {
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(slot_base), "n"(J * 4096) : "memory", "scc");
+}
+__device__ __forceinline__ void v6_dma_ld(uint32_t off, const bf16_t* base) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base) : "memory");
+}
+template <int J>
+__device__ __forceinline__ void v6_dma_full(uint32_t slot_base, uint32_t off, const bf16_t* base) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" ::"s"(slot_base), "n"(J * 4096), "v"(off),
+                 "s"(base) : "memory", "scc");
+}
 typedef unsigned int cx_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gst_nt(void* ptr, uint4 v) {
     cx_u32x4 t = {v.x, v.y, v.z, v.w};
@@ -96,14 +110,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
 
     // ---- DMA cursors.  A K-tile of one operand = 32 instructions of 1 KiB (8 rows x 128 B), 8 per wave.  A cursor is a
-    // wave-uniform 64-bit panel base (SGPR pair, set when the cursor enters an output tile) + one 32-bit byte offset per
-    // instruction (VGPR): half the address registers of 64-bit pointers and one VALU add per instruction and K-tile.
+    // wave-uniform 64-bit base (SGPR pair: the panel of the output tile, advanced by 128 B per K-tile with two SALU
+    // instructions) + one CONSTANT 32-bit byte offset per instruction (VGPR, set when the cursor enters an output tile).
+    // With one wave per SIMD the main loop is issue-bound: an LDS-DMA used to cost nine instructions between two MFMAs
+    // (a branch on "is there another tile", an SGPR reload through v_readlane for the LDS address, three SALU, s_nop,
+    // the load, a VALU offset add); it is two now -- `s_add_u32 m0, <slot base>, <imm>` in front of an MFMA (which is the
+    // wait state the M0 write needs) and the load behind it.  There is no "live" branch: past its last tile a cursor
+    // re-walks the workgroup's first tile into ring slots nobody reads (a few KiB of dummy traffic per workgroup).
     uint32_t xoff[8], woff[8];
     const bf16_t* xbase = p.X;
     const bf16_t* wbase = p.W;
     int lx_round = 0, lx_kt = 0, lx_slot = 0;
     int lw_round = 0, lw_kt = 0, lw_slot = 0;
     bool lx_live, lw_live;
+    const int first_tile = tile_of(0);
     auto x_setup = [&](int tile) {
         const int tm = tile / p.tiles_n;
         xbase = p.X + (size_t)tm * BM6 * p.ldx;
@@ -128,39 +148,45 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             woff[j] = (uint32_t)rr * (uint32_t)p.ldw * 2u + c * 16;
         }
     };
-    // one DMA instruction of the next X / W K-tile (j = 0..7); the cursor advances with the last one
     // LDS-DMA through inline asm, not the builtin: the compiler, knowing that VMEM writes LDS, guards LDS accesses it
     // cannot disambiguate with s_waitcnt vmcnt(0) -- in front of the first staging write of every epilogue here (a full
     // DMA round trip per tile), in front of every transposing read in the TN kernel below.  All DMA waits in this file
     // are explicit counted s_waitcnt + barrier.  (M0 = the wave's LDS destination; nothing else here uses M0.)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)dsm;
-    auto dma1 = [&](uint32_t off, const bf16_t* base, uint32_t lds_byte) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    const uint32_t lds_wave = lds0 + wave * 1024;      // instruction j of a K-tile lands at slot + (j * 4 + wave) * 1024
+    uint32_t x_m0 = lds_wave, w_m0 = lds_wave + 3 * XS6;
+    auto issue_x_tile = [&]() {  // a whole K-tile at once (prologue: no MFMA to put between the M0 write and the load)
+        if constexpr ((DBG & 1) != 0) return;
+        v6_dma_full<0>(x_m0, xoff[0], xbase); v6_dma_full<1>(x_m0, xoff[1], xbase); v6_dma_full<2>(x_m0, xoff[2], xbase);
+        v6_dma_full<3>(x_m0, xoff[3], xbase); v6_dma_full<4>(x_m0, xoff[4], xbase); v6_dma_full<5>(x_m0, xoff[5], xbase);
+        v6_dma_full<6>(x_m0, xoff[6], xbase); v6_dma_full<7>(x_m0, xoff[7], xbase);
     };
-    auto issue_x1 = [&](int j) {
-        dma1(xoff[j], xbase, lds0 + lx_slot * XS6 + (j * 4 + wave) * 1024);
-        xoff[j] += BK6 * 2;
+    auto issue_w_tile = [&]() {
+        if constexpr ((DBG & 1) != 0) return;
+        v6_dma_full<0>(w_m0, woff[0], wbase); v6_dma_full<1>(w_m0, woff[1], wbase); v6_dma_full<2>(w_m0, woff[2], wbase);
+        v6_dma_full<3>(w_m0, woff[3], wbase); v6_dma_full<4>(w_m0, woff[4], wbase); v6_dma_full<5>(w_m0, woff[5], wbase);
+        v6_dma_full<6>(w_m0, woff[6], wbase); v6_dma_full<7>(w_m0, woff[7], wbase);
     };
     auto x_advance = [&]() {
+        xbase += BK6;
         lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+        x_m0 = lds_wave + lx_slot * XS6;
         if (++lx_kt == nk) {
             lx_kt = 0;
             const int t = tile_of(++lx_round);
             lx_live = t < ntiles;
-            if (lx_live) x_setup(t);
+            x_setup(lx_live ? t : first_tile);
         }
     };
-    auto issue_w1 = [&](int j) {
-        dma1(woff[j], wbase, lds0 + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024);
-        woff[j] += BK6 * 2;
-    };
     auto w_advance = [&]() {
+        wbase += BK6;
         lw_slot ^= 1;
+        w_m0 = lds_wave + (3 + lw_slot) * XS6;
         if (++lw_kt == nk) {
             lw_kt = 0;
             const int t = tile_of(++lw_round);
             lw_live = t < ntiles;
-            if (lw_live) w_setup(t);
+            w_setup(lw_live ? t : first_tile);
         }
     };
 
@@ -169,25 +195,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // C = 0 form, so nothing is ever zeroed), read only by v6_read_block in the epilogue.
 
     int cp_round = 0, cp_kt = 0;
-    int cp_tile = tile_of(0);
+    int cp_tile = first_tile;
     lx_live = lw_live = cp_tile < ntiles;
-    bool x1_issued = false;
-    if (lx_live) {
-        x_setup(cp_tile);
-        w_setup(cp_tile);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) issue_x1(j);  // X of iteration 0
-        x_advance();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) issue_w1(j);  // W of iteration 0
-        w_advance();
-        if (lx_live) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) issue_x1(j);  // X of iteration 1
-            x_advance();
-            x1_issued = true;
-        }
-    }
+    if (cp_tile >= ntiles) return;  // (only when the grid is larger than the tile count: never with launch6's grid)
+    x_setup(cp_tile);
+    w_setup(cp_tile);
+    issue_x_tile();  // X of iteration 0
+    x_advance();
+    issue_w_tile();  // W of iteration 0
+    w_advance();
+    issue_x_tile();  // X of iteration 1
+    x_advance();
     int xs_slot = 0, ws_slot = 0;
 
     Frags6 F0, F1;
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
     // One k-step: 16 MFMAs on `cur`; after the first one, the 8 reads of the next k-step (into `nxt`) and up to 4 DMA
     // instructions are interleaved one per MFMA, the rest of the MFMAs follow back to back.
-    // dma_kind: 0 none, 1 W instructions j0..j0+3, 2 X instructions j0..j0+3
+    // dma_kind: 0 none, 1 W instructions j0..j0+3, 2 X instructions j0..j0+3 (M0 write | MFMA | load, see the cursors)
 #define CX_KSTEP(MMA, cur, nxt, rxs, rws, rks, dma_kind, j0)                                           \
     do {                                                                                              \
         MMA(cur, 0);                                                                                  \
@@ -220,24 +238,37 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             MMA(cur, 1 + i_);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                        \
         }                                                                                             \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                            \
-            if ((dma_kind) == 1 && w_go) issue_w1((j0) + i_);                                         \
-            if ((dma_kind) == 2 && x_go) issue_x1((j0) + i_);                                         \
-            MMA(cur, 9 + i_);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                             \
+        CX_DMA_M0(dma_kind, (j0) + 0);                                                                \
+        MMA(cur, 9);                                                                                  \
+        CX_DMA_LD(dma_kind, (j0) + 0);                                                                \
+        CX_DMA_M0(dma_kind, (j0) + 1);                                                                \
+        MMA(cur, 10);                                                                                 \
+        CX_DMA_LD(dma_kind, (j0) + 1);                                                                \
+        CX_DMA_M0(dma_kind, (j0) + 2);                                                                \
+        MMA(cur, 11);                                                                                 \
+        CX_DMA_LD(dma_kind, (j0) + 2);                                                                \
+        CX_DMA_M0(dma_kind, (j0) + 3);                                                                \
+        MMA(cur, 12);                                                                                 \
+        CX_DMA_LD(dma_kind, (j0) + 3);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
         MMA(cur, 13);                                                                                 \
         MMA(cur, 14);                                                                                 \
         MMA(cur, 15);                                                                                 \
     } while (0)
+#define CX_DMA_M0(kind, J)                                                       \
+    do {                                                                         \
+        if constexpr ((kind) == 1 && (DBG & 1) == 0) v6_dma_m0<(J)>(w_m0);        \
+        if constexpr ((kind) == 2 && (DBG & 1) == 0) v6_dma_m0<(J)>(x_m0);        \
+    } while (0)
+#define CX_DMA_LD(kind, J)                                                       \
+    do {                                                                         \
+        if constexpr ((kind) == 1 && (DBG & 1) == 0) v6_dma_ld(woff[(J)], wbase); \
+        if constexpr ((kind) == 2 && (DBG & 1) == 0) v6_dma_ld(xoff[(J)], xbase); \
+    } while (0)
 
     if (cp_tile < ntiles) {
-        // operands of iteration 0 (X_0, W_0); the only younger group is X_1 (8 ops), if issued
-        if (x1_issued) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // operands of iteration 0 (X_0, W_0); the only younger group is X_1 (8 ops)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) read_one(F0, dsm, dsm + 3 * XS6, 0, i);
@@ -250,7 +281,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     auto kt_body = [&](auto first) {
         // DMA of this iteration: W of iteration +1 (k-steps 0,1), X of iteration +2 (k-steps 2,3); both target slots
         // consumed in iteration -1.
-        const bool w_go = lw_live && !(DBG & 1), x_go = lx_live && !(DBG & 1);
         if constexpr (DBG != 0) ++n_ktiles;
         const char* xs = dsm + xs_slot * XS6;
         const char* ws = dsm + (3 + ws_slot) * XS6;
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             CX_KSTEP(mma1, F0, F1, xs, ws, 1, 1, 0);
         }
         CX_KSTEP(mma1, F1, F0, xs, ws, 2, 1, 4);
-        if (w_go) w_advance();
+        w_advance();
         CX_KSTEP(mma1, F0, F1, xs, ws, 3, 2, 0);
         // this wave's reads of the current slots are complete (F1 has landed) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -269,19 +299,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // k-step 2 (the other 4 of that K-tile follow below).  "All but the newest 4" stays correct across a tile end:
         // the epilogue's global stores are older than the next iteration's newest 4 and retire in order with them (gfx9
         // has one in-order vmcnt for loads and stores), so they can only make that wait stronger, never weaker.
-        if constexpr ((DBG & 32) == 0) {
-            if (x_go) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
+        if constexpr ((DBG & 32) == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr ((DBG & 2) == 0) __builtin_amdgcn_s_barrier();
         const char* nxs = dsm + nxs_slot * XS6;
         const char* nws = dsm + (3 + nws_slot) * XS6;
         // (at a tile end these reads fetch the first fragments of the next tile: its operands have landed too)
         CX_KSTEP(mma1, F1, F0, nxs, nws, 0, 2, 4);
-        if (x_go) x_advance();
+        x_advance();
         ++cp_kt;
         pxs_slot = xs_slot;
         pws_slot = ws_slot;
@@ -863,16 +887,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
                     asm volatile("" : "=v"(woff[0]), "=v"(woff[1]), "=v"(woff[2]), "=v"(woff[3]), "=v"(woff[4]), "=v"(woff[5]), "=v"(woff[6]), "=v"(woff[7]));
-                    if (lx_live) {
-                        x_setup(tile_of(lx_round));
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) xoff[j] += lx_kt * (BK6 * 2);
-                    }
-                    if (lw_live) {
-                        w_setup(tile_of(lw_round));
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) woff[j] += lw_kt * (BK6 * 2);
-                    }
+                    x_setup(lx_live ? tile_of(lx_round) : first_tile);
+                    xbase += lx_kt * BK6;
+                    w_setup(lw_live ? tile_of(lw_round) : first_tile);
+                    wbase += lw_kt * BK6;
                 }
                 if (cp_tile < ntiles) {
 #pragma unroll
@@ -884,6 +902,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
     }
 #undef CX_KSTEP
+#undef CX_DMA_M0
+#undef CX_DMA_LD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cursors' dummy DMAs must land before the LDS is handed on
     if constexpr (DBG != 0) {
         if (p.trace && tid == 0) {
             p.trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
@@ -947,31 +968,44 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     if (nk <= 0) return;  // (split_k <= K tiles is enforced by the launcher)
 
     // DMA: instruction q = j*4 + wave covers token rows 2q, 2q+1 of a [64 t][256 f] tile (512 B each).  Ring as in the
-    // NT kernel: three X slots (dY runs two K-tiles ahead), two W slots (A one ahead).
-    const bf16_t* xsrc[8];
-    const bf16_t* wsrc[8];
+    // NT kernel: three X slots (dY runs two K-tiles ahead), two W slots (A one ahead); cursors as in the NT kernel (SGPR
+    // base advanced per K-tile, constant per-lane offsets, M0 write | MFMA | load).  Past the last K-tile of the split a
+    // cursor stops advancing and re-loads that tile into a slot nobody reads: no "is there another tile" branch per DMA.
+    uint32_t xo[8], wo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int t = (j * 4 + wave) * 2 + (lane >> 5);
         const int c = (lane & 31) ^ ((t & 3) << 2);
-        xsrc[j] = p.X + ((size_t)kt_begin * BK6 + t) * p.ldx + m0 + c * 8;
-        wsrc[j] = p.W + ((size_t)kt_begin * BK6 + t) * p.ldw + n0 + c * 8;
+        xo[j] = (uint32_t)t * (uint32_t)p.ldx * 2u + c * 16;
+        wo[j] = (uint32_t)t * (uint32_t)p.ldw * 2u + c * 16;
     }
+    const bf16_t* xb = p.X + (size_t)kt_begin * BK6 * p.ldx + m0;
+    const bf16_t* wb = p.W + (size_t)kt_begin * BK6 * p.ldw + n0;
     const size_t xstep = (size_t)BK6 * p.ldx, wstep = (size_t)BK6 * p.ldw;
     int lx_slot = 0, lw_slot = 0;
     // LDS-DMA through inline asm (see the NT kernel): with the builtin the compiler puts s_waitcnt vmcnt(0) in front of
     // the first ds_read_b64_tr_b16 of every iteration (the intrinsic carries no alias information), serialising the ring.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)dsm;
-    auto dma1 = [&](const bf16_t* src, uint32_t lds_byte) {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory");
+    const uint32_t lds_wave = lds0 + wave * 1024;
+    uint32_t x_m0 = lds_wave, w_m0 = lds_wave + 3 * XS6;
+    auto issue_x_tile = [&]() {
+        v6_dma_full<0>(x_m0, xo[0], xb); v6_dma_full<1>(x_m0, xo[1], xb); v6_dma_full<2>(x_m0, xo[2], xb); v6_dma_full<3>(x_m0, xo[3], xb);
+        v6_dma_full<4>(x_m0, xo[4], xb); v6_dma_full<5>(x_m0, xo[5], xb); v6_dma_full<6>(x_m0, xo[6], xb); v6_dma_full<7>(x_m0, xo[7], xb);
     };
-    auto issue_x1 = [&](int j) {
-        dma1(xsrc[j], lds0 + lx_slot * XS6 + (j * 4 + wave) * 1024);
-        xsrc[j] += xstep;
+    auto issue_w_tile = [&]() {
+        v6_dma_full<0>(w_m0, wo[0], wb); v6_dma_full<1>(w_m0, wo[1], wb); v6_dma_full<2>(w_m0, wo[2], wb); v6_dma_full<3>(w_m0, wo[3], wb);
+        v6_dma_full<4>(w_m0, wo[4], wb); v6_dma_full<5>(w_m0, wo[5], wb); v6_dma_full<6>(w_m0, wo[6], wb); v6_dma_full<7>(w_m0, wo[7], wb);
     };
-    auto issue_w1 = [&](int j) {
-        dma1(wsrc[j], lds0 + (3 + lw_slot) * XS6 + (j * 4 + wave) * 1024);
-        wsrc[j] += wstep;
+    // the cursor moves on to K-tile `next` of this split if it exists (else it stays: dummy re-load) and to the next slot
+    auto x_advance = [&](int next) {
+        xb += next < nk ? xstep : 0;
+        lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+        x_m0 = lds_wave + lx_slot * XS6;
+    };
+    auto w_advance = [&](int next) {
+        wb += next < nk ? wstep : 0;
+        lw_slot ^= 1;
+        w_m0 = lds_wave + (3 + lw_slot) * XS6;
     };
 
     // L2 prefetch: both operands stream from HBM here (activations, not weights) and a DMA issued one or two K-tiles
@@ -1016,7 +1050,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 3], f.x[i >> 2]); };
     auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]); };
     // one k-step: 16 MFMAs on `cur`; the 8 fragments (16 transposing reads) of the next k-step and 4 DMA instructions
-    // ride between them.  dma_kind: 1 = W instructions j0..j0+3 (if w_go), 2 = X instructions (if x_go)
+    // ride between them.  dma_kind: 1 = W instructions j0..j0+3, 2 = X instructions j0..j0+3
 #define CX_TN_KSTEP(MMA, cur, nxt, rx, rw, rks, dma_kind, j0)                                           \
     do {                                                                                              \
         MMA(cur, 0);                                                                                  \
@@ -1026,31 +1060,41 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             MMA(cur, 1 + i_);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                        \
         }                                                                                             \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                            \
-            if ((dma_kind) == 1 && w_go) issue_w1((j0) + i_);                                         \
-            if ((dma_kind) == 2 && x_go) issue_x1((j0) + i_);                                         \
-            MMA(cur, 9 + i_);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                             \
+        CX_DMA_M0(dma_kind, (j0) + 0);                                                                \
+        MMA(cur, 9);                                                                                  \
+        CX_DMA_LD(dma_kind, (j0) + 0);                                                                \
+        CX_DMA_M0(dma_kind, (j0) + 1);                                                                \
+        MMA(cur, 10);                                                                                 \
+        CX_DMA_LD(dma_kind, (j0) + 1);                                                                \
+        CX_DMA_M0(dma_kind, (j0) + 2);                                                                \
+        MMA(cur, 11);                                                                                 \
+        CX_DMA_LD(dma_kind, (j0) + 2);                                                                \
+        CX_DMA_M0(dma_kind, (j0) + 3);                                                                \
+        MMA(cur, 12);                                                                                 \
+        CX_DMA_LD(dma_kind, (j0) + 3);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
         MMA(cur, 13);                                                                                 \
         MMA(cur, 14);                                                                                 \
         MMA(cur, 15);                                                                                 \
     } while (0)
+#define CX_DMA_M0(kind, J)                                  \
+    do {                                                    \
+        if constexpr ((kind) == 1) v6_dma_m0<(J)>(w_m0);     \
+        if constexpr ((kind) == 2) v6_dma_m0<(J)>(x_m0);     \
+    } while (0)
+#define CX_DMA_LD(kind, J)                                  \
+    do {                                                    \
+        if constexpr ((kind) == 1) v6_dma_ld(wo[(J)], wb);   \
+        if constexpr ((kind) == 2) v6_dma_ld(xo[(J)], xb);   \
+    } while (0)
 
-#pragma unroll
-    for (int j = 0; j < 8; ++j) issue_x1(j);  // X of K-tile 0
-    lx_slot = 1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) issue_w1(j);  // W of K-tile 0
-    lw_slot = 1;
-    if (nk > 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) issue_x1(j);  // X of K-tile 1
-        lx_slot = 2;
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    issue_x_tile();  // X of K-tile 0
+    x_advance(1);
+    issue_w_tile();  // W of K-tile 0
+    w_advance(1);
+    issue_x_tile();  // X of K-tile 1 (or K-tile 0 again)
+    x_advance(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) read_one(F0, 0, 0, 0, i);
@@ -1059,7 +1103,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // K-tile body (see the NT kernel): DMA of this iteration = W of K-tile t+1 (k-steps 0,1) and X of K-tile t+2
     // (k-step 2 and, after the barrier, k-step 3); `first` selects the C = 0 MFMA form.
     auto kt_body = [&](auto first, int t) {
-        const bool w_go = t + 1 < nk, x_go = t + 2 < nk;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
         if constexpr (decltype(first)::value) {
             CX_TN_KSTEP(mma1z, F0, F1, xs_slot, ws_slot, 1, 1, 0);
@@ -1067,7 +1110,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 1, 1, 0);
         }
         CX_TN_KSTEP(mma1, F1, F0, xs_slot, ws_slot, 2, 1, 4);
-        if (w_go) lw_slot ^= 1;
+        w_advance(t + 2);
         CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 3, 2, 0);
         // L2 prefetches: the newest VMEM operations of this iteration (allowed to stay outstanding below)
         const bool pf_x = t + PF_X < nk, pf_w = t + PF_W < nk;
@@ -1081,9 +1124,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the current slots are complete ...
         // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions of k-step 2 and the prefetches
-        if (!x_go) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (pf_x) {       // pf_x implies pf_w
+        if (pf_x) {              // pf_x implies pf_w
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else if (pf_w) {
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -1093,7 +1134,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         __builtin_amdgcn_s_barrier();
         // (after the last K-tile these reads fetch garbage from a landed slot; F0 is not used again)
         CX_TN_KSTEP(mma1, F1, F0, nxs_slot, nws_slot, 0, 2, 4);
-        if (x_go) lx_slot = lx_slot == 2 ? 0 : lx_slot + 1;
+        x_advance(t + 3);
         xs_slot = nxs_slot;
         ws_slot = nws_slot;
     };
@@ -1101,6 +1142,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll 1
     for (int t = 1; t < nk; ++t) kt_body(std::false_type{}, t);
 #undef CX_TN_KSTEP
+#undef CX_DMA_M0
+#undef CX_DMA_LD
 
     // ---- epilogue: fp32 partial slab of this K slice, straight from the AGPRs.  block (a, b): rows m0 + wm*128 + b*32
     // + l31, columns n0 + wn*128 + a*32 + 8q + 4hi (+0..3)
