@@ -149,6 +149,7 @@ _DEV_SIGS = {
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "cx_probe_mfma_rate16": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_probe_dma_bw": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
 }
 

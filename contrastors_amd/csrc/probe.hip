@@ -102,9 +102,47 @@ __global__ __launch_bounds__(512) void probe_mfma_rate_kernel(const uint4* __res
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// the same FLOPs per iteration from the 16x16x32 form (16 instructions of 4 passes instead of 8 of 8 passes): half the
+// accumulator-register traffic per FLOP -- does the part sustain a higher rate at its power limit with it?
+typedef __attribute__((ext_vector_type(4))) float pb_f32x4;
+__global__ __launch_bounds__(512) void probe_mfma_rate16_kernel(const uint4* __restrict__ seed, int iters, long long* cyc,
+                                                                float* sink) {
+    const uint4 a0 = seed[threadIdx.x], a1 = seed[threadIdx.x + 512], b0 = seed[threadIdx.x + 1024],
+                b1 = seed[threadIdx.x + 1536];
+    pb_f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    const pb_bf16x8 fa0 = __builtin_bit_cast(pb_bf16x8, a0), fa1 = __builtin_bit_cast(pb_bf16x8, a1);
+    const pb_bf16x8 fb0 = __builtin_bit_cast(pb_bf16x8, b0), fb1 = __builtin_bit_cast(pb_bf16x8, b1);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((i & 1) ? fa1 : fa0, (i & 2) ? fb1 : fb0, acc[i], 0, 0, 0);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 }  // namespace
 
 extern "C" {
+int cx_probe_mfma_rate16(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
+                         void* stream) {
+    if (waves < 1 || waves > 8) return CX_ERR_SHAPE;
+    hipLaunchKernelGGL(probe_mfma_rate16_kernel, dim3(nwg), dim3(64 * waves), 0, (hipStream_t)stream,
+                       (const uint4*)seed_2048x16B, iters, cycles_nwg_x8, sink);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
 int cx_probe_mfma_rate(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
                        void* stream) {
     if (waves < 1 || waves > 8) return CX_ERR_SHAPE;
