@@ -89,7 +89,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK6;
     // Tile order.  Workgroup b runs on XCD b%8 (own 4 MiB L2).  The 8 XCDs form a gm x gn grid over the tile matrix
     // (gn = p.sup_n N-groups): XCD (xi, xj) owns M-panels [m_lo, m_hi) x N-tiles [n_lo, n_hi) and its workgroups walk
@@ -102,11 +101,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int m_lo = p.tiles_m * xi / gm, m_hi = p.tiles_m * (xi + 1) / gm;
     const int n_lo = p.tiles_n * xj / gn, n_wd = p.tiles_n * (xj + 1) / gn - n_lo;
     const int nloc = (m_hi - m_lo) * n_wd;
+    // a tile is named (tm << 8) | tn (tiles_n <= 256, checked by the launcher), -1 = none: the cursors and the epilogue take
+    // tm / tn apart with a shift and a mask (integer division is ~20 SALU instructions, and it sits between two MFMAs)
     auto tile_of = [&](int round) {
         const int l = round * per_xcd + idx;
-        if (l >= nloc) return ntiles;
+        if (l >= nloc) return -1;
         const int q = l / n_wd;
-        return (m_lo + q) * p.tiles_n + n_lo + (l - q * n_wd);
+        return ((m_lo + q) << 8) | (n_lo + (l - q * n_wd));
     };
 
     // ---- DMA cursors.  A K-tile of one operand = 32 instructions of 1 KiB (8 rows x 128 B), 8 per wave.  A cursor is a
@@ -124,28 +125,37 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     int lw_round = 0, lw_kt = 0, lw_slot = 0;
     bool lx_live, lw_live;
     const int first_tile = tile_of(0);
+    // per-lane offsets of a FULL 256-row panel do not depend on the tile: they are computed once, and re-computed (with the
+    // row clamp) only when a cursor enters or leaves a partial last panel
+    bool x_clamped = true, w_clamped = true;  // "offsets are not the generic ones": forces the first computation
     auto x_setup = [&](int tile) {
-        const int tm = tile / p.tiles_n;
+        const int tm = tile >> 8;
         xbase = p.X + (size_t)tm * BM6 * p.ldx;
         const int rows = p.M - tm * BM6;  // >= 1: rows of this panel that exist (others re-read the last one)
+        if (rows < BM6 || x_clamped) {
+            x_clamped = rows < BM6;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = (j * 4 + wave) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const int rr = r < rows ? r : rows - 1;
-            xoff[j] = (uint32_t)rr * (uint32_t)p.ldx * 2u + c * 16;
+            for (int j = 0; j < 8; ++j) {
+                const int r = (j * 4 + wave) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int rr = r < rows ? r : rows - 1;
+                xoff[j] = (uint32_t)rr * (uint32_t)p.ldx * 2u + c * 16;
+            }
         }
     };
     auto w_setup = [&](int tile) {
-        const int tn = tile % p.tiles_n;
+        const int tn = tile & 255;
         wbase = p.W + (size_t)tn * BN6 * p.ldw;
         const int rows = p.N - tn * BN6;
+        if (rows < BN6 || w_clamped) {
+            w_clamped = rows < BN6;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = (j * 4 + wave) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const int rr = r < rows ? r : rows - 1;
-            woff[j] = (uint32_t)rr * (uint32_t)p.ldw * 2u + c * 16;
+            for (int j = 0; j < 8; ++j) {
+                const int r = (j * 4 + wave) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int rr = r < rows ? r : rows - 1;
+                woff[j] = (uint32_t)rr * (uint32_t)p.ldw * 2u + c * 16;
+            }
         }
     };
     // LDS-DMA through inline asm, not the builtin: the compiler, knowing that VMEM writes LDS, guards LDS accesses it
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         if (++lx_kt == nk) {
             lx_kt = 0;
             const int t = tile_of(++lx_round);
-            lx_live = t < ntiles;
+            lx_live = t >= 0;
             x_setup(lx_live ? t : first_tile);
         }
     };
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         if (++lw_kt == nk) {
             lw_kt = 0;
             const int t = tile_of(++lw_round);
-            lw_live = t < ntiles;
+            lw_live = t >= 0;
             w_setup(lw_live ? t : first_tile);
         }
     };
@@ -196,8 +206,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
     int cp_round = 0, cp_kt = 0;
     int cp_tile = first_tile;
-    lx_live = lw_live = cp_tile < ntiles;
-    if (cp_tile >= ntiles) return;  // (only when the grid is larger than the tile count: never with launch6's grid)
+    lx_live = lw_live = cp_tile >= 0;
+    if (cp_tile < 0) return;  // (only when the grid is larger than the tile count: never with launch6's grid)
     x_setup(cp_tile);
     w_setup(cp_tile);
     issue_x_tile();  // X of iteration 0
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         if constexpr ((kind) == 2 && (DBG & 1) == 0) v6_dma_ld(xoff[(J)], xbase); \
     } while (0)
 
-    if (cp_tile < ntiles) {
+    {
         // operands of iteration 0 (X_0, W_0); the only younger group is X_1 (8 ops)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
 
 #pragma unroll 1
-    while (cp_tile < ntiles) {
+    while (cp_tile >= 0) {
         cp_kt = 0;
         kt_body(std::true_type{});
 #pragma unroll 1
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
             // ---- epilogue.  Free LDS: the X slot and the W slot just consumed (32 KiB each); waves 0,1 stage in the
             // former, waves 2,3 in the latter (16 KiB per wave).  In-flight DMA targets other slots.
-            const int tn = cp_tile % p.tiles_n, tm = cp_tile / p.tiles_n;
+            const int tn = cp_tile & 255, tm = cp_tile >> 8;
             const int m0 = tm * BM6 + wm * 128, n0 = tn * BN6 + wn * 128;
             char* my = ((wave < 2) ? dsm + pxs_slot * XS6 : dsm + (3 + pws_slot) * XS6) + (wave & 1) * 16384;
             constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
@@ -887,12 +897,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
                     asm volatile("" : "=v"(woff[0]), "=v"(woff[1]), "=v"(woff[2]), "=v"(woff[3]), "=v"(woff[4]), "=v"(woff[5]), "=v"(woff[6]), "=v"(woff[7]));
+                    x_clamped = w_clamped = true;  // (forces the re-computation)
                     x_setup(lx_live ? tile_of(lx_round) : first_tile);
                     xbase += lx_kt * BK6;
                     w_setup(lw_live ? tile_of(lw_round) : first_tile);
                     wbase += lw_kt * BK6;
                 }
-                if (cp_tile < ntiles) {
+                if (cp_tile >= 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) read_one(F0, dsm + xs_slot * XS6, dsm + (3 + ws_slot) * XS6, 0, i);
                 }
@@ -1209,6 +1220,7 @@ hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream) {
 hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     p.tiles_m = (p.M + BM6 - 1) / BM6;
     p.tiles_n = (p.N + BN6 - 1) / BN6;
+    if (p.tiles_n > 256) return hipErrorInvalidValue;  // tile ids are (tm << 8) | tn: N <= 65536
     p.sup_n = cx_gemm_v6_groups(p.tiles_m, p.tiles_n, p.K);
 #ifndef CX_PRODUCT
     if (epi == GEMM_EPI_NONE && g_v6_dbg) {  // ablation builds (scripts/gemm_ablate.py)
