@@ -100,6 +100,8 @@ _SIGS = {
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
+    "cx_attn_varlen_kvpacked_fwd": (i32, [vp] * 6 + [i32, i32, i32, i32, i32, f32, vp]),
+    "cx_attn_varlen_kvpacked_bwd": (i32, [vp] * 10 + [i32, i32, i32, i32, i32, f32, vp]),
     "cx_rotary_qkv_inplace": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_rotary_apply": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_pool_normalize_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

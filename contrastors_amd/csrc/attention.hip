@@ -126,9 +126,46 @@ struct AttnParams {
     bf16_t* dqkv;          // (T,3,H,64)
     int H, T;
     float scale;
+    // kv-packed cross-attention (flash_attn_[varlen_]kvpacked_func, K3): the <true> instantiations of the general kernels
+    // read queries from `qkv` as (Tq, H, 64), keys / values from `kv` (Tk, 2, H, 64) with their own cu_seqlens, and write
+    // dq to `dqkv` as (Tq, H, 64), dk / dv to `dkv` (Tk, 2, H, 64).  T = Tq (lse / delta are (H, Tq)).  No rotary.
+    const bf16_t* kv;
+    const int32_t* cu_k;
+    bf16_t* dkv;
 };
 
+// Where a (sequence, head) problem's rows live.  X = false: packed qkv, one set of lengths (self-attention).
+struct AttnView {
+    const bf16_t *q, *k, *v;
+    size_t qs, ks;            // row strides (elements) of the query rows and of the key / value rows
+    int t0q, lenq, t0k, lenk;
+};
+template <bool X>
+CX_DEVICE AttnView attn_view(const AttnParams& p, int h, int b) {
+    AttnView w;
+    w.t0q = p.cu[b];
+    w.lenq = p.cu[b + 1] - w.t0q;
+    if constexpr (X) {
+        w.t0k = p.cu_k[b];
+        w.lenk = p.cu_k[b + 1] - w.t0k;
+        w.q = p.qkv + (size_t)h * DH;
+        w.qs = (size_t)p.H * DH;
+        w.k = p.kv + (size_t)h * DH;
+        w.v = w.k + (size_t)p.H * DH;
+        w.ks = (size_t)2 * p.H * DH;
+    } else {
+        w.t0k = w.t0q;
+        w.lenk = w.lenq;
+        w.q = p.qkv + (size_t)h * DH;
+        w.k = w.q + (size_t)p.H * DH;
+        w.v = w.k + (size_t)p.H * DH;
+        w.qs = w.ks = (size_t)3 * p.H * DH;
+    }
+    return w;
+}
+
 // ---------------------------------------------------------------------------------------------------- forward
+template <bool X>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[16384 + 8192 + 64 * TSTRIDE];
     char* Qs = smem;
@@ -136,13 +173,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     char* Vt = smem + 16384 + 8192;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    const AttnView w = attn_view<X>(p, h, b);
+    const int t0 = w.t0q, len = w.lenq;        // query side
+    const int t0k = w.t0k, lenk = w.lenk;      // key / value side (the same numbers in self-attention)
     const int q0 = blockIdx.x * 128;
     if (q0 >= len) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const size_t tok_stride = w.qs, kv_stride = w.ks;
+    const bf16_t* qbase = w.q;
+    const bf16_t* kbase = w.k;
+    const bf16_t* vbase = w.v;
 
     // stage (rotated) Q tile
 #pragma unroll
@@ -174,30 +213,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     auto prefetch = [&](int kv0) {
         const int r = tid >> 2, cp = tid & 3;
         int tk = kv0 + r;
-        tk = tk < len ? tk : len - 1;
-        const bf16_t* krow = kbase + (size_t)(t0 + tk) * tok_stride;
+        tk = tk < lenk ? tk : lenk - 1;
+        const bf16_t* krow = kbase + (size_t)(t0k + tk) * kv_stride;
         k_lo = *reinterpret_cast<const uint4*>(krow + cp * 8);
         k_hi = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
         const int kp = tid >> 3, c = tid & 7;
         int k0i = kv0 + 2 * kp, k1i = k0i + 1;
-        k0i = k0i < len ? k0i : len - 1;
-        k1i = k1i < len ? k1i : len - 1;
-        v_r0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k0i) * tok_stride + c * 8);
-        v_r1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + k1i) * tok_stride + c * 8);
+        k0i = k0i < lenk ? k0i : lenk - 1;
+        k1i = k1i < lenk ? k1i : lenk - 1;
+        v_r0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + k0i) * kv_stride + c * 8);
+        v_r1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + k1i) * kv_stride + c * 8);
     };
-    prefetch(0);
-    for (int kv0 = 0; kv0 < len; kv0 += 64) {
+    if (lenk > 0) prefetch(0);
+    for (int kv0 = 0; kv0 < lenk; kv0 += 64) {
         {
             const int r = tid >> 2, cp = tid & 3;
             int tk = kv0 + r;
-            tk = tk < len ? tk : len - 1;
+            tk = tk < lenk ? tk : lenk - 1;
             rotate_loaded(k_lo, k_hi, cp, p.cosv, p.sinv, tk);
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = k_lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = k_hi;
             write_transposed_pair(Vt, tid >> 3, (tid & 7) * 8, v_r0, v_r1);
         }
         __syncthreads();
-        if (kv0 + 64 < len) prefetch(kv0 + 64);
+        if (kv0 + 64 < lenk) prefetch(kv0 + 64);
 
         float s[2][16];
 #pragma unroll
@@ -211,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + kb * 32 + acc_row(r, hi);
-                s[kb][r] = key < len ? a[r] * sc2 : -INFINITY;
+                s[kb][r] = key < lenk ? a[r] * sc2 : -INFINITY;
             }
         }
         float mx = -INFINITY;
@@ -250,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
+    const float inv = X ? (l_tot > 0.f ? 1.f / l_tot : 0.f) : 1.f / l_tot;  // (a cross problem may have no keys: out = 0)
     const int q = q0 + wave * 32 + l31;
     // full-row stores through this wave's own Q rows (dead since the fragments were read; see store_unrotated_rows)
     char* stage = Qs + wave * 4096;
@@ -706,19 +745,22 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
 }
 
 // ---------------------------------------------------------------------------------------------------- dQ
+template <bool X>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     // Qs/dOs are only needed to build the loop-invariant register fragments; the K/V/Kt tiles alias them.
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    const AttnView w = attn_view<X>(p, h, b);
+    const int t0 = w.t0q, len = w.lenq;        // query side
+    const int t0k = w.t0k, lenk = w.lenk;      // key / value side
     const int q0 = blockIdx.x * 128;
     if (q0 >= len) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH;
+    const size_t tok_stride = w.qs, kv_stride = w.ks;
     const size_t o_stride = (size_t)p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const bf16_t* qbase = w.q;
+    const bf16_t* kbase = w.k;
+    const bf16_t* vbase = w.v;
     const bf16_t* dobase = p.dout + (size_t)h * DH;
 
     {
@@ -762,15 +804,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
 
-    for (int kv0 = 0; kv0 < len; kv0 += 64) {
+    for (int kv0 = 0; kv0 < lenk; kv0 += 64) {
         if (wave < 2) {  // K: rotated, row-major + transposed.  item = (key pair, chunk pair)
             const int kp = tid >> 2, cp = tid & 3;
             int k0i = kv0 + 2 * kp, k1i = k0i + 1;
-            k0i = k0i < len ? k0i : len - 1;
-            k1i = k1i < len ? k1i : len - 1;
+            k0i = k0i < lenk ? k0i : lenk - 1;
+            k1i = k1i < lenk ? k1i : lenk - 1;
             uint4 a_lo, a_hi, b_lo, b_hi;
-            load_row_pair(kbase + (size_t)(t0 + k0i) * tok_stride, cp, p.cosv, p.sinv, k0i, a_lo, a_hi);
-            load_row_pair(kbase + (size_t)(t0 + k1i) * tok_stride, cp, p.cosv, p.sinv, k1i, b_lo, b_hi);
+            load_row_pair(kbase + (size_t)(t0k + k0i) * kv_stride, cp, p.cosv, p.sinv, k0i, a_lo, a_hi);
+            load_row_pair(kbase + (size_t)(t0k + k1i) * kv_stride, cp, p.cosv, p.sinv, k1i, b_lo, b_hi);
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp)) = a_lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp + 4)) = a_hi;
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp)) = b_lo;
@@ -783,9 +825,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
             for (int pss = 0; pss < 4; ++pss) {
                 const int r = pss * 16 + (t2 >> 3), c = t2 & 7;
                 int tk = kv0 + r;
-                tk = tk < len ? tk : len - 1;
+                tk = tk < lenk ? tk : lenk - 1;
                 *reinterpret_cast<uint4*>(Vs + tile64_off(r, c)) =
-                    *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + tk) * tok_stride + c * 8);
+                    *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + tk) * kv_stride + c * 8);
             }
         }
         __syncthreads();
@@ -803,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + kb * 32 + acc_row(r, hi);
-                const float pr = key < len ? fast_exp2(a_s[r] * sc2 - lse2) : 0.f;
+                const float pr = key < lenk ? fast_exp2(a_s[r] * sc2 - lse2) : 0.f;
                 ds[r] = pr * (a_dp[r] - dl);
             }
 #pragma unroll
@@ -824,19 +866,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
+template <bool X>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | Qt | dOt | lse[64] | delta[64]
     __shared__ __attribute__((aligned(16))) char smem[16384 + 2 * 64 * TSTRIDE + 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    const AttnView w = attn_view<X>(p, h, b);
+    const int t0 = w.t0q, len = w.lenq;        // query side
+    const int t0k = w.t0k, lenk = w.lenk;      // key / value side: this workgroup owns keys k0 .. k0 + 127
     const int k0 = blockIdx.x * 128;
-    if (k0 >= len) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH;
+    if (k0 >= lenk) return;
+    const size_t tok_stride = w.qs, kv_stride = w.ks;
     const size_t o_stride = (size_t)p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
+    const bf16_t* qbase = w.q;
+    const bf16_t* kbase = w.k;
+    const bf16_t* vbase = w.v;
     const bf16_t* dobase = p.dout + (size_t)h * DH;
 
     {
@@ -846,12 +891,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
         for (int pss = 0; pss < 2; ++pss) {
             const int r = pss * 64 + (tid >> 2), cp = tid & 3;
             int tk = k0 + r;
-            tk = tk < len ? tk : len - 1;
+            tk = tk < lenk ? tk : lenk - 1;
             uint4 lo, hi4;
-            load_row_pair(kbase + (size_t)(t0 + tk) * tok_stride, cp, p.cosv, p.sinv, tk, lo, hi4);
+            load_row_pair(kbase + (size_t)(t0k + tk) * kv_stride, cp, p.cosv, p.sinv, tk, lo, hi4);
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
-            load_row_pair(vbase + (size_t)(t0 + tk) * tok_stride, cp, nullptr, nullptr, 0, lo, hi4);
+            load_row_pair(vbase + (size_t)(t0k + tk) * kv_stride, cp, nullptr, nullptr, 0, lo, hi4);
             *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp)) = lo;
             *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp + 4)) = hi4;
         }
@@ -873,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     float* dl_s = lse_s + 64;
 
     const int key = k0 + wave * 32 + l31;
-    const bool key_ok = key < len;
+    const bool key_ok = key < lenk;
     const float sc2 = p.scale * LOG2E;
     f32x16_t acc_dk[2], acc_dv[2];
 #pragma unroll
@@ -961,11 +1006,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
         __syncthreads();
     }
     {
-        bf16_t* kr0 = p.dqkv + (size_t)(t0 + k0 + wave * 32) * tok_stride + (size_t)(p.H + h) * DH;
-        const int valid = len - (k0 + wave * 32);
-        store_unrotated_rows(smem + wave * 4096, kr0, tok_stride, valid, acc_dk, p.scale, p.cosv, p.sinv,
-                             key_ok ? key : len - 1, hi, lane);
-        store_unrotated_rows(smem + 16384 + wave * 4096, kr0 + (size_t)p.H * DH, tok_stride, valid, acc_dv, 1.f, nullptr,
+        bf16_t* kr0 = (X ? p.dkv + (size_t)h * DH : p.dqkv + (size_t)(p.H + h) * DH) + (size_t)(t0k + k0 + wave * 32) * kv_stride;
+        const int valid = lenk - (k0 + wave * 32);
+        store_unrotated_rows(smem + wave * 4096, kr0, kv_stride, valid, acc_dk, p.scale, p.cosv, p.sinv,
+                             key_ok ? key : lenk - 1, hi, lane);
+        store_unrotated_rows(smem + 16384 + wave * 4096, kr0 + (size_t)p.H * DH, kv_stride, valid, acc_dv, 1.f, nullptr,
                              nullptr, 0, hi, lane);
     }
 }
@@ -1871,7 +1916,7 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
         hipLaunchKernelGGL(attn_fwd_s128v_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
-        hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     return done();
 }
@@ -1922,8 +1967,51 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     }
 #endif
     dim3 grid((max_seqlen + 127) / 128, H, B);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
+// kv-packed cross-attention (K3): queries (Tq, H, 64) attend to keys / values (Tk, 2, H, 64) of the same batch entry;
+// the general (streaming, any length) kernels with separate query and key views.  Work is tiled 128 queries x 64 keys:
+// the reference's use (FlashAttentionPooling, ONE latent query per sequence) fills 1/128 of a query tile -- it is a
+// bandwidth-sized op there (it reads kv once) and runs at that speed, not at MFMA speed.
+int cx_attn_varlen_kvpacked_fwd(const uint16_t* q, const uint16_t* kv, const int32_t* cu_seqlens_q,
+                                const int32_t* cu_seqlens_k, uint16_t* out, float* lse, int B, int H, int Tq,
+                                int max_seqlen_q, int max_seqlen_k, float softmax_scale, void* stream) {
+    if (B <= 0 || Tq <= 0 || max_seqlen_q <= 0) return CX_OK;
+    if (!q || !kv || !cu_seqlens_q || !cu_seqlens_k || !out || !lse || max_seqlen_k < 0) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = q; p.kv = kv; p.cu = cu_seqlens_q; p.cu_k = cu_seqlens_k; p.out = out; p.lse = lse;
+    p.H = H; p.T = Tq; p.scale = softmax_scale;
+    dim3 grid((max_seqlen_q + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
+int cx_attn_varlen_kvpacked_bwd(const uint16_t* dout, const uint16_t* q, const uint16_t* kv, const uint16_t* out,
+                                const float* lse, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, float* delta,
+                                uint16_t* dq, uint16_t* dkv, int B, int H, int Tq, int max_seqlen_q, int max_seqlen_k,
+                                float softmax_scale, void* stream) {
+    if (B <= 0) return CX_OK;
+    if (!dout || !q || !kv || !out || !lse || !cu_seqlens_q || !cu_seqlens_k || !delta || !dq || !dkv) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = q; p.kv = kv; p.cu = cu_seqlens_q; p.cu_k = cu_seqlens_k;
+    p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
+    p.dout = dout; p.delta = delta; p.dqkv = dq; p.dkv = dkv;
+    p.H = H; p.T = Tq; p.scale = softmax_scale;
+    if (Tq > 0) {
+        long nthreads = (long)Tq * H * 8;
+        int g = (int)((nthreads + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+        if (max_seqlen_q > 0)
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((max_seqlen_q + 127) / 128, H, B), dim3(256), 0,
+                               (hipStream_t)stream, p);
+    }
+    if (max_seqlen_k > 0)
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((max_seqlen_k + 127) / 128, H, B), dim3(256), 0,
+                           (hipStream_t)stream, p);
     return done();
 }
 

@@ -70,9 +70,64 @@ def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=Fal
     return out.view(B, S, *out.shape[1:])
 
 
-def flash_attn_kvpacked_func(*a, **k):
-    raise NotImplementedError("cross-attention (kv-packed) is only used by `pooling: map` -- out of round-1 scope")
+class _VarlenKVPacked(torch.autograd.Function):
+    """K3: q (Tq,H,64) x kv (Tk,2,H,64) cross-attention per batch entry (cx_attn_varlen_kvpacked_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, cu_q, cu_k, max_q, max_k, scale):
+        if q.dtype != torch.bfloat16 or q.dim() != 3 or q.shape[2] != 64:
+            raise NotImplementedError("q must be bf16 (Tq,H,64)")
+        if kv.dtype != torch.bfloat16 or kv.dim() != 4 or kv.shape[1] != 2 or kv.shape[3] != 64:
+            raise NotImplementedError("kv must be bf16 (Tk,2,H,64)")
+        if kv.shape[2] != q.shape[1]:
+            raise NotImplementedError("MQA / GQA (num_heads_kv != num_heads) is not built (the reference does not use it)")
+        q, kv = q.contiguous(), kv.contiguous()
+        Tq, H, D = q.shape
+        B = cu_q.numel() - 1
+        if cu_k.numel() != B + 1:
+            raise ValueError("cu_seqlens_q and cu_seqlens_k must describe the same batch")
+        cu_q, cu_k = cu_q.to(torch.int32), cu_k.to(torch.int32)
+        out = torch.empty(Tq, H, D, dtype=q.dtype, device=q.device)
+        lse = torch.empty(H, max(Tq, 1), dtype=torch.float32, device=q.device)
+        _C.check(_C.lib().cx_attn_varlen_kvpacked_fwd(q.data_ptr(), kv.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(),
+                                                      out.data_ptr(), lse.data_ptr(), B, H, Tq, int(max_q), int(max_k), scale,
+                                                      _C.cur_stream()), "cross-attn fwd")
+        ctx.save_for_backward(q, kv, out, lse, cu_q, cu_k)
+        ctx.meta = (B, H, Tq, int(max_q), int(max_k), scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse, cu_q, cu_k = ctx.saved_tensors
+        B, H, Tq, mq, mk, scale = ctx.meta
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.zeros_like(kv)   # (keys outside every cu_seqlens_k range, if any, get a zero gradient)
+        delta = torch.empty(H, max(Tq, 1), dtype=torch.float32, device=q.device)
+        _C.check(_C.lib().cx_attn_varlen_kvpacked_bwd(dout.data_ptr(), q.data_ptr(), kv.data_ptr(), out.data_ptr(),
+                                                      lse.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), delta.data_ptr(),
+                                                      dq.data_ptr(), dkv.data_ptr(), B, H, Tq, mq, mk, scale,
+                                                      _C.cur_stream()), "cross-attn bwd")
+        return dq, dkv, None, None, None, None, None
 
 
-def flash_attn_varlen_kvpacked_func(*a, **k):
-    raise NotImplementedError("cross-attention (kv-packed) is only used by `pooling: map` -- out of round-1 scope")
+def flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                                    softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+                                    deterministic=False, return_attn_probs=False):
+    """(Tq,H,64) x (Tk,2,H,64) -> (Tq,H,64): FlashAttentionPooling's varlen branch (sc/layers/attention.py:391-419)."""
+    _check(dropout_p, causal, return_attn_probs)
+    return _VarlenKVPacked.apply(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                                 _scale(softmax_scale, q.shape[-1]))
+
+
+def flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                             alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """(B,Sq,H,64) x (B,Sk,2,H,64) -> (B,Sq,H,64): FlashAttentionPooling's fixed-length branch (attention.py:420-428)."""
+    _check(dropout_p, causal, return_attn_probs)
+    B, Sq = q.shape[:2]
+    Sk = kv.shape[1]
+    cu_q = torch.arange(0, (B + 1) * Sq, Sq, dtype=torch.int32, device=q.device)
+    cu_k = torch.arange(0, (B + 1) * Sk, Sk, dtype=torch.int32, device=q.device)
+    out = _VarlenKVPacked.apply(q.reshape(B * Sq, *q.shape[2:]), kv.reshape(B * Sk, *kv.shape[2:]), cu_q, cu_k, Sq, Sk,
+                                _scale(softmax_scale, q.shape[-1]))
+    return out.view(B, Sq, *out.shape[1:])

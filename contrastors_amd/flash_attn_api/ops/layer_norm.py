@@ -10,8 +10,23 @@ def _as(t, dtype):
     return t if t.dtype == dtype and t.is_contiguous() else t.to(dtype).contiguous()
 
 
+def _philox_keep_mask(n: int, p: float, device) -> torch.Tensor:
+    """Boolean keep-mask of n elements from the device generator's Philox stream (the generator advances as under a torch
+    dropout, so torch.manual_seed and RandContext govern it): the kernel scales a vector of ones in place, what survives
+    is kept.  n is rounded up to the kernel's group of 4."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    n4 = (n + 3) // 4 * 4
+    ones = torch.ones(n4, dtype=torch.bfloat16, device=device)
+    _C.check(_C.lib().cx_dropout_scale(ones.data_ptr(), n4, float(p), gen.initial_seed() & (2**64 - 1), off, 0,
+                                       _C.cur_stream()), "dropout mask")
+    return (ones != 0)[:n]
+
+
 class _DropoutAddLN(torch.autograd.Function):
-    """dropout_add_layer_norm with p = 0 (SURVEY.md Appendix C): z = x0 + residual; statistics and normalisation in fp32;
+    """dropout_add_layer_norm: z = dropout_p(x0) + residual (the Philox keep-mask is applied by
+    the caller below when p > 0); statistics and normalisation in fp32;
     `out` in x0's dtype; z kept in fp32 when `residual_in_fp32` or the residual is fp32, else in x0's dtype.  Every
     operand keeps its dtype down to the kernel (cx_layernorm_fwd_mixed / _bwd_mixed): fp32 or bf16 (fp16 is cast to bf16)."""
 
@@ -64,11 +79,22 @@ class _DropoutAddLN(torch.autograd.Function):
 
 def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None,
                            prenorm=False, residual_in_fp32=False, return_dropout_mask=False):
-    if dropout_p and torch.is_grad_enabled():
-        raise NotImplementedError("residual dropout > 0 is not implemented (BASELINE configs use 0)")
-    if rowscale is not None or layerscale is not None or return_dropout_mask:
-        raise NotImplementedError("rowscale / layerscale / return_dropout_mask")
-    return _DropoutAddLN.apply(x0, residual, weight, bias, epsilon, prenorm, bool(residual_in_fp32))
+    if rowscale is not None or layerscale is not None:
+        raise NotImplementedError("rowscale / layerscale")
+    keep = None
+    if dropout_p:
+        if not 0.0 < dropout_p < 1.0:
+            raise ValueError("dropout_p must be in [0, 1)")
+        # z = x0 * mask / (1 - p) + residual: the mask multiply stays in x0's dtype (autograd gives dx0 = dz * mask / (1 - p)),
+        # the add + LayerNorm run in the fused kernel.  (The native towers fuse the mask into the LayerNorm kernel:
+        # cx_dropout_add_layernorm_fwd; this op-by-op surface takes the three extra elementwise passes.)
+        keep = _philox_keep_mask(x0.numel(), float(dropout_p), x0.device).view(x0.shape)
+        x0 = x0 * keep.to(x0.dtype) * (1.0 / (1.0 - float(dropout_p)))
+    out = _DropoutAddLN.apply(x0, residual, weight, bias, epsilon, prenorm, bool(residual_in_fp32))
+    if return_dropout_mask:
+        mask = keep if keep is not None else torch.ones_like(x0, dtype=torch.bool)
+        return (*out, mask) if isinstance(out, tuple) else (out, mask)
+    return out
 
 
 def layer_norm(x, weight, bias, epsilon):

@@ -180,6 +180,20 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
                        const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
                        uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
+
+/* ---- K3  flash_attn_kvpacked_func / flash_attn_varlen_kvpacked_func (cross-attention; sc/layers/attention.py:313-433,
+ *          FlashAttentionPooling: one latent query per sequence over the sequence's keys) ---
+ * q (Tq, H, 64), kv (Tk, 2, H, 64) bf16, batch entry b: queries cu_seqlens_q[b] .. [b+1), keys cu_seqlens_k[b] .. [b+1);
+ * out (Tq, H, 64), lse (H, Tq) fp32.  Non-causal, no dropout, no rotary, H_kv == H (the reference: "we don't really
+ * support mqa / gqa").  A query with no keys gets out = 0.  bwd: delta = fp32 scratch (H, Tq); dq (Tq, H, 64),
+ * dkv (Tk, 2, H, 64) are overwritten. */
+int cx_attn_varlen_kvpacked_fwd(const uint16_t* q, const uint16_t* kv, const int32_t* cu_seqlens_q,
+                                const int32_t* cu_seqlens_k, uint16_t* out, float* lse, int B, int H, int Tq,
+                                int max_seqlen_q, int max_seqlen_k, float softmax_scale, void* stream);
+int cx_attn_varlen_kvpacked_bwd(const uint16_t* dout, const uint16_t* q, const uint16_t* kv, const uint16_t* out,
+                                const float* lse, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, float* delta,
+                                uint16_t* dq, uint16_t* dkv, int B, int H, int Tq, int max_seqlen_q, int max_seqlen_k,
+                                float softmax_scale, void* stream);
 /* standalone K11 (apply_rotary_emb_func on a packed qkv, in place on q and k; sign=-1 gives the backward). */
 int cx_rotary_qkv_inplace(uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                           int B, int H, int T, int max_seqlen, int sign, void* stream);

@@ -105,6 +105,50 @@ def test_dropout_add_layer_norm(prenorm):
     assert rel_err(y.float(), torch.nn.functional.layer_norm(x0.detach().float(), (d,), w.detach(), b.detach(), 1e-12)) < 4e-3
 
 
+@pytest.mark.parametrize("x0_dtype,res_fp32", [(torch.bfloat16, False), (torch.float32, True)])
+def test_dropout_add_layer_norm_with_dropout(x0_dtype, res_fp32):
+    """p > 0 (flash_attn.ops.layer_norm.dropout_add_layer_norm, sc/layers/block.py:422-431 with resid_pdrop > 0): the
+    mask comes from the device generator's Philox stream -- reproducible under torch.manual_seed, replayed by RandContext
+    -- and out / gradients equal torch's LayerNorm of x0 * mask / (1 - p) + residual with THAT mask."""
+    from contrastors_amd.rand_state import RandContext
+
+    d, p = 768, 0.1
+    x0 = _r(4, 33, d, seed=6).to(x0_dtype).requires_grad_()
+    res = _r(4, 33, d, seed=7).to(torch.float32 if res_fp32 else torch.bfloat16).requires_grad_()
+    w = (1 + _r(d, seed=8, std=0.1)).requires_grad_()
+    b = _r(d, seed=9, std=0.1).requires_grad_()
+    torch.manual_seed(5)
+    ctx = RandContext([x0])
+    o, mask = dropout_add_layer_norm(x0, res, w, b, p, 1e-12, residual_in_fp32=res_fp32, return_dropout_mask=True)
+    rate = mask.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    g = _r(4, 33, d, seed=10).to(o.dtype)
+    o.backward(g)
+    xr, rr = x0.detach().float().requires_grad_(), res.detach().float().requires_grad_()
+    wr, br = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr * mask.float() / (1 - p) + rr, (d,), wr, br, 1e-12)
+    ref.backward(g.float())
+    assert rel_err(o.float(), ref) < 4e-3
+    assert rel_err(x0.grad.float(), xr.grad) < 1e-2 and rel_err(res.grad.float(), rr.grad) < 1e-2
+    assert rel_err(w.grad, wr.grad) < 1e-2 and rel_err(b.grad, br.grad) < 1e-2
+    assert (x0.grad[~mask] == 0).all()
+    # same generator state -> same mask; a later call draws a different one; RandContext replays the first
+    torch.manual_seed(5)
+    _, m2 = dropout_add_layer_norm(x0.detach(), res.detach(), w.detach(), b.detach(), p, 1e-12, residual_in_fp32=res_fp32,
+                                   return_dropout_mask=True)
+    _, m3 = dropout_add_layer_norm(x0.detach(), res.detach(), w.detach(), b.detach(), p, 1e-12, residual_in_fp32=res_fp32,
+                                   return_dropout_mask=True)
+    assert torch.equal(m2, mask) and not torch.equal(m3, mask)
+    with ctx:
+        _, m4 = dropout_add_layer_norm(x0.detach(), res.detach(), w.detach(), b.detach(), p, 1e-12,
+                                       residual_in_fp32=res_fp32, return_dropout_mask=True)
+    assert torch.equal(m4, mask)
+    # eval-style call (p = 0) is the plain op
+    o0 = dropout_add_layer_norm(x0.detach(), res.detach(), w.detach(), b.detach(), 0.0, 1e-12, residual_in_fp32=res_fp32)
+    assert rel_err(o0.float(), torch.nn.functional.layer_norm(x0.detach().float() + res.detach().float(), (d,), w.detach(),
+                                                              b.detach(), 1e-12)) < 4e-3
+
+
 def test_swiglu_and_rotary():
     x = _r(7, 50, 512, seed=12).to(torch.bfloat16).requires_grad_()
     y = _r(7, 50, 512, seed=13).to(torch.bfloat16).requires_grad_()
