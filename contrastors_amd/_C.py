@@ -19,6 +19,8 @@ vp = C.c_void_p
 i32 = C.c_int
 i64 = C.c_long
 f32 = C.c_float
+u64 = C.c_ulonglong
+u32 = C.c_uint
 
 
 class CxLayerWeights(C.Structure):
@@ -48,7 +50,7 @@ class CxEncoderDesc(C.Structure):
         ("Wpatch", vp), ("bpatch", vp), ("cls_token", vp), ("vit_pos", vp),
         ("gWpatch", vp), ("gbpatch", vp), ("gcls_token", vp), ("gvit_pos", vp),
         ("patch_dim", i32),
-        ("resid_pdrop", f32), ("embd_pdrop", f32),
+        ("resid_pdrop", f32), ("embd_pdrop", f32), ("attn_pdrop", f32),
     ]
 
 
@@ -100,6 +102,8 @@ _SIGS = {
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
+    "cx_attn_varlen_dropout_fwd": (i32, [vp] * 6 + [i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
+    "cx_attn_varlen_dropout_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
     "cx_attn_varlen_kvpacked_fwd": (i32, [vp] * 6 + [i32, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_kvpacked_bwd": (i32, [vp] * 10 + [i32, i32, i32, i32, i32, f32, vp]),
     "cx_rotary_qkv_inplace": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -151,6 +155,7 @@ _DEV_SIGS = {
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "cx_attn_dropout_keep_mask": (i32, [vp, i32, i32, i32, f32, u64, u64, u32, vp]),
     "cx_probe_mfma_rate16": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_probe_dma_bw": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
 }

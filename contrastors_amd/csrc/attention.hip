@@ -132,7 +132,24 @@ struct AttnParams {
     const bf16_t* kv;
     const int32_t* cu_k;
     bf16_t* dkv;
+    // attention dropout (attn_pdrop > 0, flash_attn_*_func(dropout_p > 0)): the <.., true> instantiations of the general
+    // kernels.  keep(b, h, q, key) is a pure function of the chunk's Philox (seed, offset), the site and the indices --
+    // forward, dQ and dK/dV kernels (and a GradCache re-forward under RandContext) regenerate it, nothing is stored.
+    CxDropout drop;
+    uint32_t drop_site;
 };
+
+// keep-scale (0 or 1 / (1 - p)) of P[q][key .. key + 3] of problem `unit` = b * H + h; key % 4 == 0
+CX_DEVICE void attn_keep4(const AttnParams& p, uint32_t unit, int q, int key, float (&keep)[4]) {
+    dropout_keep4(p.drop, p.drop_site, ((unsigned long long)unit << 40) | ((unsigned long long)(uint32_t)q << 20) | (uint32_t)(key >> 2),
+                  keep);
+}
+CX_DEVICE float attn_keep1(const AttnParams& p, uint32_t unit, int q, int key) {
+    float k4[4];
+    attn_keep4(p, unit, q, key & ~3, k4);
+    const int e = key & 3;
+    return e == 0 ? k4[0] : e == 1 ? k4[1] : e == 2 ? k4[2] : k4[3];
+}
 
 // Where a (sequence, head) problem's rows live.  X = false: packed qkv, one set of lengths (self-attention).
 struct AttnView {
@@ -165,7 +182,7 @@ CX_DEVICE AttnView attn_view(const AttnParams& p, int h, int b) {
 }
 
 // ---------------------------------------------------------------------------------------------------- forward
-template <bool X>
+template <bool X, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[16384 + 8192 + 64 * TSTRIDE];
     char* Qs = smem;
@@ -271,6 +288,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if constexpr (DROP) {  // O accumulates P * keep / (1 - p); the normaliser above is the undropped row sum
+            const int qi = q0 + wave * 32 + l31;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float k4[4];
+                    attn_keep4(p, (uint32_t)(b * p.H + h), qi, kv0 + kb * 32 + 8 * qd + 4 * hi, k4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[kb][4 * qd + e] *= k4[e];
+                }
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -745,7 +774,7 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
 }
 
 // ---------------------------------------------------------------------------------------------------- dQ
-template <bool X>
+template <bool X, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     // Qs/dOs are only needed to build the loop-invariant register fragments; the K/V/Kt tiles alias them.
     __shared__ __attribute__((aligned(16))) char smem[32768];
@@ -842,6 +871,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
                 a_dp = mfma_bf16_32x32x16(lds_read_frag(Vs, tile64_off(kb * 32 + l31, ks * 2 + hi)), dof[ks], a_dp);
             }
             float ds[16];
+            if constexpr (DROP) {  // dP reaches P only through the kept entries: dS = P * (dP * keep / (1 - p) - delta)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float k4[4];
+                    attn_keep4(p, (uint32_t)(b * p.H + h), q, kv0 + kb * 32 + 8 * qd + 4 * hi, k4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a_dp[4 * qd + e] *= k4[e];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + kb * 32 + acc_row(r, hi);
@@ -866,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
-template <bool X>
+template <bool X, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | Qt | dOt | lse[64] | delta[64]
     __shared__ __attribute__((aligned(16))) char smem[16384 + 2 * 64 * TSTRIDE + 512];
@@ -987,8 +1025,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
                     const float pv = key_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
-                    pr[r] = pv;
-                    ds[r] = pv * (a_dp[r] - dd[e]);
+                    if constexpr (DROP) {  // this lane: ONE key, four consecutive queries -> one mask word per element
+                        const float kp = attn_keep1(p, (uint32_t)(b * p.H + h), q0 + row + e, key);
+                        pr[r] = pv * kp;                          // dV = (P * keep / (1 - p))^T dO
+                        ds[r] = pv * (a_dp[r] * kp - dd[e]);
+                    } else {
+                        pr[r] = pv;
+                        ds[r] = pv * (a_dp[r] - dd[e]);
+                    }
                 }
             }
 #pragma unroll
@@ -1718,6 +1762,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
     if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
 }
 
+#ifndef CX_PRODUCT
+__global__ void attn_keep_mask_kernel(AttnParams p, unsigned char* keep, int B, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)B * p.H * S * (S / 4);
+    if (i >= n) return;
+    const int kg = (int)(i % (S / 4));
+    const int q = (int)((i / (S / 4)) % S);
+    const uint32_t unit = (uint32_t)(i / ((long)S * (S / 4)));
+    float k4[4];
+    attn_keep4(p, unit, q, kg * 4, k4);
+    unsigned char* o = keep + ((long)unit * S + q) * S + kg * 4;
+    o[0] = k4[0] != 0.f; o[1] = k4[1] != 0.f; o[2] = k4[2] != 0.f; o[3] = k4[3] != 0.f;
+}
+#endif
+
 inline int done() { return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH; }
 
 // ------------------------------------------------------------------------ forward, sequences <= 128, lean-VALU form
@@ -1971,6 +2030,62 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return done();
 }
+
+// attention dropout > 0: the general kernels at every length (the S <= 128 single-pass kernels have no mask code: attn_pdrop is
+// 0 in every shipped recipe, and the hot path keeps its registers).
+int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
+                               uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
+                               unsigned long long seed, unsigned long long offset, unsigned int site, void* stream) {
+    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
+    if (!qkv || !cu_seqlens || !out || !lse) return CX_ERR_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
+    if (!(p_drop > 0.f) || p_drop >= 1.f || max_seqlen >= (1 << 20) || (long)B * H >= (1L << 24)) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
+    p.H = H; p.T = T; p.scale = softmax_scale;
+    p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
+    dim3 grid((max_seqlen + 127) / 128, H, B);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
+int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
+                               const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
+                               uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
+                               unsigned long long seed, unsigned long long offset, unsigned int site, void* stream) {
+    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
+    if (!dout || !qkv || !out || !lse || !cu_seqlens || !delta || !dqkv) return CX_ERR_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
+    if (!(p_drop > 0.f) || p_drop >= 1.f || max_seqlen >= (1 << 20) || (long)B * H >= (1L << 24)) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin;
+    p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
+    p.dout = dout; p.delta = delta; p.dqkv = dqkv;
+    p.H = H; p.T = T; p.scale = softmax_scale;
+    p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
+    long nthreads = (long)T * H * 8;
+    int g = (int)((nthreads + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    dim3 grid((max_seqlen + 127) / 128, H, B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
+#ifndef CX_PRODUCT
+// test helper (dev library): keep[b][h][q][key] in {0, 1} of the mask the kernels above apply
+int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
+                              unsigned long long offset, unsigned int site, void* stream) {
+    if (!keep || S % 4 != 0) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.H = H;
+    p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
+    const long n = (long)B * H * S * (S / 4);
+    hipLaunchKernelGGL(attn_keep_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, keep, B, S);
+    return done();
+}
+#endif
 
 // kv-packed cross-attention (K3): queries (Tq, H, 64) attend to keys / values (Tk, 2, H, 64) of the same batch entry;
 // the general (streaming, any length) kernels with separate query and key views.  Work is tiled 128 queries x 64 keys:

@@ -139,8 +139,14 @@ struct BlockRunner {
     int attn(const CxLayerWeights& w, const uint16_t* x, int l, uint16_t* out, const uint16_t* residual, bool* folded) const {
         const int d = enc->d;
         CX_TRY(cx_gemm_bf16_nt(x, w.Wqkv, s.qkv(l), w.bqkv, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.f, stream));
-        CX_TRY(cx_attn_varlen_fwd(s.qkv(l), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(l), s.lse(l), Bc, enc->n_head, T,
-                                  max_seqlen, enc->softmax_scale, stream));
+        if (buf->drop_active && enc->attn_pdrop > 0.f) {  // dropout sites of a chunk: 2l, 2l+1 residual, 2L embeddings, 2L+1+l attention
+            CX_TRY(cx_attn_varlen_dropout_fwd(s.qkv(l), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(l), s.lse(l), Bc,
+                                              enc->n_head, T, max_seqlen, enc->softmax_scale, enc->attn_pdrop, buf->drop_seed,
+                                              buf->drop_offset, (unsigned)(2 * enc->n_layer + 1 + l), stream));
+        } else {
+            CX_TRY(cx_attn_varlen_fwd(s.qkv(l), cu_seqlens, enc->rot_cos, enc->rot_sin, s.ctx(l), s.lse(l), Bc, enc->n_head, T,
+                                      max_seqlen, enc->softmax_scale, stream));
+        }
         return proj_residual(s.ctx(l), w.Wout, w.bout, residual, out, T, d, d, folded, stream);
     }
     // one post-norm block: h_in -> h2(l).  keep = backward will read this block's intermediates
@@ -297,8 +303,14 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         CX_TRY(wgrad(dx, d, s.ctx(l), d, w.gWout, buf, T, stream));
         CX_TRY(cx_gemm_bf16_nt(dx, w.WoutT, buf->g_b, nullptr, T, d, d, d, d, d, 0, 1, 1.f, stream));
         // attention core (+ inverse rotary)
-        CX_TRY(cx_attn_varlen_bwd(buf->g_b, s.qkv(l), s.ctx(l), s.lse(l), cu_seqlens, enc->rot_cos, enc->rot_sin,
-                                  buf->delta, buf->g_wide, Bc, H, T, max_seqlen, enc->softmax_scale, stream));
+        if (buf->drop_active && enc->attn_pdrop > 0.f) {
+            CX_TRY(cx_attn_varlen_dropout_bwd(buf->g_b, s.qkv(l), s.ctx(l), s.lse(l), cu_seqlens, enc->rot_cos, enc->rot_sin,
+                                              buf->delta, buf->g_wide, Bc, H, T, max_seqlen, enc->softmax_scale, enc->attn_pdrop,
+                                              buf->drop_seed, buf->drop_offset, (unsigned)(2 * enc->n_layer + 1 + l), stream));
+        } else {
+            CX_TRY(cx_attn_varlen_bwd(buf->g_b, s.qkv(l), s.ctx(l), s.lse(l), cu_seqlens, enc->rot_cos, enc->rot_sin,
+                                      buf->delta, buf->g_wide, Bc, H, T, max_seqlen, enc->softmax_scale, stream));
+        }
         if (w.gbqkv) CX_TRY(cx_bias_grad(buf->g_wide, w.gbqkv, T, 3 * d, 3 * d, stream));
         CX_TRY(wgrad(buf->g_wide, 3 * d, attn_in, d, w.gWqkv, buf, T, stream));
         return proj_residual(buf->g_wide, w.WqkvT, nullptr, add, buf->g_b, T, d, 3 * d, folded, stream);
@@ -541,7 +553,7 @@ int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const i
     return wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream);
 }
 
-int cx_abi_version(void) { return 3; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward
+int cx_abi_version(void) { return 4; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

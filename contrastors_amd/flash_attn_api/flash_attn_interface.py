@@ -14,9 +14,17 @@ def _scale(softmax_scale, d):
     return float(softmax_scale)  # contrastors passes a 0-dim tensor (attention.py:46,163)
 
 
+def _draw_philox(device):
+    """(seed, offset) from the device generator, advanced as a torch dropout op would (RandContext replays it)."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return gen.initial_seed() & (2**64 - 1), off
+
+
 class _VarlenQKVPacked(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cu_seqlens, max_seqlen, scale):
+    def forward(ctx, qkv, cu_seqlens, max_seqlen, scale, dropout_p=0.0):
         if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] != 64:
             raise NotImplementedError("qkv must be bf16 (T,3,H,64)")
         qkv = qkv.contiguous()
@@ -25,28 +33,43 @@ class _VarlenQKVPacked(torch.autograd.Function):
         cu = cu_seqlens.to(torch.int32)
         out = torch.empty(T, H, D, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(H, T, dtype=torch.float32, device=qkv.device)
-        _C.check(_C.lib().cx_attn_varlen_fwd(qkv.data_ptr(), cu.data_ptr(), None, None, out.data_ptr(), lse.data_ptr(),
-                                             B, H, T, int(max_seqlen), scale, _C.cur_stream()), "attn fwd")
+        rng = None
+        if dropout_p:
+            rng = _draw_philox(qkv.device)
+            _C.check(_C.lib().cx_attn_varlen_dropout_fwd(qkv.data_ptr(), cu.data_ptr(), None, None, out.data_ptr(),
+                                                         lse.data_ptr(), B, H, T, int(max_seqlen), scale, float(dropout_p),
+                                                         rng[0], rng[1], 0, _C.cur_stream()), "attn fwd (dropout)")
+        else:
+            _C.check(_C.lib().cx_attn_varlen_fwd(qkv.data_ptr(), cu.data_ptr(), None, None, out.data_ptr(), lse.data_ptr(),
+                                                 B, H, T, int(max_seqlen), scale, _C.cur_stream()), "attn fwd")
         ctx.save_for_backward(qkv, out, lse, cu)
-        ctx.meta = (B, H, T, int(max_seqlen), scale)
+        ctx.meta = (B, H, T, int(max_seqlen), scale, float(dropout_p), rng)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, cu = ctx.saved_tensors
-        B, H, T, mx, scale = ctx.meta
+        B, H, T, mx, scale, p_drop, rng = ctx.meta
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(H, T, dtype=torch.float32, device=qkv.device)
-        _C.check(_C.lib().cx_attn_varlen_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                                             cu.data_ptr(), None, None, delta.data_ptr(), dqkv.data_ptr(), B, H, T, mx,
-                                             scale, _C.cur_stream()), "attn bwd")
-        return dqkv, None, None, None
+        if p_drop:
+            _C.check(_C.lib().cx_attn_varlen_dropout_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                         cu.data_ptr(), None, None, delta.data_ptr(), dqkv.data_ptr(), B, H, T,
+                                                         mx, scale, p_drop, rng[0], rng[1], 0, _C.cur_stream()),
+                     "attn bwd (dropout)")
+        else:
+            _C.check(_C.lib().cx_attn_varlen_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                 cu.data_ptr(), None, None, delta.data_ptr(), dqkv.data_ptr(), B, H, T, mx,
+                                                 scale, _C.cur_stream()), "attn bwd")
+        return dqkv, None, None, None, None
 
 
-def _check(dropout_p, causal, return_attn_probs):
-    if dropout_p:
-        raise NotImplementedError("attention dropout > 0 is not implemented (BASELINE configs use 0)")
+def _check(dropout_p, causal, return_attn_probs, dropout_ok=False):
+    if dropout_p and not dropout_ok:
+        raise NotImplementedError("attention dropout > 0 is built for the qkv-packed self-attention forms only")
+    if dropout_p and not 0.0 < dropout_p < 1.0:
+        raise ValueError("dropout_p must be in [0, 1)")
     if causal:
         raise NotImplementedError("causal attention is out of the encoder hot-path scope")
     if return_attn_probs:
@@ -56,17 +79,18 @@ def _check(dropout_p, causal, return_attn_probs):
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                                      window_size=(-1, -1), alibi_slopes=None, deterministic=False,
                                      return_attn_probs=False):
-    _check(dropout_p, causal, return_attn_probs)
-    return _VarlenQKVPacked.apply(qkv, cu_seqlens, max_seqlen, _scale(softmax_scale, qkv.shape[-1]))
+    _check(dropout_p, causal, return_attn_probs, dropout_ok=True)
+    return _VarlenQKVPacked.apply(qkv, cu_seqlens, max_seqlen, _scale(softmax_scale, qkv.shape[-1]), float(dropout_p))
 
 
 def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                               alibi_slopes=None, deterministic=False, return_attn_probs=False):
     """(B,S,3,H,64) fixed-length form (the ViT path, attention.py:220-226): same kernel, cu_seqlens = arange * S."""
-    _check(dropout_p, causal, return_attn_probs)
+    _check(dropout_p, causal, return_attn_probs, dropout_ok=True)
     B, S = qkv.shape[:2]
     cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=qkv.device)
-    out = _VarlenQKVPacked.apply(qkv.reshape(B * S, *qkv.shape[2:]), cu, S, _scale(softmax_scale, qkv.shape[-1]))
+    out = _VarlenQKVPacked.apply(qkv.reshape(B * S, *qkv.shape[2:]), cu, S, _scale(softmax_scale, qkv.shape[-1]),
+                                 float(dropout_p))
     return out.view(B, S, *out.shape[1:])
 
 

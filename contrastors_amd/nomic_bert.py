@@ -60,10 +60,7 @@ class NomicBertConfig:
     def __post_init__(self):
         if self.prenorm or self.causal or self.use_rms_norm or self.rotary_emb_interleaved:
             raise NotImplementedError("engine covers the post-norm, non-causal, LayerNorm encoder (cfg 1-3)")
-        if self.attn_pdrop:
-            raise NotImplementedError("attention-probability dropout > 0 is not implemented in the fused attention kernels "
-                                      "(every shipped recipe sets attn_pdrop 0.0); resid_pdrop / embd_pdrop are supported")
-        if not (0.0 <= self.resid_pdrop < 1.0 and 0.0 <= self.embd_pdrop < 1.0):
+        if not (0.0 <= self.resid_pdrop < 1.0 and 0.0 <= self.embd_pdrop < 1.0 and 0.0 <= self.attn_pdrop < 1.0):
             raise ValueError("dropout probabilities must be in [0, 1)")
         if self.n_embd != self.n_head * 64:
             raise NotImplementedError("head_dim must be 64")
@@ -524,6 +521,7 @@ class NomicBertEngine(torch.nn.Module):
         e.layers = C.cast(self._layers_arr, C.POINTER(_C.CxLayerWeights))
         e.pool_mode, e.normalize = self.pool_mode, 1
         e.resid_pdrop, e.embd_pdrop = float(getattr(cfg, "resid_pdrop", 0.0)), float(getattr(cfg, "embd_pdrop", 0.0))
+        e.attn_pdrop = float(getattr(cfg, "attn_pdrop", 0.0))
         self._desc = e
 
     # ------------------------------------------------------------------------------------------------ arenas
@@ -547,7 +545,7 @@ class NomicBertEngine(torch.nn.Module):
         (rand_state.py; sc/rand_state.py:6-22) snapshots and restores that state around the GradCache re-forward, so the
         second forward of a chunk regenerates the first one's masks."""
         cfg = self.config
-        active = self.training and (getattr(cfg, "resid_pdrop", 0.0) > 0 or getattr(cfg, "embd_pdrop", 0.0) > 0)
+        active = self.training and any(getattr(cfg, k, 0.0) > 0 for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop"))
         arena.desc.drop_active = int(active)
         if active:
             gen = torch.cuda.default_generators[self.device_.index if self.device_.index is not None else torch.cuda.current_device()]
@@ -558,7 +556,7 @@ class NomicBertEngine(torch.nn.Module):
     @property
     def uses_rng(self) -> bool:
         cfg = self.config
-        return self.training and (getattr(cfg, "resid_pdrop", 0.0) > 0 or getattr(cfg, "embd_pdrop", 0.0) > 0)
+        return self.training and any(getattr(cfg, k, 0.0) > 0 for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop"))
 
     def release_arena(self, arena: _ChunkArena):
         arena.emb_out = None

@@ -181,6 +181,19 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
                        const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
                        uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
 
+/* attention dropout (flash_attn_varlen_qkvpacked_func(dropout_p > 0), attn_pdrop > 0): O = (P * keep / (1 - p)) V with
+ * keep(b, h, q, key) = Philox4x32-10(seed; offset + site, (b * H + h, q, key / 4))[key % 4] >= p * 2^32 -- regenerated by
+ * the backward and by a GradCache re-forward under RandContext, never stored.  Same arguments as cx_attn_varlen_fwd/_bwd
+ * plus (p, seed, offset, site); 0 < p < 1, any max_seqlen < 2^20, B * H < 2^24. */
+int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
+                               uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale,
+                               float p_drop, unsigned long long seed, unsigned long long offset, unsigned int site,
+                               void* stream);
+int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
+                               const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
+                               uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
+                               unsigned long long seed, unsigned long long offset, unsigned int site, void* stream);
+
 /* ---- K3  flash_attn_kvpacked_func / flash_attn_varlen_kvpacked_func (cross-attention; sc/layers/attention.py:313-433,
  *          FlashAttentionPooling: one latent query per sequence over the sequence's keys) ---
  * q (Tq, H, 64), kv (Tk, 2, H, 64) bf16, batch entry b: queries cu_seqlens_q[b] .. [b+1), keys cu_seqlens_k[b] .. [b+1);
@@ -297,6 +310,7 @@ typedef struct CxEncoderDesc {
      * (resid_pdrop, sc/layers/block.py:422-431,453-462) and on the embedding-LayerNorm output (embd_pdrop).  Applied when
      * CxChunkBuffers.drop_active != 0 (training mode). */
     float resid_pdrop, embd_pdrop;
+    float attn_pdrop;   /* dropout on the attention probabilities (attn_pdrop, sc/layers/attention.py:158-182); text trunks */
 } CxEncoderDesc;
 
 /* Per-chunk activation arena (device memory owned by the caller).  save_for_backward = 0 lets every layer reuse

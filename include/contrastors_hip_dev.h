@@ -47,6 +47,9 @@ void cx_attn_set_fwd_s128(int mode);
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
 int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* stream);
 /* MFMA issue-rate probe (scripts/mfma_probe.py): see probe.hip */
+/* keep[b][h][q][key] in {0, 1}: the mask cx_attn_varlen_dropout_fwd/_bwd apply (tests) */
+int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
+                              unsigned long long offset, unsigned int site, void* stream);
 int cx_probe_mfma_rate16(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
                          void* stream);  /* the same loop from v_mfma_f32_16x16x32_bf16 */
 int cx_probe_mfma_rate(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,

@@ -64,8 +64,9 @@ def test_dropout_add_layernorm_kernel_vs_torch_with_the_same_mask(p):
     report("dropout_ln", p=p, keep_rate=rate)
 
 
-def _tower(p_resid, p_embd, n_layer=2):
-    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=1024, n_layer=n_layer, resid_pdrop=p_resid, embd_pdrop=p_embd)
+def _tower(p_resid, p_embd, n_layer=2, attn=0.0):
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=1024, n_layer=n_layer, resid_pdrop=p_resid, embd_pdrop=p_embd,
+                                          attn_pdrop=attn)
     return BiEncoder(BiEncoderConfig(pooling="mean", trunk_config=cfg), device=DEV, seed=2)
 
 
@@ -128,4 +129,86 @@ def test_grad_cache_with_dropout_uses_randcontext():
     l1 = float(grad_cache_loss(tower, q, tower, d, 4, scale))
     predicted = eps * float((direction * gvec).sum())
     report("dropout_gradcache", l0=l0, l1=l1, predicted=predicted, actual=l1 - l0)
+    assert predicted > 0 and abs((l1 - l0) - predicted) < 0.35 * predicted + 2e-3
+
+
+@pytest.mark.parametrize("S,lens", [(128, [128, 77, 128]), (320, [320, 200])])
+def test_attention_dropout_matches_torch_with_the_extracted_mask(S, lens):
+    """attn_pdrop > 0 (flash_attn_varlen_qkvpacked_func(dropout_p > 0), sc/layers/attention.py:158-182): O = (P * keep /
+    (1 - p)) V, dqkv through the same mask; keep(b, h, q, key) read back with the dev library's mask kernel."""
+    import math
+
+    import contrastors_amd.flash_attn_api as fa
+
+    H, D, p = 4, 64, 0.2
+    B = len(lens)
+    g = torch.Generator().manual_seed(12)
+    T = sum(lens)
+    qkv = (torch.randn(T, 3, H, D, generator=g) * 0.8).to(DEV).bfloat16().requires_grad_()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    torch.manual_seed(31)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    out = fa.flash_attn_varlen_qkvpacked_func(qkv, cu, max(lens), p, softmax_scale=1.0 / math.sqrt(D))
+    go = torch.randn(T, H, D, generator=g).to(DEV).bfloat16()
+    out.backward(go)
+
+    keep = torch.empty(B, H, S, S, dtype=torch.uint8, device=DEV)
+    _C.check(_C.dev_lib().cx_attn_dropout_keep_mask(keep.data_ptr(), B, H, S, p, seed, off, 0, _C.cur_stream()))
+    rate = keep[0, :, : lens[0], : lens[0]].float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    x = qkv.detach().float().requires_grad_()
+    outs = []
+    for b, n in enumerate(lens):
+        s0 = int(cu[b])
+        q, k, v = x[s0:s0 + n, 0], x[s0:s0 + n, 1], x[s0:s0 + n, 2]
+        P = torch.softmax(torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(D), dim=-1)
+        outs.append(torch.einsum("hqk,khd->qhd", P * keep[b, :, :n, :n].float() / (1 - p), v))
+    ref = torch.cat(outs)
+    ref.backward(go.float())
+    e_o, e_g = rel_err(out.float(), ref), rel_err(qkv.grad.float(), x.grad)
+    report("attn_dropout", S=S, keep_rate=rate, e_out=e_o, e_dqkv=e_g)
+    assert e_o < 1e-2 and e_g < 2e-2
+    # reproducible from the generator state; p = 0 is the plain kernel
+    torch.manual_seed(31)
+    out2 = fa.flash_attn_varlen_qkvpacked_func(qkv.detach(), cu, max(lens), p, softmax_scale=1.0 / math.sqrt(D))
+    assert torch.equal(out2, out.detach())
+
+
+def test_engine_with_attention_dropout_gradcache_is_reproducible_and_consistent():
+    """attn_pdrop through the native trunk: train != eval, the GradCache step is reproducible from the generator state
+    (pass 2 sees pass 1's masks), and its gradient is the gradient of the loss that was computed (directional check)."""
+    scale = LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=False)).to(DEV)
+    q, d = _batch(16, 32, 5), _batch(16, 32, 6)
+    res = []
+    for _ in range(2):
+        tower = _tower(0.0, 0.0, attn=0.15).train()
+        torch.manual_seed(78)
+        tower.trunk.zero_grad()
+        res.append((float(grad_cache_loss(tower, q, tower, d, 4, scale)), tower.trunk.flat_grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[0][1].abs().max())
+    tower = _tower(0.0, 0.0, attn=0.15).train()
+    with torch.no_grad():
+        e_train = tower(**q)["embedding"].clone()
+        tower.eval()
+        e_eval = tower(**q)["embedding"].clone()
+        tower.train()
+    assert not torch.equal(e_train, e_eval) and rel_err(e_train, e_eval) < 0.5
+    torch.manual_seed(78)
+    tower.trunk.zero_grad()
+    l0 = float(grad_cache_loss(tower, q, tower, d, 4, scale))
+    gvec = tower.trunk.flat_grad.clone()
+    lo, hi = tower.trunk._layout["encoder.layers.0.attn.Wqkv.weight"][0], tower.trunk.n_decay
+    direction = torch.zeros_like(gvec)
+    direction[lo:hi] = gvec[lo:hi]
+    eps = 2e-2 / float(direction.norm())
+    with torch.no_grad():
+        tower.trunk.flat_param.add_(direction, alpha=eps)
+    tower.trunk.sync_shadows()
+    torch.manual_seed(78)
+    tower.trunk.zero_grad()
+    l1 = float(grad_cache_loss(tower, q, tower, d, 4, scale))
+    predicted = eps * float((direction * gvec).sum())
+    report("attn_dropout_gradcache", l0=l0, l1=l1, predicted=predicted, actual=l1 - l0)
     assert predicted > 0 and abs((l1 - l0) - predicted) < 0.35 * predicted + 2e-3
