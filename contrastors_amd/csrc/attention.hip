@@ -12,6 +12,9 @@
 // read with the same permutation: rows {4hi..4hi+3, 8+4hi..8+4hi+3} (+16h) of a TRANSPOSED LDS tile
 // (two ds_read_b64).  Transposed tiles are built while staging (pairs of rows packed into 32-bit LDS writes).
 #include "cx_common.h"
+#ifndef CX_ATTN_PF
+#define CX_ATTN_PF 0   // L2 prefetch of the next problem in the fused S <= 128 backward: measured 595 us with, 567 us without at T = 131072
+#endif
 #include "../../include/contrastors_hip.h"
 
 namespace {
@@ -1673,7 +1676,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             dl_s[2 * kp + 1] = dpart[1];
         }
         if (tid < 128) lse_s[tid] = lse_v;
+#if CX_ATTN_PF
         if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
+#endif
         __syncthreads();
         const int row = wave * 32 + l31;  // this lane's key (dK, dV) and later its query (dQ)
         const bool row_ok = row < len;
