@@ -104,6 +104,15 @@ _SIGS = {
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_dropout_fwd": (i32, [vp] * 6 + [i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
     "cx_attn_varlen_dropout_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
+    "cx_ipc_alloc": (i32, [C.POINTER(vp), i64, i32]),
+    "cx_ipc_free": (i32, [vp]),
+    "cx_ipc_export": (i32, [vp, vp]),
+    "cx_ipc_open": (i32, [vp, C.POINTER(vp)]),
+    "cx_ipc_close": (i32, [vp]),
+    "cx_xgmi_push": (i32, [vp, vp, i64, i64, i32, vp]),
+    "cx_xgmi_scatter": (i32, [vp, vp, i32, i64, i32, vp]),
+    "cx_xgmi_signal_wait": (i32, [vp, vp, i32, i32, u32, i64, vp, vp]),
+    "cx_sum_slots_f32": (i32, [vp, vp, i64, i32, vp]),
     "cx_attn_varlen_kvpacked_fwd": (i32, [vp] * 6 + [i32, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_kvpacked_bwd": (i32, [vp] * 10 + [i32, i32, i32, i32, i32, f32, vp]),
     "cx_rotary_qkv_inplace": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -423,6 +423,27 @@ int cx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* e
                        void* stream);
 
 
+/* ---- one-shot exchange over xGMI (sc/distributed.py:5-12 gather_with_grad): receive buffers shared between the
+ * per-GPU processes by HIP IPC, every rank stores its shard straight into every peer's buffer (all 7 links at once), one
+ * flag exchange.  Host protocol: contrastors_amd/distributed.py::OneShotExchange.
+ * cx_ipc_alloc: device memory that can be exported (uncached != 0: hipDeviceMallocUncached, for the flags);
+ * cx_ipc_export / cx_ipc_open: 64-byte hipIpcMemHandle_t in / mapped pointer out.
+ * cx_xgmi_push: peer_bufs_dev[p] + dst_offset_bytes <- src[0 .. bytes) for p = 0 .. world-1 (device array of pointers).
+ * cx_xgmi_scatter: peer_bufs_dev[p] + slot * slice_bytes <- src + p * slice_bytes (the reduce-scatter's send side).
+ * cx_xgmi_signal_wait: peer_flags_dev[p][rank] = epoch for all p, then wait until my_flags[p] >= epoch for all p
+ *   (system-scope release / acquire); gives up after max_spins polls and stores 1 + p in *err_flag (uncached memory).
+ * cx_sum_slots_f32: out[i] = sum_w slots[w * n + i], n % 4 == 0.  All sizes / offsets multiples of 16 bytes. */
+int cx_ipc_alloc(void** ptr, long bytes, int uncached);
+int cx_ipc_free(void* ptr);
+int cx_ipc_export(void* ptr, unsigned char* handle64);
+int cx_ipc_open(const unsigned char* handle64, void** ptr);
+int cx_ipc_close(void* ptr);
+int cx_xgmi_push(const void* src, void* const* peer_bufs_dev, long dst_offset_bytes, long bytes, int world, void* stream);
+int cx_xgmi_scatter(const void* src, void* const* peer_bufs_dev, int slot, long slice_bytes, int world, void* stream);
+int cx_xgmi_signal_wait(unsigned int* const* peer_flags_dev, unsigned int* my_flags, int rank, int world, unsigned int epoch,
+                        long max_spins, unsigned int* err_flag, void* stream);
+int cx_sum_slots_f32(const float* slots, float* out, long n, int world, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

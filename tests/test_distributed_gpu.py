@@ -59,9 +59,10 @@ def _step(rank, world, dev, G=16, S=32, chunk=4):
     return float(loss), tower.trunk.flat_grad.detach().float().cpu().numpy()
 
 
-def _worker(rank, world, port, out_dir, backend="gloo"):
+def _worker(rank, world, port, out_dir, backend="gloo", exchange="rccl"):
     sys.path.insert(0, str(ROOT))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["CX_EXCHANGE"] = exchange
     local = rank if backend == "nccl" else 0   # RCCL: one rank per GPU; gloo: the ranks share the test box's one GPU
     torch.cuda.set_device(local)
     if backend == "nccl":
@@ -70,9 +71,83 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     else:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     loss, grad = _step(rank, world, torch.device("cuda", local))
-    np.savez(f"{out_dir}/w{rank}.npz", loss=loss, grad=grad)
+    used = 0
+    if exchange == "oneshot":
+        from contrastors_amd import distributed as cxd
+
+        used = int(cxd._ONESHOT is not None and cxd._ONESHOT.epoch >= 2)   # one all-gather + one reduce-scatter at least
+        if cxd._ONESHOT is not None:
+            cxd._ONESHOT.check()
+    np.savez(f"{out_dir}/w{rank}.npz", loss=loss, grad=grad, oneshot_used=used)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _oneshot_worker(rank, world, port, out_dir):
+    """OneShotExchange on its own: repeated all-gathers / reduce-scatters of the metric's shard size against the values
+    they must produce, a rank that runs ahead (no host sync between collectives), and the capacity check."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from contrastors_amd.distributed import OneShotExchange
+
+    dev = torch.device("cuda", 0)
+    n, d = 2048, 768
+    ex = OneShotExchange(world * n * d * 4, device=dev)
+    ok = True
+    for it in range(6):
+        mine = torch.full((n, d), float(10 * it + rank + 1), device=dev) + torch.arange(d, device=dev)[None] * 1e-3
+        got = ex.all_gather(mine)
+        want = torch.cat([torch.full((n, d), float(10 * it + r + 1), device=dev) + torch.arange(d, device=dev)[None] * 1e-3
+                          for r in range(world)])
+        ok &= bool(torch.equal(got, want))
+        g = torch.stack([torch.full((n, d), float(100 * it + 10 * rank + p), device=dev) for p in range(world)]).view(world * n, d)
+        rs = ex.reduce_scatter(g)
+        want_rs = torch.full((n, d), float(sum(100 * it + 10 * r + rank for r in range(world))), device=dev)
+        ok &= bool(torch.equal(rs, want_rs))
+        if rank == 0 and it == 2:
+            torch.cuda._sleep(200_000_000)   # rank 0 falls behind on the device: rank 1 must wait at the flags, not race ahead
+    ex.check()
+    too_big = False
+    try:
+        ex.all_gather(torch.zeros(2 * n + 8, d, device=dev))
+    except ValueError:
+        too_big = True
+    torch.cuda.synchronize()
+    np.savez(f"{out_dir}/x{rank}.npz", ok=int(ok), too_big=int(too_big), epochs=ex.epoch)
+    ex.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_shot_exchange_two_ranks_sharing_the_gpu(tmp_path):
+    """csrc/xgmi.hip + OneShotExchange: HIP-IPC receive buffers, peer stores, system-scope flags.  Two processes on the
+    test box's one GPU exercise the whole protocol (the peer buffer is then reached through the same device, not through
+    an xGMI link -- the semantics are the same, the bandwidth is for bench.py on a multi-GPU node to say)."""
+    port = 29600 + (os.getpid() % 90)
+    mp.spawn(_oneshot_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        x = np.load(tmp_path / f"x{r}.npz")
+        assert int(x["ok"]) == 1 and int(x["too_big"]) == 1 and int(x["epochs"]) == 12
+
+
+def test_two_rank_gradcache_step_with_the_one_shot_exchange(tmp_path):
+    """gather_with_grad on the one-shot path (CX_EXCHANGE=oneshot) inside the real GradCache step: the same numbers as the
+    process group's collectives."""
+    port = 29500 + (os.getpid() % 90)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "gloo", "oneshot"), nprocs=2, join=True)
+    a = [np.load(tmp_path / f"w{r}.npz") for r in range(2)]
+    assert int(a[0]["oneshot_used"]) == 1 and int(a[1]["oneshot_used"]) == 1
+    port += 1
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    mp.spawn(_worker, args=(2, port, str(ref_dir), "gloo", "rccl"), nprocs=2, join=True)
+    b = [np.load(ref_dir / f"w{r}.npz") for r in range(2)]
+    for r in range(2):
+        assert float(a[r]["loss"]) == float(b[r]["loss"])
+        denom = np.abs(b[r]["grad"]).max()
+        assert np.abs(a[r]["grad"] - b[r]["grad"]).max() <= 1e-5 * denom   # (fp32 atomics of the LayerNorm reductions)
 
 
 def test_two_rank_gradcache_step_matches_single_process(tmp_path):
@@ -106,6 +181,9 @@ def test_bench_two_ranks_prints_one_json_line():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["pairs_per_gpu"] == 32 and j["value"] > 0
     assert j["config"]["parallelism"] == "dp2" and np.isfinite(j["config"]["loss_last_step"])
+    # the one-shot exchange record: set up, verified against the process group's all-gather and timed inside bench.py
+    one = j["xgmi_allgather"]["oneshot"]
+    assert isinstance(one, dict) and one["seconds"] > 0, one
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box skips this)")
