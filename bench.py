@@ -335,7 +335,10 @@ def main():
                 if float(same.item()) != 1.0:
                     raise RuntimeError("one-shot all-gather disagrees with the process group's all-gather")
                 rec["oneshot"] = record(time_gather(ex.all_gather), "one-shot: every rank stores its shard into every peer's IPC "
-                                                                   "buffer + one system-scope flag exchange (CX_EXCHANGE=oneshot)")
+                                                                   "buffer + one system-scope flag exchange + copy-out of the "
+                                                                   "receive buffer (what CX_EXCHANGE=oneshot runs)")
+                rec["oneshot_in_place"] = record(time_gather(lambda t: ex.all_gather(t, copy=False)),
+                                                 "the same exchange, result read in the receive buffer (no copy-out)")
                 ex.check()
                 ex.close()
             except Exception as e:  # noqa: BLE001 -- the record must never take the benchmark down

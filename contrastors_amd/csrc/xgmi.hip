@@ -8,9 +8,10 @@
 // memory and are written / polled with system-scope atomics.  The reduce-scatter of the backward is the same step in the
 // other direction followed by a local sum of the W received slices.
 //
-// Host protocol (contrastors_amd/distributed.py::OneShotExchange): two data buffers alternate between consecutive
-// collectives, so a rank that runs ahead writes buffer (k+1) % 2 while a slower peer still reads buffer k % 2, and it
-// cannot reach collective k + 2 before that peer has signalled k + 1 -- which the peer enqueues behind its readers of k.
+// Host protocol (contrastors_amd/distributed.py::OneShotExchange): receive buffers are used round-robin (N_BUF >= 2), so a
+// rank that runs ahead writes buffer (k+1) % N while a slower peer still reads buffer k % N, and it cannot reach collective
+// k + 2 before that peer has signalled k + 1 -- which the peer enqueues behind its copy-out of k (results are copied out of
+// the receive buffer by default; read in place they stay valid for N - 1 further collectives).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -71,10 +72,17 @@ extern "C" {
 
 int cx_ipc_alloc(void** ptr, long bytes, int uncached) {
     if (!ptr || bytes <= 0) return CX_ERR_ARG;
+    if (uncached == 2)  // host memory the device can write and the host can poll without a stream synchronisation (error flag)
+        return ok(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocMapped | hipHostMallocCoherent));
     if (uncached) return ok(hipExtMallocWithFlags(ptr, (size_t)bytes, hipDeviceMallocUncached));
     return ok(hipMalloc(ptr, (size_t)bytes));
 }
-int cx_ipc_free(void* ptr) { return ptr ? ok(hipFree(ptr)) : CX_OK; }
+int cx_ipc_free(void* ptr) {
+    if (!ptr) return CX_OK;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) == hipSuccess && a.type == hipMemoryTypeHost) return ok(hipHostFree(ptr));
+    return ok(hipFree(ptr));
+}
 int cx_ipc_export(void* ptr, unsigned char* handle64) {
     if (!ptr || !handle64) return CX_ERR_ARG;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");

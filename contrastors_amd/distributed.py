@@ -29,13 +29,14 @@ class _RawDeviceF32:
 
 class OneShotExchange:
     """The loss path's exchange step in ONE hop over the fully connected xGMI fabric (csrc/xgmi.hip): each
-    rank owns two receive buffers of `capacity_bytes` + a flag array, exported to the other per-GPU processes with HIP IPC;
+    rank owns N_BUF receive buffers of `capacity_bytes` + a flag array, exported to the other per-GPU processes with HIP IPC;
     all_gather = every rank stores its shard into every peer's buffer + one flag exchange; reduce_scatter = the transpose
     + a local fixed-order sum.  fp32 only (the embeddings and their gradients).  Stream-ordered: no host synchronisation
-    except the error-flag read at the start of the NEXT collective (a peer that never signals makes the bounded wait give
-    up; that is reported there as a RuntimeError instead of a hang)."""
+    at all: the error flag of the bounded wait lives in mapped host memory and is polled at the start of every collective
+    (a peer that never signals makes the wait give up; that surfaces as a RuntimeError at a later call instead of a hang)."""
 
     MAX_SPINS = 4_000_000   # ~8 s of polling before a wait gives up
+    N_BUF = 4               # receive buffers, used round-robin: a result read in place stays valid for 3 more collectives
 
     def __init__(self, capacity_bytes: int, group=None, device: Optional[torch.device] = None):
         from . import _C
@@ -51,22 +52,22 @@ class OneShotExchange:
         self._own: List[int] = []
         self._opened: List[int] = []
         with torch.cuda.device(self.device):
-            own = [self._alloc(self.cap, 0), self._alloc(self.cap, 0), self._alloc(256, 1), self._alloc(256, 1)]
-            self._data, self._flags, self._err = own[:2], own[2], own[3]
-            for ptr, nfl in ((own[2], 64), (own[3], 64)):
-                torch.as_tensor(_RawDeviceF32(ptr, nfl), device=self.device).zero_()
+            nb = self.N_BUF
+            own = [self._alloc(self.cap, 0) for _ in range(nb)] + [self._alloc(256, 1), self._alloc(256, 2)]
+            self._data, self._flags, self._err = own[:nb], own[nb], own[nb + 1]
+            torch.as_tensor(_RawDeviceF32(own[nb], 64), device=self.device).zero_()
+            C.memset(self._err, 0, 256)   # mapped host memory: the wait kernel stores here, check() reads it with no sync
             torch.cuda.synchronize(self.device)
-            handles = [self._export(p) for p in own[:3]]
+            handles = [self._export(p) for p in own[: nb + 1]]
             everyone: List[Optional[list]] = [None] * self.world
             dist.all_gather_object(everyone, handles, group=group)
-            peers = [[], [], []]   # data0, data1, flags: one pointer per rank
+            peers = [[] for _ in range(nb + 1)]   # data buffers, flags: one pointer per rank
             for r, hs in enumerate(everyone):
-                for k in range(3):
+                for k in range(nb + 1):
                     peers[k].append(own[k] if r == self.rank else self._open(hs[k]))
             as_dev = lambda ptrs: torch.tensor(ptrs, dtype=torch.int64, device=self.device)  # noqa: E731
-            self._peer_data = [as_dev(peers[0]), as_dev(peers[1])]
-            self._peer_flags = as_dev(peers[2])
-            self._err_view = torch.as_tensor(_RawDeviceF32(self._err, 64), device=self.device).view(torch.int32)
+            self._peer_data = [as_dev(peers[k]) for k in range(nb)]
+            self._peer_flags = as_dev(peers[nb])
             self._views = [torch.as_tensor(_RawDeviceF32(p, self.cap // 4), device=self.device) for p in self._data]
         dist.barrier(group=group)   # nobody stores into a buffer its owner has not finished setting up
 
@@ -101,8 +102,9 @@ class OneShotExchange:
         self._own = []
 
     def check(self):
-        """Raise if a bounded wait of an earlier collective gave up (reads 4 bytes: synchronises the stream)."""
-        e = int(self._err_view[0].item())
+        """Raise if a bounded wait of a collective that has already executed gave up (a plain read of mapped host memory:
+        no synchronisation; a failure of work still queued is seen by a later call)."""
+        e = C.c_uint32.from_address(self._err).value
         if e:
             raise RuntimeError(f"one-shot xGMI exchange: rank {self.rank} never received the signal of rank {e - 1}")
 
@@ -112,7 +114,7 @@ class OneShotExchange:
         if self.epoch:
             self.check()
         self.epoch += 1
-        return self.epoch & 1
+        return self.epoch % self.N_BUF
 
     def _signal_wait(self):
         self._check(self.lib.cx_xgmi_signal_wait(self._peer_flags.data_ptr(), self._flags, self.rank, self.world,
@@ -120,8 +122,9 @@ class OneShotExchange:
                     "cx_xgmi_signal_wait")
 
     # ---- collectives
-    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
-        """(n, ...) fp32 -> (world * n, ...) in rank order."""
+    def all_gather(self, t: torch.Tensor, copy: bool = True) -> torch.Tensor:
+        """(n, ...) fp32 -> (world * n, ...) in rank order.  copy=False returns a view of the receive buffer: valid until
+        N_BUF - 1 further collectives have been issued on this exchange (peers write the buffer again after that)."""
         t = t.contiguous()
         assert t.dtype == torch.float32 and t.is_cuda
         nbytes = t.numel() * 4
@@ -131,8 +134,10 @@ class OneShotExchange:
         self._check(self.lib.cx_xgmi_push(t.data_ptr(), self._peer_data[b].data_ptr(), self.rank * nbytes, nbytes, self.world,
                                           self._stream()), "cx_xgmi_push")
         self._signal_wait()
-        # out of the receive buffer: it is written again two collectives from now, autograd may hold the result longer
-        return self._views[b][: self.world * t.numel()].clone().view((self.world * t.shape[0],) + tuple(t.shape[1:]))
+        out = self._views[b][: self.world * t.numel()]
+        if copy:  # out of the receive buffer: autograd may hold the result longer than the buffer's validity window
+            out = out.clone()
+        return out.view((self.world * t.shape[0],) + tuple(t.shape[1:]))
 
     def reduce_scatter(self, g: torch.Tensor) -> torch.Tensor:
         """(world * n, ...) fp32 -> (n, ...): sum over ranks of their slice for this rank, in rank order (deterministic)."""

@@ -426,7 +426,8 @@ int cx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* e
 /* ---- one-shot exchange over xGMI (sc/distributed.py:5-12 gather_with_grad): receive buffers shared between the
  * per-GPU processes by HIP IPC, every rank stores its shard straight into every peer's buffer (all 7 links at once), one
  * flag exchange.  Host protocol: contrastors_amd/distributed.py::OneShotExchange.
- * cx_ipc_alloc: device memory that can be exported (uncached != 0: hipDeviceMallocUncached, for the flags);
+ * cx_ipc_alloc: device memory that can be exported (uncached == 1: hipDeviceMallocUncached, for the flags; == 2: mapped
+ *   coherent HOST memory, for the error flag the host polls without synchronising);
  * cx_ipc_export / cx_ipc_open: 64-byte hipIpcMemHandle_t in / mapped pointer out.
  * cx_xgmi_push: peer_bufs_dev[p] + dst_offset_bytes <- src[0 .. bytes) for p = 0 .. world-1 (device array of pointers).
  * cx_xgmi_scatter: peer_bufs_dev[p] + slot * slice_bytes <- src + p * slice_bytes (the reduce-scatter's send side).
