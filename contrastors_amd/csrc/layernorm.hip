@@ -481,7 +481,7 @@ CX_DEVICE void store4_any(void* base, bool f32, size_t off, const float (&v)[4])
     else store4_bf16(reinterpret_cast<bf16_t*>(base) + off, v);
 }
 
-enum { LNF_X0_F32 = 1, LNF_RES_F32 = 2, LNF_OUT_F32 = 4, LNF_Z_F32 = 8 };
+enum { LNF_X0_F32 = 1, LNF_RES_F32 = 2, LNF_OUT_F32 = 4, LNF_Z_F32 = 8, LNF_RMS = 16 };  // RMS: no mean subtraction (K8)
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_mixed_kernel(const void* __restrict__ x0, const void* __restrict__ res,
@@ -504,13 +504,23 @@ __global__ __launch_bounds__(256) void ln_fwd_mixed_kernel(const void* __restric
             }
         }
         float mean, rstd;
-        row_stats<NCH>(z, D, eps, mean, rstd);
+        if (flags & LNF_RMS) {  // RMSNorm (flash_attn.ops.rms_norm): z * rsqrt(mean(z^2) + eps) * gamma (+ beta if given)
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v += z[i][e] * z[i][e];
+            mean = 0.f;
+            rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+        } else {
+            row_stats<NCH>(z, D, eps, mean, rstd);
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
-            float g[4], b[4], o[4];
+            float g[4], b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
             load4_f32(gamma + (i * 64 + lane) * 4, g);
-            load4_f32(beta + (i * 64 + lane) * 4, b);
+            if (beta) load4_f32(beta + (i * 64 + lane) * 4, b);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (z[i][e] - mean) * rstd * g[e] + b[e];
             store4_any(out, flags & LNF_OUT_F32, off, o);
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(256) void ln_bwd_mixed_kernel(const void* __restric
             }
         }
         s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
+        s2 = (flags & LNF_RMS) ? 0.f : wave_sum(s2) / (float)D;   // RMSNorm has no mean to differentiate through (mean_i = 0)
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const size_t off = (size_t)row * D + (i * 64 + lane) * 4;
@@ -816,7 +826,7 @@ int cx_dropout_scale(uint16_t* x, long n, float p, unsigned long long seed, unsi
 int cx_layernorm_fwd_mixed(const void* x0, const void* residual, const float* gamma, const float* beta, void* out, void* z_out,
                            float* mean, float* rstd, int rows, int d, float eps, int flags, void* stream) {
     if (rows <= 0) return CX_OK;
-    if (!x0 || !gamma || !beta || !out || !mean || !rstd) return CX_ERR_ARG;
+    if (!x0 || !gamma || (!beta && !(flags & LNF_RMS)) || !out || !mean || !rstd) return CX_ERR_ARG;
     CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_fwd_mixed_kernel<NCH>), dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x0,
                                          residual, gamma, beta, out, z_out, mean, rstd, rows, eps, flags));
     return done();

@@ -31,7 +31,7 @@ class _DropoutAddLN(torch.autograd.Function):
     operand keeps its dtype down to the kernel (cx_layernorm_fwd_mixed / _bwd_mixed): fp32 or bf16 (fp16 is cast to bf16)."""
 
     @staticmethod
-    def forward(ctx, x0, residual, weight, bias, eps, prenorm, residual_in_fp32):
+    def forward(ctx, x0, residual, weight, bias, eps, prenorm, residual_in_fp32, rms=False):
         shape = x0.shape
         d = shape[-1]
         f32 = torch.float32
@@ -45,13 +45,18 @@ class _DropoutAddLN(torch.autograd.Function):
         z = torch.empty(rows, d, dtype=zdt, device=x.device)
         mean = torch.empty(rows, dtype=f32, device=x.device)
         rstd = torch.empty(rows, dtype=f32, device=x.device)
-        w, b = weight.float().contiguous(), bias.float().contiguous()
-        flags = (1 if xdt == f32 else 0) | (2 if rdt == f32 else 0) | (4 if xdt == f32 else 0) | (8 if zdt == f32 else 0)
-        _C.check(_C.lib().cx_layernorm_fwd_mixed(x.data_ptr(), _C.ptr(r), w.data_ptr(), b.data_ptr(), out.data_ptr(),
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        if b is None and not rms:
+            raise ValueError("LayerNorm needs a bias")
+        flags = (1 if xdt == f32 else 0) | (2 if rdt == f32 else 0) | (4 if xdt == f32 else 0) | (8 if zdt == f32 else 0) \
+            | (16 if rms else 0)
+        _C.check(_C.lib().cx_layernorm_fwd_mixed(x.data_ptr(), _C.ptr(r), w.data_ptr(), _C.ptr(b), out.data_ptr(),
                                                  z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps), flags,
                                                  _C.cur_stream()), "layernorm fwd")
         ctx.save_for_backward(z, w, mean, rstd)
-        ctx.meta = (shape, x0.dtype, None if residual is None else residual.dtype, prenorm, weight.dtype, flags, xdt, rdt, zdt)
+        ctx.meta = (shape, x0.dtype, None if residual is None else residual.dtype, prenorm, weight.dtype, flags, xdt, rdt, zdt,
+                    bias is not None)
         out = out.view(shape).to(x0.dtype)
         if prenorm:
             return out, z.view(shape)
@@ -60,7 +65,7 @@ class _DropoutAddLN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dz_in=None):
         z, w, mean, rstd = ctx.saved_tensors
-        shape, in_dtype, res_dtype, prenorm, wdtype, flags, xdt, rdt, zdt = ctx.meta
+        shape, in_dtype, res_dtype, prenorm, wdtype, flags, xdt, rdt, zdt, has_bias = ctx.meta
         d = shape[-1]
         rows = z.shape[0]
         do = _as(dout.reshape(-1, d), xdt)
@@ -68,17 +73,17 @@ class _DropoutAddLN(torch.autograd.Function):
         dx = torch.empty(rows, d, dtype=xdt, device=z.device)
         dr = None if rdt is None else torch.empty(rows, d, dtype=rdt, device=z.device)
         dg = torch.zeros(d, dtype=torch.float32, device=z.device)
-        db = torch.zeros(d, dtype=torch.float32, device=z.device)
+        db = torch.zeros(d, dtype=torch.float32, device=z.device) if has_bias else None
         _C.check(_C.lib().cx_layernorm_bwd_mixed(do.data_ptr(), z.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                 _C.ptr(dze), dx.data_ptr(), _C.ptr(dr), dg.data_ptr(), db.data_ptr(), rows, d,
+                                                 _C.ptr(dze), dx.data_ptr(), _C.ptr(dr), dg.data_ptr(), _C.ptr(db), rows, d,
                                                  flags, _C.cur_stream()), "layernorm bwd")
         dx0 = dx.view(shape).to(in_dtype)
         dres = None if res_dtype is None else dr.view(shape).to(res_dtype)
-        return dx0, dres, dg.to(wdtype), db.to(wdtype), None, None, None
+        return dx0, dres, dg.to(wdtype), (db.to(wdtype) if has_bias else None), None, None, None, None
 
 
 def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None,
-                           prenorm=False, residual_in_fp32=False, return_dropout_mask=False):
+                           prenorm=False, residual_in_fp32=False, return_dropout_mask=False, _rms=False):
     if rowscale is not None or layerscale is not None:
         raise NotImplementedError("rowscale / layerscale")
     keep = None
@@ -90,7 +95,7 @@ def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowsc
         # cx_dropout_add_layernorm_fwd; this op-by-op surface takes the three extra elementwise passes.)
         keep = _philox_keep_mask(x0.numel(), float(dropout_p), x0.device).view(x0.shape)
         x0 = x0 * keep.to(x0.dtype) * (1.0 / (1.0 - float(dropout_p)))
-    out = _DropoutAddLN.apply(x0, residual, weight, bias, epsilon, prenorm, bool(residual_in_fp32))
+    out = _DropoutAddLN.apply(x0, residual, weight, bias, epsilon, prenorm, bool(residual_in_fp32), bool(_rms))
     if return_dropout_mask:
         mask = keep if keep is not None else torch.ones_like(x0, dtype=torch.bool)
         return (*out, mask) if isinstance(out, tuple) else (out, mask)

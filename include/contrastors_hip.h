@@ -100,7 +100,8 @@ int cx_dropout_scale(uint16_t* x, long n, float p, unsigned long long seed, unsi
 /* The same two ops with a dtype per operand, for the flash_attn.ops.layer_norm python surface (`residual_in_fp32`, fp32
  * inputs on the reference's BERT path: embedding LayerNorm fp32 in / fp32 out, layer-0 residual fp32).
  * flags: bit0 x0 is fp32, bit1 residual is fp32, bit2 out is fp32, bit3 z (the saved sum / prenorm residual output) is
- * fp32; clear = bf16 (statistics always use the unrounded fp32 sum).  bwd writes
+ * fp32; clear = bf16 (statistics always use the unrounded fp32 sum); bit4: RMSNorm (flash_attn.ops.rms_norm, K8): out =
+ * z * rsqrt(mean(z^2) + eps) * gamma (+ beta, which may then be NULL), `mean` receives 0.  bwd writes
  * dz to dx0 (x0's dtype) and, if not NULL, to dres (the residual's dtype); dout has out's dtype, dz_extra has z's. */
 int cx_layernorm_fwd_mixed(const void* x0, const void* residual, const float* gamma, const float* beta, void* out,
                            void* z_out, float* mean, float* rstd, int rows, int d, float eps, int flags, void* stream);

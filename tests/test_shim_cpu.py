@@ -114,7 +114,8 @@ class _CpuKernels:
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
-    def ln(x0, residual, weight, bias, eps, prenorm, residual_in_fp32):
+    def ln(x0, residual, weight, bias, eps, prenorm, residual_in_fp32, rms=False):
+        assert not rms
         z = x0.float() + (residual.float() if residual is not None else 0)
         out = torch.nn.functional.layer_norm(z, (z.shape[-1],), weight.float(), bias.float(), eps).to(x0.dtype)
         zdt = torch.float32 if (residual_in_fp32 or (residual is not None and residual.dtype == torch.float32)) else x0.dtype

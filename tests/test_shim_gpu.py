@@ -216,3 +216,41 @@ def test_cross_entropy_k12(dtype, N, V, inplace):
     assert max_err(per_row, want) < (5e-2 if dtype == torch.bfloat16 else 1e-4)
     with pytest.raises(NotImplementedError):
         CrossEntropyLoss(label_smoothing=0.1)
+
+
+@pytest.mark.parametrize("prenorm,with_res", [(False, False), (False, True), (True, True)])
+def test_rms_norm_k8(prenorm, with_res):
+    """flash_attn.ops.rms_norm (K8): rms_norm / dropout_add_rms_norm / RMSNorm vs torch in fp32."""
+    from contrastors_amd.flash_attn_api.ops.rms_norm import RMSNorm, dropout_add_rms_norm, rms_norm
+
+    d, eps = 768, 1e-6
+    x0 = _r(3, 41, d, seed=21).to(torch.bfloat16).requires_grad_()
+    res = _r(3, 41, d, seed=22).to(torch.bfloat16).requires_grad_() if with_res else None
+    w = (1 + _r(d, seed=23, std=0.1)).requires_grad_()
+    out = dropout_add_rms_norm(x0, res, w, None, 0.0, eps, prenorm=prenorm)
+    xr = x0.detach().float().requires_grad_()
+    rr = res.detach().float().requires_grad_() if with_res else None
+    wr = w.detach().clone().requires_grad_()
+    z = xr + rr if with_res else xr
+    ref = z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + eps) * wr
+    g = _r(3, 41, d, seed=24).to(torch.bfloat16)
+    if prenorm:
+        o, zz = out
+        g2 = _r(3, 41, d, seed=25).to(torch.bfloat16)
+        torch.autograd.backward([o, zz], [g, g2])
+        torch.autograd.backward([ref, z], [g.float(), g2.float()])
+        assert rel_err(zz.float(), z) < 4e-3
+    else:
+        o = out
+        o.backward(g)
+        ref.backward(g.float())
+    assert rel_err(o.float(), ref) < 4e-3
+    assert rel_err(x0.grad.float(), xr.grad) < 1e-2 and rel_err(w.grad, wr.grad) < 1e-2
+    if with_res:
+        assert rel_err(res.grad.float(), rr.grad) < 1e-2
+    m = RMSNorm(d, eps=eps).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(w.detach())
+    y = m(x0.detach())
+    assert m.bias is None and rel_err(y.float(), (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps) * wr).detach()) < 4e-3
+    assert torch.equal(y, rms_norm(x0.detach(), w.detach(), eps))
