@@ -300,6 +300,7 @@ def effective_chunk(tower, inputs, chunk_size: int) -> int:
     bytes_per_token = _arena_bytes_per_token(tower)
     free, _ = torch.cuda.mem_get_info(ids.device)
     free += torch.cuda.memory_reserved(ids.device) - torch.cuda.memory_allocated(ids.device)  # the allocator's own cache
+    free += sum(a.nbytes() for a in getattr(tower.trunk, "_arena_free", []))                  # arenas the engine re-uses
     tokens = int(min(262144, max(S, free / 3 / bytes_per_token)))
     want = max(chunk_size, tokens // max(S, 1))
     want = max(chunk_size, want // chunk_size * chunk_size)
