@@ -1019,16 +1019,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         w_m0 = lds_wave + (3 + lw_slot) * XS6;
     };
 
-    // L2 prefetch: both operands stream from HBM here (activations, not weights) and a DMA issued one or two K-tiles
-    // ahead does not cover the HBM latency under load.  One dword load per 128-B line of a K-tile (256 lines per operand
-    // = one load instruction per wave per operand) pulls it into L2 two iterations before its DMA is issued; the loaded
-    // value is never used (pf_sink keeps the destination register reserved).
-    constexpr int PF_X = 4, PF_W = 3;  // X's DMA runs two K-tiles ahead, W's one
-    const int pf_row = (wave * 64 + lane) >> 2, pf_line = (wave * 64 + lane) & 3;
-    const bf16_t* xpf = p.X + ((size_t)(kt_begin + PF_X) * BK6 + pf_row) * p.ldx + m0 + pf_line * 64;
-    const bf16_t* wpf = p.W + ((size_t)(kt_begin + PF_W) * BK6 + pf_row) * p.ldw + n0 + pf_line * 64;
-    uint32_t pf_sink = 0;
-
+    // (An L2 prefetch of the K-tiles 3-4 ahead -- one dword touch per 128-B line -- paid in round 1; with the two-instruction
+    // DMA issue of round 2 it costs 5-16 %: removed.  profiles/r2_vendor_blas_calibration.txt has the before / after.)
     // Fragment addressing (tn_frag6 with everything lane-dependent hoisted): with one wave per SIMD the instruction
     // stream is issue-bound, so each fragment must cost one VALU add + two transposing reads, not a dozen integer ops.
     // byte offset inside a tile = tt*512 + chunk*16 + (f&4)*2 with tt = 16*ks + 4*half + tl, (tt&3) == (tl&3):
@@ -1123,25 +1115,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         CX_TN_KSTEP(mma1, F1, F0, xs_slot, ws_slot, 2, 1, 4);
         w_advance(t + 2);
         CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 3, 2, 0);
-        // L2 prefetches: the newest VMEM operations of this iteration (allowed to stay outstanding below)
-        const bool pf_x = t + PF_X < nk, pf_w = t + PF_W < nk;
-        if (pf_x) {
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(xpf) : "memory");
-            xpf += xstep;
-        }
-        if (pf_w) {
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(wpf) : "memory");
-            wpf += wstep;
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the current slots are complete ...
-        // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions of k-step 2 and the prefetches
-        if (pf_x) {              // pf_x implies pf_w
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if (pf_w) {
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
+        // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions of k-step 2
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // (after the last K-tile these reads fetch garbage from a landed slot; F0 is not used again)
         CX_TN_KSTEP(mma1, F1, F0, nxs_slot, nws_slot, 0, 2, 4);
@@ -1159,7 +1135,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // ---- epilogue: fp32 partial slab of this K slice, straight from the AGPRs.  block (a, b): rows m0 + wm*128 + b*32
     // + l31, columns n0 + wn*128 + a*32 + 8q + 4hi (+0..3)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // MFMA -> VMEM read of the accumulators
-    if (pf_sink == 0x7fc12345u && p.dbg == -1) reinterpret_cast<volatile uint32_t*>(p.Out)[0] = pf_sink;  // keeps pf_sink live
     float* part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
