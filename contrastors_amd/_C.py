@@ -102,6 +102,7 @@ _SIGS = {
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
+    "cx_attn_varlen_bwd_prerotated": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_dropout_fwd": (i32, [vp] * 6 + [i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
     "cx_attn_varlen_dropout_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
     "cx_ipc_alloc": (i32, [C.POINTER(vp), i64, i32]),

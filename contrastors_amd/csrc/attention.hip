@@ -120,8 +120,10 @@ CX_DEVICE bf16x8_t pack_frag(const float (&v)[16], int half) {
 struct AttnParams {
     const bf16_t* qkv;     // (T,3,H,64)
     const int32_t* cu;
-    const float* cosv;
+    const float* cosv;     // rotary tables: inverse rotation of dq / dk at the stores (and the loads of the S <= 128 kernels)
     const float* sinv;
+    const float* lcos;     // general kernels: rotation of q / k rows at the LOADS; NULL when qkv was rotated in place
+    const float* lsin;     //   beforehand (long sequences: a K row would otherwise be re-rotated once per 128-query block)
     bf16_t* out;           // (T,H,64)            [fwd out / bwd: forward output]
     float* lse;            // (H,T)
     const bf16_t* dout;    // (T,H,64)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         int tq = q0 + r;
         tq = tq < len ? tq : len - 1;
         uint4 lo, hi4;
-        load_row_pair(qbase + (size_t)(t0 + tq) * tok_stride, cp, p.cosv, p.sinv, tq, lo, hi4);
+        load_row_pair(qbase + (size_t)(t0 + tq) * tok_stride, cp, p.lcos, p.lsin, tq, lo, hi4);
         *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = lo;
         *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = hi4;
     }
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             const int r = tid >> 2, cp = tid & 3;
             int tk = kv0 + r;
             tk = tk < lenk ? tk : lenk - 1;
-            rotate_loaded(k_lo, k_hi, cp, p.cosv, p.sinv, tk);
+            rotate_loaded(k_lo, k_hi, cp, p.lcos, p.lsin, tk);
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = k_lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = k_hi;
             write_transposed_pair(Vt, tid >> 3, (tid & 7) * 8, v_r0, v_r1);
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
             int tq = q0 + r;
             tq = tq < len ? tq : len - 1;
             uint4 lo, hi4;
-            load_row_pair(qbase + (size_t)(t0 + tq) * tok_stride, cp, p.cosv, p.sinv, tq, lo, hi4);
+            load_row_pair(qbase + (size_t)(t0 + tq) * tok_stride, cp, p.lcos, p.lsin, tq, lo, hi4);
             *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = lo;
             *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = hi4;
             load_row_pair(dobase + (size_t)(t0 + tq) * o_stride, cp, nullptr, nullptr, 0, lo, hi4);
@@ -843,8 +845,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
             k0i = k0i < lenk ? k0i : lenk - 1;
             k1i = k1i < lenk ? k1i : lenk - 1;
             uint4 a_lo, a_hi, b_lo, b_hi;
-            load_row_pair(kbase + (size_t)(t0k + k0i) * kv_stride, cp, p.cosv, p.sinv, k0i, a_lo, a_hi);
-            load_row_pair(kbase + (size_t)(t0k + k1i) * kv_stride, cp, p.cosv, p.sinv, k1i, b_lo, b_hi);
+            load_row_pair(kbase + (size_t)(t0k + k0i) * kv_stride, cp, p.lcos, p.lsin, k0i, a_lo, a_hi);
+            load_row_pair(kbase + (size_t)(t0k + k1i) * kv_stride, cp, p.lcos, p.lsin, k1i, b_lo, b_hi);
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp)) = a_lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp + 4)) = a_hi;
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp)) = b_lo;
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             int tk = k0 + r;
             tk = tk < lenk ? tk : lenk - 1;
             uint4 lo, hi4;
-            load_row_pair(kbase + (size_t)(t0k + tk) * kv_stride, cp, p.cosv, p.sinv, tk, lo, hi4);
+            load_row_pair(kbase + (size_t)(t0k + tk) * kv_stride, cp, p.lcos, p.lsin, tk, lo, hi4);
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
             load_row_pair(vbase + (size_t)(t0k + tk) * kv_stride, cp, nullptr, nullptr, 0, lo, hi4);
@@ -974,8 +976,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             r0i = r0i < len ? r0i : len - 1;
             r1i = r1i < len ? r1i : len - 1;
             uint4 a_lo, a_hi, b_lo, b_hi;
-            load_row_pair(qbase + (size_t)(t0 + r0i) * tok_stride, cp, p.cosv, p.sinv, r0i, a_lo, a_hi);
-            load_row_pair(qbase + (size_t)(t0 + r1i) * tok_stride, cp, p.cosv, p.sinv, r1i, b_lo, b_hi);
+            load_row_pair(qbase + (size_t)(t0 + r0i) * tok_stride, cp, p.lcos, p.lsin, r0i, a_lo, a_hi);
+            load_row_pair(qbase + (size_t)(t0 + r1i) * tok_stride, cp, p.lcos, p.lsin, r1i, b_lo, b_hi);
             *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp)) = a_lo;
             *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp + 4)) = a_hi;
             *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp)) = b_lo;
@@ -1962,7 +1964,7 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     if (!qkv || !cu_seqlens || !out || !lse) return CX_ERR_ARG;
     if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
     AttnParams p = {};
-    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = rot_cos; p.lsin = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
 #ifndef CX_PRODUCT
     if (max_seqlen <= 128 && g_fwd_s128 == 1) {
@@ -1992,7 +1994,7 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     if (!dout || !qkv || !out || !lse || !cu_seqlens || !delta || !dqkv) return CX_ERR_ARG;
     if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
     AttnParams p = {};
-    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin;
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = rot_cos; p.lsin = rot_sin;
     p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
@@ -2036,6 +2038,30 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     return done();
 }
 
+// Long sequences with rotary: the engine rotates q and k in place once (cx_rotary_qkv_inplace), runs the forward with no
+// tables at all, and calls this backward: the streaming kernels read the saved (rotated) q / k as they are -- they used to
+// re-rotate every K row once per 128-query block and every Q row once per 128-key block, 18-23 % of their time at S = 2048
+// -- and only the gradients' inverse rotation at the stores uses the tables.  Any length (always the general kernels).
+int cx_attn_varlen_bwd_prerotated(const uint16_t* dout, const uint16_t* qkv_rotated, const uint16_t* out, const float* lse,
+                                  const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
+                                  uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream) {
+    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
+    if (!dout || !qkv_rotated || !out || !lse || !cu_seqlens || !delta || !dqkv || !rot_cos || !rot_sin) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = qkv_rotated; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = nullptr; p.lsin = nullptr;
+    p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
+    p.dout = dout; p.delta = delta; p.dqkv = dqkv;
+    p.H = H; p.T = T; p.scale = softmax_scale;
+    long nthreads = (long)T * H * 8;
+    int g = (int)((nthreads + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    dim3 grid((max_seqlen + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return done();
+}
+
 // attention dropout > 0: the general kernels at every length (the S <= 128 single-pass kernels have no mask code: attn_pdrop is
 // 0 in every shipped recipe, and the hot path keeps its registers).
 int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
@@ -2046,7 +2072,7 @@ int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, c
     if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
     if (!(p_drop > 0.f) || p_drop >= 1.f || max_seqlen >= (1 << 20) || (long)B * H >= (1L << 24)) return CX_ERR_ARG;
     AttnParams p = {};
-    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.out = out; p.lse = lse;
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = rot_cos; p.lsin = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
     p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
     dim3 grid((max_seqlen + 127) / 128, H, B);
@@ -2063,7 +2089,7 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
     if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
     if (!(p_drop > 0.f) || p_drop >= 1.f || max_seqlen >= (1 << 20) || (long)B * H >= (1L << 24)) return CX_ERR_ARG;
     AttnParams p = {};
-    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin;
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = rot_cos; p.lsin = rot_sin;
     p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;

@@ -182,6 +182,13 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
                        const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
                        uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
 
+/* backward for a qkv whose q and k were rotated IN PLACE beforehand (cx_rotary_qkv_inplace; the forward is then
+ * cx_attn_varlen_fwd with NULL tables): nothing is rotated at the loads, dq / dk leave through the inverse rotation.  The
+ * engine takes this route for max_seqlen > 128 (the streaming kernels would re-rotate every row once per 128-row block). */
+int cx_attn_varlen_bwd_prerotated(const uint16_t* dout, const uint16_t* qkv_rotated, const uint16_t* out, const float* lse,
+                                  const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, float* delta,
+                                  uint16_t* dqkv, int B, int H, int T, int max_seqlen, float softmax_scale, void* stream);
+
 /* attention dropout (flash_attn_varlen_qkvpacked_func(dropout_p > 0), attn_pdrop > 0): O = (P * keep / (1 - p)) V with
  * keep(b, h, q, key) = Philox4x32-10(seed; offset + site, (b * H + h, q, key / 4))[key % 4] >= p * 2^32 -- regenerated by
  * the backward and by a GradCache re-forward under RandContext, never stored.  Same arguments as cx_attn_varlen_fwd/_bwd

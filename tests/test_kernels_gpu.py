@@ -352,6 +352,54 @@ def _attn_ref(qkv, lens, cos, sin, scale):
     return torch.cat(outs, 0)
 
 
+@pytest.mark.parametrize("lens", [[300, 129, 64], [2048, 1531], [128, 5]])
+def test_attention_prerotated_path_equals_rotate_on_load(lens):
+    """Long sequences: q and k rotated in place once (cx_rotary_qkv_inplace), forward without tables, backward through
+    cx_attn_varlen_bwd_prerotated -- against the kernels that rotate at every load (same rounding points: the rotated rows
+    are bf16 in both), and against the fp32 reference."""
+    H, D = 3, 64
+    T, B, mx = sum(lens), len(lens), max(lens)
+    qkv = bf(_randn(T, 3, H, D, seed=42))
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(max(512, mx)).float(), inv)
+    cos, sin = torch.cos(fr).to(DEV).contiguous(), torch.sin(fr).to(DEV).contiguous()
+    scale = 1 / math.sqrt(D)
+    do = bf(_randn(T, H, D, seed=43))
+
+    def run(prerot):
+        x = qkv.clone()
+        out = torch.empty(T, H, D, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(H, T, device=DEV)
+        dqkv = torch.full_like(qkv, float("nan"))
+        delta = torch.empty(H, T, device=DEV)
+        if prerot:
+            _C.check(L().cx_rotary_qkv_inplace(x.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, H, T, mx, 1, S()))
+            _C.check(L().cx_attn_varlen_fwd(x.data_ptr(), cu.data_ptr(), None, None, out.data_ptr(), lse.data_ptr(), B, H, T, mx,
+                                            scale, S()))
+            _C.check(L().cx_attn_varlen_bwd_prerotated(do.data_ptr(), x.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(),
+                                                       cos.data_ptr(), sin.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, H, T,
+                                                       mx, scale, S()))
+        else:
+            _C.check(L().cx_attn_varlen_fwd(x.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), out.data_ptr(),
+                                            lse.data_ptr(), B, H, T, mx, scale, S()))
+            _C.check(L().cx_attn_varlen_bwd(do.data_ptr(), x.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(),
+                                            cos.data_ptr(), sin.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, H, T, mx, scale, S()))
+        return out, dqkv
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert torch.isfinite(g1.float()).all()
+    qr = qkv.float().requires_grad_()
+    ref = _attn_ref(qr, lens, cos, sin, scale)
+    ref.backward(do.float())
+    e_o, e_g = rel_err(o1.float(), ref), rel_err(g1.float(), qr.grad)
+    report("attention_prerotated", lens=str(lens), e_out=e_o, e_dqkv=e_g, vs_onload_out=rel_err(o1.float(), o0.float()),
+           vs_onload_grad=rel_err(g1.float(), g0.float()))
+    assert e_o < 8e-3 and e_g < 1.5e-2
+    assert rel_err(o1.float(), o0.float()) < 4e-3 and rel_err(g1.float(), g0.float()) < 8e-3
+
+
 @pytest.mark.parametrize("rotary", [True, False])
 @pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8, [2048, 1531]])
 def test_attention_fwd_bwd(rotary, lens):
