@@ -59,10 +59,11 @@ def _step(rank, world, dev, G=16, S=32, chunk=4):
     return float(loss), tower.trunk.flat_grad.detach().float().cpu().numpy()
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", exchange="rccl"):
+def _worker(rank, world, port, out_dir, backend="gloo", exchange="rccl", resident="0"):
     sys.path.insert(0, str(ROOT))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["CX_EXCHANGE"] = exchange
+    os.environ["CX_GRADCACHE_RESIDENT"] = resident
     local = rank if backend == "nccl" else 0   # RCCL: one rank per GPU; gloo: the ranks share the test box's one GPU
     torch.cuda.set_device(local)
     if backend == "nccl":
@@ -213,3 +214,18 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["launch"].startswith("self") and j["value"] > 0
+
+
+def test_two_rank_resident_gradcache_equals_two_pass(tmp_path):
+    """CX_GRADCACHE_RESIDENT=1 on two ranks: pass 1 keeps the activations, the loss gathers across ranks in between, pass 2
+    only back-propagates -- the same loss and (to fp32-atomics noise) the same reduced gradient as the two-pass schedule."""
+    port = 29300 + (os.getpid() % 90)
+    res_dir, ref_dir = tmp_path / "res", tmp_path / "ref"
+    res_dir.mkdir()
+    ref_dir.mkdir()
+    mp.spawn(_worker, args=(2, port, str(res_dir), "gloo", "rccl", "1"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port + 1, str(ref_dir), "gloo", "rccl", "0"), nprocs=2, join=True)
+    for r in range(2):
+        a, b = np.load(res_dir / f"w{r}.npz"), np.load(ref_dir / f"w{r}.npz")
+        assert float(a["loss"]) == float(b["loss"])
+        assert np.abs(a["grad"] - b["grad"]).max() <= 1e-5 * np.abs(b["grad"]).max()
