@@ -12,10 +12,11 @@
 // read one k-step ahead, the 16 DMA instructions of the next K-tiles are spread between MFMAs, and the only
 // synchronisation per K-tile is one raw s_barrier across the 4 waves.
 //
-// LDS map (160 KiB), DMA accounting and the epilogue staging follow the 8-wave persistent kernel: three 32 KiB X slots
-// (X runs two K-tiles ahead), two 32 KiB W slots (one ahead), issue order per iteration [W of t+1][X of t+2] so that
-// "operands of t+1 landed" == s_waitcnt vmcnt(8); at a tile end vmcnt(0) so the epilogue's global stores never mix into
-// the count; epilogue staged through the two slots consumed last, 32 output rows per wave per pass.
+// LDS map (160 KiB): three 32 KiB X slots (X runs two K-tiles ahead), two 32 KiB W slots (one ahead), issue order per
+// K-tile [W of t+1 in k-steps 0,1][X of t+2 in k-steps 2,3]; "operands of t+1 landed" == s_waitcnt vmcnt(4) in front of the
+// one barrier of the K-tile (everything but the 4 X instructions just issued; the epilogue's stores are older and retire in
+// order with them on gfx9's single vmcnt).  Epilogue staged through the two slots consumed last, 32 output rows per wave
+// per pass.  Round 2: an LDS-DMA is two instructions between two MFMAs (see the cursors), tiles are named (tm << 8) | tn.
 #include "cx_common.h"
 #include "../../include/contrastors_hip.h"
 #include "gemm_params.h"
