@@ -117,6 +117,21 @@ CX_DEVICE bf16x8_t pack_frag(const float (&v)[16], int half) {
     return x.v;
 }
 
+// A-fragment of the TRANSPOSE of a row-major [t][64 f] tile (tile64_off layout) through the transposing LDS read: lane gets
+// T[i = f0 + (lane & 31)][k = t0 + 4*hi + {0..3}, t0 + 8 + 4*hi + {0..3}] -- what read_transposed_frag returns from a
+// separately staged transposed copy, without staging one (round 2: the streaming kernels kept writing V^T / K^T / Q^T /
+// dO^T tiles element by element; the tile they already stage row-major serves both orientations).
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_t64;
+CX_DEVICE bf16x8_t tile64_tr_frag(const char* tile, int f0, int t0, int lane) {
+    const int g = lane >> 4, pp = lane & 15;
+    const int t = t0 + 4 * (g >> 1) + (pp >> 2);
+    const int f = f0 + 16 * (g & 1) + 4 * (pp & 3);
+    union { bf16x4_t h[2]; bf16x8_t v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t64)(tile + tile64_off(t, f >> 3) + (f & 4) * 2));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t64)(tile + tile64_off(t + 8, f >> 3) + (f & 4) * 2));
+    return u.v;
+}
+
 struct AttnParams {
     const bf16_t* qkv;     // (T,3,H,64)
     const int32_t* cu;
@@ -189,10 +204,10 @@ CX_DEVICE AttnView attn_view(const AttnParams& p, int h, int b) {
 // ---------------------------------------------------------------------------------------------------- forward
 template <bool X, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[16384 + 8192 + 64 * TSTRIDE];
+    __shared__ __attribute__((aligned(16))) char smem[16384 + 8192 + 8192];
     char* Qs = smem;
     char* Ks = smem + 16384;
-    char* Vt = smem + 16384 + 8192;
+    char* Vs = smem + 16384 + 8192;   // V chunk row-major [64 keys][64 d]; its transpose is read with tile64_tr_frag
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     const AttnView w = attn_view<X>(p, h, b);
@@ -255,11 +270,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             rotate_loaded(k_lo, k_hi, cp, p.lcos, p.lsin, tk);
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = k_lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = k_hi;
-            write_transposed_pair(Vt, tid >> 3, (tid & 7) * 8, v_r0, v_r1);
+            *reinterpret_cast<uint4*>(Vs + tile64_off(2 * (tid >> 3), tid & 7)) = v_r0;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(2 * (tid >> 3) + 1, tid & 7)) = v_r1;
         }
         __syncthreads();
         if (kv0 + 64 < lenk) prefetch(kv0 + 64);
 
+        // raw scores; the softmax scale is folded into the exponent (p = exp2(fma(s, c, -m))), and the key mask exists only
+        // on a partial last chunk (a wave-uniform branch): the loop is VALU-bound -- 16 exponentials per 32x32 block
+        // against 8 MFMAs -- so the 32 multiplies and 64 compare / select pairs per chunk this removes are 1/3 of it
         float s[2][16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -270,17 +289,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             for (int ks = 0; ks < 4; ++ks)
                 a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + kb * 32 + acc_row(r, hi);
-                s[kb][r] = key < lenk ? a[r] * sc2 : -INFINITY;
-            }
+            for (int r = 0; r < 16; ++r) s[kb][r] = a[r];
+        }
+        if (kv0 + 64 > lenk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kb * 32 + acc_row(r, hi) >= lenk) s[kb][r] = -INFINITY;
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc2;   // (sc2 > 0: the maximum commutes with the scale)
         const float m_new = fmaxf(m_run, mx);
         const float alpha = fast_exp2(m_run - m_new);
         float psum = 0.f;
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[kb][r] = fast_exp2(s[kb][r] - m_new);
+                s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], sc2, -m_new));
                 psum += s[kb][r];
             }
         l_run = l_run * alpha + psum;
@@ -317,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
                     acc_o[db] =
-                        mfma_bf16_32x32x16(read_transposed_frag(Vt, db * 32 + l31, kb * 2 + half, hi), pf, acc_o[db]);
+                        mfma_bf16_32x32x16(tile64_tr_frag(Vs, db * 32, kb * 32 + half * 16, lane), pf, acc_o[db]);
             }
         __syncthreads();
     }
@@ -781,7 +804,7 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
 // ---------------------------------------------------------------------------------------------------- dQ
 template <bool X, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
-    // Qs/dOs are only needed to build the loop-invariant register fragments; the K/V/Kt tiles alias them.
+    // Qs/dOs are only needed to build the loop-invariant register fragments; the K / V tiles alias them.
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -825,7 +848,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 
     char* Ks = smem;
     char* Vs = smem + 8192;
-    char* Kt = smem + 16384;
     const int q = q0 + wave * 32 + l31;
     const int qc = q < len ? q : len - 1;
     const float lse2 = p.lse[(size_t)h * p.T + t0 + qc] * LOG2E;
@@ -839,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
 
     for (int kv0 = 0; kv0 < lenk; kv0 += 64) {
-        if (wave < 2) {  // K: rotated, row-major + transposed.  item = (key pair, chunk pair)
+        if (wave < 2) {  // K: rotated, row-major (its transpose for dQ comes from tile64_tr_frag).  item = (key pair, chunk pair)
             const int kp = tid >> 2, cp = tid & 3;
             int k0i = kv0 + 2 * kp, k1i = k0i + 1;
             k0i = k0i < lenk ? k0i : lenk - 1;
@@ -851,8 +873,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp + 4)) = a_hi;
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp)) = b_lo;
             *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp + 4)) = b_hi;
-            write_transposed_pair(Kt, kp, cp * 8, a_lo, b_lo);
-            write_transposed_pair(Kt, kp, 32 + cp * 8, a_hi, b_hi);
         } else {  // V row-major: 64 rows x 8 chunks over 128 threads
             const int t2 = tid - 128;
 #pragma unroll
@@ -896,8 +916,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
                 const bf16x8_t dsf = pack_frag(ds, half);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    acc_dq[db] = mfma_bf16_32x32x16(read_transposed_frag(Kt, db * 32 + l31, kb * 2 + half, hi), dsf,
-                                                    acc_dq[db]);
+                    acc_dq[db] = mfma_bf16_32x32x16(tile64_tr_frag(Ks, db * 32, kb * 32 + half * 16, lane), dsf, acc_dq[db]);
             }
         }
         __syncthreads();
@@ -911,8 +930,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------------- dK, dV
 template <bool X, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
-    // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | Qt | dOt | lse[64] | delta[64]
-    __shared__ __attribute__((aligned(16))) char smem[16384 + 2 * 64 * TSTRIDE + 512];
+    // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | lse[64] | delta[64]
+    __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     const AttnView w = attn_view<X>(p, h, b);
@@ -955,9 +974,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 
     char* Qs = smem;
     char* dOs = smem + 8192;
-    char* Qt = smem + 16384;
-    char* dOt = Qt + 64 * TSTRIDE;
-    float* lse_s = reinterpret_cast<float*>(dOt + 64 * TSTRIDE);
+    float* lse_s = reinterpret_cast<float*>(smem + 16384);   // (the transposes of Q and dO come from tile64_tr_frag)
     float* dl_s = lse_s + 64;
 
     const int key = k0 + wave * 32 + l31;
@@ -970,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
 
     for (int q0 = 0; q0 < len; q0 += 64) {
-        if (wave < 2) {  // Q rotated: row-major + transposed; item = (row pair, chunk pair)
+        if (wave < 2) {  // Q rotated, row-major; item = (row pair, chunk pair)
             const int rp = tid >> 2, cp = tid & 3;
             int r0i = q0 + 2 * rp, r1i = r0i + 1;
             r0i = r0i < len ? r0i : len - 1;
@@ -982,9 +999,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp + 4)) = a_hi;
             *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp)) = b_lo;
             *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
-            write_transposed_pair(Qt, rp, cp * 8, a_lo, b_lo);
-            write_transposed_pair(Qt, rp, 32 + cp * 8, a_hi, b_hi);
-        } else {  // dO: row-major + transposed
+        } else {  // dO: row-major
             const int t2 = tid - 128;
             const int rp = t2 >> 2, cp = t2 & 3;
             int r0i = q0 + 2 * rp, r1i = r0i + 1;
@@ -997,8 +1012,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp + 4)) = a_hi;
             *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp)) = b_lo;
             *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
-            write_transposed_pair(dOt, rp, cp * 8, a_lo, b_lo);
-            write_transposed_pair(dOt, rp, 32 + cp * 8, a_hi, b_hi);
         }
         if (tid < 64) {
             int r = q0 + tid;
@@ -1045,10 +1058,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
                 const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    acc_dv[db] = mfma_bf16_32x32x16(read_transposed_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf,
-                                                    acc_dv[db]);
-                    acc_dk[db] = mfma_bf16_32x32x16(read_transposed_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf,
-                                                    acc_dk[db]);
+                    acc_dv[db] = mfma_bf16_32x32x16(tile64_tr_frag(dOs, db * 32, qb * 32 + half * 16, lane), pf, acc_dv[db]);
+                    acc_dk[db] = mfma_bf16_32x32x16(tile64_tr_frag(Qs, db * 32, qb * 32 + half * 16, lane), dsf, acc_dk[db]);
                 }
             }
         }
