@@ -803,7 +803,7 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
 
 // ---------------------------------------------------------------------------------------------------- dQ
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     // Qs/dOs are only needed to build the loop-invariant register fragments; the K / V tiles alias them.
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -905,11 +905,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
                     for (int e = 0; e < 4; ++e) a_dp[4 * qd + e] *= k4[e];
                 }
             }
+            if (kv0 + 64 <= lenk) {  // full chunk (wave-uniform): no key mask -- 16 compare / select pairs per block less
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + kb * 32 + acc_row(r, hi);
-                const float pr = key < lenk ? fast_exp2(a_s[r] * sc2 - lse2) : 0.f;
-                ds[r] = pr * (a_dp[r] - dl);
+                for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(a_s[r], sc2, -lse2)) * (a_dp[r] - dl);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + acc_row(r, hi);
+                    const float pr = key < lenk ? fast_exp2(__builtin_fmaf(a_s[r], sc2, -lse2)) : 0.f;
+                    ds[r] = pr * (a_dp[r] - dl);
+                }
             }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(AttnParams p) {
     // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | lse[64] | delta[64]
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -979,6 +984,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 
     const int key = k0 + wave * 32 + l31;
     const bool key_ok = key < lenk;
+    const bool keys_full = k0 + 128 <= lenk;
     const float sc2 = p.scale * LOG2E;
     f32x16_t acc_dk[2], acc_dv[2];
 #pragma unroll
@@ -1042,7 +1048,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
-                    const float pv = key_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
+                    // (keys_full: every key of this workgroup's 128 exists -- wave-uniform, no per-element select)
+                    const float pe = fast_exp2(__builtin_fmaf(a_s[r], sc2, -ll[e]));
+                    const float pv = (keys_full || key_ok) ? pe : 0.f;
                     if constexpr (DROP) {  // this lane: ONE key, four consecutive queries -> one mask word per element
                         const float kp = attn_keep1(p, (uint32_t)(b * p.H + h), q0 + row + e, key);
                         pr[r] = pv * kp;                          // dV = (P * keep / (1 - p))^T dO
