@@ -182,7 +182,7 @@ CX_DEVICE void flush_param_grads(float (&dg)[NCH][4], float (&db)[NCH][4], float
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
                                                      const bf16_t* __restrict__ z, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i,
