@@ -1618,6 +1618,18 @@ CX_DEVICE bf16x8_t sw_linear_frag(const char* tile, int row, int k0, int hi) {
 }
 
 constexpr int FUSED2_LDS = 16384 * 3 + 32768;  // 80 KiB
+// CX_ATTN_TRACE (variant builds of the dev library only, scripts/attn_trace.py): wave 0 of every workgroup stamps s_memtime
+// at the phase boundaries of its first 16 problems into p.delta (unused by this kernel otherwise); vmcnt / lgkmcnt are
+// drained at the stamps so that a phase owns its own latency.
+#ifdef CX_ATTN_TRACE
+#define CX_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        if (tid == 0 && it < 16) tr[((size_t)blockIdx.x * 16 + it) * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CX_STAMP(i) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams p, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1649,10 +1661,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         }
     };
 
+#ifdef CX_ATTN_TRACE
+    long long* tr = reinterpret_cast<long long*>(p.delta);
+    int it = -1;
+#endif
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int b = u / p.H, h = u - b * p.H;
         const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
         if (len <= 0) continue;  // (uniform per workgroup)
+#ifdef CX_ATTN_TRACE
+        ++it;
+#endif
+        CX_STAMP(0);
         int ra = 2 * kp, rb = ra + 1;
         ra = ra < len ? ra : len - 1;
         rb = rb < len ? rb : len - 1;
@@ -1671,6 +1691,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
             lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
         }
+        CX_STAMP(1);  // loads landed
         // ---- K, V row-major (for this wave's key fragments), then everything that depends on dO / O / Q ----
         if (p.cosv) rotate_pair(k, cs);
         stage_rows(R3, kp, cp, k);
@@ -1700,7 +1721,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
 #if CX_ATTN_PF
         if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
 #endif
+        CX_STAMP(2);  // staged
         __syncthreads();
+        CX_STAMP(3);  // barrier
         const int row = wave * 32 + l31;  // this lane's key (dK, dV) and later its query (dQ)
         const bool row_ok = row < len;
         bf16x8_t kf[4], vf[4];
@@ -1710,6 +1733,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             vf[ks] = lds_read_frag(R3 + 16384, tile64_off(row, ks * 2 + hi));
         }
         __syncthreads();  // R3 becomes the dS tile
+        CX_STAMP(4);  // fragments + barrier
 
         const float sc2 = p.scale * LOG2E;
         f32x16_t acc_dk[2], acc_dv[2];
@@ -1756,7 +1780,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 }
             }
         }
+        CX_STAMP(5);  // main loop
         __syncthreads();  // the dS tile is complete; lse / delta, Q^T and dO^T are dead: R2 becomes Kt
+        CX_STAMP(6);  // barrier
         {   // dK, dV of this wave's 32 keys leave as full rows through the wave's slices of the dead Q^T / dO^T tiles
             bf16_t* k0 = p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)(p.H + h) * DH;
             const int pos = row_ok ? row : len - 1;
@@ -1765,8 +1791,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             store_unrotated_rows(dOt + wave * 4096, k0 + (size_t)p.H * DH, tok_stride, len - wave * 32, acc_dv, 1.f,
                                  nullptr, nullptr, 0, hi, lane);
         }
+        CX_STAMP(7);  // dK, dV stored
         stage_transposed_sw(R2, kp, cp, k);
+        CX_STAMP(8);  // Kt staged
         __syncthreads();
+        CX_STAMP(9);  // barrier
 
         // ---- dQ^T[d][q] = sum_k K^T[d][k] dS[k][q] for this wave's 32 queries ----
         f32x16_t acc_dq[2];
@@ -1781,9 +1810,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             for (int db = 0; db < 2; ++db)
                 acc_dq[db] = mfma_bf16_32x32x16(sw_linear_frag(R2, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
         }
+        CX_STAMP(10);  // dQ products
         store_unrotated_rows(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
                              len - wave * 32, acc_dq, p.scale, p.cosv, p.sinv, row_ok ? row : len - 1, hi, lane);
+        CX_STAMP(11);  // dQ stored
         __syncthreads();  // LDS is restaged by the next problem
+        CX_STAMP(12);  // barrier
     }
     if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
 }

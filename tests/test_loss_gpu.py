@@ -95,18 +95,21 @@ def test_grad_cache_loss_equals_full_batch_oracle(gold):
     grads = tower.trunk.reference_grad_dict()
     e_loss, e_loss_bf = abs(loss.item() - ref), abs(ref_bf - ref)
     worst = worst_bf = 0.0
+    table = []
     for n, gh in grads.items():
         r = sd32[n].grad
         if r is None:
             continue
         eh, eb = rel_err(gh, r), rel_err(sd_bf[n].grad, r)
+        table.append((eh / (eb + 1e-4), n, eh, eb))
         worst, worst_bf = max(worst, eh), max(worst_bf, eb)
         # the reference's own rule (tests/test_flash_bert.py:77-82): err <= 3 x err(bf16 eager), + a floor: the engine's
         # residual stream is bf16 (flash-attn's residual_in_fp32=False path) while autocast eager keeps LayerNorm in fp32,
         # which shows on LayerNorm bias gradients summed over the 2 x 8 short sequences of this fixture (3.7 % measured)
         assert eh <= 3 * eb + 3e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    table.sort(reverse=True)
     report("grad_cache", loss_hip=loss.item(), loss_ref=ref, loss_bf16_eager=ref_bf, worst_rel_grad=worst,
-           worst_rel_grad_bf16_eager=worst_bf)
+           worst_rel_grad_bf16_eager=worst_bf, worst_ratios="; ".join(f"{n} {eh:.4f}/{eb:.4f}" for _, n, eh, eb in table[:6]))
     assert e_loss <= 3 * e_loss_bf + 2e-3, "loss through bf16 encoders at logit scale 20"
 
 
