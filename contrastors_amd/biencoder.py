@@ -213,7 +213,7 @@ class DualEncoder(torch.nn.Module):
             raise AssertionError("Precomputed text model must be frozen")  # modeling_dual_encoder.py:16-18
         self.text, self.vision, self.logit_scale = text, vision, logit_scale
         self.precomputed_text = precomputed_text
-        self.use_fp8 = use_fp8  # None: the process default (loss.set_similarity_fp8); cfg 5 sets `use_fp8: true`
+        self.use_fp8 = bool(use_fp8)  # cfg 5 sets `use_fp8: true` (TrainArgs.use_fp8, passed in by ImageTextTrainer)
 
     def encode_text(self, text, normalize=True):  # modeling_dual_encoder.py:26-29
         return self.text(**text, normalize=normalize)["embedding"]

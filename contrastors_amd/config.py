@@ -7,7 +7,7 @@ are kept: Matryoshka + GradCache is rejected (config.py:70-77) and eval_strategy
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional, Union
 
 import yaml
 from pydantic import BaseModel, ConfigDict, model_validator
@@ -50,9 +50,24 @@ class TrainArgs(BaseModel):
     # the reference YAMLs carry this key (contrastive_pretrain.yaml:24) without a TrainArgs field or any code behind it;
     # here it selects the fp8 matrix-core similarity GEMM of the fused InfoNCE (BASELINE configs[4])
     use_fp8: Optional[bool] = False
+    # MI355X scheduling of the GradCache step (contrastors_amd.loss.GradCachePolicy; not reference keys).  The environment
+    # variables CX_GRADCACHE_CHUNK / CX_GRADCACHE_RESIDENT / CX_EXCHANGE override these when set.
+    gradcache_chunk: Union[int, str, None] = "auto"       # auto: chunk_size is a lower bound | exact | n
+    gradcache_resident: Union[bool, str, None] = "auto"   # auto: keep pass 1's activations when they fit | true | false
+    exchange: Optional[str] = "auto"                       # embedding exchange: auto (validated + timed at start-up) | rccl | oneshot
 
     @model_validator(mode="after")
     def _checks(self):
+        from .loss import _parse_chunk, _parse_resident   # (validate here, not at the first training step)
+
+        _parse_chunk(self.gradcache_chunk, "train_args.gradcache_chunk")
+        _parse_resident(self.gradcache_resident, "train_args.gradcache_resident")
+        if self.exchange not in (None, "auto", "rccl", "oneshot"):
+            raise ValueError(f"train_args.exchange must be auto, rccl or oneshot, got {self.exchange!r}")
+        if self.use_fp8 and self.matryoshka_dims is not None:
+            bad = [d for d in self.matryoshka_dims if d not in (256, 512, 768, 1024)]
+            if bad:
+                raise ValueError(f"use_fp8 covers similarity widths 256 / 512 / 768 / 1024; matryoshka_dims has {bad}")
         if self.eval_strategy is not None and self.eval_strategy not in ("steps", "epochs"):
             raise ValueError(f"Eval strategy {self.eval_strategy} not found in eval strategy registry")
         if self.eval_strategy == "steps" and self.eval_steps is None:

@@ -12,6 +12,9 @@
 // read with the same permutation: rows {4hi..4hi+3, 8+4hi..8+4hi+3} (+16h) of a TRANSPOSED LDS tile
 // (two ds_read_b64).  Transposed tiles are built while staging (pairs of rows packed into 32-bit LDS writes).
 #include "cx_common.h"
+#ifndef CX_ATTN_ROT_AHEAD
+#define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
+#endif
 #ifndef CX_ATTN_PF
 #define CX_ATTN_PF 0   // L2 prefetch of the next problem in the fused S <= 128 backward: measured 595 us with, 567 us without at T = 131072
 #endif
@@ -764,6 +767,16 @@ CX_DEVICE void store_unrotated(bf16_t* row, const f32x16_t (&acc)[2], float scal
 CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, int rows_valid, const f32x16_t (&acc)[2],
                                     float scale, const float* cosv, const float* sinv, int pos, int hi, int lane) {
     const int l31 = lane & 31;
+#if CX_ATTN_ROT_AHEAD
+    // the table rows are fetched ONE column group ahead of their use (8 more registers): the four global round trips of
+    // the first version were serialised, each behind whatever stores the wave had just issued (one in-order vmcnt) --
+    // phase timers put the dK / dV store phase of the fused S <= 128 backward at 10.9 k of its 44.5 k cycles per problem
+    float4 cn = make_float4(1.f, 1.f, 1.f, 1.f), sn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cosv) {
+        cn = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + 4 * hi);
+        sn = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + 4 * hi);
+    }
+#endif
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
         const int d = 8 * qd + 4 * hi;
@@ -774,8 +787,16 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
             hh[e] = acc[1][4 * qd + e] * scale;
         }
         if (cosv) {
+#if CX_ATTN_ROT_AHEAD
+            const float4 c = cn, s = sn;
+            if (qd < 3) {
+                cn = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + d + 8);
+                sn = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + d + 8);
+            }
+#else
             const float4 c = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + d);
             const float4 s = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + d);
+#endif
             const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

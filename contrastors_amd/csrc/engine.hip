@@ -271,10 +271,20 @@ int clear_pad_rows(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
     return CX_OK;
 }
 
-// ---- transformer blocks, backward.  In: gradient of the final hidden states in buf->g_a.  Out: the gradient of the
-// input embeddings as the sum of *da and *db (db may come back NULL). -------------------------------------------------
+// The gradient of a POOLED encoder's final hidden states is a rank-one pattern, w(t) * g[seq(t)] (mean / cls pooling): when
+// `pg` is given, the backward of the last LayerNorm builds it on the fly in fp32 (cx_layernorm_bwd_pooled) instead of reading
+// a bf16 copy from buf->g_a -- the rounding of that copy was the largest parity gap of round 2 (final-LayerNorm bias).
+struct PooledGrad {
+    const float* demb;
+    const float* emb;
+    const float* norm;
+    int pool_mode, normalize;
+};
+
+// ---- transformer blocks, backward.  In: gradient of the final hidden states in buf->g_a (or `pg`, see above).  Out: the
+// gradient of the input embeddings as the sum of *da and *db (db may come back NULL). ---------------------------------
 int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Slots& s, const int32_t* cu_seqlens, int Bc,
-                    int T, int max_seqlen, const uint16_t** da_out, const uint16_t** db_out, void* stream) {
+                    int T, int max_seqlen, const PooledGrad* pg, const uint16_t** da_out, const uint16_t** db_out, void* stream) {
     const int d = enc->d, I = enc->d_inner, H = enc->n_head, L = enc->n_layer;
     // MLP backward: dm -> gradients of fc2 / fc1 parameters, d(mlp input) into buf->g_b
     // `add` (optional): the residual-branch gradient that the following LayerNorm backward would add to this dgrad
@@ -354,8 +364,14 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                 continue;
             }
             // LN2: dz2 = grad of (mlp_out + h1)
-            CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
-                                    w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+            if (pg && l == L - 1) {
+                CX_TRY(cx_layernorm_bwd_pooled(pg->demb, pg->emb, pg->norm, cu_seqlens, Bc, pg->pool_mode, pg->normalize, s.z2(l),
+                                               w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, w.gln2_g, w.gln2_b, buf->ws_f32,
+                                               buf->ws_floats, T, d, stream));
+            } else {
+                CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
+                                        w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+            }
             bool f1 = false, f2 = false;
             CX_TRY(mlp_bwd(w, l, buf->g_c, s.h1(l), buf->g_c, &f1));
             // LN1: dout = dz2 (residual branch) + dh1 from the MLP (already summed in g_b when the fc1 dgrad folded it)
@@ -371,8 +387,14 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         return CX_OK;
     }
     // pre-norm: the gradient of the residual stream r rides along as dz_extra of every LayerNorm backward
-    CX_TRY(cx_layernorm_bwd(buf->g_a, nullptr, buf->zf, enc->lnf_g, buf->meanf, buf->rstdf, nullptr, buf->g_c, enc->glnf_g,
-                            enc->glnf_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+    if (pg) {
+        CX_TRY(cx_layernorm_bwd_pooled(pg->demb, pg->emb, pg->norm, cu_seqlens, Bc, pg->pool_mode, pg->normalize, buf->zf,
+                                       enc->lnf_g, buf->meanf, buf->rstdf, buf->g_c, enc->glnf_g, enc->glnf_b, buf->ws_f32,
+                                       buf->ws_floats, T, d, stream));
+    } else {
+        CX_TRY(cx_layernorm_bwd(buf->g_a, nullptr, buf->zf, enc->lnf_g, buf->meanf, buf->rstdf, nullptr, buf->g_c, enc->glnf_g,
+                                enc->glnf_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+    }
     for (int l = L - 1; l >= 0; --l) {   // invariant: buf->g_c = d(x_l + r_l) = gradient of both the MLP output and r
         const CxLayerWeights& w = enc->layers[l];
         bool unused = false;
@@ -428,11 +450,16 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     const int d = enc->d, I = enc->d_inner;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
-    CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
-                                 enc->normalize, stream));
-    const uint16_t* da = nullptr;
+    // the pooling backward rides inside the last LayerNorm's backward (fp32, never materialised); the dropout schedule
+    // keeps the two-kernel form (its LayerNorm backward also returns the masked branch gradient)
+    const PooledGrad pg{demb, emb_out, buf->pool_norm, enc->pool_mode, enc->normalize};
+    const bool fold_pool = !(buf->drop_active && enc->resid_pdrop > 0.f) && (enc->pool_mode == 0 || enc->pool_mode == 1);
+    if (!fold_pool)
+        CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
+                                     enc->normalize, stream));
+    const uint16_t* da = fold_pool ? nullptr : buf->g_a;
     const uint16_t* db = nullptr;
-    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, fold_pool ? &pg : nullptr, &da, &db, stream));
     if (buf->drop_active && enc->embd_pdrop > 0.f) {  // gradient through the embedding dropout (both branches: linear)
         CX_TRY(cx_dropout_scale(const_cast<uint16_t*>(da), (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset,
                                 2 * enc->n_layer, stream));
@@ -488,7 +515,7 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
         return CX_ERR_LAUNCH;
     const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
-    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, &da, &db, stream));
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, max_seqlen, nullptr, &da, &db, stream));
     if (buf->drop_active && enc->embd_pdrop > 0.f) {  // gradient through the embedding dropout (both branches: linear)
         CX_TRY(cx_dropout_scale(const_cast<uint16_t*>(da), (long)T * d, enc->embd_pdrop, buf->drop_seed, buf->drop_offset,
                                 2 * enc->n_layer, stream));
@@ -543,11 +570,14 @@ int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const i
     const int d = enc->d, I = enc->d_inner;
     Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
-    CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
-                                 enc->normalize, stream));
+    const PooledGrad pg{demb, emb_out, buf->pool_norm, enc->pool_mode, enc->normalize};
+    const bool fold_pool = enc->prenorm && (enc->pool_mode == 0 || enc->pool_mode == 1);   // (see cx_encoder_backward)
+    if (!fold_pool)
+        CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
+                                     enc->normalize, stream));
     const uint16_t* da = nullptr;
     const uint16_t* db = nullptr;
-    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, S, &da, &db, stream));
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, S, fold_pool ? &pg : nullptr, &da, &db, stream));
     if (db) return CX_ERR_ARG;  // (post-norm ViT would need the two branches summed first; no such model family)
     // d(embeddings) -> cls / position gradients and the contiguous d(projection) rows; pad rows of both wgrad operands
     // (patch_in was written by the forward of this chunk and is still intact) are cleared for the 64-row reduction

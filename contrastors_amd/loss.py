@@ -12,7 +12,9 @@ bidirectional, router_aux_coeff)`.  What changes is underneath:
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+import logging
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Union
 
 import torch
 import torch.distributed as dist
@@ -94,19 +96,15 @@ class _FusedInfoNCEFp8(torch.autograd.Function):
         return dq * gout, dd * gout, None, None, None, gparam
 
 
-_USE_FP8 = False
+def _infonce(q, d, labels, scale, coef, scale_param, use_fp8=False):
+    """`use_fp8` (the recipe flag configs/train/contrastive_pretrain.yaml:24, TrainArgs.use_fp8) is an explicit argument
+    all the way down: there is no process-wide switch."""
+    return (_FusedInfoNCEFp8 if use_fp8 else _FusedInfoNCE).apply(q, d, labels, scale, coef, scale_param)
 
 
-def set_similarity_fp8(enabled: bool):
-    """Process-wide default of the `use_fp8` recipe flag (configs/train/contrastive_pretrain.yaml:24): route every fused
-    InfoNCE through the fp8 similarity GEMM.  `clip_loss(..., use_fp8=...)` overrides it per call."""
-    global _USE_FP8
-    _USE_FP8 = bool(enabled)
-
-
-def _infonce(q, d, labels, scale, coef, scale_param, use_fp8=None):
-    fp8 = _USE_FP8 if use_fp8 is None else bool(use_fp8)
-    return (_FusedInfoNCEFp8 if fp8 else _FusedInfoNCE).apply(q, d, labels, scale, coef, scale_param)
+def fp8_similarity_supported(n: int, g: int, dim: int) -> bool:
+    """Shapes the fp8 similarity GEMM covers (what _FusedInfoNCEFp8 would otherwise refuse at the first step)."""
+    return n % 256 == 0 and g % 64 == 0 and dim in (256, 512, 768, 1024)
 
 
 class _FusedInfoNCE(torch.autograd.Function):
@@ -180,8 +178,12 @@ def make_labels(n_query: int, n_docs_all: int, rank: int, world: int, device) ->
 
 
 def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tracker=None, dataset="",
-              bidirectional=False, *, use_fp8=None):
-    """InfoNCE over (local queries) x (all gathered documents); see sc/loss.py:76-132 for the contract."""
+              bidirectional=False, *, use_fp8=False):
+    """InfoNCE over (local queries) x (all gathered documents); see sc/loss.py:76-132 for the contract.
+
+    One deliberate difference from the reference (INTEGRATION.md "quirks"): a label vector that would leave [0, G) -- e.g.
+    `gather_enabled=False` in a multi-rank run, where sc/loss.py:108-117 silently produces labels pointing at other ranks'
+    documents that are not there (integer-divide to 0) -- raises ValueError here instead of training on a wrong target."""
     if gather_enabled:
         document = gather_with_grad(document)
     if query.dtype != document.dtype:
@@ -269,28 +271,95 @@ def accumulate_gradients(model, chunks, cache, rand_states=None):
         surrogate.backward()
 
 
-def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional=False):
+def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional=False, *, use_fp8=False):
     """sc/loss.py:164-184: loss on detached embeddings, gradients w.r.t. the embeddings only."""
     q = query_embeddings.detach().requires_grad_()
     d = document_embeddings.detach().requires_grad_()
-    loss = clip_loss(q, d, logit_scale, gather_enabled=True, bidirectional=bidirectional)
+    loss = clip_loss(q, d, logit_scale, gather_enabled=True, bidirectional=bidirectional, use_fp8=use_fp8)
     loss.backward()
     return q.grad, d.grad, loss.detach()
 
 
-def effective_chunk(tower, inputs, chunk_size: int) -> int:
+@dataclass
+class GradCachePolicy:
+    """How grad_cache_loss schedules a step on a 288 GB part.  These are CONFIG fields (TrainArgs.gradcache_chunk /
+    gradcache_resident / use_fp8, `GradCachePolicy.from_train_args`); the environment variables of round 2
+    (CX_GRADCACHE_CHUNK, CX_GRADCACHE_RESIDENT) remain as an operator OVERRIDE on top of whatever the config says.
+      chunk     "auto": the recipe's chunk_size is a lower bound, raised until a chunk carries ~262144 tokens or its arena
+                would take a third of the free HBM | "exact": the recipe's number, literally | n: force n
+      resident  "auto": keep pass 1's activations when they need <= 80 % of the free HBM (no re-forward) | True | False
+      use_fp8   similarity GEMM of the loss on the fp8 matrix cores
+    The schedule actually taken is logged once per distinct decision (logger "contrastors_amd")."""
+    chunk: Union[str, int] = "auto"
+    resident: Union[str, bool] = "auto"
+    use_fp8: bool = False
+
+    @classmethod
+    def from_train_args(cls, ta) -> "GradCachePolicy":
+        return cls(chunk=_parse_chunk(getattr(ta, "gradcache_chunk", "auto"), "train_args.gradcache_chunk"),
+                   resident=_parse_resident(getattr(ta, "gradcache_resident", "auto"), "train_args.gradcache_resident"),
+                   use_fp8=bool(getattr(ta, "use_fp8", False)))
+
+    def with_env(self) -> "GradCachePolicy":
+        import os
+
+        c, r = os.environ.get("CX_GRADCACHE_CHUNK"), os.environ.get("CX_GRADCACHE_RESIDENT")
+        return GradCachePolicy(chunk=self.chunk if c in (None, "") else _parse_chunk(c, "CX_GRADCACHE_CHUNK"),
+                               resident=self.resident if r in (None, "") else _parse_resident(r, "CX_GRADCACHE_RESIDENT"),
+                               use_fp8=self.use_fp8)
+
+
+def _parse_chunk(v, where: str):
+    if v is None or v == "":
+        return "auto"
+    if isinstance(v, str) and v.lower() in ("auto", "exact"):
+        return v.lower()
+    try:
+        n = int(v)
+    except (TypeError, ValueError):
+        raise ValueError(f"{where} must be 'auto', 'exact' or a positive integer, got {v!r}") from None
+    if n <= 0:
+        raise ValueError(f"{where} must be 'auto', 'exact' or a positive integer, got {v!r}")
+    return n
+
+
+def _parse_resident(v, where: str):
+    if v is None or v == "":
+        return "auto"
+    if isinstance(v, bool):
+        return v
+    t = str(v).lower()
+    if t == "auto":
+        return "auto"
+    if t in ("1", "true", "yes", "on"):
+        return True
+    if t in ("0", "false", "no", "off"):
+        return False
+    raise ValueError(f"{where} must be 'auto', true / 1 or false / 0, got {v!r}")
+
+
+_LOGGED: set = set()
+
+
+def _log_once(key, msg: str):
+    if key in _LOGGED:
+        return
+    _LOGGED.add(key)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+        logging.getLogger("contrastors_amd").info(msg)
+
+
+def effective_chunk(tower, inputs, chunk_size: int, policy: Optional[GradCachePolicy] = None) -> int:
     """The GradCache chunk is a pure memory knob: embeddings, loss and gradients do not depend on it (tested to fp32
     summation order).  The reference recipes say 64 because an 80 GB part cannot hold more activations; an MI355X has
-    288 GB, and its GEMMs want >= 512 row panels per launch.  With CX_GRADCACHE_CHUNK=auto (the default) a recipe's
+    288 GB, and its GEMMs want >= 512 row panels per launch.  With policy.chunk == "auto" (the default) a recipe's
     chunk_size is therefore treated as a LOWER bound and raised -- in multiples of itself -- until a chunk carries ~262144
-    tokens or its activation arena would take more than a third of the free HBM.  CX_GRADCACHE_CHUNK=exact keeps the
-    recipe's number; CX_GRADCACHE_CHUNK=<n> forces n."""
-    import os
-
-    mode = os.environ.get("CX_GRADCACHE_CHUNK", "auto")
+    tokens or its activation arena would take more than a third of the free HBM.  "exact" keeps the recipe's number; an
+    integer forces it."""
+    mode = (policy or GradCachePolicy()).with_env().chunk
     if mode == "exact" or chunk_size is None or chunk_size <= 0:
         return chunk_size
-    if mode not in ("auto", ""):
+    if mode != "auto":
         return max(1, int(mode))
     cfg = getattr(getattr(tower, "trunk", None), "config", None)
     ids = inputs.get("input_ids") if isinstance(inputs, dict) else None
@@ -318,17 +387,17 @@ def _arena_bytes_per_token(tower) -> float:
     return kept * per_layer + (L - kept) * 2 * d + scratch
 
 
-def resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs) -> bool:
+def resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs, policy: Optional[GradCachePolicy] = None) -> bool:
     """GradCache exists because one pass cannot hold a big batch's activations (sc/loss.py:187-213 was written for 80 GB
     parts): pass 1 throws them away and pass 2 recomputes them, 4 forward-equivalents of FLOPs instead of 3.  When the
     WHOLE per-GPU batch of both towers fits in HBM (2048 pairs x 128 tokens of nomic-bert-2048: 193 GB of 288), pass 1
     can keep them and pass 2 has nothing to recompute: same embeddings, same loss, same gradients (the same kernels in the
-    same order; identical up to the fp32-atomics noise two runs of the two-pass step show), a quarter of the work gone.  CX_GRADCACHE_RESIDENT = auto | 0 | 1; `auto` keeps the
-    activations when they take <= 80 % of the free HBM."""
-    import os
-
-    mode = os.environ.get("CX_GRADCACHE_RESIDENT", "auto")
-    if mode == "0":
+    same order; identical up to the fp32-atomics noise two runs of the two-pass step show), a quarter of the work gone.
+    policy.resident = "auto" | True | False; `auto` keeps the activations when they take <= 80 % of the free HBM (and
+    grad_cache_loss falls back to the two-pass schedule if the estimate turns out wrong: torch.OutOfMemoryError there is
+    caught before any gradient has been accumulated)."""
+    mode = (policy or GradCachePolicy()).with_env().resident
+    if mode is False:
         return False
     need = 0.0
     dev = None
@@ -348,7 +417,7 @@ def resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs) -> bool:
         need += tokens * _arena_bytes_per_token(tw) * 1.03
     if dev is None:
         return False
-    if mode == "1":
+    if mode is True:
         return True
     free, _ = torch.cuda.mem_get_info(dev)
     free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
@@ -373,26 +442,52 @@ def _resident_backward(outs, cache):
 
 
 def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scale, bidirectional=False,
-                    router_aux_coeff=False):
-    """GradCache step (sc/loss.py:187-213).  Leaves parameter gradients in the towers and returns the loss."""
-    q_chunks = _split_inputs(t1_inputs, effective_chunk(tower1, t1_inputs, chunk_size))
-    d_chunks = _split_inputs(t2_inputs, effective_chunk(tower2, t2_inputs, chunk_size))
+                    router_aux_coeff=False, *, policy: Optional[GradCachePolicy] = None):
+    """GradCache step (sc/loss.py:187-213).  Leaves parameter gradients in the towers and returns the loss.  `policy`
+    (keyword-only, beyond the reference's signature) carries the MI355X scheduling decisions; see GradCachePolicy."""
+    pol = (policy or GradCachePolicy()).with_env()
+    cq, cd = effective_chunk(tower1, t1_inputs, chunk_size, pol), effective_chunk(tower2, t2_inputs, chunk_size, pol)
+    q_chunks = _split_inputs(t1_inputs, cq)
+    d_chunks = _split_inputs(t2_inputs, cd)
     was_training1, was_training2 = tower1.training, tower2.training
     sizes_q = [c["input_ids"].shape[0] for c in q_chunks]
     sizes_d = [c["input_ids"].shape[0] for c in d_chunks]
-    if resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs):
-        q_out = _resident_forward(tower1, q_chunks)
-        d_out = _resident_forward(tower2, d_chunks)
-        q_cache, d_cache, loss = cache_loss(torch.cat([o.detach() for o in q_out]), torch.cat([o.detach() for o in d_out]),
-                                            logit_scale, bidirectional=bidirectional)
-        _resident_backward(q_out, q_cache.split(sizes_q))
-        _resident_backward(d_out, d_cache.split(sizes_d))
-        del q_out, d_out
-    else:
+    resident = resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs, pol)
+    _log_once(("gradcache", chunk_size, cq, cd, resident, pol.use_fp8),
+              f"GradCache schedule: recipe chunk_size {chunk_size} -> {cq} queries / {cd} documents per chunk "
+              f"({len(q_chunks)} + {len(d_chunks)} chunks; policy.chunk = {pol.chunk!r}); "
+              f"{'pass 1 keeps its activations, no re-forward' if resident else 'two passes (re-forward)'} "
+              f"(policy.resident = {pol.resident!r}); similarity GEMM {'fp8' if pol.use_fp8 else 'fp32'}")
+    done = False
+    if resident:
+        q_out = d_out = None
+        try:
+            q_out = _resident_forward(tower1, q_chunks)
+            d_out = _resident_forward(tower2, d_chunks)
+            q_cache, d_cache, loss = cache_loss(torch.cat([o.detach() for o in q_out]), torch.cat([o.detach() for o in d_out]),
+                                                logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
+        except torch.OutOfMemoryError:
+            # the estimate of resident_activations_fit was wrong (fragmentation, another tenant of the allocator): no
+            # parameter gradient has been touched yet (the encoder backward starts below), so drop what pass 1 kept,
+            # hand the arenas back and take the two-pass schedule for this step.  policy.resident = True re-raises.
+            if pol.resident is True:
+                raise
+            _release_resident(tower1, q_out)
+            _release_resident(tower2, d_out)
+            q_out = d_out = None
+            torch.cuda.empty_cache()
+            _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
+                                          "schedule (set train_args.gradcache_resident: false to skip the attempt)")
+        else:
+            _resident_backward(q_out, q_cache.split(sizes_q))
+            _resident_backward(d_out, d_cache.split(sizes_d))
+            del q_out, d_out
+            done = True
+    if not done:
         q_rnd, d_rnd = [], []
         q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd)
         d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd)
-        q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional)
+        q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
         accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd)
         if was_training2:
             accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd)
@@ -403,3 +498,15 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             seen.add(id(tw))
             tw.sync_gradients()
     return loss
+
+
+def _release_resident(tower, outs):
+    """Give back the arenas the autograd graphs of a failed resident forward hold (see grad_cache_loss)."""
+    if not outs:
+        return
+    for o in outs:
+        fn = getattr(o, "grad_fn", None)   # the ctx of nomic_bert._EncodeFn / vit._VitEncodeFn when the tower is "plain"
+        eng, arena = getattr(fn, "engine", None), getattr(fn, "arena", None)
+        if eng is not None and arena is not None and hasattr(eng, "release_arena"):
+            eng.release_arena(arena)
+            fn.arena = None

@@ -550,8 +550,17 @@ class NomicBertEngine(torch.nn.Module):
         if active:
             gen = torch.cuda.default_generators[self.device_.index if self.device_.index is not None else torch.cuda.current_device()]
             off = gen.get_offset()
-            gen.set_offset(off + 4)  # torch keeps Philox offsets in multiples of 4
+            # the kernels key dropout site s of this chunk as Philox counter word (offset + s) (cx_common.h dropout_keep4);
+            # a chunk has 3 L + 1 sites (2l, 2l + 1 residual, 2L embeddings, 2L + 1 + l attention), so the generator moves
+            # past ALL of them -- advancing by less would hand the next chunk this chunk's streams shifted by a few sites
+            # (torch keeps Philox offsets in multiples of 4)
+            gen.set_offset(off + self.dropout_offset_stride(cfg.n_layer))
             arena.desc.drop_seed, arena.desc.drop_offset = gen.initial_seed() & (2**64 - 1), off
+
+    @staticmethod
+    def dropout_offset_stride(n_layer: int) -> int:
+        """Philox offsets one chunk consumes: its 3 L + 1 dropout sites rounded up to torch's granularity of 4."""
+        return 4 * ((3 * n_layer + 1 + 3) // 4)
 
     @property
     def uses_rng(self) -> bool:

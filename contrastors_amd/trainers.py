@@ -19,8 +19,8 @@ import torch.distributed as dist
 
 from .biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
 from .config import Config
-from .distributed import gather_with_grad
-from .loss import clip_loss, grad_cache_loss
+from .distributed import gather_with_grad, set_exchange_mode
+from .loss import GradCachePolicy, clip_loss, grad_cache_loss
 from .nomic_bert import NomicBertConfig
 from .optimizer import FusedAdamW
 
@@ -94,10 +94,10 @@ class TextTextTrainer:
         self.world = dist.get_world_size() if self.distributed else 1
         self.rank = dist.get_rank() if self.distributed else 0
         torch.manual_seed(config.data_args.seed)
-        if config.train_args.use_fp8:  # the GradCache path reaches clip_loss through the reference's fixed signature
-            from .loss import set_similarity_fp8
-
-            set_similarity_fp8(True)
+        # MI355X scheduling decisions are config (train_args.gradcache_chunk / gradcache_resident / use_fp8 / exchange),
+        # carried explicitly: no process-wide switch survives this trainer
+        self.policy = GradCachePolicy.from_train_args(config.train_args)
+        set_exchange_mode(config.train_args.exchange or "auto")
         self.model = self.get_model(config, trunk_config)
         self.total_steps = total_steps or config.train_args.num_train_steps or 10_000
         self.optimizer = self.get_optimizer(config)
@@ -171,7 +171,7 @@ class TextTextTrainer:
             raise ValueError("negatives must be folded into document_* (sc/trainers/text_text.py:346-347)")
         q, d = self._inputs(batch, "query"), self._inputs(batch, "document")
         if ta.grad_cache:
-            loss = grad_cache_loss(model, q, model, d, ta.chunk_size, scale)
+            loss = grad_cache_loss(model, q, model, d, ta.chunk_size, scale, policy=self.policy)
             self._sync_logit_scale_grad()
             return loss
         dims = ta.matryoshka_dims
@@ -187,7 +187,7 @@ class TextTextTrainer:
         for w, dim in zip(weights, dims):
             rq = torch.nn.functional.normalize(queries[:, :dim], dim=-1)
             rd = torch.nn.functional.normalize(all_documents[:, :dim], dim=-1)
-            loss = loss + w * clip_loss(rq, rd, scale)
+            loss = loss + w * clip_loss(rq, rd, scale, use_fp8=bool(ta.use_fp8))
         return loss
 
     def backward(self, loss: torch.Tensor):

@@ -78,6 +78,17 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
                      const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
                      float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream);
 
+/* Backward of the LAST LayerNorm of a pooled encoder with the pooling / normalisation backward folded in
+ * (sc/models/biencoder/modeling_biencoder.py:79-90,314-319 backward + the LayerNorm backward of sc/layers/block.py:453-462
+ * or sc/models/vit/vit.py:253-263): dout[t] = w(t) * g[seq(t)], g = d(pooled vector) from (demb, emb, norm) exactly as
+ * cx_pool_normalize_bwd computes it, w = 1/len (pool_mode 0, mean) or [t first token] (pool_mode 1, cls).  dout stays in
+ * fp32 registers: the bf16 rounding of a materialised dout showed in the final LayerNorm's bias gradient (3.7 % vs the
+ * fp32 oracle on the reference's GradCache fixture, where bf16-eager is 0.5 % off).  rows = total tokens. */
+int cx_layernorm_bwd_pooled(const float* demb, const float* emb, const float* norm, const int32_t* cu_seqlens, int B,
+                            int pool_mode, int normalize, const uint16_t* z, const float* gamma, const float* mean,
+                            const float* rstd, uint16_t* dz, float* dgamma, float* dbeta, float* ws, long ws_floats, int rows,
+                            int d, void* stream);
+
 /* dropout p > 0 (flash_attn.ops.layer_norm.dropout_add_layer_norm(p > 0), sc/layers/block.py:422-431,453-462 with
  * resid_pdrop > 0): z = dropout_p(x0) + residual, out = LN(z).  The keep-mask is Philox4x32-10(seed; offset + site,
  * element group) -- a pure function of the torch generator's (seed, offset) the host drew for this chunk, so backward and

@@ -13,12 +13,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tokens", type=int, default=131072)
 ap.add_argument("--heads", type=int, default=12)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--bwd-mode", type=int, default=None, help="cx_attn_set_bwd_s128 (dev library): 4 fused3 (default), 3 fused2, ...")
+ap.add_argument("--seqs", type=str, default="128,197,512,2048,8192")
 a = ap.parse_args()
 lib = _C.dev_lib()
+if a.bwd_mode is not None:
+    lib.cx_attn_set_bwd_s128(a.bwd_mode)
 s = torch.cuda.current_stream().cuda_stream
 H, D = a.heads, 64
 print("S      B     fwd us   fwd TF    bwd us   bwd TF   (FLOP: fwd 4*S*S*D per seq-head, bwd 2.5x)")
-for S in (128, 197, 512, 2048, 8192):
+for S in [int(x) for x in a.seqs.split(",")]:
     B = max(1, a.tokens // S)
     T = B * S
     qkv = (torch.randn(T, 3 * H * D, device="cuda") * 0.5).to(torch.bfloat16)

@@ -95,6 +95,39 @@ def test_engine_dropout_train_vs_eval_and_randcontext_replay():
     assert float((e1 - e_eval).abs().max()) < 0.5 and float(F.cosine_similarity(e1, e_eval).min()) > 0.8
 
 
+def test_dropout_streams_of_consecutive_chunks_do_not_alias():
+    """the kernels draw site s of a chunk from Philox counter (offset + s); a chunk owns 3 L + 1 sites, so the
+    generator has to advance past all of them or chunk k + 1's site s replays chunk k's site s + 4."""
+    from contrastors_amd.nomic_bert import NomicBertEngine
+
+    NL = 2
+    tower = _tower(0.1, 0.1, n_layer=NL, attn=0.1).train()
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    b = _batch(4, 32, 5)
+    o0 = gen.get_offset()
+    with torch.no_grad():
+        tower(**b)
+    o1 = gen.get_offset()
+    assert o1 - o0 == NomicBertEngine.dropout_offset_stride(NL) >= 3 * NL + 1 and (o1 - o0) % 4 == 0
+    # and at the kernel: the mask of (offset, site 4) == the mask of (offset + 4, site 0) -- which is why 4 was not enough
+    # -- while (offset + stride, any site of the next chunk) shares no counter with this chunk's sites
+    rows, d = 64, 768
+    x0 = torch.randn(rows, d, device=DEV).to(torch.bfloat16)
+    g, bb = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+
+    def z_of(off, site):
+        out, z = torch.empty_like(x0), torch.empty_like(x0)
+        mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        _C.check(L().cx_dropout_add_layernorm_fwd(x0.data_ptr(), 0, g.data_ptr(), bb.data_ptr(), out.data_ptr(), z.data_ptr(),
+                                                 mean.data_ptr(), rstd.data_ptr(), rows, d, 1e-5, 0.5, 77, off, site, S()))
+        return z
+    assert torch.equal(z_of(100, 4), z_of(104, 0))
+    stride = NomicBertEngine.dropout_offset_stride(NL)
+    cur = [z_of(100, s) for s in range(3 * NL + 1)]
+    nxt = [z_of(100 + stride, s) for s in range(3 * NL + 1)]
+    assert not any(torch.equal(a, c) for a in cur for c in nxt)
+
+
 def test_grad_cache_with_dropout_uses_randcontext():
     """Pass 2 must see pass 1's masks (sc/loss.py:141-145,156-158): with the replay the step is reproducible from a given
     generator state and its gradient is the gradient of the loss that was actually computed."""

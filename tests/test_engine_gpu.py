@@ -120,7 +120,8 @@ def test_engine_full_architecture_vs_oracle(arch):
         eh, eb = rel_err(gh, r32), rel_err(r16.float(), r32)
         if eh / (eb + 1e-4) > worst_ratio:
             worst_ratio, worst_name = eh / (eb + 1e-4), n
-        assert eh <= 3 * eb + 2e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+        # 12-layer architecture: the reference's 3 x bf16-eager rule with NO additive floor (1e-4 only guards eb = 0)
+        assert eh <= 3 * (eb + 1e-4), f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
     report("engine_full", arch=arch, e_emb_hip=e_hip, e_emb_bf16=e_b, mean_hip=m_hip, mean_bf16=m_b,
            worst_grad_ratio=worst_ratio, worst_grad_name=worst_name)
     # reference rule only: with these random (std 0.05, un-trained) weights bf16 eager itself is ~4e-2 off fp32
@@ -197,6 +198,6 @@ def test_engine_maximum_sizes_and_empty(case):
            **{k + "_hip": v[0] for k, v in rep.items()}, **{k + "_bf16": v[1] for k, v in rep.items()})
     assert e_hip <= 3 * e_b + 1e-4
     for k, (eh, eb) in rep.items():  # the reference's rule (tests/test_flash_bert.py:77-82), as in the S = 128 test
-        assert eh <= 3 * eb + 2e-2, f"{k}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+        assert eh <= 3 * eb + 1e-2, f"{k}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
     if case == "ntk_4096":  # the table was re-based: plain rotary at these positions gives a different answer
         assert eng._rot_len == S and eng.rot_cos.shape[0] == S

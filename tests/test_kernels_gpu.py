@@ -488,6 +488,65 @@ def test_pool_normalize(mode, normalize):
     assert rel_err(dh.float(), hr.grad) < 4e-3
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("normalize", [1, 0])
+def test_layernorm_bwd_pooled_keeps_the_pooled_gradient_in_fp32(mode, normalize):
+    """cx_layernorm_bwd_pooled = pooling / normalisation backward + LayerNorm backward of the last LayerNorm in one kernel
+    (round 3): against torch fp32 autograd through LN -> pool -> normalize, and against the two-kernel
+    route it replaces -- whose bf16 copy of dout is what the parameter gradients lose."""
+    lens, d = [128, 5, 77, 1, 64, 0, 33], 768
+    T, B = sum(lens), len(lens)
+    z = bf(_randn(T, d, seed=60))
+    g, b = 1 + _randn(d, seed=61, std=0.1), _randn(d, seed=62, std=0.1)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    out = torch.empty_like(z)
+    mean, rstd = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+    _C.check(L().cx_layernorm_fwd(z.data_ptr(), None, g.data_ptr(), b.data_ptr(), out.data_ptr(), None, mean.data_ptr(),
+                                  rstd.data_ptr(), T, d, 1e-12, S()))
+    emb, nrm = torch.zeros(B, d, device=DEV), torch.ones(B, device=DEV)
+    _C.check(L().cx_pool_normalize_fwd(out.data_ptr(), cu.data_ptr(), emb.data_ptr(), nrm.data_ptr(), B, d, mode, normalize, S()))
+    gup = _randn(B, d, seed=63)
+    # torch fp32 reference on the same bf16 z (the final hidden states enter the pooling in bf16 on both sides)
+    zr, gr, br = z.float().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    ln = torch.nn.functional.layer_norm(zr, (d,), gr, br, 1e-12)
+    h = ln + (ln.to(torch.bfloat16).float() - ln).detach()   # value: the bf16 hidden states the pooling read; gradient: identity
+    parts, t0, keep = [], 0, []
+    for i, l in enumerate(lens):
+        if l > 0:
+            parts.append(h[t0] if mode == 1 else h[t0:t0 + l].mean(0))
+            keep.append(i)
+        t0 += l
+    pooled = torch.stack(parts)
+    ref = torch.nn.functional.normalize(pooled, dim=-1) if normalize else pooled
+    ref.backward(gup[keep])
+    dz = torch.full_like(z, float("nan"))
+    dg, dbeta = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ws = torch.empty(512 * d, device=DEV)
+    _C.check(L().cx_layernorm_bwd_pooled(gup.data_ptr(), emb.data_ptr(), nrm.data_ptr(), cu.data_ptr(), B, mode, normalize,
+                                         z.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dz.data_ptr(),
+                                         dg.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), T, d, S()))
+    assert torch.isfinite(dz.float()).all()
+    e_dz, e_dg, e_db = rel_err(dz.float(), zr.grad), rel_err(dg, gr.grad), rel_err(dbeta, br.grad)
+    # the route it replaces: bf16 dout in HBM, then the plain LayerNorm backward
+    dh = torch.zeros_like(z)
+    _C.check(L().cx_pool_normalize_bwd(gup.data_ptr(), emb.data_ptr(), nrm.data_ptr(), cu.data_ptr(), dh.data_ptr(), B, d, mode,
+                                       normalize, S()))
+    dz2, dg2, db2 = torch.empty_like(z), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    _C.check(L().cx_layernorm_bwd(dh.data_ptr(), None, z.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+                                  dz2.data_ptr(), dg2.data_ptr(), db2.data_ptr(), ws.data_ptr(), ws.numel(), T, d, S()))
+    e_db2 = rel_err(db2, br.grad)
+    report("layernorm_pooled", mode=mode, normalize=normalize, e_dz=e_dz, e_dg=e_dg, e_db=e_db, e_db_two_kernels=e_db2)
+    assert e_dz < 8e-3, "dz is stored in bf16"
+    assert e_dg < 2e-3 and e_db < 1e-5, "parameter gradients: fp32 dout, fp32 sums"
+    assert e_db <= e_db2 + 1e-7
+    # deterministic, and accumulating
+    dz3, dg3, db3 = torch.empty_like(z), torch.ones(d, device=DEV), torch.ones(d, device=DEV)
+    _C.check(L().cx_layernorm_bwd_pooled(gup.data_ptr(), emb.data_ptr(), nrm.data_ptr(), cu.data_ptr(), B, mode, normalize,
+                                         z.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dz3.data_ptr(),
+                                         dg3.data_ptr(), db3.data_ptr(), ws.data_ptr(), ws.numel(), T, d, S()))
+    assert torch.equal(dz, dz3) and rel_err(dg3 - 1, dg) < 1e-5 and rel_err(db3 - 1, dbeta) < 1e-5
+
+
 # --------------------------------------------------------------------------------------------------------- InfoNCE
 def _infonce(q, d, labels, scale, coef, want_dscale=False):
     N, dim = q.shape

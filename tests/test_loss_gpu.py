@@ -103,10 +103,11 @@ def test_grad_cache_loss_equals_full_batch_oracle(gold):
         eh, eb = rel_err(gh, r), rel_err(sd_bf[n].grad, r)
         table.append((eh / (eb + 1e-4), n, eh, eb))
         worst, worst_bf = max(worst, eh), max(worst_bf, eb)
-        # the reference's own rule (tests/test_flash_bert.py:77-82): err <= 3 x err(bf16 eager), + a floor: the engine's
-        # residual stream is bf16 (flash-attn's residual_in_fp32=False path) while autocast eager keeps LayerNorm in fp32,
-        # which shows on LayerNorm bias gradients summed over the 2 x 8 short sequences of this fixture (3.7 % measured)
-        assert eh <= 3 * eb + 3e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+        # the reference's own rule (tests/test_flash_bert.py:77-82): err <= 3 x err(bf16 eager), + a floor of 1e-2 (was 3e-2
+        # in round 2: the final LayerNorm's bias gradient was 3.7 % off because the pooled gradient went through a bf16
+        # copy; cx_layernorm_bwd_pooled keeps it in fp32).  What is left is the bf16 residual stream (flash-attn's
+        # residual_in_fp32=False path) against autocast-eager's fp32 LayerNorms: ~2 x on the other LayerNorm biases.
+        assert eh <= 3 * eb + 1e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
     table.sort(reverse=True)
     report("grad_cache", loss_hip=loss.item(), loss_ref=ref, loss_bf16_eager=ref_bf, worst_rel_grad=worst,
            worst_rel_grad_bf16_eager=worst_bf, worst_ratios="; ".join(f"{n} {eh:.4f}/{eb:.4f}" for _, n, eh, eb in table[:6]))

@@ -88,7 +88,8 @@ def test_vit_b16_vs_oracle():
         table.append((eh / (eb + 1e-4), n, eh, eb))
         if eh / (eb + 1e-4) > worst_ratio:
             worst_ratio, worst_name = eh / (eb + 1e-4), n
-        assert eh <= 3 * eb + 2e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+        # ViT-B/16 blocks: the 3 x bf16-eager rule with no additive floor (1e-4 only guards eb = 0)
+        assert eh <= 3 * (eb + 1e-4), f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
     table.sort(reverse=True)
     report("vit_b16", e_emb_hip=e_hip, e_emb_bf16=e_b, worst_grad_ratio=worst_ratio, worst_grad_name=worst_name,
            worst_ratios="; ".join(f"{n} {eh:.4f}/{eb:.4f}" for _, n, eh, eb in table[:6]))
