@@ -83,6 +83,7 @@ class BiEncoder(torch.nn.Module):
         if config.gradient_checkpointing:  # modeling_biencoder.py:261-262
             self.trunk.gradient_checkpointing_enable()
         self.frozen_trunk = bool(config.freeze)
+        self.overlap_reduce = True   # train_args.overlap_grad_reduce: start the gradient all-reduce inside the last backward
         if self.frozen_trunk:
             self.trunk.eval()
             for p in self.trunk.parameters():
@@ -131,11 +132,20 @@ class BiEncoder(torch.nn.Module):
         return {"embedding": emb, "router_logits": None, "router_loss": None, "tokens_per_expert": None}
 
     # ---- data-parallel plumbing (what DDP does for the reference, sc/trainers/text_text.py:163-180) -------------
+    def arm_overlapped_reduce(self, when_last_outstanding: bool = False):
+        """Declare the trunk's next backward (or the one consuming its last saved forward) the step's final gradient
+        contribution: its per-block gradient slices are all-reduced on a side stream while the remaining blocks are still
+        being differentiated (NomicBertEngine.arm_overlapped_reduce); sync_gradients() then only waits and rescales."""
+        if not self.frozen_trunk and self.overlap_reduce:
+            self.trunk.arm_overlapped_reduce(when_last_outstanding)
+
     def sync_gradients(self):
-        """Average the flat gradient buffer over ranks: ONE all-reduce over RCCL/xGMI per optimizer step."""
+        """Average the flat gradient buffer over ranks (RCCL over xGMI): either the per-block all-reduces an armed final
+        backward already put in flight (waited for here), or ONE blocking all-reduce of the whole buffer."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             W = dist.get_world_size()
-            dist.all_reduce(self.trunk.flat_grad, op=dist.ReduceOp.SUM)
+            if not self.trunk.finish_overlapped_reduce():
+                dist.all_reduce(self.trunk.flat_grad, op=dist.ReduceOp.SUM)
             self.trunk.flat_grad.div_(W)
             for p in self.proj.parameters():
                 if p.grad is not None:

@@ -55,10 +55,11 @@ class TrainArgs(BaseModel):
     gradcache_chunk: Union[int, str, None] = "auto"       # auto: chunk_size is a lower bound | exact | n
     gradcache_resident: Union[bool, str, None] = "auto"   # auto: keep pass 1's activations when they fit | true | false
     exchange: Optional[str] = "auto"                       # embedding exchange: auto (validated + timed at start-up) | rccl | oneshot
+    overlap_grad_reduce: bool = True                       # per-block gradient all-reduce inside the step's last backward (DDP-style)
 
     @model_validator(mode="after")
     def _checks(self):
-        from .loss import _parse_chunk, _parse_resident   # (validate here, not at the first training step)
+        from .policy import _parse_chunk, _parse_resident   # (validate here, not at the first training step)
 
         _parse_chunk(self.gradcache_chunk, "train_args.gradcache_chunk")
         _parse_resident(self.gradcache_resident, "train_args.gradcache_resident")

@@ -22,6 +22,12 @@ namespace {
 
 inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
+// CxChunkBuffers.layer_events: block l's (or, at index n_layer, the embeddings') parameter gradients are complete
+inline int mark_grads_done(const CxChunkBuffers* buf, int idx, void* stream) {
+    if (!buf->layer_events || !buf->layer_events[idx]) return CX_OK;
+    return hipEventRecord((hipEvent_t)buf->layer_events[idx], (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
 // Slot mapping.  mode 0: every layer shares slot 0 (no-grad pass); 1: one slot per layer (saved for backward);
 // 2 (activation checkpointing, sc/models/encoder/modeling_nomic_bert.py:339-365, sc/models/vit/vit.py:200-231): only the
 // tensor that carries a block's INPUT keeps one slot per layer -- h2 (the previous block's output) for post-norm trunks,
@@ -361,6 +367,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                 CX_TRY(attn_bwd(w, l, buf->g_d, h_in, buf->g_a, &f2));
                 da = f2 ? buf->g_b : buf->g_a;
                 db = f2 ? nullptr : buf->g_b;
+                CX_TRY(mark_grads_done(buf, l, stream));
                 continue;
             }
             // LN2: dz2 = grad of (mlp_out + h1)
@@ -381,6 +388,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
             CX_TRY(attn_bwd(w, l, buf->g_a, h_in, buf->g_a, &f2));
             da = f2 ? buf->g_b : buf->g_a;  // dz1 (residual branch into h_in) [+ the attention branch when folded]
             db = f2 ? nullptr : buf->g_b;   // attention branch into h_in
+            CX_TRY(mark_grads_done(buf, l, stream));
         }
         *da_out = da;
         *db_out = db;
@@ -410,6 +418,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         CX_TRY(attn_bwd(w, l, buf->g_a, s.h1(l), nullptr, &unused));   // -> g_b = d h1
         CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), /*dz_extra*/ buf->g_a,
                                 buf->g_c, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+        CX_TRY(mark_grads_done(buf, l, stream));
     }
     *da_out = buf->g_c;
     *db_out = nullptr;
@@ -469,14 +478,17 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     }
     // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
     // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
-    if (sort_ids && sort_perm)
-        return cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+    if (sort_ids && sort_perm) {
+        CX_TRY(cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                                       buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                                       enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, enc->vocab, sort_ids,
-                                      sort_perm, buf->g_wide, stream);
-    return cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
-                           buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
-                           enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);
+                                      sort_perm, buf->g_wide, stream));
+    } else {
+        CX_TRY(cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+                               buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
+                               enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream));
+    }
+    return mark_grads_done(buf, enc->n_layer, stream);
 }
 
 // ---- token-level outputs (MLM head, sc/models/encoder/modeling_nomic_bert.py:590-669): same trunk, no pooling ------
@@ -525,14 +537,17 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
     }
     // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
     // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
-    if (sort_ids && sort_perm)
-        return cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+    if (sort_ids && sort_perm) {
+        CX_TRY(cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                                       buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                                       enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, enc->vocab, sort_ids,
-                                      sort_perm, buf->g_wide, stream);
-    return cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
-                           buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
-                           enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream);
+                                      sort_perm, buf->g_wide, stream));
+    } else {
+        CX_TRY(cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
+                               buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
+                               enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, stream));
+    }
+    return mark_grads_done(buf, enc->n_layer, stream);
 }
 
 // ---- ViT image tower -------------------------------------------------------------------------------------------------
@@ -590,10 +605,11 @@ int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const i
     }
     CX_TRY(cx_vit_assemble_bwd(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, stream));
     if (enc->gbpatch) CX_TRY(cx_bias_grad(buf->patch_proj, enc->gbpatch, Tp, d, d, stream));
-    return wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream);
+    CX_TRY(wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream));
+    return mark_grads_done(buf, enc->n_layer, stream);
 }
 
-int cx_abi_version(void) { return 4; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop
+int cx_abi_version(void) { return 5; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

@@ -51,25 +51,52 @@ class OneShotExchange:
         self.epoch = 0
         self._own: List[int] = []
         self._opened: List[int] = []
-        with torch.cuda.device(self.device):
-            nb = self.N_BUF
-            own = [self._alloc(self.cap, 0) for _ in range(nb)] + [self._alloc(256, 1), self._alloc(256, 2)]
-            self._data, self._flags, self._err = own[:nb], own[nb], own[nb + 1]
-            torch.as_tensor(_RawDeviceF32(own[nb], 64), device=self.device).zero_()
-            C.memset(self._err, 0, 256)   # mapped host memory: the wait kernel stores here, check() reads it with no sync
-            torch.cuda.synchronize(self.device)
-            handles = [self._export(p) for p in own[: nb + 1]]
-            everyone: List[Optional[list]] = [None] * self.world
-            dist.all_gather_object(everyone, handles, group=group)
-            peers = [[] for _ in range(nb + 1)]   # data buffers, flags: one pointer per rank
-            for r, hs in enumerate(everyone):
-                for k in range(nb + 1):
-                    peers[k].append(own[k] if r == self.rank else self._open(hs[k]))
-            as_dev = lambda ptrs: torch.tensor(ptrs, dtype=torch.int64, device=self.device)  # noqa: E731
-            self._peer_data = [as_dev(peers[k]) for k in range(nb)]
-            self._peer_flags = as_dev(peers[nb])
-            self._views = [torch.as_tensor(_RawDeviceF32(p, self.cap // 4), device=self.device) for p in self._data]
+        # Set-up is three phases so that a LOCAL failure (allocation, IPC export / open) can never leave the other ranks
+        # blocked in a collective: every rank reaches every all_gather_object, carrying either its data or its error, and
+        # all of them raise together.
+        nb = self.N_BUF
+        own, handles, err = [], None, None
+        try:
+            with torch.cuda.device(self.device):
+                own = [self._alloc(self.cap, 0) for _ in range(nb)] + [self._alloc(256, 1), self._alloc(256, 2)]
+                self._data, self._flags, self._err = own[:nb], own[nb], own[nb + 1]
+                torch.as_tensor(_RawDeviceF32(own[nb], 64), device=self.device).zero_()
+                C.memset(self._err, 0, 256)   # mapped host memory: the wait kernel stores here, check() reads it with no sync
+                torch.cuda.synchronize(self.device)
+                handles = [self._export(p) for p in own[: nb + 1]]
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {self.rank}: {e}"
+        everyone: List[Optional[object]] = [None] * self.world
+        dist.all_gather_object(everyone, handles if err is None else RuntimeError(err), group=group)
+        bad = [h for h in everyone if isinstance(h, Exception)]
+        if not bad:
+            try:
+                with torch.cuda.device(self.device):
+                    peers = [[] for _ in range(nb + 1)]   # data buffers, flags: one pointer per rank
+                    for r, hs in enumerate(everyone):
+                        for k in range(nb + 1):
+                            peers[k].append(own[k] if r == self.rank else self._open(hs[k]))
+                    as_dev = lambda ptrs: torch.tensor(ptrs, dtype=torch.int64, device=self.device)  # noqa: E731
+                    self._peer_data = [as_dev(peers[k]) for k in range(nb)]
+                    self._peer_flags = as_dev(peers[nb])
+                    self._views = [torch.as_tensor(_RawDeviceF32(p, self.cap // 4), device=self.device) for p in self._data]
+            except Exception as e:  # noqa: BLE001
+                err = f"rank {self.rank}: {e}"
+            oks: List[Optional[object]] = [None] * self.world
+            dist.all_gather_object(oks, err, group=group)
+            bad = [RuntimeError(o) for o in oks if o is not None]
+        if bad:
+            self._teardown_local()
+            raise RuntimeError(f"one-shot exchange set-up failed ({bad[0]})")
         dist.barrier(group=group)   # nobody stores into a buffer its owner has not finished setting up
+
+    def _teardown_local(self):
+        for p in self._opened:
+            self.lib.cx_ipc_close(p)
+        self._opened = []
+        for p in self._own:
+            self.lib.cx_ipc_free(p)
+        self._own = []
 
     # ---- memory plumbing
     def _alloc(self, nbytes: int, uncached: int) -> int:
@@ -157,27 +184,179 @@ class OneShotExchange:
         return out
 
 
+# ---- which path carries gather_with_grad: decided ONCE per process, by measurement -----------------
+# mode "auto" (TrainArgs.exchange default; CX_EXCHANGE overrides): at the first exchange of fp32 CUDA embeddings every
+# rank (1) sets the one-shot exchange up, (2) checks its all-gather and reduce-scatter bit-exact against the process
+# group's collectives (RCCL on a real node) on integer-valued data, (3) times both at the call's own payload, and (4) takes
+# the faster one -- the verdict is computed from MAX-over-ranks timings that are identical everywhere, and every step that
+# can fail locally is followed by an agreement collective, so all ranks always choose the same path.  "rccl" skips all of
+# it; "oneshot" keeps steps 1-2 and skips the race.  What happened is kept in exchange_report().
 _ONESHOT: Optional[OneShotExchange] = None
-_ONESHOT_BROKEN = False
+_EXCHANGE_MODE = "auto"
+_EXCHANGE_CHOICE: Optional[str] = None      # None = not decided yet; "oneshot" | "pg"
+_EXCHANGE_REPORT: dict = {}
 
 
-def _oneshot_for(nbytes_total: int, device) -> Optional[OneShotExchange]:
-    """CX_EXCHANGE=oneshot: the one-shot path for fp32 CUDA tensors (set up on first use; 64 MiB buffers cover 8 x 2048 x
-    768 fp32 = 50 MB).  Any failure in the set-up disables it for the process and the RCCL collectives take over.  The
-    default is RCCL: the one-shot path has run on 2 processes sharing one GPU (tests/test_distributed_gpu.py) but not yet
-    on a multi-GPU node; `bench.py --gpus N` times both and says so in its xgmi_allgather record."""
-    global _ONESHOT, _ONESHOT_BROKEN
-    if os.environ.get("CX_EXCHANGE", "rccl") != "oneshot" or _ONESHOT_BROKEN:
-        return None
-    if _ONESHOT is None or _ONESHOT.cap < nbytes_total:
+def set_exchange_mode(mode: str):
+    """Config entry point (train_args.exchange): auto | rccl | oneshot.  Changing it re-opens the decision."""
+    global _EXCHANGE_MODE, _EXCHANGE_CHOICE
+    if mode not in ("auto", "rccl", "oneshot"):
+        raise ValueError(f"exchange mode must be auto, rccl or oneshot, got {mode!r}")
+    if mode != _EXCHANGE_MODE:
+        _EXCHANGE_MODE, _EXCHANGE_CHOICE = mode, None
+
+
+def exchange_mode() -> str:
+    env = os.environ.get("CX_EXCHANGE")
+    if env:
+        if env not in ("auto", "rccl", "oneshot"):
+            raise ValueError(f"CX_EXCHANGE must be auto, rccl or oneshot, got {env!r}")
+        return env
+    return _EXCHANGE_MODE
+
+
+def exchange_report() -> dict:
+    """What the selection measured and decided (bench.py prints it; the trainers log it once)."""
+    return dict(_EXCHANGE_REPORT)
+
+
+def reset_exchange():
+    """Forget the decision and release the one-shot buffers (tests; a re-initialised process group)."""
+    global _ONESHOT, _EXCHANGE_CHOICE
+    if _ONESHOT is not None:
         try:
+            _ONESHOT.close()
+        except Exception:  # noqa: BLE001
+            pass
+    _ONESHOT, _EXCHANGE_CHOICE = None, None
+    _EXCHANGE_REPORT.clear()
+
+
+def _agree(ok: bool, device) -> bool:
+    """MIN over ranks of a flag: every rank takes the same branch."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def _pg_all_gather(t: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
+def _pg_reduce_scatter(g: torch.Tensor, n: int) -> torch.Tensor:
+    if dist.get_backend() == "nccl":
+        out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
+        return out
+    # gloo (CPU tests, two processes sharing one GPU) has no reduce_scatter: all-reduce and keep our slice (same result)
+    g = g.clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    r = dist.get_rank()
+    return g[r * n: (r + 1) * n].contiguous()
+
+
+def _time_us(fn, iters: int = 5) -> float:
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def _select_exchange(shard: torch.Tensor) -> Optional[OneShotExchange]:
+    """Run the selection described above for shards shaped like `shard` ((n, d) fp32 on this rank's GPU)."""
+    global _ONESHOT, _EXCHANGE_CHOICE
+    mode = exchange_mode()
+    W, rank, dev = dist.get_world_size(), dist.get_rank(), shard.device
+    rep = {"mode": mode, "backend": dist.get_backend(), "world": W, "shard_bytes": shard.numel() * 4}
+    _EXCHANGE_REPORT.clear()
+    _EXCHANGE_REPORT.update(rep)
+    if mode == "rccl":
+        _EXCHANGE_CHOICE = "pg"
+        _EXCHANGE_REPORT.update(choice="pg", reason="configured")
+        return None
+    # (1) set-up: collective by construction (see OneShotExchange.__init__)
+    try:
+        if _ONESHOT is None or _ONESHOT.cap < W * shard.numel() * 4:
             if _ONESHOT is not None:
                 _ONESHOT.close()
-            _ONESHOT = OneShotExchange(max(nbytes_total, 64 << 20), device=device)
-        except Exception as e:  # noqa: BLE001
-            warnings.warn(f"one-shot xGMI exchange unavailable ({e}); using the process group's collectives")
-            _ONESHOT, _ONESHOT_BROKEN = None, True
-            return None
+                _ONESHOT = None
+            _ONESHOT = OneShotExchange(max(W * shard.numel() * 4, 64 << 20), device=dev)
+        err = None
+    except Exception as e:  # noqa: BLE001  (raised on every rank together)
+        err = str(e)
+    if err is not None:
+        warnings.warn(f"one-shot xGMI exchange unavailable ({err}); using the process group's collectives")
+        _ONESHOT, _EXCHANGE_CHOICE = None, "pg"
+        _EXCHANGE_REPORT.update(choice="pg", reason=f"set-up failed: {err}")
+        return None
+    ex = _ONESHOT
+    # (2) bit-exact check against the process group on integer-valued data (fp32 sums of small integers are exact in any
+    # order, so RCCL's ring order and the one-shot path's rank order must agree to the last bit)
+    n = shard.shape[0]
+    rows = torch.arange(n * shard[0].numel(), device=dev, dtype=torch.float32).reshape(shard.shape) % 251
+    probe = rows + 1000.0 * (rank + 1)
+    gprobe = (torch.arange(W * n * shard[0].numel(), device=dev, dtype=torch.float32).reshape((W * n,) + tuple(shard.shape[1:])) % 127
+              ) * (rank + 1)
+    ok, why = True, ""
+    try:
+        a_ref, a_got = _pg_all_gather(probe), ex.all_gather(probe)
+        r_ref, r_got = _pg_reduce_scatter(gprobe, n), ex.reduce_scatter(gprobe)
+        torch.cuda.synchronize(dev)
+        ex.check()
+        if not torch.equal(a_ref, a_got):
+            ok, why = False, "all-gather differs from the process group's"
+        elif not torch.equal(r_ref, r_got):
+            ok, why = False, "reduce-scatter differs from the process group's"
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, str(e)
+    if not _agree(ok, dev):
+        warnings.warn(f"one-shot xGMI exchange failed its check against the process group ({why or 'on another rank'}); "
+                      "using the process group's collectives")
+        _EXCHANGE_CHOICE = "pg"
+        _EXCHANGE_REPORT.update(choice="pg", verified=False, reason=f"verification failed: {why or 'on another rank'}")
+        return None
+    _EXCHANGE_REPORT.update(verified=True)
+    if mode == "oneshot":
+        _EXCHANGE_CHOICE = "oneshot"
+        _EXCHANGE_REPORT.update(choice="oneshot", reason="configured")
+        return ex
+    # (3) + (4) the race, at this call's payload: all-gather + reduce-scatter of the step, MAX over ranks
+    g_full = torch.zeros((W * n,) + tuple(shard.shape[1:]), dtype=torch.float32, device=dev)
+    t_one = _time_us(lambda: (ex.all_gather(shard), ex.reduce_scatter(g_full)))
+    t_pg = _time_us(lambda: (_pg_all_gather(shard), _pg_reduce_scatter(g_full, n)))
+    t = torch.tensor([t_one, t_pg], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_one, t_pg = float(t[0]), float(t[1])
+    _EXCHANGE_CHOICE = "oneshot" if t_one < t_pg else "pg"
+    _EXCHANGE_REPORT.update(choice=_EXCHANGE_CHOICE, oneshot_us=round(t_one, 1), pg_us=round(t_pg, 1),
+                            reason="faster of the two on this node (all-gather + reduce-scatter at the step's payload)")
+    if rank == 0:
+        import logging
+
+        logging.getLogger("contrastors_amd").info(
+            f"embedding exchange: one-shot xGMI {t_one:.0f} us vs {dist.get_backend()} {t_pg:.0f} us per all-gather + "
+            f"reduce-scatter of {W} x {shard.numel() * 4} B (verified bit-exact) -> {_EXCHANGE_CHOICE}")
+    return ex if _EXCHANGE_CHOICE == "oneshot" else None
+
+
+def _oneshot_for(shard: torch.Tensor) -> Optional[OneShotExchange]:
+    """The one-shot exchange when it carries this process's gather_with_grad, else None (the process group does)."""
+    global _ONESHOT
+    if _EXCHANGE_CHOICE is None:
+        return _select_exchange(shard)
+    if _EXCHANGE_CHOICE != "oneshot" or _ONESHOT is None:
+        return None
+    need = dist.get_world_size() * shard.numel() * 4
+    if _ONESHOT.cap < need:   # a larger batch than the one the buffers were sized for: same on every rank -> collective
+        _ONESHOT.close()
+        _ONESHOT = OneShotExchange(need, device=shard.device)
     return _ONESHOT
 
 
@@ -187,28 +366,18 @@ class _AllGatherCat(torch.autograd.Function):
         W = dist.get_world_size()
         t = t.contiguous()
         ctx.n = t.shape[0]
-        ex = _oneshot_for(W * t.numel() * 4, t.device) if (t.is_cuda and t.dtype == torch.float32 and (t.numel() * 4) % 16 == 0) else None
+        ex = _oneshot_for(t) if (t.is_cuda and t.dtype == torch.float32 and (t.numel() * 4) % 16 == 0 and t.ndim >= 2) else None
         ctx.oneshot = ex is not None
         if ex is not None:
             return ex.all_gather(t)
-        out = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t)
-        return out
+        return _pg_all_gather(t)
 
     @staticmethod
     def backward(ctx, g: torch.Tensor) -> torch.Tensor:
         g = g.contiguous()
-        rank = dist.get_rank()
         if ctx.oneshot and _ONESHOT is not None and g.dtype == torch.float32:
             return _ONESHOT.reduce_scatter(g)
-        if dist.get_backend() == "nccl":
-            out = torch.empty((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
-            return out
-        # gloo (CPU tests) has no reduce_scatter: all-reduce and keep our slice (same result)
-        g = g.clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        return g[rank * ctx.n: (rank + 1) * ctx.n].contiguous()
+        return _pg_reduce_scatter(g, ctx.n)
 
 
 def gather_with_grad(t: torch.Tensor) -> torch.Tensor:

@@ -13,14 +13,14 @@ bidirectional, router_aux_coeff)`.  What changes is underneath:
 from __future__ import annotations
 
 import logging
-from dataclasses import dataclass
-from typing import Dict, List, Optional, Union
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
 
 from . import _C
 from .distributed import gather_with_grad
+from .policy import GradCachePolicy
 from .rand_state import RandContext
 
 
@@ -260,11 +260,16 @@ def get_chunked_embeddings(model, chunks, rand_states=None):
     return torch.cat(embs, dim=0)
 
 
-def accumulate_gradients(model, chunks, cache, rand_states=None):
+def accumulate_gradients(model, chunks, cache, rand_states=None, final: bool = False):
     """Pass 2 (sc/loss.py:149-161): re-forward under the chunk's saved RNG state, back-propagate the cached embedding
-    gradient through it."""
+    gradient through it.  `final`: this call's last chunk completes the tower's gradients for the step -- its backward
+    starts the data-parallel reduction block by block (the reference's DDP does the same on the chunk it does not wrap in
+    no_sync, sc/loss.py:151)."""
+    n = len(chunks)
     for i, (c, g) in enumerate(zip(chunks, cache)):
         state = rand_states[i] if rand_states is not None else RandContext(c, needed=False)
+        if final and i == n - 1 and hasattr(model, "arm_overlapped_reduce"):
+            model.arm_overlapped_reduce()
         with state:
             out = model(**c)["embedding"]
         surrogate = torch.dot(out.flatten(), g.flatten().to(out.dtype))
@@ -278,64 +283,6 @@ def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional
     loss = clip_loss(q, d, logit_scale, gather_enabled=True, bidirectional=bidirectional, use_fp8=use_fp8)
     loss.backward()
     return q.grad, d.grad, loss.detach()
-
-
-@dataclass
-class GradCachePolicy:
-    """How grad_cache_loss schedules a step on a 288 GB part.  These are CONFIG fields (TrainArgs.gradcache_chunk /
-    gradcache_resident / use_fp8, `GradCachePolicy.from_train_args`); the environment variables of round 2
-    (CX_GRADCACHE_CHUNK, CX_GRADCACHE_RESIDENT) remain as an operator OVERRIDE on top of whatever the config says.
-      chunk     "auto": the recipe's chunk_size is a lower bound, raised until a chunk carries ~262144 tokens or its arena
-                would take a third of the free HBM | "exact": the recipe's number, literally | n: force n
-      resident  "auto": keep pass 1's activations when they need <= 80 % of the free HBM (no re-forward) | True | False
-      use_fp8   similarity GEMM of the loss on the fp8 matrix cores
-    The schedule actually taken is logged once per distinct decision (logger "contrastors_amd")."""
-    chunk: Union[str, int] = "auto"
-    resident: Union[str, bool] = "auto"
-    use_fp8: bool = False
-
-    @classmethod
-    def from_train_args(cls, ta) -> "GradCachePolicy":
-        return cls(chunk=_parse_chunk(getattr(ta, "gradcache_chunk", "auto"), "train_args.gradcache_chunk"),
-                   resident=_parse_resident(getattr(ta, "gradcache_resident", "auto"), "train_args.gradcache_resident"),
-                   use_fp8=bool(getattr(ta, "use_fp8", False)))
-
-    def with_env(self) -> "GradCachePolicy":
-        import os
-
-        c, r = os.environ.get("CX_GRADCACHE_CHUNK"), os.environ.get("CX_GRADCACHE_RESIDENT")
-        return GradCachePolicy(chunk=self.chunk if c in (None, "") else _parse_chunk(c, "CX_GRADCACHE_CHUNK"),
-                               resident=self.resident if r in (None, "") else _parse_resident(r, "CX_GRADCACHE_RESIDENT"),
-                               use_fp8=self.use_fp8)
-
-
-def _parse_chunk(v, where: str):
-    if v is None or v == "":
-        return "auto"
-    if isinstance(v, str) and v.lower() in ("auto", "exact"):
-        return v.lower()
-    try:
-        n = int(v)
-    except (TypeError, ValueError):
-        raise ValueError(f"{where} must be 'auto', 'exact' or a positive integer, got {v!r}") from None
-    if n <= 0:
-        raise ValueError(f"{where} must be 'auto', 'exact' or a positive integer, got {v!r}")
-    return n
-
-
-def _parse_resident(v, where: str):
-    if v is None or v == "":
-        return "auto"
-    if isinstance(v, bool):
-        return v
-    t = str(v).lower()
-    if t == "auto":
-        return "auto"
-    if t in ("1", "true", "yes", "on"):
-        return True
-    if t in ("0", "false", "no", "off"):
-        return False
-    raise ValueError(f"{where} must be 'auto', true / 1 or false / 0, got {v!r}")
 
 
 _LOGGED: set = set()
@@ -435,10 +382,12 @@ def _resident_forward(model, chunks):
         return [model(**c)["embedding"] for c in chunks]
 
 
-def _resident_backward(outs, cache):
-    for o, g in zip(outs, cache):
-        if o.requires_grad:
-            o.backward(g.to(o.dtype))
+def _resident_backward(model, outs, cache, final: bool = False):
+    live = [(o, g) for o, g in zip(outs, cache) if o.requires_grad]
+    for i, (o, g) in enumerate(live):
+        if final and i == len(live) - 1 and hasattr(model, "arm_overlapped_reduce"):
+            model.arm_overlapped_reduce()
+        o.backward(g.to(o.dtype))
 
 
 def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scale, bidirectional=False,
@@ -479,8 +428,8 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")
         else:
-            _resident_backward(q_out, q_cache.split(sizes_q))
-            _resident_backward(d_out, d_cache.split(sizes_d))
+            _resident_backward(tower1, q_out, q_cache.split(sizes_q), final=tower1 is not tower2 or not was_training2)
+            _resident_backward(tower2, d_out, d_cache.split(sizes_d), final=True)
             del q_out, d_out
             done = True
     if not done:
@@ -488,9 +437,10 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
         q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd)
         d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd)
         q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
-        accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd)
+        # (a tower shared by both sides has its gradients complete only after the document pass)
+        accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd, final=tower1 is not tower2 or not was_training2)
         if was_training2:
-            accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd)
+            accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd, final=True)
     # data-parallel reduction of the accumulated gradients: once per step, one flat buffer per distinct tower
     seen = set()
     for tw, active in ((tower1, was_training1), (tower2, was_training2)):
@@ -507,6 +457,6 @@ def _release_resident(tower, outs):
     for o in outs:
         fn = getattr(o, "grad_fn", None)   # the ctx of nomic_bert._EncodeFn / vit._VitEncodeFn when the tower is "plain"
         eng, arena = getattr(fn, "engine", None), getattr(fn, "arena", None)
-        if eng is not None and arena is not None and hasattr(eng, "release_arena"):
-            eng.release_arena(arena)
+        if eng is not None and arena is not None and hasattr(eng, "abandon_arena"):
+            eng.abandon_arena(arena)
             fn.arena = None

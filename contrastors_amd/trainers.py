@@ -20,7 +20,8 @@ import torch.distributed as dist
 from .biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
 from .config import Config
 from .distributed import gather_with_grad, set_exchange_mode
-from .loss import GradCachePolicy, clip_loss, grad_cache_loss
+from .loss import clip_loss, grad_cache_loss
+from .policy import GradCachePolicy
 from .nomic_bert import NomicBertConfig
 from .optimizer import FusedAdamW
 
@@ -121,6 +122,7 @@ class TextTextTrainer:
                                  nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
                              trunk_config=trunk_config)
         model = BiEncoder(bc, device=self.device).train()
+        model.overlap_reduce = bool(config.train_args.overlap_grad_reduce)
         _load_initial_weights(model, ma, explicit_arch=trunk_config is not None)
         model.broadcast_parameters(0)  # what DDP's constructor does
         scale = LogitScale(SimpleNamespace(logit_scale=ma.logit_scale, trainable_logit_scale=ma.trainable_logit_scale))
@@ -193,6 +195,9 @@ class TextTextTrainer:
     def backward(self, loss: torch.Tensor):
         if self.config.train_args.grad_cache:
             return  # gradients were accumulated inside grad_cache_loss (text_text.py:292-302)
+        # the tower ran twice in this graph (queries, documents): the backward that consumes its last saved forward
+        # completes its gradients and starts their reduction block by block
+        self.model["model"].arm_overlapped_reduce(when_last_outstanding=True)
         loss.backward()
         self.model["model"].sync_gradients()
         self._sync_logit_scale_grad()
@@ -305,6 +310,7 @@ class ImageTextTrainer(TextTextTrainer):
                                  nomic_encoder=ma.nomic_encoder,
                                  seq_len=ma.seq_len, trunk_config=trunk)
             tower = BiEncoder(bc, device=self.device).train()
+            tower.overlap_reduce = bool(config.train_args.overlap_grad_reduce)
             _load_initial_weights(tower, ma, explicit_arch=trunk is not None)
             tower.broadcast_parameters(0)
             towers.append(tower)
@@ -340,6 +346,8 @@ class ImageTextTrainer(TextTextTrainer):
         return self.model["model"](text, vision)
 
     def backward(self, loss):
+        for t in self._trainable_towers():
+            t.arm_overlapped_reduce(when_last_outstanding=True)
         loss["loss"].backward()
         for t in self._trainable_towers():
             t.sync_gradients()

@@ -191,6 +191,7 @@ class ViTEngine(NomicBertEngine):
         if save_for_backward:
             arena.emb_out = out
             arena.normalize = self._desc.normalize
+            self._outstanding += 1
             return out, arena
         return out, None
 
@@ -199,10 +200,11 @@ class ViTEngine(NomicBertEngine):
         B = pixels_or_B if isinstance(pixels_or_B, int) else pixels_or_B.shape[0]
         demb = demb.to(torch.float32).contiguous()
         self._desc.normalize = arena.normalize
+        fires = self._begin_backward(arena)
         rc = self.lib.cx_vit_backward(C.byref(self._desc), C.byref(arena.desc), self._cu_seqlens(B).data_ptr(), B,
                                       self.config.n_patch, demb.data_ptr(), arena.emb_out.data_ptr(), _C.cur_stream())
         _C.check(rc, "cx_vit_backward")
-        self.release_arena(arena)
+        self._end_backward(arena, fires)
 
     def forward(self, pixels: torch.Tensor, attention_mask=None, normalize: Optional[bool] = None) -> torch.Tensor:
         if torch.is_grad_enabled() and self.training:

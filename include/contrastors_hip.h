@@ -376,6 +376,13 @@ typedef struct CxChunkBuffers {
     int drop_active;
     unsigned long long drop_seed, drop_offset;
     uint16_t* g_d;
+    /* Optional (NULL = none): HOST array of n_layer + 1 hipEvent_t.  A backward call records layer_events[l] on `stream`
+     * right after the last kernel that writes block l's parameter gradients (blocks run L-1 ... 0), and
+     * layer_events[n_layer] after the embedding (text) / patch-projection (ViT) gradients, i.e. at the end of the call.
+     * The data-parallel gradient reduction of a step's LAST backward starts on block l's slice of the flat gradient as
+     * soon as its event fires, overlapped with the blocks still differentiating -- what DDP's bucket hooks do for the
+     * reference (sc/trainers/text_text.py:163-170). */
+    void* const* layer_events;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.
