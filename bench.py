@@ -19,8 +19,11 @@ The JSON line carries, besides the contract fields:
   weak          the same step at 2048 pairs per GPU (global batch 2048 x N: SURVEY.md §8(d) asks for both curves)
   resident      2048 pairs per GPU with pass 1's activations kept in HBM (no re-forward; identical results)
   dropin_chunk64  (N = 1) the same step at the reference recipe's GradCache chunk_size 64 (contrastive_pretrain.yaml:15)
+  exchange      (N > 1) what carries the embedding exchange: set up, verified bit-exact against RCCL, timed, faster one chosen
   xgmi_allgather  (N > 1) the embedding all-gather of the loss timed on its own, against 7 x 153 GB/s of xGMI per GPU
-  cpu_baseline  (N = 1) oracle = CPU restatement of the reference, one 64-pair chunk forward + backward, min of 3
+  cfg1 / cfg3 / lit / clip  (N = 1) the other BASELINE configs at their per-GPU shapes, each with its own roofline fraction
+  cpu_baseline  (N = 1) oracle = CPU restatement of the reference: one 64-pair cfg-2 chunk forward + backward, and the
+                cfg-1 full step (bert-base, B = 32, S = 64: forward, backward, InfoNCE, AdamW) on the host cores
 """
 from __future__ import annotations
 
@@ -42,6 +45,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0      # MI355X dense fp8 MFMA
 GFLOP_PER_PAIR = 236.84       # 2 seqs x 4 fwd-equivalents x 29.595 GFLOP + loss
 XGMI_PEAK_GBS = 7 * 153.0     # per GPU, each direction
 WEAK_PAIRS_PER_GPU = 2048     # per-GPU b = 2048 fixed
@@ -61,6 +65,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the metric
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the weak-scaling and chunk-64 records")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the cfg1 / cfg3 / lit / clip records (N = 1)")
+    ap.add_argument("--only-config-legs", type=str, default="", help=argparse.SUPPRESS)  # profiling: e.g. cfg3 or lit,clip
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     # every 7th GEMM launch is timed with HIP events: a stride coprime to the launch pattern's periods (4 GEMMs per layer
     # forward, 8 per layer backward) so that the sample walks through every shape; a stride of 8 always lands on the
@@ -132,10 +138,230 @@ def cpu_baseline(seq_len: int) -> dict:
         step(pairs)
         times.append(time.perf_counter() - t0)
     dt = min(times)
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"one {pairs}-pair chunk x seq {seq_len}, direct fwd+bwd+InfoNCE (3x fwd FLOPs, no GradCache "
-                      f"re-forward), fp32 torch-CPU oracle port (the reference tree is absent on the GPU box), min of "
-                      f"{reps} reps = {dt:.2f} s (all: {', '.join(f'{t:.2f}' for t in times)})"}
+    out = {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": f"one {pairs}-pair chunk x seq {seq_len}, direct fwd+bwd+InfoNCE (3x fwd FLOPs, no GradCache "
+                     f"re-forward), fp32 torch-CPU oracle port (the reference tree is absent on the GPU box), min of "
+                     f"{reps} reps = {dt:.2f} s (all: {', '.join(f'{t:.2f}' for t in times)})"}
+    # BASELINE configs[0] / SURVEY.md §8(d): the reference's own CPU-runnable case as a FULL step -- bert-base-uncased
+    # bi-encoder, paired InfoNCE, batch 32, seq 64: forward, backward, loss, clip, AdamW on the host cores
+    del sd
+    cfg1 = NomicBertConfig.bert_base_uncased()
+    ns1 = SimpleNamespace(**{k: getattr(cfg1, k) for k in cfg1.__dataclass_fields__})
+    sd1 = encoder_ref.random_state_dict(ns1, 0)
+    params = [v.requires_grad_(True) for v in sd1.values()]
+    opt = torch.optim.AdamW(params, lr=2e-5, weight_decay=0.01)
+    B1, S1 = 32, 64
+    q1 = torch.randint(1000, 30522, (B1, S1), generator=g)
+    d1 = torch.randint(1000, 30522, (B1, S1), generator=g)
+    m1 = torch.ones(B1, S1, dtype=torch.long)
+
+    def step1():
+        opt.zero_grad(set_to_none=True)
+        loss = infonce_ref.clip_loss_ref(encoder_ref.biencoder_embedding(sd1, ns1, q1, m1),
+                                         encoder_ref.biencoder_embedding(sd1, ns1, d1, m1), 50.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+
+    step1()
+    t1 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step1()
+        t1.append(time.perf_counter() - t0)
+    out["cfg1_full_step"] = {"value": B1 / min(t1), "unit": "pairs/s", "ms_per_step": 1e3 * min(t1), "cores": cores,
+                             "sample": f"configs[0]: bert-base bi-encoder, B = {B1}, S = {S1}, full step (fwd + bwd + InfoNCE + clip + "
+                                       f"AdamW), fp32 torch-CPU oracle port, min of 3 = {min(t1):.2f} s"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------- the other BASELINE configs
+# Each leg runs its config's per-GPU SHAPE on one GPU (synthetic inputs, random-init weights of the named architecture) as a
+# full training step and reports examples/s + the fraction of the bf16 MFMA peak its ALGORITHMIC encoder FLOPs amount to
+# (re-computation under activation checkpointing is not counted as work).
+def _fwd_flop_per_token(d, mlp_cols, S):   # 2 * (Wqkv + Wout + fc1 + fc2) + QK^T and PV
+    return 2.0 * d * (3 * d + d + mlp_cols) + 4.0 * S * d
+
+
+def _time_steps(torch, step, warmup, steps):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+
+
+def _pct(sorted_ms, q):
+    return sorted_ms[min(len(sorted_ms) - 1, max(0, int(round(q * (len(sorted_ms) - 1)))))]
+
+
+def leg_cfg1(torch, dev, steps):
+    """configs[0] on the HIP path (its CPU twin is cpu_baseline.cfg1_full_step): bert-base bi-encoder, B = 32, S = 64, direct
+    step.  M = 2048 token rows per GEMM launch: the launch-bound end of the design, reported so that it is on record."""
+    from contrastors_amd.config import Config, DataArgs, ModelArgs, TrainArgs
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from contrastors_amd.trainers import TextTextTrainer
+
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=1, grad_cache=False,
+                                      schedule_type="linear", max_grad_norm=1.0, clamp_logits=False),
+                 data_args=DataArgs(batch_size=32, seed=3),
+                 model_args=ModelArgs(logit_scale=50.0, pooling="mean", model_name="bert-base-uncased", seq_len=64))
+    tr = TextTextTrainer(cfg, torch.bfloat16, device=dev, trunk_config=NomicBertConfig.bert_base_uncased(), total_steps=1000)
+    g = torch.Generator().manual_seed(7)
+    B, S = 32, 64
+    batch = {}
+    for side in ("query", "document"):
+        batch[f"{side}_input_ids"] = torch.randint(1000, 30522, (B, S), generator=g).to(dev)
+        batch[f"{side}_seqlens"] = [S] * B
+    ms = _time_steps(torch, lambda: tr.training_step(batch), 3, max(steps, 10))
+    flop = 3 * 2 * B * S * 12 * _fwd_flop_per_token(768, 2 * 3072, S)
+    med = _pct(ms, 0.5)
+    return {"workload": "configs[0]: bert-base-uncased bi-encoder, paired InfoNCE, B = 32, S = 64, direct step (HIP path)",
+            "value": B / (med * 1e-3), "unit": "pairs/s", "ms_per_step": med, "p10_ms": _pct(ms, 0.1), "p90_ms": _pct(ms, 0.9),
+            "steps": len(ms), "frac_of_mfma_peak": flop / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+            "note": "2048 token rows per GEMM launch: far below one round of 256 x 256 tiles on 256 CUs"}
+
+
+def leg_cfg3(torch, dev, steps):
+    """configs[2] per-GPU shape: 32 queries + 256 documents (1 positive + 7 hard negatives each) x 2048 tokens, Matryoshka
+    {768, 512, 256, 128}, hamming, activation checkpointing, direct step (sc/trainers/text_text.py:324-378)."""
+    from contrastors_amd.config import Config, DataArgs, ModelArgs, TrainArgs
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from contrastors_amd.trainers import TextTextTrainer
+
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=1, grad_cache=False,
+                                      schedule_type="linear", max_grad_norm=1.0, clamp_logits=False,
+                                      matryoshka_dims=[768, 512, 256, 128]),
+                 data_args=DataArgs(batch_size=32, seed=3),
+                 model_args=ModelArgs(logit_scale=50.0, pooling="mean", model_name="nomic-embed-text-v1", hamming=True,
+                                      num_negatives=7, gradient_checkpointing=True, seq_len=2048))
+    tr = TextTextTrainer(cfg, torch.bfloat16, device=dev, trunk_config=NomicBertConfig.nomic_bert_2048(), total_steps=1000)
+    g = torch.Generator().manual_seed(8)
+    S, nq, nd = 2048, 32, 256
+    batch = {}
+    for side, n in (("query", nq), ("document", nd)):
+        batch[f"{side}_input_ids"] = torch.randint(1000, 30522, (n, S), generator=g).to(dev)
+        batch[f"{side}_seqlens"] = [S] * n
+    torch.cuda.reset_peak_memory_stats(dev)
+    ms = _time_steps(torch, lambda: tr.training_step(batch), 1, max(2, min(steps, 5)))
+    tokens = (nq + nd) * S
+    fwd = tokens * 12 * _fwd_flop_per_token(768, 2 * 3072 + 3072, S)
+    med = _pct(ms, 0.5)
+    return {"workload": "configs[2]: nomic-embed-text-v1 finetune, 32 queries + 256 documents x 2048 tokens per GPU, Matryoshka "
+                        "{768,512,256,128}, hamming, activation checkpointing, direct step",
+            "value": nq / (med * 1e-3), "unit": "query examples/s", "tokens_per_s": tokens / (med * 1e-3), "ms_per_step": med,
+            "p10_ms": _pct(ms, 0.1), "p90_ms": _pct(ms, 0.9), "steps": len(ms),
+            "roofline": {"bound": "mfma", "achieved": 3 * fwd / (med * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 3 * fwd / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "executed_frac": 4 * fwd / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "note": "algorithmic = 3 forward-equivalents of 302 MFLOP/token (attention = 25 %); executed adds the "
+                                 "checkpoint re-forward"},
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+
+
+def leg_image_text(torch, dev, steps, clip: bool):
+    """configs[3] (LiT: frozen ViT-B/16 image tower, trainable BERT-base text tower) and configs[4] (CLIP: both trained, fp8
+    similarity, global batch 32768) at the per-GPU shape of an 8-GPU job: 4096 (image, text) pairs, text seq 77.  On one GPU
+    the other seven ranks' gathered embeddings are stand-ins (28672 random unit vectors), so the loss has its real
+    4096 x 32768 shape in both directions."""
+    import torch.nn.functional as F
+
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
+    from contrastors_amd.loss import _infonce, _scale_of
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from contrastors_amd.optimizer import FusedAdamW
+    from contrastors_amd.vit import ViTConfig
+
+    n, G, S_t = 4096, 32768, 77
+    vis = BiEncoder(BiEncoderConfig(model_name="vit_base_patch16_224", pooling="cls", freeze=not clip,
+                                    gradient_checkpointing=clip, trunk_config=ViTConfig.vit_base_patch16_224()),
+                    device=dev, seed=1).train()
+    txt = BiEncoder(BiEncoderConfig(model_name="bert-base-uncased", pooling="mean",
+                                    trunk_config=NomicBertConfig.bert_base_uncased()), device=dev, seed=2).train()
+    scale = LogitScale(SimpleNamespace(logit_scale=1 / 0.07, trainable_logit_scale=False)).to(dev)
+    towers = [txt] + ([vis] if clip else [])
+    groups = [{"params": [], "weight_decay": 0.01}, {"params": [], "weight_decay": 0.0}]
+    for t in towers:
+        gq = t.param_groups(0.01)
+        groups[0]["params"] += gq[0]["params"]
+        groups[1]["params"] += gq[1]["params"]
+    opt = FusedAdamW(groups, lr=1e-4, betas=(0.9, 0.98), eps=1e-6)
+    g = torch.Generator().manual_seed(9)
+    pixels = torch.randn(n, 3, 224, 224, generator=g).to(dev).bfloat16()
+    t_in = {"input_ids": torch.randint(1000, 30522, (n, S_t), generator=g).to(dev), "seqlens": [S_t] * n}
+    others_t = F.normalize(torch.randn(G - n, 768, generator=g), dim=-1).to(dev)
+    others_v = F.normalize(torch.randn(G - n, 768, generator=g), dim=-1).to(dev)
+    labels = torch.arange(n, device=dev)
+    sc, sp = _scale_of(scale)
+    loss_ms = []
+
+    def step():
+        for t in towers:
+            t.trunk.zero_grad()
+        v = F.normalize(vis(input_ids=pixels, normalize=False)["embedding"], dim=-1, p=2)
+        te = F.normalize(txt(**t_in, normalize=False)["embedding"], dim=-1, p=2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        coef = 0.5 * (G // n) / n
+        loss = (_infonce(v, torch.cat([te, others_t]), labels, sc, coef, sp, clip)
+                + _infonce(te, torch.cat([v, others_v]), labels, sc, coef, sp, clip))
+        e1.record()
+        loss.backward()
+        opt.step(max_grad_norm=1.0)
+        for t in towers:
+            t.trunk.sync_shadows()
+        loss_ms.append((e0, e1))
+        return loss
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    ms = _time_steps(torch, step, 1, max(2, min(steps, 5)))
+    med = _pct(ms, 0.5)
+    f_img = n * 197 * 12 * _fwd_flop_per_token(768, 2 * 3072, 197) + n * 196 * 2.0 * 768 * 768
+    f_txt = n * S_t * 12 * _fwd_flop_per_token(768, 2 * 3072, S_t)
+    flop = (3 * f_img if clip else f_img) + 3 * f_txt
+    lf = sorted(a.elapsed_time(b) for a, b in loss_ms[1:])
+    loss_fwd_ms = _pct(lf, 0.5)
+    loss_flop = 2 * 2.0 * n * G * 768
+    rec = {"workload": ("configs[4]: CLIP-style ViT-B/16 + BERT-base, both towers trained (ViT with activation checkpointing), "
+                        "fp8 MFMA similarity, 4096 pairs per GPU against 32768 gathered" if clip else
+                        "configs[3]: LiT, frozen ViT-B/16 image tower + trainable BERT-base text tower, 4096 pairs per GPU "
+                        "against 32768 gathered, exact fp32 similarity"),
+           "value": n / (med * 1e-3), "unit": "pairs/s per GPU", "ms_per_step": med, "p10_ms": _pct(ms, 0.1),
+           "p90_ms": _pct(ms, 0.9), "steps": len(ms),
+           "roofline": {"bound": "mfma", "achieved": flop / (med * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flop / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "note": "algorithmic encoder FLOPs: image 35.1 GFLOP x " + ("3" if clip else "1 (frozen)") +
+                                ", text 13.4 GFLOP x 3 per pair"},
+           "loss_forward": {"ms": loss_fwd_ms, "flop": loss_flop, "achieved": loss_flop / (loss_fwd_ms * 1e-3) / 1e12,
+                            "peak": PEAK_FP8_TFLOPS if clip else 157.3, "unit": "TFLOP/s",
+                            "frac": loss_flop / (loss_fwd_ms * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if clip else 157.3),
+                            "kernel": "infonce_fp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4) + row quantisation" if clip else
+                                      "sgemm_nt_kernel<LSE> (v_mfma_f32_32x32x2_f32, exact)",
+                            "note": "both directions of the 4096 x 32768 x 768 similarity + online log-sum-exp"},
+           "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+    return rec
+
+
+def run_config_legs(torch, dev, steps):
+    import gc
+
+    out = {}
+    for name, fn in (("cfg1", lambda: leg_cfg1(torch, dev, steps)), ("cfg3", lambda: leg_cfg3(torch, dev, steps)),
+                     ("lit", lambda: leg_image_text(torch, dev, steps, clip=False)),
+                     ("clip", lambda: leg_image_text(torch, dev, steps, clip=True))):
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- a secondary record must never take the headline down
+            out[name] = f"failed: {type(e).__name__}: {e}"[:300]
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
 
 
 def _free_port() -> int:
@@ -184,13 +410,24 @@ def main():
 
     from contrastors_amd import _C
     from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
-    from contrastors_amd.distributed import gather_with_grad
+    from contrastors_amd.distributed import exchange_report, gather_with_grad
     from contrastors_amd.loss import grad_cache_loss
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.optimizer import FusedAdamW
+    from contrastors_amd.policy import GradCachePolicy
 
-    os.environ["CX_GRADCACHE_CHUNK"] = "exact"  # --chunk-size is taken literally in every leg but the drop-in one
-    os.environ["CX_GRADCACHE_RESIDENT"] = "0"   # the metric is the two-pass GradCache step; the `resident` record is separate
+    if args.only_config_legs:   # (rocprofv3 of one secondary leg: scripts/gpu_r3_final.sh)
+        want = set(args.only_config_legs.split(","))
+        fns = {"cfg1": lambda: leg_cfg1(torch, dev, args.steps), "cfg3": lambda: leg_cfg3(torch, dev, args.steps),
+               "lit": lambda: leg_image_text(torch, dev, args.steps, False), "clip": lambda: leg_image_text(torch, dev, args.steps, True)}
+        print(json.dumps({k: fns[k]() for k in fns if k in want}), flush=True)
+        return
+    for k in ("CX_GRADCACHE_CHUNK", "CX_GRADCACHE_RESIDENT"):   # the legs below state their schedule as config, not environment
+        os.environ.pop(k, None)
+    # --chunk-size is taken literally in every leg but the drop-in one; the metric is the two-pass GradCache step (the
+    # `resident` record is separate)
+    POL = {"metric": GradCachePolicy(chunk="exact", resident=False), "resident": GradCachePolicy(chunk="exact", resident=True),
+           "dropin": GradCachePolicy(chunk="auto", resident=False)}
     lib = _C.lib()
     G, S = args.global_batch, args.seq_len
     assert G % world == 0
@@ -209,8 +446,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(pairs_per_gpu: int, chunk: int, steps: int, warmup: int, prof: bool):
-        """W untimed + K timed steps at `pairs_per_gpu` pairs on every rank; returns the max-over-ranks wall time."""
+    def run_leg(pairs_per_gpu: int, chunk: int, steps: int, warmup: int, prof: bool, policy=None, step_ms=None):
+        """W untimed + K timed steps at `pairs_per_gpu` pairs on every rank; returns the max-over-ranks wall time.  step_ms (a
+        list) receives the per-step durations of this rank from events recorded between the steps (no synchronisation
+        inside the timed region)."""
+        policy = policy or POL["metric"]
         # synthetic (query, document) token ids, SURVEY.md §8(d): staged on the device before timing
         g = torch.Generator().manual_seed(1234 + rank)
         q_ids = torch.randint(1000, 30522, (pairs_per_gpu, S), generator=g)
@@ -223,7 +463,7 @@ def main():
 
         def step():
             tower.trunk.zero_grad()
-            loss = grad_cache_loss(tower, q_in, tower, d_in, chunk, scale)
+            loss = grad_cache_loss(tower, q_in, tower, d_in, chunk, scale, policy=policy)
             opt.step(max_grad_norm=1.0)  # global-norm clip + AdamW fused (cx_grad_sq_norm + cx_adamw_clip_step)
             sched.step()
             tower.trunk.sync_shadows()
@@ -234,11 +474,18 @@ def main():
         fence()
         if prof:
             lib.cx_prof_gemm_config(1, args.prof_stride)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if step_ms is not None else None
         t0 = time.perf_counter()
-        for _ in range(steps):
+        if marks:
+            marks[0].record()
+        for i in range(steps):
             loss = step()
+            if marks:
+                marks[i + 1].record()
         fence()
         dt = time.perf_counter() - t0
+        if marks:
+            step_ms.extend(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,7 +493,8 @@ def main():
 
     # ---- the metric: global batch 16384 (strong scaling) -------------------------------------------------------------
     b = G // world
-    dt, loss_last = run_leg(b, args.chunk_size, args.steps, args.warmup, prof=True)
+    step_ms = []
+    dt, loss_last = run_leg(b, args.chunk_size, args.steps, args.warmup, prof=True, step_ms=step_ms)
     ms, fl = C.c_double(), C.c_double()
     n_t, n_all = C.c_long(), C.c_long()
     lib.cx_prof_gemm_collect(C.byref(ms), C.byref(fl), C.byref(n_t), C.byref(n_all))
@@ -267,34 +515,30 @@ def main():
         # the same 2048 pairs per GPU with the activations of pass 1 kept in HBM (193 GB of 288): nothing to recompute in
         # pass 2, identical loss and gradients (tests/test_loss_gpu.py), 3 forward-equivalents of FLOPs instead of 4
         if G >= WEAK_PAIRS_PER_GPU:
-            os.environ["CX_GRADCACHE_RESIDENT"] = "1"
             try:
-                rdt, _ = run_leg(WEAK_PAIRS_PER_GPU, args.chunk_size, args.steps, 1, prof=False)
+                rdt, _ = run_leg(WEAK_PAIRS_PER_GPU, args.chunk_size, args.steps, 1, prof=False, policy=POL["resident"])
                 extra["resident"] = {"value": WEAK_PAIRS_PER_GPU * world * args.steps / rdt, "unit": "pairs/s",
                                      "pairs_per_gpu": WEAK_PAIRS_PER_GPU, "global_batch": WEAK_PAIRS_PER_GPU * world,
                                      "ms_per_step": 1e3 * rdt / args.steps, "steps": args.steps,
                                      "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
-                                     "note": "GradCache with pass 1's activations resident (CX_GRADCACHE_RESIDENT=auto, the "
-                                             "library default, picks this whenever the per-GPU batch fits: 8 GPUs x 2048 "
+                                     "note": "GradCache with pass 1's activations resident (train_args.gradcache_resident: auto, the "
+                                             "library default, picks this whenever the per-GPU batch fits -- and falls back to two "
+                                             "passes on an out-of-memory error: 8 GPUs x 2048 "
                                              "pairs is the metric's own per-GPU shape); same loss bit for bit, gradients equal up to fp32-atomics order, "
                                              "encoder FLOPs 3/4 of the two-pass step. NOT the headline: `value` stays two-pass"}
             except torch.OutOfMemoryError:
                 extra["resident"] = "activations of 2048 pairs per GPU did not fit beside this run's other buffers"
-            os.environ["CX_GRADCACHE_RESIDENT"] = "0"
         # what an unmodified reference YAML gets: GradCache chunk_size 64 (8192 token rows per GEMM launch)
         if world == 1 and args.chunk_size != 64:
             nb = min(b, 2048)
-            os.environ["CX_GRADCACHE_CHUNK"] = "exact"   # chunk_size 64 taken literally: 8192 token rows per launch
-            cdt, _ = run_leg(nb, 64, few, 1, prof=False)
-            os.environ["CX_GRADCACHE_CHUNK"] = "auto"    # the default: the recipe's 64 is a lower bound on a 288 GB part
-            adt, _ = run_leg(nb, 64, few, 1, prof=False)
-            os.environ["CX_GRADCACHE_CHUNK"] = "exact"
+            cdt, _ = run_leg(nb, 64, few, 1, prof=False)                         # chunk_size 64 taken literally: 8192 token rows per launch
+            adt, _ = run_leg(nb, 64, few, 1, prof=False, policy=POL["dropin"])   # the default: the recipe's 64 is a lower bound on a 288 GB part
             extra["dropin_chunk64"] = {"value": nb * few / adt, "unit": "pairs/s", "recipe_chunk_size": 64,
                                        "global_batch": nb, "ms_per_step": 1e3 * adt / few, "steps": few,
                                        "exact_chunk64": {"value": nb * few / cdt, "ms_per_step": 1e3 * cdt / few},
                                        "note": "reference recipe chunk_size 64 (contrastive_pretrain.yaml:15): `value` is what "
-                                               "an unmodified YAML gets (CX_GRADCACHE_CHUNK=auto raises the chunk to ~131072 "
-                                               "tokens, results unchanged), exact_chunk64 = the literal 64 (CX_GRADCACHE_CHUNK="
+                                               "an unmodified YAML gets (train_args.gradcache_chunk: auto raises the chunk to ~262144 "
+                                               "tokens, results unchanged), exact_chunk64 = the literal 64 (gradcache_chunk: "
                                                "exact); loss rows x 2048 documents, encoder work per pair unchanged"}
         # the loss path's one exchange step on its own: all-gather of (16384 / N, 768) fp32 embeddings per rank, through the
         # process group (RCCL) and through the one-shot peer-store path (csrc/xgmi.hip), against 7 x 153 GB/s of xGMI per GPU
@@ -321,39 +565,45 @@ def main():
                         "peak": XGMI_PEAK_GBS, "unit": "GB/s", "frac": recv / seconds / 1e9 / XGMI_PEAK_GBS, "collective": what}
 
             rec = {}
-            if backend == "nccl":
-                rec["rccl"] = record(time_gather(gather_with_grad), "RCCL all_gather_into_tensor, one fused buffer in rank order")
+            # what the data path ITSELF decided at its first exchange (warm-up step): set-up, bit-exact check against the
+            # process group, race at the step's payload, faster one taken on every rank (contrastors_amd/distributed.py)
+            extra["exchange"] = exchange_report()
+            rec["process_group"] = record(time_gather(lambda t: dist.all_gather_into_tensor(
+                torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device), t)),
+                f"{backend} all_gather_into_tensor, one fused buffer in rank order" + (" (RCCL over xGMI)" if backend == "nccl" else ""))
             try:
-                from contrastors_amd.distributed import OneShotExchange
+                from contrastors_amd import distributed as cxd
 
-                ex = OneShotExchange(world * emb.numel() * 4, device=dev)
-                got = ex.all_gather(emb)
-                ref = torch.empty_like(got)
-                dist.all_gather_into_tensor(ref, emb)
-                same = torch.tensor([float(torch.equal(got, ref))], device=dev)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                if float(same.item()) != 1.0:
-                    raise RuntimeError("one-shot all-gather disagrees with the process group's all-gather")
+                ex = cxd._ONESHOT   # the exchange the selection set up and verified (None if it was unavailable)
+                if ex is None:
+                    raise RuntimeError(str(extra["exchange"].get("reason", "not set up")))
                 rec["oneshot"] = record(time_gather(ex.all_gather), "one-shot: every rank stores its shard into every peer's IPC "
                                                                    "buffer + one system-scope flag exchange + copy-out of the "
-                                                                   "receive buffer (what CX_EXCHANGE=oneshot runs)")
+                                                                   "receive buffer")
                 rec["oneshot_in_place"] = record(time_gather(lambda t: ex.all_gather(t, copy=False)),
                                                  "the same exchange, result read in the receive buffer (no copy-out)")
                 ex.check()
-                ex.close()
             except Exception as e:  # noqa: BLE001 -- the record must never take the benchmark down
                 rec["oneshot"] = f"unavailable: {type(e).__name__}: {e}"[:300]
-            if rec:
-                rec["note"] = ("the data path uses the process group's collectives unless CX_EXCHANGE=oneshot; under the shared-GPU "
-                               "test backend the numbers are not xGMI numbers") if backend != "nccl" else \
-                    "the data path uses the process group's collectives unless CX_EXCHANGE=oneshot"
-                extra["xgmi_allgather"] = rec
+            rec["carried_by"] = extra["exchange"].get("choice")
+            rec["note"] = ("the step's gather_with_grad runs on `carried_by` (chosen by measurement at start-up, "
+                           "train_args.exchange: auto)" + ("; under the shared-GPU test backend the numbers are not xGMI numbers"
+                                                          if backend != "nccl" else ""))
+            extra["xgmi_allgather"] = rec
+    if world == 1 and not args.no_extra_legs and not args.no_config_legs:
+        # the other BASELINE configs at their per-GPU shapes (the metric's tower is released first: they need the HBM)
+        import gc
+
+        del tower, opt, sched
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra.update(run_config_legs(torch, dev, args.steps))
     if rank == 0:
         # HBM bytes per GEMM launch: not measurable from inside the process; taken from the committed rocprofv3 PMC
         # passes of this same command line (scripts/gpu_round.sh PMC=1 -> scripts/pmc_traffic.py) when they were
         # collected at the same launch sizes (same GradCache chunk), else null.
         traffic, traffic_src = None, None
-        for name in ("r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
+        for name in ("r3_pmc_gemm_traffic.json", "r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
             try:
                 tj = json.load(open(ROOT / "profiles" / name))
                 if tj.get("grad_cache_chunk") == min(args.chunk_size, b):
@@ -367,6 +617,9 @@ def main():
             "metric": "query-doc pairs/sec (whole node), nomic-bert-2048 seq128 global-batch 16384",
             "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            # per-step durations of rank 0 (events between the steps of the same timed region; SURVEY.md §8(d): median + p10 / p90)
+            "step_ms": {"median": _pct(sorted(step_ms), 0.5), "p10": _pct(sorted(step_ms), 0.1), "p90": _pct(sorted(step_ms), 0.9),
+                        "min": min(step_ms), "max": max(step_ms), "n": len(step_ms)},
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: nomic-bert-2048 bi-encoder contrastive pretrain step (GradCache, "
                                    "paired InfoNCE scale 50, AdamW, clip 1.0)",

@@ -378,8 +378,15 @@ def _resident_forward(model, chunks):
     if not model.training or getattr(model, "frozen_trunk", False):
         with torch.no_grad():
             return [model(**c)["embedding"] for c in chunks]
-    with torch.enable_grad():
-        return [model(**c)["embedding"] for c in chunks]
+    outs = []
+    try:
+        with torch.enable_grad():
+            for c in chunks:
+                outs.append(model(**c)["embedding"])
+    except torch.OutOfMemoryError:
+        _release_resident(model, outs)   # the chunks that did fit: hand their arenas back before the caller falls back
+        raise
+    return outs
 
 
 def _resident_backward(model, outs, cache, final: bool = False):
@@ -419,11 +426,11 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             # the estimate of resident_activations_fit was wrong (fragmentation, another tenant of the allocator): no
             # parameter gradient has been touched yet (the encoder backward starts below), so drop what pass 1 kept,
             # hand the arenas back and take the two-pass schedule for this step.  policy.resident = True re-raises.
-            if pol.resident is True:
-                raise
             _release_resident(tower1, q_out)
             _release_resident(tower2, d_out)
             q_out = d_out = None
+            if pol.resident is True:
+                raise
             torch.cuda.empty_cache()
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")

@@ -232,6 +232,11 @@ def test_bench_two_ranks_prints_one_json_line():
     # the one-shot exchange record: set up, verified against the process group's all-gather and timed inside bench.py
     one = j["xgmi_allgather"]["oneshot"]
     assert isinstance(one, dict) and one["seconds"] > 0, one
+    # ... by the data path itself, at its first exchange: verified against the process group, raced, the faster one taken
+    ex = j["exchange"]
+    assert ex["mode"] == "auto" and ex["verified"] is True and ex["choice"] in ("oneshot", "pg") and ex["oneshot_us"] > 0, ex
+    assert j["xgmi_allgather"]["carried_by"] == ex["choice"]
+    assert j["step_ms"]["n"] == 1 and j["step_ms"]["median"] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box skips this)")

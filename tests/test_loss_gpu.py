@@ -302,6 +302,64 @@ def test_resident_activation_gradcache_equals_two_pass(monkeypatch):
     assert not resident_activations_fit(tower, {"input_ids": ids}, tower, {"input_ids": ids})
 
 
+def test_resident_schedule_falls_back_to_two_pass_on_out_of_memory(monkeypatch, caplog):
+    """ADVICE r2 / VERDICT r2 item 3: if keeping pass 1's activations runs out of memory (the estimate of
+    resident_activations_fit cannot see fragmentation), the step must not die: no parameter gradient has been touched at
+    that point, the kept arenas go back to the engine and the two-pass schedule runs.  policy.resident = True re-raises.
+    Also: the policy is a config object (GradCachePolicy), the decision is logged once."""
+    import logging
+
+    import contrastors_amd.loss as L_
+    from contrastors_amd.policy import GradCachePolicy
+
+    scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    B, S = 32, 64
+    q = {"input_ids": torch.randint(1000, 8192, (B, S), generator=g).to(DEV), "seqlens": [S] * B}
+    d = {"input_ids": torch.randint(1000, 8192, (B, S), generator=g).to(DEV), "seqlens": [S - 3] * B}
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=8192, n_layer=2)
+    tower = BiEncoder(BiEncoderConfig(model_name="nomic", pooling="mean", trunk_config=cfg), device=DEV, seed=12).train()
+    monkeypatch.delenv("CX_GRADCACHE_RESIDENT", raising=False)
+    monkeypatch.delenv("CX_GRADCACHE_CHUNK", raising=False)
+    pol2 = GradCachePolicy(chunk="exact", resident=False)
+    tower.trunk.zero_grad()
+    want = grad_cache_loss(tower, q, tower, d, 8, scale, policy=pol2)
+    g_want = tower.trunk.flat_grad.clone()
+
+    real = tower.trunk.forward_chunk
+    calls = {"n": 0, "fail_at": 7}   # 4 query chunks fit, the 3rd document chunk does not
+
+    def flaky(vb, save_for_backward, *a, **k):
+        if save_for_backward:
+            calls["n"] += 1
+            if calls["n"] == calls["fail_at"]:
+                raise torch.OutOfMemoryError("simulated: HIP out of memory")
+        return real(vb, save_for_backward, *a, **k)
+
+    monkeypatch.setattr(tower.trunk, "forward_chunk", flaky)
+    L_._LOGGED.clear()
+    tower.trunk.zero_grad()
+    with caplog.at_level(logging.INFO, logger="contrastors_amd"):
+        got = grad_cache_loss(tower, q, tower, d, 8, scale, policy=GradCachePolicy(chunk="exact", resident="auto"))
+    assert calls["n"] > 7 and float(got) == float(want)
+    assert float((tower.trunk.flat_grad - g_want).norm()) <= 1e-5 * float(g_want.norm())
+    assert tower.trunk._outstanding == 0, "the abandoned forwards are not waiting for a backward"
+    text = " ".join(r.getMessage() for r in caplog.records)
+    assert "GradCache schedule" in text and "falling back to the two-pass" in text
+    # an explicit `resident: true` is an order, not a hint
+    calls["n"], calls["fail_at"] = 0, 3
+    tower.trunk.zero_grad()
+    with pytest.raises(torch.OutOfMemoryError):
+        grad_cache_loss(tower, q, tower, d, 8, scale, policy=GradCachePolicy(chunk="exact", resident=True))
+    assert tower.trunk._outstanding == 0
+    # the environment variable is an operator override on top of the config
+    monkeypatch.setenv("CX_GRADCACHE_RESIDENT", "0")
+    assert GradCachePolicy(resident=True).with_env().resident is False
+    monkeypatch.setenv("CX_GRADCACHE_CHUNK", "many")
+    with pytest.raises(ValueError, match="CX_GRADCACHE_CHUNK"):
+        GradCachePolicy().with_env()
+
+
 def test_metric_size_step_is_chunk_invariant_and_deterministic():
     """BASELINE.json configs[1] at its FULL size on one GPU (global batch 16384 x seq 128, 12 layers, vocab 30528; the
     bench's GradCache chunk 2048 = 262 144 token rows per GEMM launch, the shapes profiles/ is measured on), through the
