@@ -81,7 +81,8 @@ _SIGS = {
     "cx_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "cx_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
-    "cx_layernorm_bwd_pooled": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cx_layernorm_bwd_pooled": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cx_layernorm_bwd_colsum": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "cx_dropout_add_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, C.c_ulonglong, C.c_ulonglong,
                                            C.c_uint, vp]),
     "cx_dropout_add_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, C.c_ulonglong,
@@ -101,6 +102,7 @@ _SIGS = {
     "cx_bias_gelu_fwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "cx_bias_gelu_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cx_bias_gelu_bwd_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd_prerotated": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
@@ -127,6 +129,9 @@ _SIGS = {
     "cx_vit_forward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, vp, i32, i32, i32, i32, i32,
                              i32, vp, vp]),
     "cx_vit_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, i32, vp, vp, vp]),
+    "cx_vit_forward_hidden": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, vp, i32, i32, i32, i32, i32,
+                                    i32, vp, vp]),
+    "cx_vit_backward_hidden": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, i32, vp, vp]),
     "cx_xent_fwd": (i32, [vp, i32, vp, vp, vp, i32, i32, i64, f32, i64, vp]),
     "cx_xent_bwd": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i64, i64, f32, i64, vp]),
     "cx_grad_sq_norm": (i32, [vp, i64, vp, vp]),

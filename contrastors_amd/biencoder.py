@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .distributed import gather_with_grad
 from .nomic_bert import NomicBertConfig, NomicBertEngine, VarlenBatch, _EncodeFn
-from .vit import ViTConfig, ViTEngine, _VitEncodeFn
+from .vit import ViTConfig, ViTEngine, _VitEncodeFn, _VitHiddenFn
 
 
 @dataclass
@@ -74,12 +74,25 @@ class BiEncoder(torch.nn.Module):
         self.config = config
         if not config.encoder:
             raise NotImplementedError("decoder trunks are out of the hot-path scope (SURVEY.md §2a #15)")
-        if config.pooling not in ("mean", "cls"):
+        if config.pooling not in ("mean", "cls", "map"):
+            # "last" (modeling_biencoder.py:52-77) picks a decoder trunk's eos token; decoder trunks are out of scope
             raise NotImplementedError(f"pooling={config.pooling!r}")
         trunk_cfg = config.trunk_config or _default_trunk_config(config.model_name)
         self.is_vision = isinstance(trunk_cfg, ViTConfig)  # image tower: `input_ids` carries the pixel tensor
+        if config.pooling == "map" and not self.is_vision:
+            raise NotImplementedError("pooling='map' serves the image tower: the reference's masked (text) branch of "
+                                      "MultiHeadAttentionPooling does not run (modeling_biencoder.py:134-148)")
         engine_cls = ViTEngine if self.is_vision else NomicBertEngine
-        self.trunk = engine_cls(trunk_cfg, device=device, pooling=config.pooling, normalize=True, seed=seed)
+        self.trunk = engine_cls(trunk_cfg, device=device, pooling="cls" if config.pooling == "map" else config.pooling,
+                                normalize=True, seed=seed)
+        # `pooling: map` (configs/train/nomic_embed_vision_v1.5.yaml:69): attention-pooling head above the trunk's hidden states
+        self.selector = None
+        if config.pooling == "map":
+            from .map_pooling import MultiHeadAttentionPooling
+
+            if seed is not None:
+                torch.manual_seed(seed + 1)
+            self.selector = MultiHeadAttentionPooling(trunk_cfg, device=device)
         if config.gradient_checkpointing:  # modeling_biencoder.py:261-262
             self.trunk.gradient_checkpointing_enable()
         self.frozen_trunk = bool(config.freeze)
@@ -104,10 +117,17 @@ class BiEncoder(torch.nn.Module):
 
     def forward(self, input_ids, attention_mask=None, is_padded_inputs=True, normalize=True, binarize=False,
                 seqlens=None, **kwargs):
-        plain = (not self.hamming) and isinstance(self.proj, torch.nn.Identity) and not binarize
+        plain = (not self.hamming) and isinstance(self.proj, torch.nn.Identity) and not binarize and self.selector is None
         eng_norm = bool(normalize) and plain
         differentiable = torch.is_grad_enabled() and self.training and not self.frozen_trunk
-        if self.is_vision:  # (B, 3, H, W) pixels, no mask (modeling_biencoder.py:84-86)
+        if self.selector is not None:  # attention pooling over the trunk's final hidden states
+            if differentiable:
+                hidden = _VitHiddenFn.apply(self.trunk.flat_decay, self.trunk, input_ids)
+            else:
+                with torch.no_grad():
+                    hidden, _ = self.trunk.forward_hidden_chunk(input_ids, False)
+            emb = self.selector(hidden, None, None)
+        elif self.is_vision:  # (B, 3, H, W) pixels, no mask (modeling_biencoder.py:84-86)
             if differentiable:
                 emb = _VitEncodeFn.apply(self.trunk.flat_decay, self.trunk, input_ids, eng_norm)
             else:
@@ -147,7 +167,7 @@ class BiEncoder(torch.nn.Module):
             if not self.trunk.finish_overlapped_reduce():
                 dist.all_reduce(self.trunk.flat_grad, op=dist.ReduceOp.SUM)
             self.trunk.flat_grad.div_(W)
-            for p in self.proj.parameters():
+            for p in self._head_parameters():
                 if p.grad is not None:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                     p.grad.div_(W)
@@ -155,9 +175,20 @@ class BiEncoder(torch.nn.Module):
     def broadcast_parameters(self, src: int = 0):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.trunk.flat_param, src)
-            for p in self.proj.parameters():
+            for p in self._head_parameters():
                 dist.broadcast(p.data, src)
             self.trunk.sync_shadows()
+
+    def _head_parameters(self):
+        """torch parameters above the flat trunk buffers: the projection and the attention-pooling head."""
+        yield from self.proj.parameters()
+        if self.selector is not None:
+            yield from self.selector.parameters()
+
+    def _head_named_parameters(self):
+        yield from (("proj." + n, p) for n, p in self.proj.named_parameters())
+        if self.selector is not None:
+            yield from (("selector." + n, p) for n, p in self.selector.named_parameters())
 
     def no_sync(self):  # API parity with DDP-wrapped towers (sc/loss.py:151); reduction is explicit here
         import contextlib
@@ -177,6 +208,8 @@ class BiEncoder(torch.nn.Module):
         os.makedirs(output_dir, exist_ok=True)
         sd = {f"trunk.{k}": v.detach().cpu().contiguous() for k, v in self.trunk.reference_state_dict().items()}
         sd.update({f"proj.{k}": v.detach().cpu().contiguous() for k, v in self.proj.state_dict().items()})
+        if self.selector is not None:
+            sd.update({f"selector.{k}": v.detach().cpu().contiguous() for k, v in self.selector.state_dict().items()})
         save_file(sd, os.path.join(output_dir, "model.safetensors"))
         cfg = {k: v for k, v in dataclasses.asdict(self.config).items() if k != "trunk_config"}
         cfg["trunk_config"] = dataclasses.asdict(self.trunk.config)
@@ -194,14 +227,18 @@ class BiEncoder(torch.nn.Module):
         proj = {k[5:]: v for k, v in sd.items() if k.startswith("proj.")}
         if proj:
             self.proj.load_state_dict(proj)
+        sel = {k[9:]: v for k, v in sd.items() if k.startswith("selector.")}
+        if sel and self.selector is not None:
+            self.selector.load_state_dict(sel, strict=strict)
         return self
 
     def param_groups(self, weight_decay: float):
         """decay / no-decay groups of sc/optimizer.py:16-25 over the flat buffers."""
         groups = [{"params": [self.trunk.flat_decay], "weight_decay": weight_decay},
                   {"params": [self.trunk.flat_nodecay], "weight_decay": 0.0}]
-        proj_w = [p for n, p in self.proj.named_parameters() if p.ndim >= 2]
-        proj_b = [p for n, p in self.proj.named_parameters() if p.ndim < 2]
+        # sc/optimizer.py:16-25: ndim < 2 after squeeze, "bias" in the name -> no decay (the pooling head's (1, 1, d) latent too)
+        proj_w = [p for n, p in self._head_named_parameters() if p.squeeze().ndim >= 2 and "bias" not in n]
+        proj_b = [p for n, p in self._head_named_parameters() if not (p.squeeze().ndim >= 2 and "bias" not in n)]
         if proj_w:
             groups[0]["params"] += proj_w
         if proj_b:

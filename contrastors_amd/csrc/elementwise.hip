@@ -222,20 +222,60 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const bf16_t* __rest
     }
 }
 
-// dbias[n] += sum_t dY[t][n].  Block = 32 column-chunks (256 columns) x 8 row lanes.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dY, float* __restrict__ dbias,
-                                                        int T, int N, int ld) {
+// dbias[n] += sum_t dY[t][n].  Block = 32 column-chunks (256 columns) x 8 row lanes; every thread keeps four 16-byte loads
+// in flight (round 3: one load per iteration and at most 192 blocks left this HBM-bound reduction at 1.2-4 TB/s -- 6.5 % of
+// the CLIP step, profiles/r3_kernel_summary_clip_before_bias_fusion.txt).  GELU = true (cx_bias_gelu_bwd_colsum) is the
+// backward of bias + erf-GELU with the bias gradient of the SAME pass: dpre = dact * gelu'(pre + bias) is written and its
+// column sums accumulated, instead of a second kernel reading dpre back.
+template <bool GELU>
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ pre,
+                                                     const float* __restrict__ bias, bf16_t* __restrict__ dpre,
+                                                     float* __restrict__ dbias, int T, int N, int ld) {
     __shared__ float red[8][256];
     const int tid = threadIdx.x;
     const int cch = tid & 31, rl = tid >> 5;
     const int col = blockIdx.x * 256 + cch * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (col < N) {
-        for (int t = blockIdx.y * 8 + rl; t < T; t += gridDim.y * 8) {
-            float v[8];
-            unpack8(*reinterpret_cast<const uint4*>(dY + (size_t)t * ld + col), v);
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (GELU && bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        }
+        const int step = gridDim.y * 8;
+        constexpr int U = GELU ? 2 : 4;
+        for (int t0 = blockIdx.y * 8 + rl; t0 < T; t0 += U * step) {
+            uint4 a[U], x[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += v[e];
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * step;
+                const int tc = t < T ? t : T - 1;
+                a[u] = *reinterpret_cast<const uint4*>(dY + (size_t)tc * ld + col);
+                if (GELU) x[u] = *reinterpret_cast<const uint4*>(pre + (size_t)tc * ld + col);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * step;
+                if (t >= T) break;
+                float v[8];
+                unpack8(a[u], v);
+                if (GELU) {
+                    float xv[8], o[8];
+                    unpack8(x[u], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = xv[e] + bb[e];
+                        float gauss;
+                        const float cdf = gelu_cdf(z, gauss);
+                        o[e] = v[e] * (cdf + z * 0.3989422804014327f * gauss);
+                    }
+                    const uint4 pk = pack8(o);
+                    *reinterpret_cast<uint4*>(dpre + (size_t)t * ld + col) = pk;
+                    unpack8(pk, v);   // the bias gradient sums what the next kernels read: the bf16 dpre
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += v[e];
+            }
         }
     }
 #pragma unroll
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int r = 0; r < 8; ++r) tot += red[r][tid];
     const int c = blockIdx.x * 256 + tid;
-    if (c < N) unsafeAtomicAdd(dbias + c, tot);
+    if (c < N && dbias) unsafeAtomicAdd(dbias + c, tot);
 }
 
 // ------------------------------------------------------------------------------------------ pooling
@@ -448,14 +488,33 @@ int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bia
     return done();
 }
 
+// row groups per 256-column block: enough blocks for ~4 per CU, never more than one per 256 rows (a small problem is ONE
+// block per column block: a single atomic per column, i.e. bit-reproducible -- tests/test_checkpoint_gpu.py relies on it)
+static int colsum_rows_grid(int T, int N) {
+    const int colblocks = (N + 255) / 256;
+    int gy = (1024 + colblocks - 1) / colblocks;
+    const int cap = (T + 255) / 256;
+    if (gy > cap) gy = cap;
+    if (gy > 512) gy = 512;
+    return gy < 1 ? 1 : gy;
+}
+
 int cx_bias_grad(const uint16_t* dY, float* dbias, int T, int N, int ld, void* stream) {
     if (T <= 0 || N <= 0) return CX_OK;
     if ((N % 8) || (ld % 8)) return CX_ERR_ALIGN;
-    int gy = (T + 8 * 16 - 1) / (8 * 16);
-    if (gy > 64) gy = 64;
-    if (gy < 1) gy = 1;
-    dim3 grid((N + 255) / 256, gy);
-    hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, dbias, T, N, ld);
+    dim3 grid((N + 255) / 256, colsum_rows_grid(T, N));
+    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, (const bf16_t*)nullptr,
+                       (const float*)nullptr, (bf16_t*)nullptr, dbias, T, N, ld);
+    return done();
+}
+
+int cx_bias_gelu_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, float* dbias, int T,
+                            int I, void* stream) {
+    if (T <= 0) return CX_OK;
+    if (I % 8) return CX_ERR_SHAPE;
+    if (!dact || !pre || !dpre) return CX_ERR_ARG;
+    dim3 grid((I + 255) / 256, colsum_rows_grid(T, I));
+    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dact, pre, bias, dpre, dbias, T, I, I);
     return done();
 }
 

@@ -295,9 +295,10 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
     // MLP backward: dm -> gradients of fc2 / fc1 parameters, d(mlp input) into buf->g_b
     // `add` (optional): the residual-branch gradient that the following LayerNorm backward would add to this dgrad
     // output; folded into the last GEMM's epilogue when the fused kernel covers the shape (*folded).
+    // (bias_done: the LayerNorm backward that produced dm / dx already accumulated its column sums = this bias gradient)
     auto mlp_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dm, const uint16_t* mlp_in, const uint16_t* add,
-                       bool* folded) -> int {
-        if (w.gbfc2) CX_TRY(cx_bias_grad(dm, w.gbfc2, T, d, d, stream));
+                       bool* folded, bool bias_done) -> int {
+        if (w.gbfc2 && !bias_done) CX_TRY(cx_bias_grad(dm, w.gbfc2, T, d, d, stream));
         CX_TRY(wgrad(dm, d, s.act(l), I, w.gWfc2, buf, T, stream));
         int fused = CX_ERR_SHAPE;
         if (enc->gated)  // fc2 dgrad + SwiGLU backward in one kernel: d(act) never touches HBM
@@ -312,17 +313,17 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                 CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
         } else {
             // (yg holds the biased pre-activation when the forward took the fused kernel: same predicate as there)
-            CX_TRY(cx_bias_gelu_bwd(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide, T, I,
-                                    stream));
-            if (w.gbfc1) CX_TRY(cx_bias_grad(buf->g_wide, w.gbfc1, T, I, I, stream));
+            // GELU backward and the fc1 bias gradient in one pass over (dact, pre)
+            CX_TRY(cx_bias_gelu_bwd_colsum(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide,
+                                           w.gbfc1, T, I, stream));
         }
         CX_TRY(wgrad(buf->g_wide, s.wfc1, mlp_in, d, w.gWfc1, buf, T, stream));
         return proj_residual(buf->g_wide, w.Wfc1T, nullptr, add, buf->g_b, T, d, s.wfc1, folded, stream);
     };
     // attention backward: dx (grad of the out_proj output) -> parameter gradients, d(attention input) into buf->g_b
     auto attn_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dx, const uint16_t* attn_in, const uint16_t* add,
-                        bool* folded) -> int {
-        if (w.gbout) CX_TRY(cx_bias_grad(dx, w.gbout, T, d, d, stream));
+                        bool* folded, bool bias_done) -> int {
+        if (w.gbout && !bias_done) CX_TRY(cx_bias_grad(dx, w.gbout, T, d, d, stream));
         CX_TRY(wgrad(dx, d, s.ctx(l), d, w.gWout, buf, T, stream));
         CX_TRY(cx_gemm_bf16_nt(dx, w.WoutT, buf->g_b, nullptr, T, d, d, d, d, d, 0, 1, 1.f, stream));
         // attention core (+ inverse rotary)
@@ -340,6 +341,22 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         if (w.gbqkv) CX_TRY(cx_bias_grad(buf->g_wide, w.gbqkv, T, 3 * d, 3 * d, stream));
         CX_TRY(wgrad(buf->g_wide, 3 * d, attn_in, d, w.gWqkv, buf, T, stream));
         return proj_residual(buf->g_wide, w.WqkvT, nullptr, add, buf->g_b, T, d, 3 * d, folded, stream);
+    };
+    // LayerNorm backward whose dz is the gradient of (Linear output + residual): `gbias` (the Linear's bias gradient, may be
+    // NULL) rides along as the column sums of dz when the kernel has its workspace; *done says whether it did
+    auto ln_bwd = [&](const uint16_t* a, const uint16_t* b2, const uint16_t* z, const float* g, const float* mean,
+                      const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* gg, float* gb, float* gbias,
+                      bool* done) -> int {
+        *done = false;
+        if (gbias) {
+            const int rc = cx_layernorm_bwd_colsum(a, b2, z, g, mean, rstd, dz_extra, dz, gg, gb, gbias, buf->ws_f32,
+                                                   buf->ws_floats, T, d, stream);
+            if (rc != CX_ERR_ARG) {
+                *done = rc == CX_OK;
+                return rc;
+            }
+        }
+        return cx_layernorm_bwd(a, b2, z, g, mean, rstd, dz_extra, dz, gg, gb, buf->ws_f32, buf->ws_floats, T, d, stream);
     };
     // activation checkpointing (slot mode 2): the block's intermediates are recomputed from its saved input into slot 0
     // right before its backward (bit-identical: every kernel on the path is deterministic)
@@ -360,32 +377,35 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                 CX_TRY(cx_dropout_add_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, buf->g_d, w.gln2_g,
                                                     w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, p, buf->drop_seed,
                                                     buf->drop_offset, 2 * l + 1, stream));
-                CX_TRY(mlp_bwd(w, l, buf->g_d, s.h1(l), buf->g_c, &f1));   // -> g_b = d h1 (+ dz2 when folded)
+                CX_TRY(mlp_bwd(w, l, buf->g_d, s.h1(l), buf->g_c, &f1, false));   // -> g_b = d h1 (+ dz2 when folded)
                 CX_TRY(cx_dropout_add_layernorm_bwd(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l),
                                                     s.rstd1(l), buf->g_a, buf->g_d, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats,
                                                     T, d, p, buf->drop_seed, buf->drop_offset, 2 * l, stream));
-                CX_TRY(attn_bwd(w, l, buf->g_d, h_in, buf->g_a, &f2));
+                CX_TRY(attn_bwd(w, l, buf->g_d, h_in, buf->g_a, &f2, false));
                 da = f2 ? buf->g_b : buf->g_a;
                 db = f2 ? nullptr : buf->g_b;
                 CX_TRY(mark_grads_done(buf, l, stream));
                 continue;
             }
-            // LN2: dz2 = grad of (mlp_out + h1)
+            // LN2: dz2 = grad of (mlp_out + h1); its column sums are fc2's bias gradient
+            bool b2_done = false, b1_done = false;
             if (pg && l == L - 1) {
+                const bool cs = w.gbfc2 && buf->ws_f32 && buf->ws_floats >= 3L * d * 256;
                 CX_TRY(cx_layernorm_bwd_pooled(pg->demb, pg->emb, pg->norm, cu_seqlens, Bc, pg->pool_mode, pg->normalize, s.z2(l),
-                                               w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, w.gln2_g, w.gln2_b, buf->ws_f32,
-                                               buf->ws_floats, T, d, stream));
+                                               w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, w.gln2_g, w.gln2_b,
+                                               cs ? w.gbfc2 : nullptr, buf->ws_f32, buf->ws_floats, T, d, stream));
+                b2_done = cs;
             } else {
-                CX_TRY(cx_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g,
-                                        w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+                CX_TRY(ln_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), nullptr, buf->g_c, w.gln2_g, w.gln2_b, w.gbfc2,
+                              &b2_done));
             }
             bool f1 = false, f2 = false;
-            CX_TRY(mlp_bwd(w, l, buf->g_c, s.h1(l), buf->g_c, &f1));
-            // LN1: dout = dz2 (residual branch) + dh1 from the MLP (already summed in g_b when the fc1 dgrad folded it)
-            CX_TRY(cx_layernorm_bwd(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l),
-                                    s.rstd1(l), nullptr, buf->g_a, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d,
-                                    stream));
-            CX_TRY(attn_bwd(w, l, buf->g_a, h_in, buf->g_a, &f2));
+            CX_TRY(mlp_bwd(w, l, buf->g_c, s.h1(l), buf->g_c, &f1, b2_done));
+            // LN1: dout = dz2 (residual branch) + dh1 from the MLP (already summed in g_b when the fc1 dgrad folded it);
+            // the column sums of its dz are out_proj's bias gradient
+            CX_TRY(ln_bwd(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), nullptr,
+                          buf->g_a, w.gln1_g, w.gln1_b, w.gbout, &b1_done));
+            CX_TRY(attn_bwd(w, l, buf->g_a, h_in, buf->g_a, &f2, b1_done));
             da = f2 ? buf->g_b : buf->g_a;  // dz1 (residual branch into h_in) [+ the attention branch when folded]
             db = f2 ? nullptr : buf->g_b;   // attention branch into h_in
             CX_TRY(mark_grads_done(buf, l, stream));
@@ -394,30 +414,38 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         *db_out = db;
         return CX_OK;
     }
-    // pre-norm: the gradient of the residual stream r rides along as dz_extra of every LayerNorm backward
-    if (pg) {
-        CX_TRY(cx_layernorm_bwd_pooled(pg->demb, pg->emb, pg->norm, cu_seqlens, Bc, pg->pool_mode, pg->normalize, buf->zf,
-                                       enc->lnf_g, buf->meanf, buf->rstdf, buf->g_c, enc->glnf_g, enc->glnf_b, buf->ws_f32,
-                                       buf->ws_floats, T, d, stream));
-    } else {
-        CX_TRY(cx_layernorm_bwd(buf->g_a, nullptr, buf->zf, enc->lnf_g, buf->meanf, buf->rstdf, nullptr, buf->g_c, enc->glnf_g,
-                                enc->glnf_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+    // pre-norm: the gradient of the residual stream r rides along as dz_extra of every LayerNorm backward.  g_c (= dz of
+    // ln_f, then of each block's LN1) is the gradient of the fc2 output of the block BELOW it in the loop, g_a (= dz of LN2)
+    // that of the out_proj output of the same block: their column sums are those bias gradients.
+    bool bias_c_done = false;   // "the kernel that wrote g_c accumulated layers[l].gbfc2"
+    {
+        float* gb_top = enc->layers[L - 1].gbfc2;
+        if (pg) {
+            const bool cs = gb_top && buf->ws_f32 && buf->ws_floats >= 3L * d * 256;
+            CX_TRY(cx_layernorm_bwd_pooled(pg->demb, pg->emb, pg->norm, cu_seqlens, Bc, pg->pool_mode, pg->normalize, buf->zf,
+                                           enc->lnf_g, buf->meanf, buf->rstdf, buf->g_c, enc->glnf_g, enc->glnf_b,
+                                           cs ? gb_top : nullptr, buf->ws_f32, buf->ws_floats, T, d, stream));
+            bias_c_done = cs;
+        } else {
+            CX_TRY(ln_bwd(buf->g_a, nullptr, buf->zf, enc->lnf_g, buf->meanf, buf->rstdf, nullptr, buf->g_c, enc->glnf_g,
+                          enc->glnf_b, gb_top, &bias_c_done));
+        }
     }
     for (int l = L - 1; l >= 0; --l) {   // invariant: buf->g_c = d(x_l + r_l) = gradient of both the MLP output and r
         const CxLayerWeights& w = enc->layers[l];
-        bool unused = false;
+        bool unused = false, bias_a_done = false;
         if (s.mode == 2) {
             const uint16_t* xo = nullptr;
             const uint16_t* ro = nullptr;
             bool fo = false;
             CX_TRY(run.pre_block(l, s.z1(l), nullptr, true, true, /*up_only*/ true, &xo, &ro, &fo));
         }
-        CX_TRY(mlp_bwd(w, l, buf->g_c, s.h2(l), nullptr, &unused));    // -> g_b = d h2
-        CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), /*dz_extra*/ buf->g_c,
-                                buf->g_a, w.gln2_g, w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, stream));
-        CX_TRY(attn_bwd(w, l, buf->g_a, s.h1(l), nullptr, &unused));   // -> g_b = d h1
-        CX_TRY(cx_layernorm_bwd(buf->g_b, nullptr, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), /*dz_extra*/ buf->g_a,
-                                buf->g_c, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+        CX_TRY(mlp_bwd(w, l, buf->g_c, s.h2(l), nullptr, &unused, bias_c_done));    // -> g_b = d h2
+        CX_TRY(ln_bwd(buf->g_b, nullptr, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), /*dz_extra*/ buf->g_c, buf->g_a, w.gln2_g,
+                      w.gln2_b, w.gbout, &bias_a_done));
+        CX_TRY(attn_bwd(w, l, buf->g_a, s.h1(l), nullptr, &unused, bias_a_done));   // -> g_b = d h1
+        CX_TRY(ln_bwd(buf->g_b, nullptr, s.z1(l), w.ln1_g, s.mean1(l), s.rstd1(l), /*dz_extra*/ buf->g_a, buf->g_c, w.gln1_g,
+                      w.gln1_b, l > 0 ? enc->layers[l - 1].gbfc2 : nullptr, &bias_c_done));
         CX_TRY(mark_grads_done(buf, l, stream));
     }
     *da_out = buf->g_c;
@@ -425,6 +453,76 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
     return CX_OK;
 }
 
+}  // namespace
+
+namespace {
+// pooled embeddings (emb_out) or, for poolers that live above the C-ABI (sc MultiHeadAttentionPooling, `pooling: map`),
+// the final hidden states themselves (hidden_out, (T, d) bf16 after ln_f)
+int vit_forward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
+                     const int32_t* cu_seqlens, int Bc, int Cc, int H, int W, int patch, int save_for_backward, float* emb_out,
+                     uint16_t* hidden_out, void* stream) {
+    if (Bc <= 0) return CX_OK;
+    if (!enc || !buf || patch <= 0 || (H % patch) || (W % patch)) return CX_ERR_ARG;
+    const int P = (H / patch) * (W / patch), S = P + 1, T = Bc * S;
+    CX_TRY(check_desc(enc, buf, T));
+    if (!enc->Wpatch || !enc->cls_token || !enc->vit_pos || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
+    if (enc->patch_dim != Cc * patch * patch || (enc->patch_dim % 64) != 0) return CX_ERR_SHAPE;
+    (void)hipGetLastError();
+    const int d = enc->d, I = enc->d_inner;
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
+    CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
+    CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
+                           enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
+    CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
+    const uint16_t* h_final = nullptr;
+    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, s.mode, &h_final, stream));
+    if (hidden_out)
+        return hipMemcpyAsync(hidden_out, h_final, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+    return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
+                                 stream);
+}
+
+int vit_backward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc, int n_patch,
+                      const float* demb, const float* emb_out, const uint16_t* dhidden, void* stream) {
+    if (Bc <= 0) return CX_OK;
+    if (!enc || !buf || n_patch <= 0) return CX_ERR_ARG;
+    const int P = n_patch, S = P + 1, T = Bc * S;
+    CX_TRY(check_desc(enc, buf, T));
+    if ((!dhidden && (!demb || !emb_out)) || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
+    CX_TRY(check_bwd_buffers(buf));
+    (void)hipGetLastError();
+    const int d = enc->d, I = enc->d_inner;
+    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
+    CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
+    const PooledGrad pg{demb, emb_out, buf->pool_norm, enc->pool_mode, enc->normalize};
+    const bool fold_pool = !dhidden && enc->prenorm && (enc->pool_mode == 0 || enc->pool_mode == 1);   // (see cx_encoder_backward)
+    if (dhidden) {
+        if (hipMemcpyAsync(buf->g_a, dhidden, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream) != hipSuccess)
+            return CX_ERR_LAUNCH;
+    } else if (!fold_pool) {
+        CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
+                                     enc->normalize, stream));
+    }
+    const uint16_t* da = nullptr;
+    const uint16_t* db = nullptr;
+    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, S, fold_pool ? &pg : nullptr, &da, &db, stream));
+    if (db) return CX_ERR_ARG;  // (post-norm ViT would need the two branches summed first; no such model family)
+    // d(embeddings) -> cls / position gradients and the contiguous d(projection) rows; pad rows of both wgrad operands
+    // (patch_in was written by the forward of this chunk and is still intact) are cleared for the 64-row reduction
+    const int Tp = Bc * P, Tpp = (int)round_up(Tp, 64);
+    if (Tpp > Tp) {
+        if (hipMemsetAsync(buf->patch_proj + (size_t)Tp * d, 0, (size_t)(Tpp - Tp) * d * 2, (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(buf->patch_in + (size_t)Tp * enc->patch_dim, 0, (size_t)(Tpp - Tp) * enc->patch_dim * 2,
+                           (hipStream_t)stream) != hipSuccess)
+            return CX_ERR_LAUNCH;
+    }
+    CX_TRY(cx_vit_assemble_bwd(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, stream));
+    if (enc->gbpatch) CX_TRY(cx_bias_grad(buf->patch_proj, enc->gbpatch, Tp, d, d, stream));
+    CX_TRY(wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream));
+    return mark_grads_done(buf, enc->n_layer, stream);
+}
 }  // namespace
 
 extern "C" {
@@ -554,59 +652,29 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
 int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
                    const int32_t* cu_seqlens, int Bc, int Cc, int H, int W, int patch, int save_for_backward,
                    float* emb_out, void* stream) {
-    if (Bc <= 0) return CX_OK;
-    if (!enc || !buf || patch <= 0 || (H % patch) || (W % patch)) return CX_ERR_ARG;
-    const int P = (H / patch) * (W / patch), S = P + 1, T = Bc * S;
-    CX_TRY(check_desc(enc, buf, T));
-    if (!enc->Wpatch || !enc->cls_token || !enc->vit_pos || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
-    if (enc->patch_dim != Cc * patch * patch || (enc->patch_dim % 64) != 0) return CX_ERR_SHAPE;
-    (void)hipGetLastError();
-    const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
-    CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
-    CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
-                           enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
-    CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
-    const uint16_t* h_final = nullptr;
-    CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, s.mode, &h_final, stream));
-    return cx_pool_normalize_fwd(h_final, cu_seqlens, emb_out, buf->pool_norm, Bc, d, enc->pool_mode, enc->normalize,
-                                 stream);
+    if (Bc > 0 && !emb_out) return CX_ERR_ARG;
+    return vit_forward_impl(enc, buf, pixels, pixels_bf16, cu_seqlens, Bc, Cc, H, W, patch, save_for_backward, emb_out, nullptr,
+                            stream);
 }
 
 int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc, int n_patch,
                     const float* demb, const float* emb_out, void* stream) {
-    if (Bc <= 0) return CX_OK;
-    if (!enc || !buf || n_patch <= 0) return CX_ERR_ARG;
-    const int P = n_patch, S = P + 1, T = Bc * S;
-    CX_TRY(check_desc(enc, buf, T));
-    if (!demb || !emb_out || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
-    CX_TRY(check_bwd_buffers(buf));
-    (void)hipGetLastError();
-    const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
-    CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
-    const PooledGrad pg{demb, emb_out, buf->pool_norm, enc->pool_mode, enc->normalize};
-    const bool fold_pool = enc->prenorm && (enc->pool_mode == 0 || enc->pool_mode == 1);   // (see cx_encoder_backward)
-    if (!fold_pool)
-        CX_TRY(cx_pool_normalize_bwd(demb, emb_out, buf->pool_norm, cu_seqlens, buf->g_a, Bc, d, enc->pool_mode,
-                                     enc->normalize, stream));
-    const uint16_t* da = nullptr;
-    const uint16_t* db = nullptr;
-    CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, S, fold_pool ? &pg : nullptr, &da, &db, stream));
-    if (db) return CX_ERR_ARG;  // (post-norm ViT would need the two branches summed first; no such model family)
-    // d(embeddings) -> cls / position gradients and the contiguous d(projection) rows; pad rows of both wgrad operands
-    // (patch_in was written by the forward of this chunk and is still intact) are cleared for the 64-row reduction
-    const int Tp = Bc * P, Tpp = (int)round_up(Tp, 64);
-    if (Tpp > Tp) {
-        if (hipMemsetAsync(buf->patch_proj + (size_t)Tp * d, 0, (size_t)(Tpp - Tp) * d * 2, (hipStream_t)stream) != hipSuccess ||
-            hipMemsetAsync(buf->patch_in + (size_t)Tp * enc->patch_dim, 0, (size_t)(Tpp - Tp) * enc->patch_dim * 2,
-                           (hipStream_t)stream) != hipSuccess)
-            return CX_ERR_LAUNCH;
-    }
-    CX_TRY(cx_vit_assemble_bwd(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, stream));
-    if (enc->gbpatch) CX_TRY(cx_bias_grad(buf->patch_proj, enc->gbpatch, Tp, d, d, stream));
-    CX_TRY(wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream));
-    return mark_grads_done(buf, enc->n_layer, stream);
+    return vit_backward_impl(enc, buf, cu_seqlens, Bc, n_patch, demb, emb_out, nullptr, stream);
+}
+
+// token-level outputs of the image tower (the hidden states after ln_f), for poolers above the C-ABI
+int cx_vit_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
+                          const int32_t* cu_seqlens, int Bc, int Cc, int H, int W, int patch, int save_for_backward,
+                          uint16_t* hidden_out, void* stream) {
+    if (Bc > 0 && !hidden_out) return CX_ERR_ARG;
+    return vit_forward_impl(enc, buf, pixels, pixels_bf16, cu_seqlens, Bc, Cc, H, W, patch, save_for_backward, nullptr, hidden_out,
+                            stream);
+}
+
+int cx_vit_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc, int n_patch,
+                           const uint16_t* dhidden, void* stream) {
+    if (Bc > 0 && !dhidden) return CX_ERR_ARG;
+    return vit_backward_impl(enc, buf, cu_seqlens, Bc, n_patch, nullptr, nullptr, dhidden, stream);
 }
 
 int cx_abi_version(void) { return 5; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled

@@ -135,6 +135,33 @@ CX_DEVICE void store_param_partials(float (&dg)[NCH][4], float (&db)[NCH][4], fl
         mine[c] = sacc;
     }
 }
+// third vector of a backward that also returns the column sums of its dz (the bias gradient of the Linear whose output
+// the LayerNorm consumed): block partials in part3[blk][D], folded by ln_param_reduce_kernel like the other two
+template <int NCH>
+CX_DEVICE void store_colsum_partials(float (&dc)[NCH][4], float* part3, float* smem) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) smem[wave * D + (i * 64 + lane) * 4 + e] = dc[i][e];
+    __syncthreads();
+    float* mine = part3 + (size_t)blockIdx.x * D;
+    for (int c = threadIdx.x; c < D; c += 256) mine[c] = smem[c] + smem[D + c] + smem[2 * D + c] + smem[3 * D + c];
+}
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part3, float* dst, int nblocks, int D) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float sacc = 0.f;
+    if (col < D) {
+#pragma unroll 4
+        for (int b = grp; b < nblocks; b += 4) sacc += part3[(size_t)b * D + col];
+    }
+    red[grp][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (grp == 0 && col < D) dst[col] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
 
 // 64 columns x 4 block-groups per workgroup: each thread sums every 4th block's partial for its column (independent,
 // unrolled loads), then the 4 groups are folded through LDS.
@@ -181,22 +208,29 @@ CX_DEVICE void flush_param_grads(float (&dg)[NCH][4], float (&db)[NCH][4], float
     }
 }
 
-template <int NCH>
-__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
+// CS (round 3): also accumulate the column sums of the dz this kernel writes -- dz is the gradient of (Linear output +
+// residual), so its column sums ARE the bias gradient of that Linear (fc2 / out_proj; sc FusedDense backward's `db`).
+// The standalone cx_bias_grad passes they replace re-read dz: 2 x T x d x 2 bytes per block, 6.5 % of the CLIP step.
+// The sums take what is STORED (the bf16-rounded dz), like the standalone kernel did.
+template <int NCH, bool CS>
+__global__ __launch_bounds__(256, CS ? 3 : 4) void ln_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
                                                      const bf16_t* __restrict__ z, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i,
                                                      const bf16_t* __restrict__ dz_extra, bf16_t* __restrict__ dz,
-                                                     float* dgamma, float* dbeta, float* part, int rows) {
+                                                     float* dgamma, float* dbeta, float* part, float* part3, int rows) {
     constexpr int D = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float g[NCH][4], dg[NCH][4], db[NCH][4];
+    float g[NCH][4], dg[NCH][4], db[NCH][4], dc[CS ? NCH : 1][4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            dg[i][e] = db[i][e] = 0.f;
+            if (CS) dc[i][e] = 0.f;
+        }
     }
     const int stride = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
@@ -255,7 +289,18 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += t[e];
             }
-            store4_bf16(dz + off, o);
+            if constexpr (CS) {
+                uint2 u;
+                u.x = pack_bf16x2(o[0], o[1]);
+                u.y = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(dz + off) = u;
+                float r[4];
+                unpack4_bf16(u, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dc[i][e] += r[e];
+            } else {
+                store4_bf16(dz + off, o);
+            }
         }
     }
     if (part) {
@@ -263,6 +308,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16_t* __restrict
     } else {
         flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
     }
+    if constexpr (CS) store_colsum_partials<NCH>(dc, part3, smem);
 }
 
 // Backward of the LAST LayerNorm of a pooled encoder with the pooling backward folded in (round 3).  The gradient of the
@@ -274,23 +320,26 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16_t* __restrict
 // where bf16-eager (fp32 LayerNorm) is 0.5 % off, ln_f.bias of ViT-B/16 0.18 % vs 0.04 %.  Here dout never leaves fp32
 // and never touches HBM.  One workgroup per sequence (grid-stride), one wave per row; parameter gradients through the
 // deterministic two-stage reduction.
-template <int NCH>
-__global__ __launch_bounds__(256, 4) void ln_bwd_pooled_kernel(const float* __restrict__ demb, const float* __restrict__ emb,
+template <int NCH, bool CS>
+__global__ __launch_bounds__(256, CS ? 3 : 4) void ln_bwd_pooled_kernel(const float* __restrict__ demb, const float* __restrict__ emb,
                                                             const float* __restrict__ norm, const int32_t* __restrict__ cu,
                                                             int B, int mode, int normalize, const bf16_t* __restrict__ z,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                             const float* __restrict__ rstd_i, bf16_t* __restrict__ dz,
-                                                            float* dgamma, float* dbeta, float* part) {
+                                                            float* dgamma, float* dbeta, float* part, float* part3) {
     constexpr int D = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [8 * D] (parameter partials; the first D floats hold g) + 4
     float* red = smem + 8 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float g[NCH][4], dg[NCH][4], db[NCH][4];
+    float g[NCH][4], dg[NCH][4], db[NCH][4], dc[CS ? NCH : 1][4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            dg[i][e] = db[i][e] = 0.f;
+            if (CS) dc[i][e] = 0.f;
+        }
     }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -346,7 +395,16 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_pooled_kernel(const float* __re
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (g[i][e] * dy[i][e] - s1 * xh[i][e] - s2) * rstd;
-                store4_bf16(dz + (size_t)row * D + (i * 64 + lane) * 4, o);
+                uint2 u;
+                u.x = pack_bf16x2(o[0], o[1]);
+                u.y = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(dz + (size_t)row * D + (i * 64 + lane) * 4) = u;
+                if (CS) {
+                    float r[4];
+                    unpack4_bf16(u, r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dc[i][e] += r[e];
+                }
             }
         }
         __syncthreads();  // g and red are rewritten for the next sequence
@@ -356,6 +414,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_pooled_kernel(const float* __re
     } else {
         flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
     }
+    if constexpr (CS) store_colsum_partials<NCH>(dc, part3, smem);
 }
 
 template <int NCH>
@@ -842,9 +901,12 @@ int cx_layernorm_fwd(const uint16_t* x0, const uint16_t* residual, const float* 
     return done();
 }
 
-int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
-                     const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
-                     float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream) {
+namespace {
+// Shared launcher.  dz_colsum != NULL: fp32[d] += column sums of the dz written (needs the workspace: the sums go through
+// the deterministic two-stage reduction like dgamma / dbeta).
+int ln_bwd_launch(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma, const float* mean,
+                  const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma, float* dbeta, float* dz_colsum,
+                  float* ws, long ws_floats, int rows, int d, void* stream) {
     if (rows <= 0) return CX_OK;
     if (!dout_a || !z || !gamma || !mean || !rstd || !dz) return CX_ERR_ARG;
     const size_t smem = (size_t)8 * d * sizeof(float);
@@ -852,42 +914,76 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
     // without: one block per CU and 2*d atomics per block
     int grid = ln_grid_bwd(rows);
     float* part = nullptr;
-    if (ws && ws_floats >= (long)2 * d * 256) {
-        long cap = ws_floats / (2L * d);
+    const long per_block = (dz_colsum ? 3L : 2L) * d;
+    if (ws && ws_floats >= per_block * 256) {
+        long cap = ws_floats / per_block;
         grid = (rows + 3) / 4;
         if (grid > 768) grid = 768;  // 3 blocks per CU = the kernel's occupancy (130 VGPRs): one resident round, few partials
         if (grid > cap) grid = (int)cap;
         part = ws;
     }
-    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
-                                         dout_b, z, gamma, mean, rstd, dz_extra, dz, dgamma, dbeta, part, rows));
+    if (dz_colsum && !part) return CX_ERR_ARG;
+    float* part3 = dz_colsum ? part + (size_t)grid * 2 * d : nullptr;
+    if (dz_colsum) {
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                             dout_b, z, gamma, mean, rstd, dz_extra, dz, dgamma, dbeta, part, part3, rows));
+    } else {
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                             dout_b, z, gamma, mean, rstd, dz_extra, dz, dgamma, dbeta, part, part3, rows));
+    }
     if (part && (dgamma || dbeta))
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part,
                            dgamma, dbeta, grid, d);
+    if (dz_colsum)
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part3, dz_colsum, grid, d);
     return done();
+}
+}  // namespace
+
+int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                     const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
+                     float* dbeta, float* ws, long ws_floats, int rows, int d, void* stream) {
+    return ln_bwd_launch(dout_a, dout_b, z, gamma, mean, rstd, dz_extra, dz, dgamma, dbeta, nullptr, ws, ws_floats, rows, d, stream);
+}
+
+int cx_layernorm_bwd_colsum(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                            const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
+                            float* dbeta, float* dz_colsum, float* ws, long ws_floats, int rows, int d, void* stream) {
+    return ln_bwd_launch(dout_a, dout_b, z, gamma, mean, rstd, dz_extra, dz, dgamma, dbeta, dz_colsum, ws, ws_floats, rows, d, stream);
 }
 
 int cx_layernorm_bwd_pooled(const float* demb, const float* emb, const float* norm, const int32_t* cu_seqlens, int B,
                             int pool_mode, int normalize, const uint16_t* z, const float* gamma, const float* mean,
-                            const float* rstd, uint16_t* dz, float* dgamma, float* dbeta, float* ws, long ws_floats, int rows,
-                            int d, void* stream) {
+                            const float* rstd, uint16_t* dz, float* dgamma, float* dbeta, float* dz_colsum, float* ws,
+                            long ws_floats, int rows, int d, void* stream) {
     if (rows <= 0 || B <= 0) return CX_OK;
     if (!demb || !emb || !norm || !cu_seqlens || !z || !gamma || !mean || !rstd || !dz) return CX_ERR_ARG;
     const size_t smem = ((size_t)8 * d + 8) * sizeof(float);
     int grid = B < 256 ? B : 256;
     float* part = nullptr;
-    if (ws && ws_floats >= (long)2 * d * 256) {
-        const long cap = ws_floats / (2L * d);
+    const long per_block = (dz_colsum ? 3L : 2L) * d;
+    if (ws && ws_floats >= per_block * 256) {
+        const long cap = ws_floats / per_block;
         grid = B < 768 ? B : 768;
         if (grid > cap) grid = (int)cap;
         part = ws;
     }
-    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_pooled_kernel<NCH>), dim3(grid), dim3(256), smem, (hipStream_t)stream, demb, emb,
-                                         norm, cu_seqlens, B, pool_mode, normalize, z, gamma, mean, rstd, dz, dgamma, dbeta,
-                                         part));
+    if (dz_colsum && !part) return CX_ERR_ARG;
+    float* part3 = dz_colsum ? part + (size_t)grid * 2 * d : nullptr;
+    if (dz_colsum) {
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_pooled_kernel<NCH, true>), dim3(grid), dim3(256), smem, (hipStream_t)stream,
+                                             demb, emb, norm, cu_seqlens, B, pool_mode, normalize, z, gamma, mean, rstd, dz, dgamma,
+                                             dbeta, part, part3));
+    } else {
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_pooled_kernel<NCH, false>), dim3(grid), dim3(256), smem, (hipStream_t)stream,
+                                             demb, emb, norm, cu_seqlens, B, pool_mode, normalize, z, gamma, mean, rstd, dz, dgamma,
+                                             dbeta, part, part3));
+    }
     if (part && (dgamma || dbeta))
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part,
                            dgamma, dbeta, grid, d);
+    if (dz_colsum)
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part3, dz_colsum, grid, d);
     return done();
 }
 

@@ -206,6 +206,38 @@ class ViTEngine(NomicBertEngine):
         _C.check(rc, "cx_vit_backward")
         self._end_backward(arena, fires)
 
+    # ---- token-level outputs (poolers above the C-ABI: `pooling: map`): (B, n_patch + 1, d) bf16 after ln_f ------------
+    def forward_hidden_chunk(self, pixels: torch.Tensor, save_for_backward: bool):
+        cfg = self.config
+        pixels = self._check_pixels(pixels)
+        B = pixels.shape[0]
+        S = cfg.n_patch + 1
+        hidden = torch.empty(B, S, cfg.n_embd, dtype=torch.bfloat16, device=self.device_)
+        arena = self._get_arena(B * S, B, save_for_backward)
+        rc = self.lib.cx_vit_forward_hidden(C.byref(self._desc), C.byref(arena.desc), pixels.data_ptr(),
+                                            int(pixels.dtype == torch.bfloat16), self._cu_seqlens(B).data_ptr(), B,
+                                            cfg.num_channels, cfg.img_size, cfg.img_size, cfg.patch_size,
+                                            int(save_for_backward), hidden.data_ptr(), _C.cur_stream())
+        _C.check(rc, "cx_vit_forward_hidden")
+        if save_for_backward:
+            arena.emb_out = hidden   # (marks the arena as holding a saved forward)
+            self._outstanding += 1
+            return hidden, arena
+        return hidden, None
+
+    def backward_hidden_chunk(self, B: int, arena: _ChunkArena, dhidden: torch.Tensor):
+        dh = dhidden.to(torch.bfloat16).contiguous()
+        fires = self._begin_backward(arena)
+        rc = self.lib.cx_vit_backward_hidden(C.byref(self._desc), C.byref(arena.desc), self._cu_seqlens(B).data_ptr(), B,
+                                             self.config.n_patch, dh.data_ptr(), _C.cur_stream())
+        _C.check(rc, "cx_vit_backward_hidden")
+        self._end_backward(arena, fires)
+
+    def hidden_states(self, pixels: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and self.training:
+            return _VitHiddenFn.apply(self.flat_decay, self, pixels)
+        return self.forward_hidden_chunk(pixels, False)[0]
+
     def forward(self, pixels: torch.Tensor, attention_mask=None, normalize: Optional[bool] = None) -> torch.Tensor:
         if torch.is_grad_enabled() and self.training:
             return _VitEncodeFn.apply(self.flat_decay, self, pixels, normalize)
@@ -226,3 +258,18 @@ class _VitEncodeFn(torch.autograd.Function):
     def backward(ctx, demb):
         ctx.engine.backward_chunk(ctx.B, ctx.arena, demb)
         return None, None, None, None
+
+
+class _VitHiddenFn(torch.autograd.Function):
+    """Token-level twin of _VitEncodeFn: hidden states out, d(hidden) in, parameter gradients into the flat buffer."""
+
+    @staticmethod
+    def forward(ctx, _anchor, engine: ViTEngine, pixels: torch.Tensor):
+        hidden, arena = engine.forward_hidden_chunk(pixels, True)
+        ctx.engine, ctx.B, ctx.arena = engine, pixels.shape[0], arena
+        return hidden
+
+    @staticmethod
+    def backward(ctx, dhidden):
+        ctx.engine.backward_hidden_chunk(ctx.B, ctx.arena, dhidden)
+        return None, None, None

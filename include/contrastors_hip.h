@@ -86,8 +86,15 @@ int cx_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const uint1
  * fp32 oracle on the reference's GradCache fixture, where bf16-eager is 0.5 % off).  rows = total tokens. */
 int cx_layernorm_bwd_pooled(const float* demb, const float* emb, const float* norm, const int32_t* cu_seqlens, int B,
                             int pool_mode, int normalize, const uint16_t* z, const float* gamma, const float* mean,
-                            const float* rstd, uint16_t* dz, float* dgamma, float* dbeta, float* ws, long ws_floats, int rows,
-                            int d, void* stream);
+                            const float* rstd, uint16_t* dz, float* dgamma, float* dbeta, float* dz_colsum, float* ws,
+                            long ws_floats, int rows, int d, void* stream);
+/* cx_layernorm_bwd that also accumulates dz_colsum[n] += sum_t dz[t][n] (fp32[d]; also a trailing argument of the pooled
+ * form above, NULL = off): dz is the gradient of (Linear output + residual), so this IS the bias gradient of that Linear
+ * (FusedDense backward's db for fc2 / out_proj of the BERT-base and ViT towers) without a second pass over dz.  Needs
+ * the workspace (CX_ERR_ARG otherwise: call cx_layernorm_bwd + cx_bias_grad). */
+int cx_layernorm_bwd_colsum(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                            const float* mean, const float* rstd, const uint16_t* dz_extra, uint16_t* dz, float* dgamma,
+                            float* dbeta, float* dz_colsum, float* ws, long ws_floats, int rows, int d, void* stream);
 
 /* dropout p > 0 (flash_attn.ops.layer_norm.dropout_add_layer_norm(p > 0), sc/layers/block.py:422-431,453-462 with
  * resid_pdrop > 0): z = dropout_p(x0) + residual, out = LN(z).  The keep-mask is Philox4x32-10(seed; offset + site,
@@ -177,6 +184,10 @@ int cx_gemm_bf16_swiglu_bwd(const uint16_t* dY, const uint16_t* W, const uint16_
 int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream);
 int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, int T, int I,
                      void* stream);
+/* The same backward with the bias gradient of the same pass: dbias[n] += sum_t dpre[t][n] (fp32 atomics; dbias may be NULL).
+ * Replaces cx_bias_gelu_bwd + cx_bias_grad (the second kernel re-read dpre: T x I x 2 bytes). */
+int cx_bias_gelu_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, float* dbias, int T,
+                            int I, void* stream);
 /* dbias[n] += sum_t dY[t][n]  (fp32 atomic accumulate; bgrad half of FusedDense backward). */
 int cx_bias_grad(const uint16_t* dY, float* dbias, int T, int N, int ld, void* stream);
 
@@ -426,6 +437,14 @@ int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const vo
                    float* emb_out, void* stream);
 int cx_vit_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc,
                     int n_patch, const float* demb, const float* emb_out, void* stream);
+/* Token-level twins (as cx_encoder_forward_hidden / _backward_hidden for the text trunk): hidden_out / dhidden are the
+ * (Bc * (n_patch + 1), d) bf16 hidden states after ln_f and their gradient -- for poolers that live above the C-ABI
+ * (sc/models/biencoder/modeling_biencoder.py:93-156 MultiHeadAttentionPooling, `pooling: map` of the vision recipes). */
+int cx_vit_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
+                          const int32_t* cu_seqlens, int Bc, int Cc, int H, int W, int patch, int save_for_backward,
+                          uint16_t* hidden_out, void* stream);
+int cx_vit_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const int32_t* cu_seqlens, int Bc, int n_patch,
+                           const uint16_t* dhidden, void* stream);
 
 /* ---- K12  fused softmax cross-entropy over a vocabulary-sized class axis (flash_attn.losses.cross_entropy.
  *      CrossEntropyLoss, csrc/xentropy; sc/models/encoder/modeling_nomic_bert.py:603-610).  logits: (N, V) bf16

@@ -154,6 +154,39 @@ def gen_vit(name, cfgd, seed):
     print(name, "hidden", tuple(hid.shape))
 
 
+def gen_map_pool(name, seed):
+    """tests/golden/map_pool_tiny.npz: the reference's own MultiHeadAttentionPooling (modeling_biencoder.py:93-156) on CPU
+    in fp32, applied to random (B, S, d) hidden states: output, gradient of the hidden states and of every parameter."""
+    from transformers import GPT2Config
+
+    from oracle import map_pool_ref
+
+    bi = ref_import.load_biencoder()
+    d, H, inner, eps = 256, 4, 512, 1e-6
+    c = GPT2Config(n_embd=d, n_head=H, n_inner=inner, activation_function="gelu", layer_norm_epsilon=eps, attn_pdrop=0.0,
+                   use_flash_attn=True, fused_bias_fc=False, qkv_proj_bias=True, mlp_fc1_bias=True, mlp_fc2_bias=True,
+                   use_rms_norm=False, causal=False)
+    m = bi.MultiHeadAttentionPooling(c).float()
+    sd = map_pool_ref.random_state_dict(d, inner, seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    g = torch.Generator().manual_seed(seed + 1)
+    hidden = torch.randn(5, 17, d, generator=g).requires_grad_()
+    probe = torch.randn(5, d, generator=g)
+    out = m(hidden, None, None)          # attention_mask=None: the image-tower branch (the masked one cannot run, see map_pooling.py)
+    (out * probe).sum().backward()
+    rec = {"hidden": hidden.detach().numpy(), "probe": probe.numpy(), "out": out.detach().numpy(),
+           "g/hidden": hidden.grad.numpy(), "n_head": np.array(H), "eps": np.array(eps), "seed": np.array(seed)}
+    # (weights are map_pool_ref.random_state_dict(d, inner, seed): not stored; matrices keep their norm and a corner)
+    for k, p_ in m.named_parameters():
+        gk = p_.grad.detach()
+        rec["gnorm/" + k] = np.array(float(gk.norm()))
+        rec["g/" + k] = (gk[:16, :16] if gk.ndim == 2 else gk).numpy()
+    rec["weight_checksum"] = checksum(sd)
+    np.savez_compressed(GOLD / f"{name}.npz", d=np.array(d), inner=np.array(inner), **rec)
+    print(name, "out", tuple(out.shape), "params", sorted(k for k, _ in m.named_parameters()))
+
+
 def hf_bert_state_dict(L=2, d=8, inter=16, vocab=10, types=2, pos=12, seed=11, gamma_beta=False, roberta=False):
     """A BertForPreTraining-shaped state dict with HF key names (random values): the input of the remap goldens."""
     g = torch.Generator().manual_seed(seed)
@@ -469,6 +502,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixture
         gen_vit("vit_tiny", TINY_VIT, 5)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "map_pool":
+        gen_map_pool("map_pool_tiny", 9)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mlm":
         gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
         gen_mlm("mlm_bert_tiny", TINY_BERT, 22)
@@ -489,6 +525,7 @@ if __name__ == "__main__":
     gen_clip_loss_single()
     gen_multirank()
     gen_vit("vit_tiny", TINY_VIT, 5)
+    gen_map_pool("map_pool_tiny", 9)
     gen_hf_remap()
     gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)
     gen_mlm("mlm_bert_tiny", TINY_BERT, 22)

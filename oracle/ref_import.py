@@ -114,6 +114,49 @@ def load_vit():
     return vit
 
 
+def load_biencoder():
+    """-> the reference's sc/models/biencoder/modeling_biencoder.py (LogitScale, the pooling selectors incl.
+    MultiHeadAttentionPooling, BiEncoder) importable on a CPU-only host: everything load_vit() arranges, plus import-only
+    stand-ins for the MoE pieces of the text encoder package (megablocks, sc/layers/moe.py: out of scope, never called) and
+    the exact softmax attention in place of the third-party kv-packed attention core the pooling head calls."""
+    vit = load_vit()
+    import torch
+
+    for name, path in (("contrastors.models.biencoder", REF_ROOT / "models" / "biencoder"),):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [str(path)]
+            sys.modules[name] = m
+    mb_layers = sys.modules["megablocks.layers"]
+    for attr in ("moe", "mlp", "router", "common", "mpu"):
+        if not hasattr(mb_layers, attr):
+            setattr(mb_layers, attr, types.SimpleNamespace())
+    if "contrastors.layers.moe" not in sys.modules:
+        m = types.ModuleType("contrastors.layers.moe")
+        m.__spec__ = M.ModuleSpec("contrastors.layers.moe", None)
+        m.MoEBlock = object
+        sys.modules["contrastors.layers.moe"] = m
+    # `contrastors.models.vit` is the synthetic package of load_vit() (its __init__ wants timm): give it the names the
+    # biencoder module imports from it -- the real ViTModel, and import-only placeholders for the hub config converters
+    pkg = sys.modules["contrastors.models.vit"]
+    pkg.ViTModel = vit.ViTModel
+    for conv in ("clip_config_to_vit_config", "dino_config_to_vit_config", "hf_vit_config_to_vit_config", "timm_name_to_vit_config"):
+        if not hasattr(pkg, conv):
+            setattr(pkg, conv, None)
+    bi = importlib.import_module("contrastors.models.biencoder.modeling_biencoder")
+    ratt = importlib.import_module("contrastors.layers.attention")
+
+    def exact_kvpacked(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, **kw):
+        assert dropout_p == 0.0 and not causal
+        k, v = kv.unbind(2)  # (B, Sk, H, D)
+        sc = float(softmax_scale) if softmax_scale is not None else q.shape[-1] ** -0.5
+        att = torch.einsum("bshd,bthd->bhst", q, k) * sc
+        return torch.einsum("bhst,bthd->bshd", att.softmax(-1), v)
+
+    ratt.flash_attn_kvpacked_func = exact_kvpacked
+    return bi
+
+
 def load_bert_remap():
     """-> the reference's sc/models/encoder/bert.py (config conversion + HF <-> flash state-dict remapping), loaded by
     file path so that the package __init__ (which wants flash_attn) never runs."""

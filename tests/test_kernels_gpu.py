@@ -230,12 +230,20 @@ def test_layernorm_fwd_bwd(d, rows):
                                   rstd.data_ptr(), None, dz.data_ptr(), dg.data_ptr(), dbeta.data_ptr(), None, 0, rows,
                                   d, S()))
     # two-stage (workspace) parameter-gradient reduction: same numbers, accumulates on top of existing values
-    ws = torch.empty(512 * d, device=DEV)
+    ws = torch.empty(1024 * d, device=DEV)
     dz2, dg2, db2 = torch.empty_like(x0), torch.ones(d, device=DEV), torch.ones(d, device=DEV)
     _C.check(L().cx_layernorm_bwd(da.data_ptr(), db_.data_ptr(), z.data_ptr(), g.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), None, dz2.data_ptr(), dg2.data_ptr(), db2.data_ptr(), ws.data_ptr(),
                                   ws.numel(), rows, d, S()))
     assert torch.equal(dz, dz2) and rel_err(dg2 - 1, dg) < 1e-5 and rel_err(db2 - 1, dbeta) < 1e-5
+    # the same backward returning the column sums of its dz (bias gradient of the Linear in front), with a dz_extra term
+    ex = bf(_randn(rows, d, seed=16))
+    dz4, dg4, db4, cs4 = torch.empty_like(x0), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.ones(d, device=DEV)
+    _C.check(L().cx_layernorm_bwd_colsum(da.data_ptr(), db_.data_ptr(), z.data_ptr(), g.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), ex.data_ptr(), dz4.data_ptr(), dg4.data_ptr(), db4.data_ptr(),
+                                         cs4.data_ptr(), ws.data_ptr(), ws.numel(), rows, d, S()))
+    assert rel_err(dg4, dg) < 1e-5 and rel_err(db4, dbeta) < 1e-5
+    assert rel_err(dz4.float(), (dz.float() + ex.float())) < 8e-3 and rel_err(cs4 - 1, dz4.float().sum(0)) < 1e-5
     e_dz, e_dg, e_db = rel_err(dz.float(), zr.grad), rel_err(dg, gr.grad), rel_err(dbeta, br.grad)
     report("layernorm", d=d, rows=rows, e_dz=e_dz, e_dg=e_dg, e_db=e_db)
     assert e_dz < 8e-3, "dz is stored in bf16 and xhat is rebuilt from bf16 z"
@@ -521,10 +529,10 @@ def test_layernorm_bwd_pooled_keeps_the_pooled_gradient_in_fp32(mode, normalize)
     ref.backward(gup[keep])
     dz = torch.full_like(z, float("nan"))
     dg, dbeta = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
-    ws = torch.empty(512 * d, device=DEV)
+    ws = torch.empty(1024 * d, device=DEV)
     _C.check(L().cx_layernorm_bwd_pooled(gup.data_ptr(), emb.data_ptr(), nrm.data_ptr(), cu.data_ptr(), B, mode, normalize,
                                          z.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dz.data_ptr(),
-                                         dg.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), T, d, S()))
+                                         dg.data_ptr(), dbeta.data_ptr(), None, ws.data_ptr(), ws.numel(), T, d, S()))
     assert torch.isfinite(dz.float()).all()
     e_dz, e_dg, e_db = rel_err(dz.float(), zr.grad), rel_err(dg, gr.grad), rel_err(dbeta, br.grad)
     # the route it replaces: bf16 dout in HBM, then the plain LayerNorm backward
@@ -540,11 +548,13 @@ def test_layernorm_bwd_pooled_keeps_the_pooled_gradient_in_fp32(mode, normalize)
     assert e_dg < 2e-3 and e_db < 1e-5, "parameter gradients: fp32 dout, fp32 sums"
     assert e_db <= e_db2 + 1e-7
     # deterministic, and accumulating
-    dz3, dg3, db3 = torch.empty_like(z), torch.ones(d, device=DEV), torch.ones(d, device=DEV)
+    # ... and, with a column-sum target, the bias gradient of the Linear in front of the LayerNorm in the same pass
+    dz3, dg3, db3, cs3 = torch.empty_like(z), torch.ones(d, device=DEV), torch.ones(d, device=DEV), torch.ones(d, device=DEV)
     _C.check(L().cx_layernorm_bwd_pooled(gup.data_ptr(), emb.data_ptr(), nrm.data_ptr(), cu.data_ptr(), B, mode, normalize,
                                          z.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dz3.data_ptr(),
-                                         dg3.data_ptr(), db3.data_ptr(), ws.data_ptr(), ws.numel(), T, d, S()))
+                                         dg3.data_ptr(), db3.data_ptr(), cs3.data_ptr(), ws.data_ptr(), ws.numel(), T, d, S()))
     assert torch.equal(dz, dz3) and rel_err(dg3 - 1, dg) < 1e-5 and rel_err(db3 - 1, dbeta) < 1e-5
+    assert rel_err(cs3 - 1, dz.float().sum(0)) < 1e-5
 
 
 # --------------------------------------------------------------------------------------------------------- InfoNCE

@@ -145,6 +145,31 @@ def test_vit_restatement_matches_reference(gold):
             np.testing.assert_allclose(got.numpy(), g[key], atol=2e-5, rtol=1e-4)
 
 
+def test_map_pooling_restatement_matches_reference(gold):
+    """oracle/map_pool_ref.py vs the reference's own MultiHeadAttentionPooling (modeling_biencoder.py:93-156; `pooling: map`
+    of the vision recipes) on CPU fp32: output, gradient of the hidden states, every parameter-gradient norm and slice."""
+    from oracle import map_pool_ref
+
+    g = gold("map_pool_tiny")
+    sd = map_pool_ref.random_state_dict(int(g["d"]), int(g["inner"]), int(g["seed"]))
+    cs = np.array([float(sum(v.double().sum() for v in sd.values())),
+                   float(sum((v.double() ** 2).sum() for v in sd.values()))])
+    np.testing.assert_allclose(cs, g["weight_checksum"], rtol=1e-12)
+    for v in sd.values():
+        v.requires_grad_(True)
+    hidden = torch.from_numpy(g["hidden"]).requires_grad_()
+    out = map_pool_ref.map_pool(sd, hidden, int(g["n_head"]), float(g["eps"]))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=2e-6, rtol=1e-5)
+    (out * torch.from_numpy(g["probe"])).sum().backward()
+    np.testing.assert_allclose(hidden.grad.numpy(), g["g/hidden"], atol=2e-6, rtol=1e-4)
+    for k in g.files:
+        if k.startswith("gnorm/"):
+            n = k[6:]
+            assert abs(float(sd[n].grad.norm()) - float(g[k])) <= 1e-4 * max(1e-3, float(g[k])), n
+            got = sd[n].grad[:16, :16] if sd[n].grad.ndim == 2 else sd[n].grad
+            np.testing.assert_allclose(got.numpy(), g["g/" + n], atol=2e-6, rtol=1e-4)
+
+
 @pytest.mark.parametrize("name", ["mlm_nomic_tiny", "mlm_bert_tiny"])
 def test_mlm_restatement_matches_reference(gold, name):
     """oracle/mlm_ref.py vs the reference's eager NomicBertForPreTraining (loss, target logits, every gradient norm)."""

@@ -191,3 +191,82 @@ def test_dual_encoder_precomputed_text_lit():
     assert float(text.trunk.flat_grad.abs().max()) == 0.0
     assert live.encode_image(pix).shape == (n, 256)
 
+
+
+def test_map_pooling_head_on_the_vit_tower_matches_the_oracle(gold):
+    """`pooling: map` (configs/train/nomic_embed_vision_v1.5.yaml:69): BiEncoder(ViT) + the attention
+    pooling head.  (1) The head alone on the reference-generated golden's hidden states vs the reference's own output
+    (oracle/map_pool_ref.py is pinned to the same file on CPU); (2) the whole tower -- native ViT hidden states, head on the
+    HIP GEMM / K3 attention kernels, gradient back through cx_vit_backward_hidden -- vs the fp32 oracle composition, with
+    the 3 x bf16-eager rule."""
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig
+    from contrastors_amd.map_pooling import MultiHeadAttentionPooling
+    from oracle import map_pool_ref
+
+    g = gold("map_pool_tiny")
+    d, inner, H, eps = int(g["d"]), int(g["inner"]), int(g["n_head"]), float(g["eps"])
+    sd_head = map_pool_ref.random_state_dict(d, inner, int(g["seed"]))
+    hc = SimpleNamespace(n_embd=d, n_head=H, n_inner=inner, layer_norm_epsilon=eps, activation_function="gelu",
+                         qkv_proj_bias=True, mlp_fc1_bias=True, mlp_fc2_bias=True, use_rms_norm=False)
+    head = MultiHeadAttentionPooling(hc, device=DEV)
+    head.load_state_dict(sd_head)
+    hid = torch.from_numpy(g["hidden"]).to(DEV)
+    h16 = hid.to(torch.bfloat16).requires_grad_()
+    out = head(h16, None, None)
+    want = torch.from_numpy(g["out"]).to(DEV)
+    assert max_err(out, want) < 3e-2 and rel_err(out, want) < 8e-3, "bf16 hidden states and GEMMs vs the fp32 reference"
+    (out * torch.from_numpy(g["probe"]).to(DEV)).sum().backward()
+    assert rel_err(h16.grad.float(), torch.from_numpy(g["g/hidden"]).to(DEV)) < 2e-2
+    for k in g.files:
+        if k.startswith("gnorm/"):
+            n = k[6:]
+            got = dict(head.named_parameters())[n].grad
+            assert abs(float(got.norm()) - float(g[k])) <= 3e-2 * float(g[k]) + 1e-6, n
+
+    # (2) the whole tower
+    vg = gold("vit_tiny")
+    dd = {k[4:]: vg[k].item() for k in vg.files if k.startswith("cfg/")}
+    cfg, ns = ViTConfig(**dd), SimpleNamespace(**dd)
+    assert cfg.n_embd == d and cfg.n_head == H
+    sd = vit_ref.random_state_dict(ns, int(vg["seed"]))
+    tower = BiEncoder(BiEncoderConfig(model_name="vit", pooling="map", trunk_config=cfg), device=DEV, seed=4).train()
+    tower.trunk.load_reference_state_dict(sd)
+    tower.selector.load_state_dict(sd_head)
+    pix = torch.from_numpy(vg["pixels"]).to(DEV)
+    probe = torch.randn(pix.shape[0], d, generator=torch.Generator().manual_seed(3)).to(DEV)
+    tower.trunk.zero_grad()
+    emb = tower(input_ids=pix)["embedding"]
+    (emb * probe).sum().backward()
+    assert tower.trunk._outstanding == 0
+
+    def oracle(bf16):
+        sdd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd.items()}
+        shd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd_head.items()}
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            hidden = vit_ref.vit_hidden(sdd, ns, pix)
+            e = torch.nn.functional.normalize(map_pool_ref.map_pool(shd, hidden.float() if not bf16 else hidden, H, eps).float(), dim=-1)
+        (e.float() * probe).sum().backward()
+        return e.float(), sdd, shd
+
+    ref, sd32, sh32 = oracle(False)
+    ref16, sd16, sh16 = oracle(True)
+    e_hip, e_b = max_err(emb, ref), max_err(ref16, ref)
+    assert e_hip <= 3 * e_b + 1e-4 and e_hip < 5e-3, (e_hip, e_b)
+    grads = tower.trunk.reference_grad_dict()
+    worst = 0.0
+    for n, gh in grads.items():
+        eh, eb = rel_err(gh.reshape(-1), sd32[n].grad.reshape(-1)), rel_err(sd16[n].grad.float().reshape(-1), sd32[n].grad.reshape(-1))
+        worst = max(worst, eh / (eb + 1e-4))
+        assert eh <= 3 * eb + 1e-2, f"{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    for n, p_ in tower.selector.named_parameters():
+        eh, eb = rel_err(p_.grad.reshape(-1), sh32[n].grad.reshape(-1)), rel_err(sh16[n].grad.float().reshape(-1), sh32[n].grad.reshape(-1))
+        worst = max(worst, eh / (eb + 1e-4))
+        assert eh <= 3 * eb + 1e-2, f"selector.{n}: rel grad err {eh:.4f} vs bf16 eager {eb:.4f}"
+    report("vit_map_pooling", e_emb_hip=e_hip, e_emb_bf16=e_b, worst_grad_ratio=worst)
+    # text towers and decoder-only poolings say so instead of silently doing something else
+    from contrastors_amd.nomic_bert import NomicBertConfig
+
+    with pytest.raises(NotImplementedError):
+        BiEncoder(BiEncoderConfig(model_name="t", pooling="map", trunk_config=NomicBertConfig.nomic_bert_2048(n_layer=1)), device=DEV)
+    with pytest.raises(NotImplementedError):
+        BiEncoder(BiEncoderConfig(model_name="t", pooling="last", trunk_config=cfg), device=DEV)
