@@ -575,12 +575,12 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
                                     2 * enc->n_layer, stream));
     }
     // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
-    // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
+    // (T, >= 3d) bf16 = room for the (T, d) fp32 row gradients), fp32 atomics otherwise
     if (sort_ids && sort_perm) {
         CX_TRY(cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                                       buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                                       enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, enc->vocab, sort_ids,
-                                      sort_perm, buf->g_wide, stream));
+                                      sort_perm, reinterpret_cast<float*>(buf->g_wide), stream));
     } else {
         CX_TRY(cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                                buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
@@ -634,12 +634,12 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
                                     2 * enc->n_layer, stream));
     }
     // word rows: deterministic segmented reduction when the host supplied the sorted token order (g_wide is free by now:
-    // (T, >= 3d) bf16 holds the (T, d) row gradients), fp32 atomics otherwise
+    // (T, >= 3d) bf16 = room for the (T, d) fp32 row gradients), fp32 atomics otherwise
     if (sort_ids && sort_perm) {
         CX_TRY(cx_embed_ln_bwd_sorted(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                                       buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,
                                       enc->gemb_ln_g, enc->gemb_ln_b, T, S, d, enc->padding_idx, enc->vocab, sort_ids,
-                                      sort_perm, buf->g_wide, stream));
+                                      sort_perm, reinterpret_cast<float*>(buf->g_wide), stream));
     } else {
         CX_TRY(cx_embed_ln_bwd(da, db, input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                                buf->emb_mean, buf->emb_rstd, enc->gword_emb, enc->gtype_emb, enc->gpos_emb,

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ word, const float* __restrict__ type0,
     const float* __restrict__ pos_emb, const float* __restrict__ gamma, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, float* dword, float* dtype0, float* dpos, float* dgamma, float* dbeta, int T,
-    int S, int padding_idx, bf16_t* __restrict__ dz_out) {
+    int S, int padding_idx, float* __restrict__ dz_out) {
     constexpr int D = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -541,7 +541,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
                 if (dpos) unsafeAtomicAdd(dpos + (size_t)pos * D + col + e, o);
             }
             // sorted path: the row gradient goes to scratch, embed_scatter_sorted_kernel sums it per vocabulary row
-            if (dz_out) store4_bf16(dz_out + (size_t)t * D + col, ov);
+            // fp32 row gradients for the sorted reduction (round 3, ADVICE r2: a bf16 scratch cost every addend 8 bits, and
+            // frequent tokens -- [CLS], [SEP] -- sum thousands of them)
+            if (dz_out) *reinterpret_cast<float4*>(dz_out + (size_t)t * D + col) = make_float4(ov[0], ov[1], ov[2], ov[3]);
         }
     }
     flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(
 // dz[perm[lo + w]], dz[perm[lo + w + 4]], ... (each in token order), the four partials are folded in wave order and the
 // row is read-modify-written once, by its only owner.  Bit-reproducible.
 template <int NCH>
-__global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const bf16_t* __restrict__ dz, const int32_t* __restrict__ sorted_ids,
+__global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const float* __restrict__ dz, const int32_t* __restrict__ sorted_ids,
                                                                    const int32_t* __restrict__ perm, float* __restrict__ dword, int T,
                                                                    int vocab, int padding_idx) {
     constexpr int D = NCH * 256;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const bf16_t*
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 float r[4];
-                load4_bf16(dz + (size_t)t * D + (i * 64 + lane) * 4, r);
+                load4_f32(dz + (size_t)t * D + (i * 64 + lane) * 4, r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][e] += r[e];
             }
@@ -1077,7 +1079,7 @@ int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_
     CX_LN_DISPATCH(d, hipLaunchKernelGGL((embed_ln_bwd_kernel<NCH>), dim3(ln_grid_bwd(T)), dim3(256), smem,
                                          (hipStream_t)stream, dout_a, dout_b, input_ids, indices, word, type0,
                                          pos_emb, gamma, mean, rstd, dword, dtype0, dpos, dgamma, dbeta, T, S,
-                                         padding_idx, (bf16_t*)nullptr));
+                                         padding_idx, (float*)nullptr));
     return done();
 }
 
@@ -1085,7 +1087,7 @@ int cx_embed_ln_bwd_sorted(const uint16_t* dout_a, const uint16_t* dout_b, const
                            const int32_t* indices, const float* word, const float* type0, const float* pos_emb,
                            const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
                            float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, int vocab,
-                           const int32_t* sorted_ids, const int32_t* perm, uint16_t* dz_scratch, void* stream) {
+                           const int32_t* sorted_ids, const int32_t* perm, float* dz_scratch, void* stream) {
     if (T <= 0) return CX_OK;
     if (!dout_a || !input_ids || !indices || !word || !type0 || !gamma || !mean || !rstd) return CX_ERR_ARG;
     if (!sorted_ids || !perm || !dz_scratch || vocab <= 0) return CX_ERR_ARG;

@@ -143,14 +143,14 @@ int cx_embed_ln_bwd(const uint16_t* dout_a, const uint16_t* dout_b, const int64_
 
 /* The same backward with the word-embedding rows reduced WITHOUT atomics: `sorted_ids` = the chunk's T token ids in
  * ascending order (stable), `perm` = the token index each sorted entry came from (both int32[T], prepared by the host
- * with one device sort per chunk), dz_scratch = (T, d) bf16.  One workgroup per vocabulary row sums its tokens in token
+ * with one device sort per chunk), dz_scratch = (T, d) fp32 (the row gradients are not rounded before they are summed).  One workgroup per vocabulary row sums its tokens in token
  * order: deterministic, and ~10x faster than 100 M fp32 atomics per 131072-token chunk.  dpos / dtype0 / dgamma / dbeta as
  * above. */
 int cx_embed_ln_bwd_sorted(const uint16_t* dout_a, const uint16_t* dout_b, const int64_t* input_ids,
                            const int32_t* indices, const float* word, const float* type0, const float* pos_emb,
                            const float* gamma, const float* mean, const float* rstd, float* dword, float* dtype0,
                            float* dpos, float* dgamma, float* dbeta, int T, int S, int d, int padding_idx, int vocab,
-                           const int32_t* sorted_ids, const int32_t* perm, uint16_t* dz_scratch, void* stream);
+                           const int32_t* sorted_ids, const int32_t* perm, float* dz_scratch, void* stream);
 
 /* ---- K10 swiglu (flash_attn.ops.activations.swiglu; sc/layers/mlp.py:75) and GELU(erf) (mlp.py:30-34) ----
  * yg:(T, 2*I) holds y = fc11(x) and gate = fc12(x);  act = silu(gate) * y, fp32 math, one rounding.
