@@ -51,6 +51,7 @@ class CxEncoderDesc(C.Structure):
         ("gWpatch", vp), ("gbpatch", vp), ("gcls_token", vp), ("gvit_pos", vp),
         ("patch_dim", i32),
         ("resid_pdrop", f32), ("embd_pdrop", f32), ("attn_pdrop", f32),
+        ("mlp_act", i32), ("lnpre_g", vp), ("lnpre_b", vp), ("glnpre_g", vp), ("glnpre_b", vp),
     ]
 
 
@@ -62,7 +63,7 @@ class CxChunkBuffers(C.Structure):
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
             "ws_f32",
         )
-    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp), ("layer_events", C.POINTER(vp))]
+    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp), ("layer_events", C.POINTER(vp)), ("zpre", vp)]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.
@@ -99,10 +100,13 @@ _SIGS = {
     "cx_gemm_bf16_nt_residual": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_swiglu_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_bias_gelu": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cx_gemm_bf16_bias_act": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_bias_gelu_fwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "cx_bias_gelu_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "cx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "cx_bias_gelu_bwd_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
+    "cx_bias_act_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cx_bias_act_bwd_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd_prerotated": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),

@@ -49,6 +49,26 @@ CX_DEVICE float gelu_cdf(float v, float& gauss) {
     return 0.5f * (1.f + copysignf(erf_abs, v));
 }
 
+// MLP activations of the plain (non-gated) MLP, selected at run time (sc/layers/mlp.py:8-34 `activation`; block.py:45-52):
+//   CX_ACT_GELU        exact-erf GELU (BERT-base, HF / timm ViTs)
+//   CX_ACT_QUICK_GELU  x * sigmoid(1.702 x) (sc/layers/activations.py:4-5; the OpenAI-CLIP image tower, sc/models/vit/clip.py)
+// act_val: activation value; act_grad: d act / d v.
+enum { CX_ACT_GELU = 0, CX_ACT_QUICK_GELU = 1 };
+CX_DEVICE float act_val(float v, int act) {
+    if (act == CX_ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
+    float gauss;
+    return v * gelu_cdf(v, gauss);
+}
+CX_DEVICE float act_grad(float v, int act) {
+    if (act == CX_ACT_QUICK_GELU) {
+        const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
+        return s * (1.f + 1.702f * v * (1.f - s));
+    }
+    float gauss;
+    const float cdf = gelu_cdf(v, gauss);
+    return cdf + v * 0.3989422804014327f * gauss;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
 
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const bf16_t* __restrict__ pre,
                                                             const float* __restrict__ bias,
-                                                            bf16_t* __restrict__ act, long T, int I) {
+                                                            bf16_t* __restrict__ act, long T, int I, int kind) {
     const int chunks = I >> 3;
     const long total = T * chunks;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -185,9 +185,7 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const bf16_t* __rest
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = x[e] + bb[e];
-            float gauss;
-            o[e] = v * gelu_cdf(v, gauss);
+            o[e] = act_val(x[e] + bb[e], kind);
         }
         *reinterpret_cast<uint4*>(act + t * (long)I + c) = pack8(o);
     }
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const bf16_t* __rest
 template <bool GELU>
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ pre,
                                                      const float* __restrict__ bias, bf16_t* __restrict__ dpre,
-                                                     float* __restrict__ dbias, int T, int N, int ld) {
+                                                     float* __restrict__ dbias, int T, int N, int ld, int kind) {
     __shared__ float red[8][256];
     const int tid = threadIdx.x;
     const int cch = tid & 31, rl = tid >> 5;
@@ -264,10 +262,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
                     unpack8(x[u], xv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float z = xv[e] + bb[e];
-                        float gauss;
-                        const float cdf = gelu_cdf(z, gauss);
-                        o[e] = v[e] * (cdf + z * 0.3989422804014327f * gauss);
+                        o[e] = v[e] * act_grad(xv[e] + bb[e], kind);
                     }
                     const uint4 pk = pack8(o);
                     *reinterpret_cast<uint4*>(dpre + (size_t)t * ld + col) = pk;
@@ -472,10 +467,15 @@ int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T
 }
 
 int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream) {
+    return cx_bias_act_fwd(pre, bias, act, T, I, CX_ACT_GELU, stream);
+}
+
+int cx_bias_act_fwd(const uint16_t* pre, const float* bias, uint16_t* act_out, int T, int I, int act, void* stream) {
     if (T <= 0) return CX_OK;
     if (I % 8) return CX_ERR_SHAPE;
+    if (act != CX_ACT_GELU && act != CX_ACT_QUICK_GELU) return CX_ERR_ARG;
     hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0,
-                       (hipStream_t)stream, pre, bias, act, (long)T, I);
+                       (hipStream_t)stream, pre, bias, act_out, (long)T, I, act);
     return done();
 }
 
@@ -504,17 +504,22 @@ int cx_bias_grad(const uint16_t* dY, float* dbias, int T, int N, int ld, void* s
     if ((N % 8) || (ld % 8)) return CX_ERR_ALIGN;
     dim3 grid((N + 255) / 256, colsum_rows_grid(T, N));
     hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, (const bf16_t*)nullptr,
-                       (const float*)nullptr, (bf16_t*)nullptr, dbias, T, N, ld);
+                       (const float*)nullptr, (bf16_t*)nullptr, dbias, T, N, ld, 0);
     return done();
 }
 
 int cx_bias_gelu_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, float* dbias, int T,
                             int I, void* stream) {
+    return cx_bias_act_bwd_colsum(dact, pre, bias, dpre, dbias, T, I, CX_ACT_GELU, stream);
+}
+
+int cx_bias_act_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, float* dbias, int T,
+                           int I, int act, void* stream) {
     if (T <= 0) return CX_OK;
     if (I % 8) return CX_ERR_SHAPE;
-    if (!dact || !pre || !dpre) return CX_ERR_ARG;
+    if (!dact || !pre || !dpre || (act != CX_ACT_GELU && act != CX_ACT_QUICK_GELU)) return CX_ERR_ARG;
     dim3 grid((I + 255) / 256, colsum_rows_grid(T, I));
-    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dact, pre, bias, dpre, dbias, T, I, I);
+    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dact, pre, bias, dpre, dbias, T, I, I, act);
     return done();
 }
 

@@ -131,11 +131,11 @@ struct BlockRunner {
         }
         // bias + erf-GELU in the GEMM epilogue; yg then holds the biased pre-activation, which backward reads with a
         // NULL bias.  Shapes the fused kernel does not cover take the two-kernel route (yg without the bias).
-        const int rc = cx_gemm_bf16_bias_gelu(x, w.Wfc1, w.bfc1, keep ? s.yg(l) : nullptr, s.act(l), T, s.wfc1, d, d, d, s.wfc1,
-                                              I, stream);
+        const int rc = cx_gemm_bf16_bias_act(x, w.Wfc1, w.bfc1, keep ? s.yg(l) : nullptr, s.act(l), T, s.wfc1, d, d, d, s.wfc1,
+                                             I, enc->mlp_act, stream);
         if (rc != CX_ERR_SHAPE) return rc;
         CX_TRY(cx_gemm_bf16_nt(x, w.Wfc1, s.yg(l), nullptr, T, s.wfc1, d, d, d, s.wfc1, 0, 1, 1.f, stream));
-        return cx_bias_gelu_fwd(s.yg(l), w.bfc1, s.act(l), T, I, stream);
+        return cx_bias_act_fwd(s.yg(l), w.bfc1, s.act(l), T, I, enc->mlp_act, stream);
     }
     int mlp(const CxLayerWeights& w, const uint16_t* x, int l, uint16_t* out, const uint16_t* residual, bool keep,
             bool* folded) const {
@@ -314,8 +314,8 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         } else {
             // (yg holds the biased pre-activation when the forward took the fused kernel: same predicate as there)
             // GELU backward and the fc1 bias gradient in one pass over (dact, pre)
-            CX_TRY(cx_bias_gelu_bwd_colsum(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide,
-                                           w.gbfc1, T, I, stream));
+            CX_TRY(cx_bias_act_bwd_colsum(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide,
+                                          w.gbfc1, T, I, enc->mlp_act, stream));
         }
         CX_TRY(wgrad(buf->g_wide, s.wfc1, mlp_in, d, w.gWfc1, buf, T, stream));
         return proj_residual(buf->g_wide, w.Wfc1T, nullptr, add, buf->g_b, T, d, s.wfc1, folded, stream);
@@ -473,7 +473,14 @@ int vit_forward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const 
     CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
     CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
                            enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
-    CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
+    if (enc->lnpre_g) {   // CLIP flavour (sc/models/vit/vit.py:180): LayerNorm on [cls | patches] + pos before the first block
+        if (!enc->lnpre_b || !buf->zpre) return CX_ERR_ARG;
+        CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->zpre, Bc, P, d, stream));
+        CX_TRY(cx_layernorm_fwd(buf->zpre, nullptr, enc->lnpre_g, enc->lnpre_b, buf->h0, nullptr, buf->emb_mean, buf->emb_rstd, T, d,
+                                enc->ln_eps, stream));
+    } else {
+        CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
+    }
     const uint16_t* h_final = nullptr;
     CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, s.mode, &h_final, stream));
     if (hidden_out)
@@ -509,6 +516,12 @@ int vit_backward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const
     const uint16_t* db = nullptr;
     CX_TRY(blocks_backward(enc, buf, s, cu_seqlens, Bc, T, S, fold_pool ? &pg : nullptr, &da, &db, stream));
     if (db) return CX_ERR_ARG;  // (post-norm ViT would need the two branches summed first; no such model family)
+    if (enc->lnpre_g) {   // through the pre-LayerNorm: da (= g_c) -> g_a
+        if (!buf->zpre) return CX_ERR_ARG;
+        CX_TRY(cx_layernorm_bwd(da, nullptr, buf->zpre, enc->lnpre_g, buf->emb_mean, buf->emb_rstd, nullptr, buf->g_a,
+                                enc->glnpre_g, enc->glnpre_b, buf->ws_f32, buf->ws_floats, T, d, stream));
+        da = buf->g_a;
+    }
     // d(embeddings) -> cls / position gradients and the contiguous d(projection) rows; pad rows of both wgrad operands
     // (patch_in was written by the forward of this chunk and is still intact) are cleared for the 64-row reduction
     const int Tp = Bc * P, Tpp = (int)round_up(Tp, 64);

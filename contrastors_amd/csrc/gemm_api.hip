@@ -207,12 +207,18 @@ int cx_gemm_bf16_nt_residual(const uint16_t* X, const uint16_t* W, uint16_t* Out
 // kernel does not cover the shape (caller then runs GEMM + cx_bias_gelu_fwd).
 int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M, int N,
                            int K, int ldx, int ldw, int ld_pre, int ld_act, void* stream) {
+    return cx_gemm_bf16_bias_act(X, W, bias, Pre, Act, M, N, K, ldx, ldw, ld_pre, ld_act, 0, stream);
+}
+
+int cx_gemm_bf16_bias_act(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M, int N,
+                          int K, int ldx, int ldw, int ld_pre, int ld_act, int act, void* stream) {
     if (M <= 0 || N <= 0) return CX_OK;
-    if (!Act) return CX_ERR_ARG;
+    if (!Act || (act != 0 && act != 1)) return CX_ERR_ARG;
     if (K <= 0 || (K % 64) != 0 || (N % 8) != 0 || (ld_act % 8) != 0 || (Pre && (ld_pre % 8) != 0)) return CX_ERR_SHAPE;
     if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
     GemmParams p = base_params(X, W, Pre, bias, M, N, K, ldx, ldw, ld_pre);
     p.Out2 = Act; p.ldo2 = ld_act;
+    p.act = act;
     ProfScope prof(2.0 * (double)M * (double)N * (double)K, (hipStream_t)stream);
     return cx_launch_gemm_v6(p, GEMM_EPI_GELU, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }

@@ -707,10 +707,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     v[e] = pre[a][4 * q + e];
-                                    if (which == 1) {
-                                        float gauss;
-                                        v[e] *= gelu_cdf(v[e], gauss);
-                                    }
+                                    if (which == 1) v[e] = act_val(v[e], p.act);   // erf GELU or quick_gelu (uniform branch)
                                 }
                                 uint2 pk;
                                 pk.x = pack_bf16x2(v[0], v[1]);

@@ -17,6 +17,7 @@ struct GemmParams {
     int tiles_m, tiles_n, split_k;
     float alpha;
     int dbg;    // experiments only: bit0 = no DMA in the main loop, bit1 = no LDS reads / MFMA
+    int act;    // GEMM_EPI_GELU epilogue: CX_ACT_GELU (erf, default 0) or CX_ACT_QUICK_GELU
     void* Out2; // SwiGLU epilogue: activation output (M, N/2) bf16
     int ldo2;
     int sup_m, sup_n;  // v2: L2 super-tile (sup_m x sup_n tiles walked together); 0 = plain row-major order

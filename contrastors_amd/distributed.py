@@ -220,6 +220,18 @@ def exchange_report() -> dict:
     return dict(_EXCHANGE_REPORT)
 
 
+def check_exchange(sync: bool = False):
+    """Surface a failed one-shot collective NOW rather than at the next one: the bounded wait of csrc/xgmi.hip gives up
+    after ~8 s of polling when a peer never signals and reports through mapped host memory, which is only read at the start
+    of the following collective.  The trainers call this once per optimizer step with sync=True -- one stream
+    synchronisation per step (hundreds of milliseconds of work) so that a dead peer stops THIS step."""
+    if _ONESHOT is None or _EXCHANGE_CHOICE != "oneshot":
+        return
+    if sync:
+        torch.cuda.current_stream(_ONESHOT.device).synchronize()
+    _ONESHOT.check()
+
+
 def reset_exchange():
     """Forget the decision and release the one-shot buffers (tests; a re-initialised process group)."""
     global _ONESHOT, _EXCHANGE_CHOICE

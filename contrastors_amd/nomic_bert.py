@@ -137,6 +137,8 @@ class _ChunkArena:
         if patch_dim:  # ViT front end: patchified pixels and their projection
             t["patch_in"] = torch.empty(T_cap, patch_dim, **bf)
             t["patch_proj"] = torch.empty(T_cap, d, **bf)
+        if getattr(cfg, "prepre_layernom", False):  # CLIP flavour: the pre-LayerNorm's input, kept for its backward
+            t["zpre"] = torch.empty(T_cap, d, **bf)
         if with_backward:
             wide = max(3 * d, wfc1, patch_dim)
             for n in ("g_a", "g_b", "g_c"):

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from .biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
 from .config import Config
-from .distributed import gather_with_grad, set_exchange_mode
+from .distributed import check_exchange, gather_with_grad, set_exchange_mode
 from .loss import clip_loss, grad_cache_loss
 from .policy import GradCachePolicy
 from .nomic_bert import NomicBertConfig
@@ -214,6 +214,8 @@ class TextTextTrainer:
         self.scheduler.step()
         model.trunk.sync_shadows()
         self.step += 1
+        if self.world > 1:
+            check_exchange(sync=True)   # a peer that never signalled stops this step, not the next one
         return loss.detach()
 
     # ---- checkpoint / resume (sc/trainers/base.py:275-344: <dir>/model, optimizer.pt, scheduler.pt,
@@ -373,6 +375,8 @@ class ImageTextTrainer(TextTextTrainer):
             with torch.no_grad():
                 ls.clamp_(0, float(np.log(ta.logit_max)))
         self.step += 1
+        if self.world > 1:
+            check_exchange(sync=True)
         return out["loss"].detach()
 
 

@@ -44,6 +44,9 @@ class ViTConfig:
     mlp_fc1_bias: bool = True
     mlp_fc2_bias: bool = True
     patch_embed_bias: bool = True
+    # the OpenAI-CLIP image tower (sc/models/vit/clip.py:14-58): activation_function "quick_gelu", a LayerNorm on the
+    # embeddings ahead of the first block (`prepre_layernom`, reference spelling), no patch bias, eps 1e-5
+    prepre_layernom: bool = False
     rotary_emb_fraction: float = 0.0
     resid_pdrop: float = 0.0
     embd_pdrop: float = 0.0
@@ -53,8 +56,8 @@ class ViTConfig:
     def __post_init__(self):
         if self.n_embd != self.n_head * 64:
             raise NotImplementedError("head_dim must be 64")
-        if self.activation_function not in ("gelu", "gelu_new", "gelu_python"):
-            raise NotImplementedError(f"activation {self.activation_function!r} (ViT towers use the erf GELU MLP)")
+        if self.activation_function not in ("gelu", "gelu_new", "gelu_python", "quick_gelu"):
+            raise NotImplementedError(f"activation {self.activation_function!r} (image towers: erf GELU or quick_gelu MLPs)")
         if not self.prenorm:
             raise NotImplementedError("post-norm ViT")
         if any(p != 0 for p in (self.resid_pdrop, self.embd_pdrop, self.attn_pdrop, self.drop_path_rate)):
@@ -83,6 +86,18 @@ class ViTConfig:
         """google/vit-base-patch16-224 (the image tower of BASELINE configs 4 and 5)."""
         return cls(**kw)
 
+    @property
+    def mlp_act(self) -> int:   # CxEncoderDesc.mlp_act
+        return 1 if self.activation_function == "quick_gelu" else 0
+
+    @classmethod
+    def clip_vit_base_patch16(cls, **kw) -> "ViTConfig":
+        """openai/clip-vit-base-patch16's image tower through sc/models/vit/clip.py:14-58: quick_gelu, pre-LayerNorm, no
+        patch-embedding bias, LayerNorm eps 1e-5."""
+        base = dict(activation_function="quick_gelu", prepre_layernom=True, patch_embed_bias=False, layer_norm_epsilon=1e-5)
+        base.update(kw)
+        return cls(**base)
+
 
 class ViTEngine(NomicBertEngine):
     """Image trunk + pooling.  Inherits the flat fp32 parameter / gradient buffers, bf16 shadows and chunk arenas."""
@@ -108,6 +123,8 @@ class ViTEngine(NomicBertEngine):
             decay += dl
             nodecay += nl
         nodecay += [("ln_f.weight", (d,)), ("ln_f.bias", (d,))]
+        if cfg.prepre_layernom:
+            nodecay += [("prepre_layernom.weight", (d,)), ("prepre_layernom.bias", (d,))]
         return decay, nodecay
 
     def _is_linear(self, name: str) -> bool:
@@ -125,7 +142,7 @@ class ViTEngine(NomicBertEngine):
                 view = self.flat_param[off: off + n]
                 if name.endswith(".bias") or name == "embeddings.cls_token":
                     view.zero_()
-                elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "ln_f.weight":
+                elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name in ("ln_f.weight", "prepre_layernom.weight"):
                     view.fill_(1.0)
                 else:
                     std = cfg.initializer_range
@@ -151,6 +168,9 @@ class ViTEngine(NomicBertEngine):
         e.vit_pos, e.gvit_pos = P("embeddings.pos_embed"), G("embeddings.pos_embed")
         e.gWpatch = G("embeddings.proj.weight")
         e.patch_dim = cfg.patch_dim
+        e.mlp_act = cfg.mlp_act
+        e.lnpre_g, e.lnpre_b = P("prepre_layernom.weight"), P("prepre_layernom.bias")
+        e.glnpre_g, e.glnpre_b = G("prepre_layernom.weight"), G("prepre_layernom.bias")
 
     # ---- compute --------------------------------------------------------------------------------------------------
     def _cu_seqlens(self, B: int) -> torch.Tensor:

@@ -174,6 +174,11 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
  * CX_ERR_SHAPE = shape not covered by the fused kernel (run cx_gemm_bf16_nt + cx_bias_gelu_fwd instead). */
 int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M,
                            int N, int K, int ldx, int ldw, int ld_pre, int ld_act, void* stream);
+/* The same with the activation selected at run time (sc/layers/mlp.py:8-34 `activation`): act = 0 exact-erf GELU (BERT-base,
+ * HF / timm ViTs), 1 quick_gelu = x * sigmoid(1.702 x) (sc/layers/activations.py:4-5: the OpenAI-CLIP image tower,
+ * sc/models/vit/clip.py:14-58). */
+int cx_gemm_bf16_bias_act(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M,
+                          int N, int K, int ldx, int ldw, int ld_pre, int ld_act, int act, void* stream);
 /* fc2 dgrad of the gated MLP with the backward of `swiglu` (flash_attn.ops.activations, sc/layers/mlp.py:75) fused into
  * the epilogue: dYG (M, 2I) = d swiglu(YG) applied to dAct = dY W^T, YG / dYG in the interleaved-by-32 layout of
  * cx_gemm_bf16_swiglu; W: (I, K) row-major (the transposed fc2 weight).  dAct is never written to memory.
@@ -188,6 +193,10 @@ int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bia
  * Replaces cx_bias_gelu_bwd + cx_bias_grad (the second kernel re-read dpre: T x I x 2 bytes). */
 int cx_bias_gelu_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, float* dbias, int T,
                             int I, void* stream);
+/* ... and both directions with the activation selected at run time (act as in cx_gemm_bf16_bias_act). */
+int cx_bias_act_fwd(const uint16_t* pre, const float* bias, uint16_t* act_out, int T, int I, int act, void* stream);
+int cx_bias_act_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, float* dbias, int T,
+                           int I, int act, void* stream);
 /* dbias[n] += sum_t dY[t][n]  (fp32 atomic accumulate; bgrad half of FusedDense backward). */
 int cx_bias_grad(const uint16_t* dY, float* dbias, int T, int N, int ld, void* stream);
 
@@ -341,6 +350,10 @@ typedef struct CxEncoderDesc {
      * CxChunkBuffers.drop_active != 0 (training mode). */
     float resid_pdrop, embd_pdrop;
     float attn_pdrop;   /* dropout on the attention probabilities (attn_pdrop, sc/layers/attention.py:158-182); text trunks */
+    /* ---- the OpenAI-CLIP flavour of the image tower (sc/models/vit/clip.py:14-58; round 3) ---- */
+    int mlp_act;                                   /* plain MLP activation: 0 exact-erf GELU, 1 quick_gelu (cx_gemm_bf16_bias_act) */
+    const float* lnpre_g; const float* lnpre_b;    /* `prepre_layernom` (sc/models/vit/vit.py:128-132,180): LayerNorm on the */
+    float* glnpre_g; float* glnpre_b;              /* embeddings ahead of the first block; NULL = none */
 } CxEncoderDesc;
 
 /* Per-chunk activation arena (device memory owned by the caller).  save_for_backward = 0 lets every layer reuse
@@ -394,6 +407,9 @@ typedef struct CxChunkBuffers {
      * soon as its event fires, overlapped with the blocks still differentiating -- what DDP's bucket hooks do for the
      * reference (sc/trainers/text_text.py:163-170). */
     void* const* layer_events;
+    /* image towers with a pre-LayerNorm (CxEncoderDesc.lnpre_g): its input, (T, d), kept for backward; statistics in
+     * emb_mean / emb_rstd (the slots the text trunk's embedding LayerNorm uses) */
+    uint16_t* zpre;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.

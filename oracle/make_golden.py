@@ -104,6 +104,8 @@ def gen_encoder(name, cfgd, seed):
 
 TINY_VIT = dict(n_embd=256, n_layer=2, n_head=4, n_inner=512, img_size=32, patch_size=8, num_channels=3,
                 layer_norm_epsilon=1e-6)
+TINY_VIT_CLIP = dict(TINY_VIT, layer_norm_epsilon=1e-5, activation_function="quick_gelu", prepre_layernom=True,
+                     patch_embed_bias=False)
 
 
 def gen_vit(name, cfgd, seed):
@@ -112,14 +114,16 @@ def gen_vit(name, cfgd, seed):
 
     vit = ref_import.load_vit()
     cfg = cfg_ns(cfgd)
+    clip = bool(getattr(cfg, "prepre_layernom", False))   # the OpenAI-CLIP flavour (sc/models/vit/clip.py:14-58)
     c = GPT2Config(
-        n_embd=cfg.n_embd, n_layer=cfg.n_layer, n_head=cfg.n_head, n_inner=cfg.n_inner, activation_function="gelu",
+        n_embd=cfg.n_embd, n_layer=cfg.n_layer, n_head=cfg.n_head, n_inner=cfg.n_inner,
+        activation_function=getattr(cfg, "activation_function", "gelu"),
         vocab_size=0, n_positions=0, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
         layer_norm_epsilon=cfg.layer_norm_epsilon, initializer_range=0.02, bos_token_id=None, eos_token_id=None,
-        drop_path_rate=0.0, prepre_layernom=False, layer_scale=False, layer_scale_init=None, img_size=cfg.img_size,
+        drop_path_rate=0.0, prepre_layernom=clip, layer_scale=False, layer_scale_init=None, img_size=cfg.img_size,
         patch_size=cfg.patch_size, num_channels=cfg.num_channels, prenorm=True, parallel_block=False,
         parallel_block_tied_norm=False, rotary_emb_fraction=0, tie_word_embeddings=False, fused_dropout_add_ln=False,
-        fused_bias_fc=False, patch_embed_bias=True, use_flash_attn=False, qkv_proj_bias=True, mlp_fc1_bias=True,
+        fused_bias_fc=False, patch_embed_bias=bool(getattr(cfg, "patch_embed_bias", True)), use_flash_attn=False, qkv_proj_bias=True, mlp_fc1_bias=True,
         mlp_fc2_bias=True, use_rms_norm=False, causal=False, hidden_features_scaling_factor=1.0, mask_token=False,
         learned_pos_embedding=False, patch_dropout=0, sinusoidal_pos_embedding=False)
     m = vit.ViTModel(c).float()
@@ -499,8 +503,9 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     GOLD.mkdir(parents=True, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixture
+    if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixtures
         gen_vit("vit_tiny", TINY_VIT, 5)
+        gen_vit("vit_clip_tiny", TINY_VIT_CLIP, 6)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "map_pool":
         gen_map_pool("map_pool_tiny", 9)
@@ -525,6 +530,7 @@ if __name__ == "__main__":
     gen_clip_loss_single()
     gen_multirank()
     gen_vit("vit_tiny", TINY_VIT, 5)
+    gen_vit("vit_clip_tiny", TINY_VIT_CLIP, 6)
     gen_map_pool("map_pool_tiny", 9)
     gen_hf_remap()
     gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)

@@ -41,6 +41,12 @@ def random_state_dict(cfg, seed: int) -> Dict[str, torch.Tensor]:
         for n in ("norm1", "norm2"):
             sd[p + n + ".weight"], sd[p + n + ".bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
     sd["ln_f.weight"], sd["ln_f.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    # the OpenAI-CLIP flavour (sc/models/vit/clip.py:14-58): pre-LayerNorm, no patch-embedding bias -- drawn LAST so that
+    # the plain fixtures' weights do not move
+    if getattr(cfg, "prepre_layernom", False):
+        sd["prepre_layernom.weight"], sd["prepre_layernom.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    if not getattr(cfg, "patch_embed_bias", True):
+        del sd["embeddings.proj.bias"]
     return sd
 
 
@@ -54,9 +60,15 @@ def vit_hidden(sd: Dict[str, torch.Tensor], cfg, pixels: torch.Tensor) -> torch.
     """-> (B, P+1, d) output of ln_f."""
     d, H = cfg.n_embd, cfg.n_head
     eps = cfg.layer_norm_epsilon
-    x = patchify(pixels.float(), cfg.patch_size) @ sd["embeddings.proj.weight"].T + sd["embeddings.proj.bias"]
+    x = patchify(pixels.float(), cfg.patch_size) @ sd["embeddings.proj.weight"].T
+    if "embeddings.proj.bias" in sd:
+        x = x + sd["embeddings.proj.bias"]
     B = x.shape[0]
     x = torch.cat([sd["embeddings.cls_token"].expand(B, 1, d), x], 1) + sd["embeddings.pos_embed"]
+    if "prepre_layernom.weight" in sd:   # sc/models/vit/vit.py:128-132,180
+        x = F.layer_norm(x, (d,), sd["prepre_layernom.weight"], sd["prepre_layernom.bias"], eps)
+    quick = getattr(cfg, "activation_function", "gelu") == "quick_gelu"   # sc/layers/activations.py:4-5
+    act = (lambda t: t * torch.sigmoid(1.702 * t)) if quick else F.gelu
     hidden, residual = x, None
     for l in range(cfg.n_layer):
         p = f"layers.{l}."
@@ -69,7 +81,7 @@ def vit_hidden(sd: Dict[str, torch.Tensor], cfg, pixels: torch.Tensor) -> torch.
         a = ctx @ sd[p + "attn.out_proj.weight"].T + sd[p + "attn.out_proj.bias"]
         residual = a + residual
         h = F.layer_norm(residual, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
-        y = F.gelu(h @ sd[p + "mlp.fc1.weight"].T + sd[p + "mlp.fc1.bias"])
+        y = act(h @ sd[p + "mlp.fc1.weight"].T + sd[p + "mlp.fc1.bias"])
         hidden = y @ sd[p + "mlp.fc2.weight"].T + sd[p + "mlp.fc2.bias"]
     return F.layer_norm(hidden + residual, (d,), sd["ln_f.weight"], sd["ln_f.bias"], eps)
 

@@ -115,10 +115,12 @@ def test_gradcache_ddp_two_ranks(gold):
             assert abs(float(sd[n].grad.norm()) - float(g[k])) <= 2e-3 * max(1e-3, float(g[k])), n
 
 
-def test_vit_restatement_matches_reference(gold):
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_clip_tiny"])
+def test_vit_restatement_matches_reference(gold, name):
     """oracle/vit_ref.py vs the reference's own ViTModel python (sc/models/vit/vit.py) on CPU fp32: hidden states,
-    pooled embeddings for both poolings, every parameter-gradient norm and five gradient slices."""
-    g = gold("vit_tiny")
+    pooled embeddings for both poolings, every parameter-gradient norm and five gradient slices.  vit_clip_tiny = the
+    OpenAI-CLIP flavour (sc/models/vit/clip.py:14-58): quick_gelu, pre-LayerNorm, no patch-embedding bias."""
+    g = gold(name)
     cfg = _cfg(g)
     sd = vit_ref.random_state_dict(cfg, int(g["seed"]))
     cs = np.array([float(sum(v.double().sum() for v in sd.values())),

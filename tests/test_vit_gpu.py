@@ -35,9 +35,12 @@ def _run(cfg, ns, sd, pix, pooling, probe):
     return emb, eng.reference_grad_dict()
 
 
+@pytest.mark.parametrize("fixture", ["vit_tiny", "vit_clip_tiny"])
 @pytest.mark.parametrize("pooling", ["cls", "mean"])
-def test_vit_matches_reference_golden(gold, pooling):
-    g = gold("vit_tiny")
+def test_vit_matches_reference_golden(gold, pooling, fixture):
+    """vit_clip_tiny: the OpenAI-CLIP flavour of the tower (quick_gelu in the fused fc1 epilogue and its backward, the
+    pre-LayerNorm ahead of the first block, no patch-embedding bias; sc/models/vit/clip.py:14-58)."""
+    g = gold(fixture)
     d = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg/")}
     cfg, ns = ViTConfig(**d), SimpleNamespace(**d)
     sd = vit_ref.random_state_dict(ns, int(g["seed"]))
