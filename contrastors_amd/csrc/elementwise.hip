@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     }
 }
 
+template <int kind>
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const bf16_t* __restrict__ pre,
                                                             const float* __restrict__ bias,
-                                                            bf16_t* __restrict__ act, long T, int I, int kind) {
+                                                            bf16_t* __restrict__ act, long T, int I) {
     const int chunks = I >> 3;
     const long total = T * chunks;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -225,10 +226,10 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const bf16_t* __rest
 // the CLIP step, profiles/r3_kernel_summary_clip_before_bias_fusion.txt).  GELU = true (cx_bias_gelu_bwd_colsum) is the
 // backward of bias + erf-GELU with the bias gradient of the SAME pass: dpre = dact * gelu'(pre + bias) is written and its
 // column sums accumulated, instead of a second kernel reading dpre back.
-template <bool GELU>
+template <bool GELU, int kind = 0>
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ pre,
                                                      const float* __restrict__ bias, bf16_t* __restrict__ dpre,
-                                                     float* __restrict__ dbias, int T, int N, int ld, int kind) {
+                                                     float* __restrict__ dbias, int T, int N, int ld) {
     __shared__ float red[8][256];
     const int tid = threadIdx.x;
     const int cch = tid & 31, rl = tid >> 5;
@@ -474,8 +475,12 @@ int cx_bias_act_fwd(const uint16_t* pre, const float* bias, uint16_t* act_out, i
     if (T <= 0) return CX_OK;
     if (I % 8) return CX_ERR_SHAPE;
     if (act != CX_ACT_GELU && act != CX_ACT_QUICK_GELU) return CX_ERR_ARG;
-    hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0,
-                       (hipStream_t)stream, pre, bias, act_out, (long)T, I, act);
+    if (act == CX_ACT_QUICK_GELU)
+        hipLaunchKernelGGL(bias_gelu_fwd_kernel<CX_ACT_QUICK_GELU>, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0,
+                           (hipStream_t)stream, pre, bias, act_out, (long)T, I);
+    else
+        hipLaunchKernelGGL(bias_gelu_fwd_kernel<CX_ACT_GELU>, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0,
+                           (hipStream_t)stream, pre, bias, act_out, (long)T, I);
     return done();
 }
 
@@ -504,7 +509,7 @@ int cx_bias_grad(const uint16_t* dY, float* dbias, int T, int N, int ld, void* s
     if ((N % 8) || (ld % 8)) return CX_ERR_ALIGN;
     dim3 grid((N + 255) / 256, colsum_rows_grid(T, N));
     hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, (const bf16_t*)nullptr,
-                       (const float*)nullptr, (bf16_t*)nullptr, dbias, T, N, ld, 0);
+                       (const float*)nullptr, (bf16_t*)nullptr, dbias, T, N, ld);
     return done();
 }
 
@@ -519,7 +524,12 @@ int cx_bias_act_bwd_colsum(const uint16_t* dact, const uint16_t* pre, const floa
     if (I % 8) return CX_ERR_SHAPE;
     if (!dact || !pre || !dpre || (act != CX_ACT_GELU && act != CX_ACT_QUICK_GELU)) return CX_ERR_ARG;
     dim3 grid((I + 255) / 256, colsum_rows_grid(T, I));
-    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dact, pre, bias, dpre, dbias, T, I, I, act);
+    if (act == CX_ACT_QUICK_GELU)
+        hipLaunchKernelGGL((colsum_kernel<true, CX_ACT_QUICK_GELU>), grid, dim3(256), 0, (hipStream_t)stream, dact, pre, bias, dpre,
+                           dbias, T, I, I);
+    else
+        hipLaunchKernelGGL((colsum_kernel<true, CX_ACT_GELU>), grid, dim3(256), 0, (hipStream_t)stream, dact, pre, bias, dpre, dbias,
+                           T, I, I);
     return done();
 }
 

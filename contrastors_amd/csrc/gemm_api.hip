@@ -220,7 +220,7 @@ int cx_gemm_bf16_bias_act(const uint16_t* X, const uint16_t* W, const float* bia
     p.Out2 = Act; p.ldo2 = ld_act;
     p.act = act;
     ProfScope prof(2.0 * (double)M * (double)N * (double)K, (hipStream_t)stream);
-    return cx_launch_gemm_v6(p, GEMM_EPI_GELU, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+    return cx_launch_gemm_v6(p, act == 1 ? GEMM_EPI_QGELU : GEMM_EPI_GELU, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
 // fc2 dgrad of the gated MLP with the SwiGLU backward fused into the epilogue: dYG (M, 2I) = swiglu'(YG) * (dY W^T), where

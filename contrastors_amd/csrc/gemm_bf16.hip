@@ -927,7 +927,7 @@ int cx_gemm_bf16_bias_act(const uint16_t* X, const uint16_t* W, const float* bia
         }
         ++g_prof.launches;
     }
-    const hipError_t e = cx_launch_gemm_v6(p, GEMM_EPI_GELU, (hipStream_t)stream);
+    const hipError_t e = cx_launch_gemm_v6(p, act == 1 ? GEMM_EPI_QGELU : GEMM_EPI_GELU, (hipStream_t)stream);
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }

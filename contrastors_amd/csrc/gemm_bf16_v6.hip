@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         if (m < p.M) gst(dyg + (size_t)m * p.ldo + c0 + ch * 8, vv);
                     }
                 }
-            } else if constexpr (EPI == GEMM_EPI_GELU) {
+            } else if constexpr (EPI == GEMM_EPI_GELU || EPI == GEMM_EPI_QGELU) {
                 // fc1 of the plain MLP (sc/layers/mlp.py:30-34): pre = acc + bias (bf16, kept for backward when p.Out is
                 // set), act = gelu_erf(pre).  The standalone op sees the bf16-rounded pre-activation; so does this one.
 #pragma unroll
@@ -707,7 +707,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     v[e] = pre[a][4 * q + e];
-                                    if (which == 1) v[e] = act_val(v[e], p.act);   // erf GELU or quick_gelu (uniform branch)
+                                    // (the activation is a compile-time property of the instantiation: a run-time branch
+                                    // here cost the erf kernel 24 %, profiles/r3_kernel_summary_clip.txt history)
+                                    if (which == 1) v[e] = act_val(v[e], EPI == GEMM_EPI_QGELU ? CX_ACT_QUICK_GELU : CX_ACT_GELU);
                                 }
                                 uint2 pk;
                                 pk.x = pack_bf16x2(v[0], v[1]);
@@ -1217,6 +1219,7 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
 #endif
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
            : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
+           : epi == GEMM_EPI_QGELU ? launch6<GEMM_EPI_QGELU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD ? launch6<GEMM_EPI_SWIGLU_BWD>(p, stream)
                                   : launch6<GEMM_EPI_NONE>(p, stream);
 }

@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 enum { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_F32_ATOMIC = 2, GEMM_OUT_F32_PARTIAL = 3 };
-enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1, GEMM_EPI_GELU = 2, GEMM_EPI_SWIGLU_BWD = 3 };  // GELU: Out2 = gelu(acc + bias), Out (optional) = acc + bias
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1, GEMM_EPI_GELU = 2, GEMM_EPI_SWIGLU_BWD = 3,
+       GEMM_EPI_QGELU = 4 };  // GELU / QGELU: Out2 = act(acc + bias), Out (optional) = acc + bias; act = erf GELU / quick_gelu
 // SWIGLU_BWD: acc = d(act); Out2 = YG (INPUT, (M, 2N) interleaved by 32), Out = dYG (same layout)
 
 struct GemmParams {
@@ -17,7 +18,7 @@ struct GemmParams {
     int tiles_m, tiles_n, split_k;
     float alpha;
     int dbg;    // experiments only: bit0 = no DMA in the main loop, bit1 = no LDS reads / MFMA
-    int act;    // GEMM_EPI_GELU epilogue: CX_ACT_GELU (erf, default 0) or CX_ACT_QUICK_GELU
+    int act;    // cx_gemm_bf16_bias_act: CX_ACT_GELU (erf, default 0) or CX_ACT_QUICK_GELU -> GEMM_EPI_GELU / GEMM_EPI_QGELU
     void* Out2; // SwiGLU epilogue: activation output (M, N/2) bf16
     int ldo2;
     int sup_m, sup_n;  // v2: L2 super-tile (sup_m x sup_n tiles walked together); 0 = plain row-major order

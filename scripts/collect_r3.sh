@@ -8,6 +8,7 @@ cp $O/kernel_summary.txt profiles/r3_kernel_summary_gb16384.txt
 cp $O/kernel_stats.csv profiles/r3_rocprofv3_kernel_stats_gb16384.csv
 cp $O/pmc_FETCH_SIZE_summary.txt profiles/r3_pmc_FETCH_SIZE_summary.txt
 cp $O/pmc_WRITE_SIZE_summary.txt profiles/r3_pmc_WRITE_SIZE_summary.txt
+cp $O/pmc_gemm_traffic.json profiles/r3_pmc_gemm_traffic.json
 cp $O/pmc_sq_summary.txt profiles/r3_pmc_sq_step_summary.txt
 for leg in cfg3 lit clip; do cp $O/kernel_summary_$leg.txt profiles/r3_kernel_summary_$leg.txt; done
 cp $O/pmc_clip_FETCH_SIZE_summary.txt profiles/r3_pmc_clip_FETCH_SIZE_summary.txt

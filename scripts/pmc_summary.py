@@ -12,5 +12,5 @@ for r in csv.DictReader(open(path)):
     a[0] += float(r["Counter_Value"])
     a[1] += 1
 print(f"# {ctr}: sum over dispatches / dispatch count (raw counter units, KB for FETCH_SIZE/WRITE_SIZE)")
-for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:20]:
+for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
     print(f"{s:16.1f} total {n:7d} calls {s/n:14.2f} avg  {k}")
