@@ -3,9 +3,10 @@
 // The embedding all-gather of sc/distributed.py:5-12 moves 2048 x 768 fp32 = 6.3 MB per rank: far too small for a ring
 // (7 serial hops, each latency-bound).  MI355X nodes are fully connected -- every GPU has a direct xGMI link to each of the
 // other seven -- so the natural schedule is ONE step: every rank stores its shard straight into the other ranks' receive
-// buffers, all seven links of every GPU busy at once, then one flag exchange.  Buffers are plain hipMalloc memory shared
-// between the per-GPU processes with HIP IPC handles (dmabuf; HSA_ENABLE_IPC_MODE_LEGACY=0); flags live in uncached
-// memory and are written / polled with system-scope atomics.  The reduce-scatter of the backward is the same step in the
+// buffers, all seven links of every GPU busy at once, then one flag exchange.  Buffers are device memory shared between
+// the per-GPU processes with HIP IPC handles (dmabuf; HSA_ENABLE_IPC_MODE_LEGACY=0); receive buffers and flags are
+// allocated uncached (fine-grained, hipDeviceMallocUncached -- the host side's choice, cx_ipc_alloc) so that a peer's
+// stores can never hide behind a stale line of the reader's L2; flags are written / polled with system-scope atomics.  The reduce-scatter of the backward is the same step in the
 // other direction followed by a local sum of the W received slices.
 //
 // Host protocol (contrastors_amd/distributed.py::OneShotExchange): receive buffers are used round-robin (N_BUF >= 2), so a

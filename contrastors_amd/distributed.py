@@ -58,7 +58,11 @@ class OneShotExchange:
         own, handles, err = [], None, None
         try:
             with torch.cuda.device(self.device):
-                own = [self._alloc(self.cap, 0) for _ in range(nb)] + [self._alloc(256, 1), self._alloc(256, 2)]
+                # receive buffers AND flags are uncached (fine-grained) device memory, as RCCL's own receive buffers are:
+                # peers store into them over xGMI while this GPU's kernels read them, and only memory that bypasses the
+                # reader's L2 is guaranteed to show remote stores without a stale line in between (a buffer is re-used
+                # every N_BUF collectives).  The consumers stream through them once (clone / fixed-order sum).
+                own = [self._alloc(self.cap, 1) for _ in range(nb)] + [self._alloc(256, 1), self._alloc(256, 2)]
                 self._data, self._flags, self._err = own[:nb], own[nb], own[nb + 1]
                 torch.as_tensor(_RawDeviceF32(own[nb], 64), device=self.device).zero_()
                 C.memset(self._err, 0, 256)   # mapped host memory: the wait kernel stores here, check() reads it with no sync
