@@ -55,6 +55,7 @@ class TrainArgs(BaseModel):
     gradcache_chunk: Union[int, str, None] = "auto"       # auto: chunk_size is a lower bound | exact | n
     gradcache_resident: Union[bool, str, None] = "auto"   # auto: keep pass 1's activations when they fit | true | false
     exchange: Optional[str] = "auto"                       # embedding exchange: auto (validated + timed at start-up) | rccl | oneshot
+    exchange_timeout_s: float = 120.0                      # one-shot exchange: how long a GPU polls for a peer's signal before giving up
     overlap_grad_reduce: bool = True                       # per-block gradient all-reduce inside the step's last backward (DDP-style)
 
     @model_validator(mode="after")

@@ -35,7 +35,9 @@ class OneShotExchange:
     at all: the error flag of the bounded wait lives in mapped host memory and is polled at the start of every collective
     (a peer that never signals makes the wait give up; that surfaces as a RuntimeError at a later call instead of a hang)."""
 
-    MAX_SPINS = 4_000_000   # ~8 s of polling before a wait gives up
+    SPINS_PER_SECOND = 500_000   # measured: one poll of an uncached flag + s_sleep(8) is ~2 us
+    MAX_SPINS = 60_000_000       # ~2 min of polling before a wait gives up (set_exchange_timeout / train_args.exchange_timeout_s):
+                                 # long enough for a peer that stalls in its data loader or writes a checkpoint, short of RCCL's watchdog
     N_BUF = 4               # receive buffers, used round-robin: a result read in place stays valid for 3 more collectives
 
     def __init__(self, capacity_bytes: int, group=None, device: Optional[torch.device] = None):
@@ -210,6 +212,13 @@ def set_exchange_mode(mode: str):
         _EXCHANGE_MODE, _EXCHANGE_CHOICE = mode, None
 
 
+def set_exchange_timeout(seconds: float):
+    """How long a rank's GPU polls for a peer's signal before the collective gives up (train_args.exchange_timeout_s)."""
+    if not seconds > 0:
+        raise ValueError(f"exchange timeout must be positive, got {seconds!r}")
+    OneShotExchange.MAX_SPINS = max(1000, int(seconds * OneShotExchange.SPINS_PER_SECOND))
+
+
 def exchange_mode() -> str:
     env = os.environ.get("CX_EXCHANGE")
     if env:
@@ -226,7 +235,7 @@ def exchange_report() -> dict:
 
 def check_exchange(sync: bool = False):
     """Surface a failed one-shot collective NOW rather than at the next one: the bounded wait of csrc/xgmi.hip gives up
-    after ~8 s of polling when a peer never signals and reports through mapped host memory, which is only read at the start
+    after its timeout (~2 min by default) when a peer never signals and reports through mapped host memory, which is only read at the start
     of the following collective.  The trainers call this once per optimizer step with sync=True -- one stream
     synchronisation per step (hundreds of milliseconds of work) so that a dead peer stops THIS step."""
     if _ONESHOT is None or _EXCHANGE_CHOICE != "oneshot":

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from .biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
 from .config import Config
-from .distributed import check_exchange, gather_with_grad, set_exchange_mode
+from .distributed import check_exchange, gather_with_grad, set_exchange_mode, set_exchange_timeout
 from .loss import clip_loss, grad_cache_loss
 from .policy import GradCachePolicy
 from .nomic_bert import NomicBertConfig
@@ -99,6 +99,7 @@ class TextTextTrainer:
         # carried explicitly: no process-wide switch survives this trainer
         self.policy = GradCachePolicy.from_train_args(config.train_args)
         set_exchange_mode(config.train_args.exchange or "auto")
+        set_exchange_timeout(config.train_args.exchange_timeout_s)
         self.model = self.get_model(config, trunk_config)
         self.total_steps = total_steps or config.train_args.num_train_steps or 10_000
         self.optimizer = self.get_optimizer(config)
@@ -248,6 +249,10 @@ class TextTextTrainer:
             torch.save({"step": self.step}, os.path.join(output_dir, "trainer_state.pt"))
         torch.save({"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "random": random.getstate(),
                     "cuda": torch.cuda.get_rng_state_all()}, os.path.join(output_dir, f"random_states_{self.rank}.pt"))
+        if self.world > 1:   # rank 0 wrote ~2 GB: nobody runs ahead into the next step's exchange meanwhile
+            import torch.distributed as dist
+
+            dist.barrier()
 
     def load_state(self, input_dir: str):
         import os
