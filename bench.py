@@ -410,7 +410,7 @@ def main():
 
     from contrastors_amd import _C
     from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
-    from contrastors_amd.distributed import exchange_report, gather_with_grad
+    from contrastors_amd.distributed import exchange_report, gather_with_grad, set_exchange_timeout
     from contrastors_amd.loss import grad_cache_loss
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.optimizer import FusedAdamW
@@ -422,6 +422,7 @@ def main():
                "lit": lambda: leg_image_text(torch, dev, args.steps, False), "clip": lambda: leg_image_text(torch, dev, args.steps, True)}
         print(json.dumps({k: fns[k]() for k in fns if k in want}), flush=True)
         return
+    set_exchange_timeout(20.0)   # ranks of a benchmark arrive together: a peer 20 s late is a failed exchange (-> process group), not a stall
     for k in ("CX_GRADCACHE_CHUNK", "CX_GRADCACHE_RESIDENT"):   # the legs below state their schedule as config, not environment
         os.environ.pop(k, None)
     # --chunk-size is taken literally in every leg but the drop-in one; the metric is the two-pass GradCache step (the
