@@ -42,3 +42,26 @@ for name, N, K in (("qkv fwd", 3 * d, d), ("out fwd", d, d), ("fc1 fwd", 2 * I, 
             best[gn] = min(best.get(gn, 1e30), t)
     lib.cx_gemm_set_debug(0)
     print(f"{name:10s} N={N:5d} K={K:5d}   " + "   ".join(f"gn={g or 'auto'}: {t:7.1f} us" for g, t in best.items()))
+
+
+# the fused-epilogue kernels of the step (fc1 + SwiGLU with / without the (y, gate) save, fc2-dgrad + SwiGLU backward): their
+# epilogue streams go through the same L2 as the operand panels
+xx = torch.randn(T, d, device="cuda").bfloat16()
+w1 = (torch.randn(2 * I, d, device="cuda") * 0.05).bfloat16()
+w2t = (torch.randn(I, d, device="cuda") * 0.05).bfloat16()
+yg = torch.randn(T, 2 * I, device="cuda").bfloat16()
+dyg = torch.empty(T, 2 * I, device="cuda", dtype=torch.bfloat16)
+act = torch.empty(T, I, device="cuda", dtype=torch.bfloat16)
+fused = {
+    "fc1+swiglu save": lambda: lib.cx_gemm_bf16_swiglu(xx.data_ptr(), w1.data_ptr(), yg.data_ptr(), act.data_ptr(), T, I, d, d, d, 2 * I, I, s),
+    "fc1+swiglu": lambda: lib.cx_gemm_bf16_swiglu(xx.data_ptr(), w1.data_ptr(), None, act.data_ptr(), T, I, d, d, d, 2 * I, I, s),
+    "fc2dgrad+swiglu_bwd": lambda: lib.cx_gemm_bf16_swiglu_bwd(xx.data_ptr(), w2t.data_ptr(), yg.data_ptr(), dyg.data_ptr(), T, I, d, d, d, 2 * I, s),
+}
+for name, fn in fused.items():
+    best = {}
+    for _ in range(3):
+        for gn in (0, 1, 2, 4, 8):
+            lib.cx_gemm_set_debug(gn << 8)
+            best[gn] = min(best.get(gn, 1e30), timeit(fn))
+    lib.cx_gemm_set_debug(0)
+    print(f"{name:20s}   " + "   ".join(f"gn={g or 'auto'}: {t:7.1f} us" for g, t in best.items()))
