@@ -227,16 +227,29 @@ def leg_cfg1(torch, dev, steps):
             "note": "2048 token rows per GEMM launch: far below one round of 256 x 256 tiles on 256 CUs"}
 
 
-def leg_cfg3(torch, dev, steps):
+def _selective(rec):
+    """What the `selective_checkpointing` sub-record of a leg keeps of a second run of the same leg with
+    train_args.checkpoint_keep_layers = "auto" (the library default; the leg's own record takes the recipe literally)."""
+    keys = ("value", "unit", "ms_per_step", "p10_ms", "p90_ms", "steps", "peak_hbm_gb", "kept_blocks")
+    out = {k: rec[k] for k in keys if k in rec}
+    out["frac_of_mfma_peak"] = rec["roofline"]["frac"]
+    out["note"] = ("same step, same results bit for bit: the warm-up step takes the recipe literally and measures the step's peak "
+                   "HBM, from then on the top blocks keep their activations as far as 90 % of the device minus that peak "
+                   "allows (CxChunkBuffers.ckpt_keep) and only the blocks below them are recomputed in backward")
+    return out
+
+
+def leg_cfg3(torch, dev, steps, keep=0):
     """configs[2] per-GPU shape: 32 queries + 256 documents (1 positive + 7 hard negatives each) x 2048 tokens, Matryoshka
-    {768, 512, 256, 128}, hamming, activation checkpointing, direct step (sc/trainers/text_text.py:324-378)."""
+    {768, 512, 256, 128}, hamming, activation checkpointing, direct step (sc/trainers/text_text.py:324-378).  keep = 0: the
+    recipe's `gradient_checkpointing: true` taken literally (every block recomputed); "auto": selective checkpointing."""
     from contrastors_amd.config import Config, DataArgs, ModelArgs, TrainArgs
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.trainers import TextTextTrainer
 
     cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=1, grad_cache=False,
                                       schedule_type="linear", max_grad_norm=1.0, clamp_logits=False,
-                                      matryoshka_dims=[768, 512, 256, 128]),
+                                      matryoshka_dims=[768, 512, 256, 128], checkpoint_keep_layers=keep),
                  data_args=DataArgs(batch_size=32, seed=3),
                  model_args=ModelArgs(logit_scale=50.0, pooling="mean", model_name="nomic-embed-text-v1", hamming=True,
                                       num_negatives=7, gradient_checkpointing=True, seq_len=2048))
@@ -260,11 +273,13 @@ def leg_cfg3(torch, dev, steps):
                          "frac": 3 * fwd / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "executed_frac": 4 * fwd / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "note": "algorithmic = 3 forward-equivalents of 302 MFLOP/token (attention = 25 %); executed adds the "
-                                 "checkpoint re-forward"},
-            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+                                 "checkpoint re-forward (all of it when every block is recomputed)"},
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+            "checkpoint_keep_layers": keep,
+            "kept_blocks": [{"arena_tokens": t, "kept": k, "of": 12} for t, k in sorted(tr.model["model"].trunk._keep_logged)]}
 
 
-def leg_image_text(torch, dev, steps, clip: bool):
+def leg_image_text(torch, dev, steps, clip: bool, keep=0):
     """configs[3] (LiT: frozen ViT-B/16 image tower, trainable BERT-base text tower) and configs[4] (CLIP: both trained, fp8
     similarity, global batch 32768) at the per-GPU shape of an 8-GPU job: 4096 (image, text) pairs, text seq 77.  On one GPU
     the other seven ranks' gathered embeddings are stand-ins (28672 random unit vectors), so the loss has its real
@@ -279,7 +294,8 @@ def leg_image_text(torch, dev, steps, clip: bool):
 
     n, G, S_t = 4096, 32768, 77
     vis = BiEncoder(BiEncoderConfig(model_name="vit_base_patch16_224", pooling="cls", freeze=not clip,
-                                    gradient_checkpointing=clip, trunk_config=ViTConfig.vit_base_patch16_224()),
+                                    gradient_checkpointing=clip, checkpoint_keep_layers=keep,
+                                    trunk_config=ViTConfig.vit_base_patch16_224()),
                     device=dev, seed=1).train()
     txt = BiEncoder(BiEncoderConfig(model_name="bert-base-uncased", pooling="mean",
                                     trunk_config=NomicBertConfig.bert_base_uncased()), device=dev, seed=2).train()
@@ -344,6 +360,9 @@ def leg_image_text(torch, dev, steps, clip: bool):
                                       "sgemm_nt_kernel<LSE> (v_mfma_f32_32x32x2_f32, exact)",
                             "note": "both directions of the 4096 x 32768 x 768 similarity + online log-sum-exp"},
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+    if clip:
+        rec["checkpoint_keep_layers"] = keep
+        rec["kept_blocks"] = [{"arena_tokens": t, "kept": k, "of": 12} for t, k in sorted(vis.trunk._keep_logged)]
     return rec
 
 
@@ -358,6 +377,17 @@ def run_config_legs(torch, dev, steps):
             out[name] = fn()
         except Exception as e:  # noqa: BLE001 -- a secondary record must never take the headline down
             out[name] = f"failed: {type(e).__name__}: {e}"[:300]
+        gc.collect()
+        torch.cuda.empty_cache()
+    # the two legs whose recipes switch activation checkpointing on, once more with selective checkpointing ("auto")
+    for name, fn in (("cfg3", lambda: leg_cfg3(torch, dev, steps, keep="auto")),
+                     ("clip", lambda: leg_image_text(torch, dev, steps, clip=True, keep="auto"))):
+        if not isinstance(out.get(name), dict):
+            continue
+        try:
+            out[name]["selective_checkpointing"] = _selective(fn())
+        except Exception as e:  # noqa: BLE001
+            out[name]["selective_checkpointing"] = f"failed: {type(e).__name__}: {e}"[:300]
         gc.collect()
         torch.cuda.empty_cache()
     return out
@@ -419,8 +449,18 @@ def main():
     if args.only_config_legs:   # (rocprofv3 of one secondary leg: scripts/gpu_r3_final.sh)
         want = set(args.only_config_legs.split(","))
         fns = {"cfg1": lambda: leg_cfg1(torch, dev, args.steps), "cfg3": lambda: leg_cfg3(torch, dev, args.steps),
-               "lit": lambda: leg_image_text(torch, dev, args.steps, False), "clip": lambda: leg_image_text(torch, dev, args.steps, True)}
-        print(json.dumps({k: fns[k]() for k in fns if k in want}), flush=True)
+               "lit": lambda: leg_image_text(torch, dev, args.steps, False), "clip": lambda: leg_image_text(torch, dev, args.steps, True),
+               "cfg3_selective": lambda: leg_cfg3(torch, dev, args.steps, keep="auto"),
+               "clip_selective": lambda: leg_image_text(torch, dev, args.steps, True, keep="auto")}
+        import gc
+
+        recs = {}
+        for k in fns:
+            if k in want:
+                recs[k] = fns[k]()
+                gc.collect()
+                torch.cuda.empty_cache()
+        print(json.dumps(recs), flush=True)
         return
     set_exchange_timeout(20.0)   # ranks of a benchmark arrive together: a peer 20 s late is a failed exchange (-> process group), not a stall
     for k in ("CX_GRADCACHE_CHUNK", "CX_GRADCACHE_RESIDENT"):   # the legs below state their schedule as config, not environment

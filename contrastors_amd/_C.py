@@ -63,7 +63,7 @@ class CxChunkBuffers(C.Structure):
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
             "ws_f32",
         )
-    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp), ("layer_events", C.POINTER(vp)), ("zpre", vp)]
+    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp), ("layer_events", C.POINTER(vp)), ("zpre", vp), ("ckpt_keep", i32)]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.

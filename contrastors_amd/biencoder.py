@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Union
 
 import numpy as np
 import torch
@@ -36,6 +36,9 @@ class BiEncoderConfig:
     hamming: bool = False
     pretrained: bool = False
     gradient_checkpointing: bool = False
+    # (not a reference field) selective checkpointing on a 288 GB part: how many blocks keep their activations although
+    # gradient_checkpointing is on -- "auto" = as many as the free HBM takes, 0 = the reference's behaviour (all recomputed)
+    checkpoint_keep_layers: Union[int, str] = "auto"
     encoder: bool = True
     seq_len: int = 2048
     trunk_config: Optional[object] = None  # NomicBertConfig or ViTConfig: no hub access, the architecture is explicit
@@ -94,7 +97,7 @@ class BiEncoder(torch.nn.Module):
                 torch.manual_seed(seed + 1)
             self.selector = MultiHeadAttentionPooling(trunk_cfg, device=device)
         if config.gradient_checkpointing:  # modeling_biencoder.py:261-262
-            self.trunk.gradient_checkpointing_enable()
+            self.trunk.gradient_checkpointing_enable(keep_layers=config.checkpoint_keep_layers)
         self.frozen_trunk = bool(config.freeze)
         self.overlap_reduce = True   # train_args.overlap_grad_reduce: start the gradient all-reduce inside the last backward
         if self.frozen_trunk:

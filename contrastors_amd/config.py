@@ -57,13 +57,17 @@ class TrainArgs(BaseModel):
     exchange: Optional[str] = "auto"                       # embedding exchange: auto (validated + timed at start-up) | rccl | oneshot
     exchange_timeout_s: float = 120.0                      # one-shot exchange: how long a GPU polls for a peer's signal before giving up
     overlap_grad_reduce: bool = True                       # per-block gradient all-reduce inside the step's last backward (DDP-style)
+    # model_args.gradient_checkpointing is a memory knob sized for 80 GB parts: auto = the top blocks keep their activations
+    # as far as the free HBM allows (bit-identical results, less re-forward) | n blocks | 0 = recompute every block
+    checkpoint_keep_layers: Union[int, str, None] = "auto"
 
     @model_validator(mode="after")
     def _checks(self):
-        from .policy import _parse_chunk, _parse_resident   # (validate here, not at the first training step)
+        from .policy import _parse_chunk, _parse_keep, _parse_resident   # (validate here, not at the first training step)
 
         _parse_chunk(self.gradcache_chunk, "train_args.gradcache_chunk")
         _parse_resident(self.gradcache_resident, "train_args.gradcache_resident")
+        _parse_keep(self.checkpoint_keep_layers, "train_args.checkpoint_keep_layers")
         if self.exchange not in (None, "auto", "rccl", "oneshot"):
             raise ValueError(f"train_args.exchange must be auto, rccl or oneshot, got {self.exchange!r}")
         if self.use_fp8 and self.matryoshka_dims is not None:

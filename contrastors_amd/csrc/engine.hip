@@ -33,13 +33,19 @@ inline int mark_grads_done(const CxChunkBuffers* buf, int idx, void* stream) {
 // tensor that carries a block's INPUT keeps one slot per layer -- h2 (the previous block's output) for post-norm trunks,
 // z1 (the complete residual stream at LN1) for pre-norm trunks -- everything else lives in slot 0 and is recomputed
 // block by block during backward.
+// Selective checkpointing (round 3; CxChunkBuffers.ckpt_keep = k): a recipe's `gradient_checkpointing: true` was written
+// for 80 GB parts; on 288 GB most of a step's activations fit.  The TOP k blocks (l >= L - k) keep all their
+// intermediates in slots 1 .. k exactly as mode 1 would, only the blocks below them share slot 0 and are recomputed:
+// k / L of the re-forward disappears, the results stay bit-identical (the same kernels on the same data either way).
 struct Slots {
     const CxChunkBuffers* b;
     const CxEncoderDesc* e;
     long T_cap;
     int d, I, wfc1;  // wfc1 = width of the fc1 output (2I gated, I plain)
     int mode;
-    int sl(int s) const { return mode == 1 ? s : 0; }
+    int first_kept;  // mode 2: blocks l >= first_kept own slot 1 + l - first_kept; below it: slot 0, recomputed in backward
+    bool kept(int s) const { return mode == 1 || (mode == 2 && s >= first_kept); }   // block s's intermediates survive the forward
+    int sl(int s) const { return mode == 1 ? s : (mode == 2 && s >= first_kept) ? 1 + s - first_kept : 0; }
     int sl_in(int s) const { return mode == 0 ? 0 : s; }   // the per-layer tensor of the checkpointing mode
     uint16_t* qkv(int s) const { return b->qkv + (size_t)sl(s) * T_cap * 3 * d; }
     uint16_t* ctx(int s) const { return b->ctx + (size_t)sl(s) * T_cap * d; }
@@ -55,6 +61,14 @@ struct Slots {
     float* mean2(int s) const { return b->mean2 + (size_t)sl(s) * T_cap; }
     float* rstd2(int s) const { return b->rstd2 + (size_t)sl(s) * T_cap; }
 };
+
+// save: 0 no-grad pass, 1 saving forward / backward (the arena's `checkpoint` / `ckpt_keep` pick the slot mode)
+Slots make_slots(const CxEncoderDesc* enc, const CxChunkBuffers* buf, int save) {
+    const int L = enc->n_layer;
+    int keep = buf->ckpt_keep < 0 ? 0 : buf->ckpt_keep > L ? L : buf->ckpt_keep;
+    return Slots{buf, enc, buf->T_cap, enc->d, enc->d_inner, enc->gated ? 2 * enc->d_inner : enc->d_inner,
+                 save ? (buf->checkpoint ? 2 : 1) : 0, L - keep};
+}
 
 int check_desc(const CxEncoderDesc* e, const CxChunkBuffers* b, int T) {
     if (!e || !b || !e->layers) return CX_ERR_ARG;
@@ -221,11 +235,11 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
                    void* stream) {
     const int d = enc->d, L = enc->n_layer;
     const BlockRunner run{enc, buf, s, cu_seqlens, Bc, T, max_seqlen, stream};
-    const bool keep = save == 1;  // save == 2 (checkpointing): only the block inputs are kept, by the slot mapping
+    // (checkpointing: a recomputed block keeps only its input, by the slot mapping; the blocks above first_kept keep all)
     if (!enc->prenorm) {
         const uint16_t* h_in = h0;
         for (int l = 0; l < L; ++l) {
-            CX_TRY(run.post_block(l, h_in, keep));
+            CX_TRY(run.post_block(l, h_in, save != 0 && s.kept(l)));
             h_in = s.h2(l);
         }
         *h_final = h_in;
@@ -237,7 +251,7 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
     const uint16_t* r = nullptr;   // residual stream
     bool r_folded = false;         // the residual stream was already added into x by a GEMM epilogue
     for (int l = 0; l < L; ++l) {
-        CX_TRY(run.pre_block(l, x, r, r_folded, keep, false, &x, &r, &r_folded));
+        CX_TRY(run.pre_block(l, x, r, r_folded, save != 0 && s.kept(l), false, &x, &r, &r_folded));
         // checkpointing keeps ONE tensor per block, the complete residual stream z1(l): needs the fc2 epilogue fold
         if (save == 2 && !r_folded) return CX_ERR_SHAPE;
     }
@@ -367,7 +381,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         for (int l = L - 1; l >= 0; --l) {
             const CxLayerWeights& w = enc->layers[l];
             const uint16_t* h_in = (l == 0) ? buf->h0 : s.h2(l - 1);
-            if (s.mode == 2) CX_TRY(run.post_block(l, h_in, true));
+            if (!s.kept(l)) CX_TRY(run.post_block(l, h_in, true));
             if (run.drop()) {
                 // dropout between every sub-layer output and the residual add: the LayerNorm backward returns the
                 // residual's gradient (dz) and the masked, rescaled gradient of the sub-layer output (dx0, in g_d)
@@ -434,7 +448,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
     for (int l = L - 1; l >= 0; --l) {   // invariant: buf->g_c = d(x_l + r_l) = gradient of both the MLP output and r
         const CxLayerWeights& w = enc->layers[l];
         bool unused = false, bias_a_done = false;
-        if (s.mode == 2) {
+        if (!s.kept(l)) {
             const uint16_t* xo = nullptr;
             const uint16_t* ro = nullptr;
             bool fo = false;
@@ -469,7 +483,7 @@ int vit_forward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const 
     if (enc->patch_dim != Cc * patch * patch || (enc->patch_dim % 64) != 0) return CX_ERR_SHAPE;
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
+    const Slots s = make_slots(enc, buf, save_for_backward);
     CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
     CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
                            enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
@@ -500,7 +514,7 @@ int vit_backward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const
     CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
+    const Slots s = make_slots(enc, buf, 1);
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     const PooledGrad pg{demb, emb_out, buf->pool_norm, enc->pool_mode, enc->normalize};
     const bool fold_pool = !dhidden && enc->prenorm && (enc->pool_mode == 0 || enc->pool_mode == 1);   // (see cx_encoder_backward)
@@ -547,7 +561,7 @@ int cx_encoder_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, cons
     CX_TRY(check_desc(enc, buf, T));
     (void)hipGetLastError();  // a stale error of some earlier, unrelated runtime call must not fail this launch train
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
+    const Slots s = make_slots(enc, buf, save_for_backward);
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
     if (buf->drop_active && enc->embd_pdrop > 0.f)  // modeling_nomic_bert.py:534-535: dropout on the embedding-LN output
@@ -568,7 +582,7 @@ int cx_encoder_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, con
     CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
+    const Slots s = make_slots(enc, buf, 1);
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     // the pooling backward rides inside the last LayerNorm's backward (fp32, never materialised); the dropout schedule
     // keeps the two-kernel form (its LayerNorm backward also returns the masked branch gradient)
@@ -611,7 +625,7 @@ int cx_encoder_forward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* bu
     if (!hidden_out) return CX_ERR_ARG;
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (save_for_backward ? (buf->checkpoint ? 2 : 1) : 0)};
+    const Slots s = make_slots(enc, buf, save_for_backward);
     CX_TRY(cx_embed_ln_fwd(input_ids, indices, enc->word_emb, enc->type_emb, enc->pos_emb, enc->emb_ln_g,
                            enc->emb_ln_b, buf->h0, buf->emb_mean, buf->emb_rstd, T, S, d, enc->ln_eps, stream));
     if (buf->drop_active && enc->embd_pdrop > 0.f)  // modeling_nomic_bert.py:534-535: dropout on the embedding-LN output
@@ -631,7 +645,7 @@ int cx_encoder_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* b
     CX_TRY(check_bwd_buffers(buf));
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
-    Slots s{buf, enc, buf->T_cap, d, I, enc->gated ? 2 * I : I, (buf->checkpoint ? 2 : 1)};
+    const Slots s = make_slots(enc, buf, 1);
     CX_TRY(clear_pad_rows(enc, buf, s, T, stream));
     if (hipMemcpyAsync(buf->g_a, dhidden, (size_t)T * d * sizeof(uint16_t), hipMemcpyDeviceToDevice,
                        (hipStream_t)stream) != hipSuccess)
@@ -690,7 +704,7 @@ int cx_vit_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, 
     return vit_backward_impl(enc, buf, cu_seqlens, Bc, n_patch, nullptr, nullptr, dhidden, stream);
 }
 
-int cx_abi_version(void) { return 5; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled
+int cx_abi_version(void) { return 6; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

@@ -12,6 +12,7 @@ bidirectional, router_aux_coeff)`.  What changes is underneath:
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 from typing import Dict, List, Optional
 
@@ -379,8 +380,10 @@ def _resident_forward(model, chunks):
         with torch.no_grad():
             return [model(**c)["embedding"] for c in chunks]
     outs = []
+    trunk = getattr(model, "trunk", None)
+    suspended = trunk.selective_checkpointing_suspended() if hasattr(trunk, "selective_checkpointing_suspended") else contextlib.nullcontext()
     try:
-        with torch.enable_grad():
+        with torch.enable_grad(), suspended:   # (one arena per chunk stays alive: see selective_checkpointing_suspended)
             for c in chunks:
                 outs.append(model(**c)["embedding"])
     except torch.OutOfMemoryError:

@@ -15,16 +15,20 @@ Memory layout (sized for 288 GB HBM3E):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import logging
 import math
+import os
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import _C
+from .policy import _parse_keep
 
 
 @dataclass
@@ -98,22 +102,51 @@ def _round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
+def parse_checkpoint_keep(v, where: str, default: Union[int, str] = 0) -> Union[int, str]:
+    """checkpoint_keep_layers: a non-negative integer or "auto" (None / "" -> `default`); see policy._parse_keep."""
+    return default if v is None or v == "" else _parse_keep(v, where)
+
+
+_HBM_GRANTED: Dict[int, int] = {}
+
+
+def _hbm_grant(device, delta: int) -> int:
+    """Per-device ledger of the bytes selective checkpointing has promised to (or already built into) arenas beyond their
+    literal-checkpointing size.  Returns the balance after adding `delta`."""
+    idx = device.index if getattr(device, "index", None) is not None else 0
+    _HBM_GRANTED[idx] = max(0, _HBM_GRANTED.get(idx, 0) + int(delta))
+    return _HBM_GRANTED[idx]
+
+
 class _ChunkArena:
     """Device memory for one in-flight chunk (CxChunkBuffers).  `n_slots` = 1 for no-grad forwards, n_layer else."""
 
+    probation = False   # "auto" selective checkpointing: first use, literal; its successor is sized from the measured peak
+    granted = 0         # bytes of the per-device ledger this arena holds (returned when it is destroyed)
+
+    def __del__(self):
+        if self.granted:
+            try:
+                _hbm_grant(self._device, -self.granted)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+
     def __init__(self, cfg: NomicBertConfig, T_cap: int, n_slots: int, with_backward: bool, B_cap: int,
-                 device: torch.device, checkpoint: bool = False):
+                 device: torch.device, checkpoint: bool = False, keep_layers: int = 0):
         d, I, H = cfg.n_embd, cfg.n_inner, cfg.n_head
         wfc1 = 2 * I if cfg.gated else I
         bf = dict(dtype=torch.bfloat16, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         self.T_cap, self.n_slots, self.with_backward, self.B_cap = T_cap, n_slots, with_backward, B_cap
+        self._device = device
         self.checkpoint = bool(checkpoint and with_backward)
-        # activation checkpointing: only the tensor carrying a block's input keeps one slot per layer (CxChunkBuffers)
+        # activation checkpointing: only the tensor carrying a block's input keeps one slot per layer (CxChunkBuffers);
+        # selective checkpointing: the top `keep_layers` blocks keep everything (slots 1 .. keep), the rest share slot 0
+        self.keep_layers = max(0, min(int(keep_layers), n_slots)) if self.checkpoint else 0
         kept = ("z1" if getattr(cfg, "prenorm", False) else "h2") if self.checkpoint else None
         n_layer_slots = n_slots
         if self.checkpoint:
-            n_slots = 1
+            n_slots = 1 + self.keep_layers
         t: Dict[str, torch.Tensor] = {}
         t["h0"] = torch.empty(T_cap, d, **bf)
         t["emb_mean"] = torch.empty(T_cap, **f32)
@@ -160,6 +193,8 @@ class _ChunkArena:
                 self.desc.ws_floats = t["ws_f32"].numel() if "ws_f32" in t else 0
             elif name == "checkpoint":
                 self.desc.checkpoint = int(self.checkpoint)
+            elif name == "ckpt_keep":
+                self.desc.ckpt_keep = int(self.keep_layers)
             elif name in ("drop_active", "drop_seed", "drop_offset"):
                 setattr(self.desc, name, 0)
             else:
@@ -168,6 +203,15 @@ class _ChunkArena:
 
     def nbytes(self) -> int:
         return sum(x.numel() * x.element_size() for x in self.tensors.values())
+
+    @staticmethod
+    def slot_bytes_per_token(cfg) -> int:
+        """What ONE more slot of the per-layer buffers costs per token (the price of keeping a block under selective
+        checkpointing): qkv, ctx, lse, three of z1 / h1 / z2 / h2 (the fourth is the per-layer input tensor a checkpointing
+        arena holds anyway), the LayerNorm statistics, the fc1 pre-activation and the activation."""
+        d, I, H = cfg.n_embd, cfg.n_inner, cfg.n_head
+        wfc1 = 2 * I if cfg.gated else I
+        return 2 * (3 * d + d + 3 * d + wfc1 + I) + 4 * (H + 4)
 
 
 _FULL_CACHE: Dict[tuple, tuple] = {}
@@ -292,6 +336,10 @@ class NomicBertEngine(torch.nn.Module):
         # BiEncoderConfig.gradient_checkpointing (sc/models/biencoder/modeling_biencoder.py:261-262): a saving forward
         # keeps one (T, d) tensor per block and backward recomputes the rest block by block (engine.hip, slot mode 2)
         self.gradient_checkpointing = False
+        self.checkpoint_keep: Union[int, str] = 0   # blocks that keep their activations under checkpointing: n | "auto"
+        self._keep_logged: set = set()
+        self._keep_suspended = 0   # > 0: "auto" keeps nothing (a caller that lines up MANY arenas budgets the HBM itself)
+        self._keep_plan: Dict[object, int] = {}   # T_cap -> blocks the next arena of that size keeps ("auto", measured)
         self.sync_shadows()
 
     # ------------------------------------------------------------------------------------------------ parameters
@@ -540,10 +588,90 @@ class NomicBertEngine(torch.nn.Module):
                 self._arena_nograd = a
             return a
         ck = bool(self.gradient_checkpointing)
-        for i, a in enumerate(self._arena_free):
-            if a.T_cap >= T_cap and a.B_cap >= B and a.checkpoint == ck:
-                return self._arena_free.pop(i)
-        return _ChunkArena(self.config, T_cap, self.config.n_layer, True, max(B, 1), self.device_, checkpoint=ck)
+        # best fit: with two arena sizes in rotation (32 queries / 256 documents of cfg 3) a first-fit search hands the small
+        # chunk the big arena and then has to build a second big one
+        fits = [i for i, a in enumerate(self._arena_free) if a.T_cap >= T_cap and a.B_cap >= B and a.checkpoint == ck]
+        if fits:
+            return self._arena_free.pop(min(fits, key=lambda i: self._arena_free[i].T_cap))
+        L = self.config.n_layer
+        keep = self._checkpoint_keep_for(T_cap) if ck else 0
+        if keep > 0:
+            try:
+                a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=True, keep_layers=keep)
+                a.granted = self._keep_plan.pop(("granted", T_cap), 0)   # the ledger entry now belongs to the arena
+                self._log_keep(T_cap, keep)
+                return a
+            except torch.OutOfMemoryError:
+                # (fragmentation, another tenant of the device): nothing has been computed yet -> take the recipe literally
+                torch.cuda.empty_cache()
+                _hbm_grant(self.device_, -self._keep_plan.pop(("granted", T_cap), 0))
+                if self._keep_mode() != "auto":
+                    raise   # an explicit number is a demand, not a hint
+                self._keep_plan[T_cap] = 0
+                logging.getLogger("contrastors_amd").info(
+                    "selective checkpointing: keeping %d of %d blocks ran out of memory at %d tokens; recomputing every block",
+                    keep, L, T_cap)
+        a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=ck)
+        a.probation = ck and self._keep_mode() == "auto" and not self._keep_suspended and T_cap not in self._keep_plan
+        return a
+
+    # ---- selective activation checkpointing (round 3): `gradient_checkpointing: true` is a memory knob sized for 80 GB ----
+    # An integer `checkpoint_keep` is taken literally.  "auto" MEASURES instead of estimating: the first use of an arena takes
+    # the recipe literally (every block recomputed); when its backward has run, the step's real peak is known -- other
+    # towers' arenas, the loss, the optimizer included -- and the arena is rebuilt for its next use with as many kept
+    # blocks as `CKPT_HBM_FRACTION` of the device minus that peak pays for.  A per-device ledger (`_hbm_grant`) keeps two
+    # arenas (query / document side, two towers) from spending the same headroom twice.
+    CKPT_HBM_FRACTION = 0.90
+
+    def _keep_mode(self) -> Union[int, str]:
+        return parse_checkpoint_keep(os.environ.get("CX_CHECKPOINT_KEEP"), "CX_CHECKPOINT_KEEP", default=self.checkpoint_keep)
+
+    def _checkpoint_keep_for(self, T_cap: int) -> int:
+        """Blocks of a NEW checkpointing arena that keep their intermediates (CxChunkBuffers.ckpt_keep)."""
+        mode, L = self._keep_mode(), self.config.n_layer
+        if mode != "auto":
+            return max(0, min(int(mode), L))
+        return 0 if self._keep_suspended else int(self._keep_plan.get(T_cap, 0))
+
+    def _plan_keep(self, arena: _ChunkArena) -> bool:
+        """Called when a probation arena's backward has been enqueued (release_arena): decide how many blocks its successor
+        keeps.  True = the arena is to be dropped (its successor is built by the next saving forward)."""
+        arena.probation = False
+        if self._keep_mode() != "auto" or self._keep_suspended:
+            return False
+        L, T_cap = self.config.n_layer, arena.T_cap
+        per_keep = T_cap * _ChunkArena.slot_bytes_per_token(self.config)
+        total = torch.cuda.get_device_properties(self.device_).total_memory
+        peak = torch.cuda.max_memory_allocated(self.device_)
+        budget = self.CKPT_HBM_FRACTION * total - peak - _hbm_grant(self.device_, 0)
+        keep = int(max(0, min(L, budget // max(per_keep, 1))))
+        self._keep_plan[T_cap] = keep
+        if keep == 0:
+            return False
+        _hbm_grant(self.device_, keep * per_keep)
+        self._keep_plan[("granted", T_cap)] = keep * per_keep   # handed to the successor arena when it is built
+        return True
+
+    @contextlib.contextmanager
+    def selective_checkpointing_suspended(self):
+        """A schedule that keeps many arenas alive at once (GradCache with resident activations: one per chunk) has already
+        budgeted the HBM for the recipe's literal checkpointing; `auto` stays out of its way."""
+        self._keep_suspended += 1
+        try:
+            yield
+        finally:
+            self._keep_suspended -= 1
+
+    def _log_keep(self, T_cap: int, keep: int):
+        key = (T_cap, keep)
+        if key in self._keep_logged:
+            return
+        self._keep_logged.add(key)
+        L = self.config.n_layer
+        logging.getLogger("contrastors_amd").info(
+            "selective checkpointing: %d-token arena keeps the activations of %d of %d blocks (%.1f GB), %d are recomputed "
+            "in backward (checkpoint_keep_layers = %r)", T_cap, keep, L,
+            keep * T_cap * _ChunkArena.slot_bytes_per_token(self.config) / 1e9, L - keep, self.checkpoint_keep)
 
     def _arm_dropout(self, arena: _ChunkArena):
         """Dropout is active in training mode when the config asks for it.  The Philox (seed, offset) of the chunk comes
@@ -573,15 +701,17 @@ class NomicBertEngine(torch.nn.Module):
         cfg = self.config
         return self.training and any(getattr(cfg, k, 0.0) > 0 for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop"))
 
-    def release_arena(self, arena: _ChunkArena):
+    def release_arena(self, arena: _ChunkArena, used: bool = True):
         arena.emb_out = None
         arena.desc.layer_events = None
+        if used and getattr(arena, "probation", False) and self._plan_keep(arena):
+            return   # dropped: the next saving forward builds its successor with the planned number of kept blocks
         self._arena_free.append(arena)
 
     def abandon_arena(self, arena: _ChunkArena):
         """A saved forward whose backward will never run (grad_cache_loss falling back after an out-of-memory error)."""
         self._outstanding = max(0, self._outstanding - 1)
-        self.release_arena(arena)
+        self.release_arena(arena, used=False)
 
     # ---- data-parallel gradient reduction overlapped with the step's last backward (what DDP's bucket hooks do for the
     #      reference, sc/trainers/text_text.py:163-170; VERDICT r2 item 3) ------------------------------------------------
@@ -666,9 +796,13 @@ class NomicBertEngine(torch.nn.Module):
         self._ov_works = None
         return True
 
-    def gradient_checkpointing_enable(self, enabled: bool = True):
+    def gradient_checkpointing_enable(self, enabled: bool = True, keep_layers: Union[int, str, None] = None):
+        """`keep_layers` (beyond the reference's signature): how many blocks keep their activations anyway -- an integer,
+        or "auto" = as many as the free HBM takes (selective checkpointing; results are bit-identical for every value)."""
         self.gradient_checkpointing = bool(enabled)
-        self._arena_free = [a for a in self._arena_free if a.checkpoint == self.gradient_checkpointing]
+        if keep_layers is not None:
+            self.checkpoint_keep = parse_checkpoint_keep(keep_layers, "checkpoint_keep_layers")
+        self._arena_free = []   # (arenas of the other mode, or built for another keep count, are not reused)
 
     # ------------------------------------------------------------------------------------------------ compute
     def forward_chunk(self, vb: VarlenBatch, save_for_backward: bool, normalize: Optional[bool] = None,
@@ -780,7 +914,8 @@ class _EncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, demb):
-        ctx.engine.backward_chunk(ctx.vb, ctx.arena, demb)
+        arena, ctx.arena = ctx.arena, None   # (a graph that outlives its backward must not keep the arena alive)
+        ctx.engine.backward_chunk(ctx.vb, arena, demb)
         return None, None, None, None
 
 
@@ -795,5 +930,6 @@ class _HiddenFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dhidden):
-        ctx.engine.backward_hidden_chunk(ctx.vb, ctx.arena, dhidden)
+        arena, ctx.arena = ctx.arena, None
+        ctx.engine.backward_hidden_chunk(ctx.vb, arena, dhidden)
         return None, None, None

@@ -63,3 +63,20 @@ def _parse_resident(v, where: str):
     if t in ("0", "false", "no", "off"):
         return False
     raise ValueError(f"{where} must be 'auto', true / 1 or false / 0, got {v!r}")
+
+
+def _parse_keep(v, where: str):
+    """checkpoint_keep_layers (selective activation checkpointing): 'auto' or a non-negative integer; None -> 'auto'."""
+    if v is None or v == "":
+        return "auto"
+    if isinstance(v, str) and v.strip().lower() == "auto":
+        return "auto"
+    if isinstance(v, bool):
+        raise ValueError(f"{where} must be 'auto' or a non-negative integer, got {v!r}")
+    try:
+        n = int(v)
+    except (TypeError, ValueError):
+        raise ValueError(f"{where} must be 'auto' or a non-negative integer, got {v!r}") from None
+    if n < 0:
+        raise ValueError(f"{where} must be 'auto' or a non-negative integer, got {v!r}")
+    return n

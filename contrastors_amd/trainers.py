@@ -21,7 +21,7 @@ from .biencoder import BiEncoder, BiEncoderConfig, DualEncoder, LogitScale
 from .config import Config
 from .distributed import check_exchange, gather_with_grad, set_exchange_mode, set_exchange_timeout
 from .loss import clip_loss, grad_cache_loss
-from .policy import GradCachePolicy
+from .policy import GradCachePolicy, _parse_keep
 from .nomic_bert import NomicBertConfig
 from .optimizer import FusedAdamW
 
@@ -120,7 +120,8 @@ class TextTextTrainer:
         bc = BiEncoderConfig(model_name=ma.model_name or "", pooling=ma.pooling, logit_scale=ma.logit_scale,
                              trainable_logit_scale=ma.trainable_logit_scale, projection_dim=ma.projection_dim,
                              freeze=ma.freeze, hamming=ma.hamming, gradient_checkpointing=ma.gradient_checkpointing,
-                                 nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
+                             checkpoint_keep_layers=_parse_keep(config.train_args.checkpoint_keep_layers, "train_args.checkpoint_keep_layers"),
+                             nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
                              trunk_config=trunk_config)
         model = BiEncoder(bc, device=self.device).train()
         model.overlap_reduce = bool(config.train_args.overlap_grad_reduce)
@@ -314,6 +315,7 @@ class ImageTextTrainer(TextTextTrainer):
             bc = BiEncoderConfig(model_name=ma.model_name or "", pooling=ma.pooling, logit_scale=ma.logit_scale,
                                  trainable_logit_scale=ma.trainable_logit_scale, projection_dim=ma.projection_dim,
                                  freeze=ma.freeze, hamming=ma.hamming, gradient_checkpointing=ma.gradient_checkpointing,
+                                 checkpoint_keep_layers=_parse_keep(config.train_args.checkpoint_keep_layers, "train_args.checkpoint_keep_layers"),
                                  nomic_encoder=ma.nomic_encoder,
                                  seq_len=ma.seq_len, trunk_config=trunk)
             tower = BiEncoder(bc, device=self.device).train()

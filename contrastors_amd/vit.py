@@ -276,7 +276,8 @@ class _VitEncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, demb):
-        ctx.engine.backward_chunk(ctx.B, ctx.arena, demb)
+        arena, ctx.arena = ctx.arena, None   # (a graph that outlives its backward must not keep the arena alive)
+        ctx.engine.backward_chunk(ctx.B, arena, demb)
         return None, None, None, None
 
 
@@ -291,5 +292,6 @@ class _VitHiddenFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dhidden):
-        ctx.engine.backward_hidden_chunk(ctx.B, ctx.arena, dhidden)
+        arena, ctx.arena = ctx.arena, None
+        ctx.engine.backward_hidden_chunk(ctx.B, arena, dhidden)
         return None, None, None

@@ -410,6 +410,12 @@ typedef struct CxChunkBuffers {
     /* image towers with a pre-LayerNorm (CxEncoderDesc.lnpre_g): its input, (T, d), kept for backward; statistics in
      * emb_mean / emb_rstd (the slots the text trunk's embedding LayerNorm uses) */
     uint16_t* zpre;
+    /* selective activation checkpointing (cx_abi_version >= 6; meaningful with checkpoint != 0): the TOP ckpt_keep blocks
+     * (l >= n_layer - ckpt_keep) keep all their intermediates -- every per-layer buffer then has 1 + ckpt_keep slots, slot 0
+     * shared by the recomputed blocks, slot 1 + l - (n_layer - ckpt_keep) owned by kept block l -- and backward recomputes
+     * only the blocks below them.  0 = the reference's behaviour (every block recomputed).  A memory knob like
+     * `checkpoint` itself: results are bit-identical for every value (tests/test_checkpoint_gpu.py). */
+    int ckpt_keep;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.

@@ -22,10 +22,10 @@ DEV = "cuda"
 DIMS = [768, 512, 256, 128]
 
 
-def _trainer(n_layer, vocab, checkpointing=False, batch=4):
+def _trainer(n_layer, vocab, checkpointing=False, batch=4, keep=0):
     cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=1, grad_cache=False,
                                       schedule_type="linear", max_grad_norm=1.0, clamp_logits=False,
-                                      matryoshka_dims=DIMS),
+                                      matryoshka_dims=DIMS, checkpoint_keep_layers=keep),
                  data_args=DataArgs(batch_size=batch, seed=3),
                  model_args=ModelArgs(logit_scale=50.0, pooling="mean", model_name="cfg3", hamming=True, num_negatives=7,
                                       gradient_checkpointing=checkpointing, seq_len=2048))
@@ -137,8 +137,36 @@ def test_cfg3_baseline_per_gpu_shape_fits_with_checkpointing():
     for side, n in (("query", 32), ("document", 256)):
         batch[f"{side}_input_ids"] = torch.randint(1000, 30522, (n, S), generator=g)
         batch[f"{side}_seqlens"] = np.full(n, S)
+    p_init = tr.model["model"].trunk.flat_param.clone()
     loss = tr.training_step(batch)
     torch.cuda.synchronize()
     peak = (torch.cuda.max_memory_allocated() - base) / 2**30
     report("cfg3_baseline_shape", loss=float(loss), peak_hbm_gb=peak, tokens=288 * S)
     assert np.isfinite(float(loss)) and peak < 120.0
+    # the same step with train_args.checkpoint_keep_layers: auto (the library default): the blocks that fit keep their
+    # activations (the recipe's checkpointing was sized for 80 GB), the loss is the same number, the HBM gets used
+    loss_lit = float(loss)
+    del tr
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    tr, tc = _trainer(n_layer=12, vocab=30528, checkpointing=True, batch=32, keep="auto")
+    trunk = tr.model["model"].trunk
+    trunk.flat_param.copy_(p_init)
+    trunk.sync_shadows()
+    del p_init
+    losses = []
+    for _ in range(2):   # first use of the arenas: literal, the step's peak is measured; second: rebuilt with kept blocks
+        trunk.zero_grad()
+        loss = tr.forward_step(batch)
+        losses.append(float(loss))
+        tr.backward(loss)
+    torch.cuda.synchronize()
+    kept = sorted(trunk._keep_logged)   # (T_cap, blocks kept) of every upgraded arena this engine built
+    peak_auto = (torch.cuda.max_memory_allocated() - base) / 2**30
+    total = torch.cuda.get_device_properties(0).total_memory / 2**30
+    report("cfg3_baseline_shape_selective", loss=losses[-1], peak_hbm_gb=peak_auto, kept=[list(k) for k in kept])
+    assert losses[0] == loss_lit and losses[1] == loss_lit, (losses, loss_lit)
+    assert kept and all(k > 0 for _, k in kept), kept
+    assert peak < peak_auto < 0.93 * total, (peak, peak_auto, total)

@@ -80,3 +80,125 @@ def test_checkpointed_vit_tower_is_bit_identical():
         res[ck] = (emb.clone(), eng.flat_grad.clone())
     assert torch.equal(res[False][0], res[True][0])
     assert torch.equal(res[False][1], res[True][1]), float((res[False][1] - res[True][1]).abs().max())
+
+
+# ---- selective checkpointing (round 3): the top k blocks keep their activations, only the rest are recomputed -------------
+@pytest.mark.parametrize("arch", ["nomic", "bert"])
+def test_selective_checkpointing_is_bit_identical_for_every_keep_count(arch):
+    """CxChunkBuffers.ckpt_keep = 0 .. L: same embeddings, same Linear / LayerNorm gradients bit for bit as the engine
+    without checkpointing (keep = L is that engine's schedule on a checkpointing arena), arena size strictly in between."""
+    L = 4
+    cfg = (NomicBertConfig.nomic_bert_2048(vocab_size=2048, n_layer=L) if arch == "nomic"
+           else NomicBertConfig.bert_base_uncased(vocab_size=2048, n_layer=L))
+    ns = SimpleNamespace(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    sd = encoder_ref.random_state_dict(ns, 12)
+    ids, lens, g = _ragged(5, 200, 2048, 6)
+    vb = VarlenBatch.from_lengths(ids, lens)
+    probe = torch.randn(5, cfg.n_embd, generator=g).to(DEV)
+
+    def run(ck, keep):
+        eng = NomicBertEngine(cfg, device=DEV)
+        eng.load_reference_state_dict(sd)
+        eng.train()
+        eng.gradient_checkpointing_enable(ck, keep_layers=keep)
+        emb, arena = eng.forward_chunk(vb, True)
+        assert arena.checkpoint == ck and arena.keep_layers == (keep if ck else 0)
+        nbytes = arena.nbytes()
+        eng.zero_grad()
+        eng.backward_chunk(vb, arena, probe)
+        torch.cuda.synchronize()
+        return emb.clone(), eng.reference_grad_dict(), nbytes
+
+    emb0, g0, full_bytes = run(False, 0)
+    sizes = []
+    for keep in range(L + 1):
+        emb, gk, nbytes = run(True, keep)
+        sizes.append(nbytes)
+        assert torch.equal(emb0, emb), keep
+        for name, a in g0.items():
+            b = gk[name]
+            if ".layers." in name and not name.endswith(".bias"):
+                assert torch.equal(a, b), (keep, name, float((a - b).abs().max()))
+            else:
+                assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-30, (keep, name)
+    assert all(x < y for x, y in zip(sizes, sizes[1:])), sizes
+    report("checkpoint_selective", arch=arch, arena_bytes_by_keep=sizes, arena_bytes_full=full_bytes)
+
+
+def test_selective_checkpointing_vit_tower_is_bit_identical():
+    from contrastors_amd.vit import ViTConfig, ViTEngine
+
+    cfg = ViTConfig(n_embd=256, n_layer=3, n_head=4, n_inner=1024, img_size=64, patch_size=16)
+    g = torch.Generator().manual_seed(9)
+    pixels = torch.randn(6, 3, 64, 64, generator=g).to(DEV)
+    probe = torch.randn(6, cfg.n_embd, generator=g).to(DEV)
+    res = {}
+    for key, (ck, keep) in {"plain": (False, 0), "k1": (True, 1), "k2": (True, 2), "k3": (True, 3)}.items():
+        eng = ViTEngine(cfg, device=DEV, pooling="cls", seed=5)
+        eng.train()
+        eng.gradient_checkpointing_enable(ck, keep_layers=keep)
+        emb, arena = eng.forward_chunk(pixels, True)
+        assert arena.keep_layers == keep
+        eng.zero_grad()
+        eng.backward_chunk(pixels, arena, probe)
+        torch.cuda.synchronize()
+        res[key] = (emb.clone(), eng.flat_grad.clone())
+    for key in ("k1", "k2", "k3"):
+        assert torch.equal(res["plain"][0], res[key][0]), key
+        assert torch.equal(res["plain"][1], res[key][1]), (key, float((res["plain"][1] - res[key][1]).abs().max()))
+
+
+def test_auto_keep_measures_the_first_use_then_keeps_what_fits():
+    """checkpoint_keep_layers = 'auto': the first use of an arena takes the recipe literally (every block recomputed); once
+    its backward has run the step's peak HBM is known and the arena's successor keeps what the headroom pays for -- all
+    four blocks of this small problem -- with the same embeddings and gradients; the per-device ledger is settled when
+    the arena dies; a suspended engine (resident GradCache lines up one arena per chunk) stays literal; CX_CHECKPOINT_KEEP
+    overrides the config."""
+    import gc
+    import os
+
+    from contrastors_amd import nomic_bert as nb
+
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=2048, n_layer=4)
+    eng = NomicBertEngine(cfg, device=DEV, seed=1)
+    eng.train()
+    eng.gradient_checkpointing_enable(True, keep_layers="auto")
+    ids, lens, g = _ragged(4, 128, 2048, 2)
+    vb = VarlenBatch.from_lengths(ids, lens)
+    probe = torch.randn(4, cfg.n_embd, generator=g).to(DEV)
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    ledger0 = nb._hbm_grant(eng.device_, 0)
+    res = []
+    for step in range(3):
+        emb, arena = eng.forward_chunk(vb, True)
+        assert arena.keep_layers == (0 if step == 0 else 4), (step, arena.keep_layers)
+        assert arena.probation == (step == 0)
+        eng.zero_grad()
+        eng.backward_chunk(vb, arena, probe)
+        torch.cuda.synchronize()
+        res.append((emb.clone(), eng.flat_grad.clone()))
+    del arena
+    assert nb._hbm_grant(eng.device_, 0) > ledger0 and eng._keep_plan[vb.T if vb.T % 128 == 0 else (vb.T + 127) // 128 * 128] == 4
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[1][0], res[2][0])
+    lin = slice(eng._lin_begin, eng._lin_end)   # Linear weights: bit-identical; the rest carries fp32-atomics order noise
+    assert torch.equal(res[0][1][lin], res[1][1][lin]) and torch.equal(res[1][1][lin], res[2][1][lin])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[0][1].abs().max())
+    eng._arena_free.clear()
+    gc.collect()
+    assert nb._hbm_grant(eng.device_, 0) == ledger0      # the arena returned its grant
+    eng._keep_plan.clear()
+    with eng.selective_checkpointing_suspended():
+        for _ in range(2):
+            _, arena = eng.forward_chunk(vb, True)
+            assert arena.keep_layers == 0 and not arena.probation
+            eng.backward_chunk(vb, arena, probe)
+    eng._arena_free.clear()
+    os.environ["CX_CHECKPOINT_KEEP"] = "1"
+    try:
+        _, arena = eng.forward_chunk(vb, True)
+        assert arena.keep_layers == 1 and not arena.probation
+        eng.abandon_arena(arena)
+    finally:
+        del os.environ["CX_CHECKPOINT_KEEP"]

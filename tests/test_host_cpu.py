@@ -113,3 +113,35 @@ def test_lr_horizon_follows_set_total_steps():
         t.optimizer.step()
         t.scheduler.step()
     assert abs(lrs[9] - 1.0) < 1e-6 and lrs[0] == pytest.approx(0.1) and lrs[99] < 0.02
+
+
+def test_selective_checkpointing_arena_and_config():
+    """checkpoint_keep_layers: the arena of a checkpointed forward has 1 + k slots per intermediate buffer and L slots of the
+    block-input tensor; the config accepts 'auto' / n and rejects the rest (train_args.checkpoint_keep_layers)."""
+    import pytest as _pt
+    from contrastors_amd.config import TrainArgs
+    from contrastors_amd.nomic_bert import NomicBertConfig, _ChunkArena, parse_checkpoint_keep
+    from contrastors_amd.vit import ViTConfig
+
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=512, n_layer=6, n_embd=128, n_head=2, n_inner=256)
+    cpu = torch.device("cpu")
+    full = _ChunkArena(cfg, 256, 6, True, 4, cpu)
+    lit = _ChunkArena(cfg, 256, 6, True, 4, cpu, checkpoint=True)
+    sel = _ChunkArena(cfg, 256, 6, True, 4, cpu, checkpoint=True, keep_layers=2)
+    assert (full.desc.checkpoint, lit.desc.checkpoint, sel.desc.checkpoint) == (0, 1, 1)
+    assert (full.desc.ckpt_keep, lit.desc.ckpt_keep, sel.desc.ckpt_keep) == (0, 0, 2)
+    assert sel.tensors["qkv"].shape[0] == 3 and sel.tensors["yg"].shape[0] == 3 and sel.tensors["h1"].shape[0] == 3
+    assert sel.tensors["h2"].shape[0] == 6 and lit.tensors["h2"].shape[0] == 6 and lit.tensors["qkv"].shape[0] == 1
+    per_slot = _ChunkArena.slot_bytes_per_token(cfg) * 256
+    assert sel.nbytes() - lit.nbytes() == 2 * per_slot
+    assert lit.nbytes() < sel.nbytes() < full.nbytes()
+    # a pre-norm (image) trunk keeps z1 per block
+    vcfg = ViTConfig(n_embd=128, n_layer=4, n_head=2, n_inner=256, img_size=32, patch_size=16)
+    v = _ChunkArena(vcfg, 128, 4, True, 4, cpu, checkpoint=True, keep_layers=9)   # clamped to n_layer
+    assert v.desc.ckpt_keep == 4 and v.tensors["z1"].shape[0] == 4 and v.tensors["h2"].shape[0] == 5
+    assert _ChunkArena(cfg, 256, 6, True, 4, cpu, checkpoint=False, keep_layers=3).desc.ckpt_keep == 0
+    assert parse_checkpoint_keep(None, "x", default="auto") == "auto" and parse_checkpoint_keep("3", "x") == 3
+    assert TrainArgs(checkpoint_keep_layers=0).checkpoint_keep_layers == 0 and TrainArgs().checkpoint_keep_layers == "auto"
+    for bad in (-1, "some"):
+        with _pt.raises(ValueError):
+            TrainArgs(checkpoint_keep_layers=bad)
