@@ -99,6 +99,9 @@ _SIGS = {
     "cx_gemm_bf16_swiglu": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_nt_residual": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_swiglu_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "cx_gemm_bf16_swiglu_gate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cx_gemm_bf16_swiglu_bwd_gate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cx_swiglu_bwd_gate": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "cx_gemm_bf16_bias_gelu": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_bias_act": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_bias_gelu_fwd": (i32, [vp, vp, vp, i32, i32, vp]),

@@ -167,6 +167,35 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     }
 }
 
+// SwiGLU backward from (act, gate): the forward saved the gate alone next to the activation (cx_gemm_bf16_swiglu_gate);
+// y is recovered inside the derivative, d gate = d * y * silu'(g) with y = act / silu(g) = d * act * (1 / g + 1 - sigmoid(g)).
+// dyg: (T, 2I) in the interleaved-by-32 layout the fc1 dgrad / wgrad GEMMs consume.
+__global__ __launch_bounds__(256) void swiglu_bwd_gate_kernel(const bf16_t* __restrict__ dact, const bf16_t* __restrict__ act,
+                                                              const bf16_t* __restrict__ gate, bf16_t* __restrict__ dyg,
+                                                              long T, int I) {
+    const int chunks = I >> 3;
+    const long total = T * chunks;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long t = i / chunks;
+        const int c = (int)(i - t * chunks) * 8;
+        float a[8], g[8], d[8], dy[8], dg[8];
+        unpack8(*reinterpret_cast<const uint4*>(act + t * (long)I + c), a);
+        unpack8(*reinterpret_cast<const uint4*>(gate + t * (long)I + c), g);
+        unpack8(*reinterpret_cast<const uint4*>(dact + t * (long)I + c), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = sigmoidf_(g[e]);
+            dy[e] = g[e] * s * d[e];
+            const float rg = __builtin_amdgcn_rcpf(fabsf(g[e]) < 1e-30f ? 1.f : g[e]);   // (g = 0 <=> act = 0)
+            dg[e] = d[e] * a[e] * (rg + 1.f - s);
+        }
+        bf16_t* orow = dyg + t * (2L * I);
+        *reinterpret_cast<uint4*>(orow + ycol(c, I, 1)) = pack8(dy);
+        *reinterpret_cast<uint4*>(orow + gcol(c, I, 1)) = pack8(dg);
+    }
+}
+
 template <int kind>
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const bf16_t* __restrict__ pre,
                                                             const float* __restrict__ bias,
@@ -464,6 +493,16 @@ int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T
     if ((I % 8) || (layout && (I % 32))) return CX_ERR_SHAPE;
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                        dact, yg, dyg, (long)T, I, layout);
+    return done();
+}
+
+int cx_swiglu_bwd_gate(const uint16_t* dact, const uint16_t* act, const uint16_t* gate, uint16_t* dyg, int T, int I,
+                       void* stream) {
+    if (T <= 0) return CX_OK;
+    if (!dact || !act || !gate || !dyg) return CX_ERR_ARG;
+    if (I % 32) return CX_ERR_SHAPE;
+    hipLaunchKernelGGL(swiglu_bwd_gate_kernel, dim3(grid_for((long)T * (I / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       dact, act, gate, dyg, (long)T, I);
     return done();
 }
 

@@ -41,7 +41,7 @@ struct Slots {
     const CxChunkBuffers* b;
     const CxEncoderDesc* e;
     long T_cap;
-    int d, I, wfc1;  // wfc1 = width of the fc1 output (2I gated, I plain)
+    int d, I, wfc1;  // wfc1 = width of the fc1 output (2I gated, I plain) = width of its gradient in g_wide
     int mode;
     int first_kept;  // mode 2: blocks l >= first_kept own slot 1 + l - first_kept; below it: slot 0, recomputed in backward
     bool kept(int s) const { return mode == 1 || (mode == 2 && s >= first_kept); }   // block s's intermediates survive the forward
@@ -54,7 +54,9 @@ struct Slots {
     uint16_t* h1(int s) const { return b->h1 + (size_t)sl(s) * T_cap * d; }
     float* mean1(int s) const { return b->mean1 + (size_t)sl(s) * T_cap; }
     float* rstd1(int s) const { return b->rstd1 + (size_t)sl(s) * T_cap; }
-    uint16_t* yg(int s) const { return b->yg + (size_t)sl(s) * T_cap * wfc1; }
+    // what the MLP's first projection keeps for backward, (T, I) per slot: the biased pre-activation of the plain MLP, the
+    // GATE of the gated one (round 3: y is recovered from act = y * silu(gate); cx_gemm_bf16_swiglu_gate)
+    uint16_t* yg(int s) const { return b->yg + (size_t)sl(s) * T_cap * I; }
     uint16_t* act(int s) const { return b->act + (size_t)sl(s) * T_cap * I; }
     uint16_t* z2(int s) const { return b->z2 + (size_t)sl(s) * T_cap * d; }
     uint16_t* h2(int s) const { return b->h2 + (size_t)(e->prenorm ? sl(s) : sl_in(s)) * T_cap * d; }
@@ -140,8 +142,8 @@ struct BlockRunner {
     int mlp_up(const CxLayerWeights& w, const uint16_t* x, int l, bool keep) const {
         const int d = enc->d, I = enc->d_inner;
         if (enc->gated) {
-            // fc11 || fc12 + SwiGLU in one kernel; the pre-activation pair is only written when backward needs it
-            return cx_gemm_bf16_swiglu(x, w.Wfc1, keep ? s.yg(l) : nullptr, s.act(l), T, I, d, d, d, s.wfc1, I, stream);
+            // fc11 || fc12 + SwiGLU in one kernel; the gate is only written when backward needs it
+            return cx_gemm_bf16_swiglu_gate(x, w.Wfc1, keep ? s.yg(l) : nullptr, s.act(l), T, I, d, d, d, I, I, stream);
         }
         // bias + erf-GELU in the GEMM epilogue; yg then holds the biased pre-activation, which backward reads with a
         // NULL bias.  Shapes the fused kernel does not cover take the two-kernel route (yg without the bias).
@@ -316,7 +318,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         CX_TRY(wgrad(dm, d, s.act(l), I, w.gWfc2, buf, T, stream));
         int fused = CX_ERR_SHAPE;
         if (enc->gated)  // fc2 dgrad + SwiGLU backward in one kernel: d(act) never touches HBM
-            fused = cx_gemm_bf16_swiglu_bwd(dm, w.Wfc2T, s.yg(l), buf->g_wide, T, I, d, d, d, s.wfc1, stream);
+            fused = cx_gemm_bf16_swiglu_bwd_gate(dm, w.Wfc2T, s.act(l), s.yg(l), buf->g_wide, T, I, d, d, d, I, s.wfc1, stream);
         if (fused != CX_ERR_SHAPE) {
             CX_TRY(fused);
         } else {
@@ -324,7 +326,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         }
         if (enc->gated) {
             if (fused == CX_ERR_SHAPE)
-                CX_TRY(cx_swiglu_bwd(buf->g_act, s.yg(l), buf->g_wide, T, I, /*interleaved*/ 1, stream));
+                CX_TRY(cx_swiglu_bwd_gate(buf->g_act, s.act(l), s.yg(l), buf->g_wide, T, I, stream));
         } else {
             // (yg holds the biased pre-activation when the forward took the fused kernel: same predicate as there)
             // GELU backward and the fc1 bias gradient in one pass over (dact, pre)

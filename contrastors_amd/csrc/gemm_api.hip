@@ -188,6 +188,21 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
+// The same GEMM whose optional save is the GATE alone: G (may be NULL): (M, I) bf16 = bf16(X Wg^T), plain column order.
+// With the activation (which fc2 needs anyway) it determines the SwiGLU backward (cx_gemm_bf16_swiglu_bwd_gate): the saving
+// forward writes 2 (M, I) tensors instead of 3, and the activation arena loses a quarter of its bytes per token and layer.
+int cx_gemm_bf16_swiglu_gate(const uint16_t* X, const uint16_t* W, uint16_t* G, uint16_t* Act, int M, int I, int K, int ldx,
+                             int ldw, int ld_g, int ld_act, void* stream) {
+    if (M <= 0 || I <= 0) return CX_OK;
+    if (K <= 0 || (K % BK) != 0 || (I % 32) != 0 || (ld_g % 8) != 0 || (ld_act % 8) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (!Act) return CX_ERR_ARG;
+    GemmParams p = base_params(X, W, G, nullptr, M, 2 * I, K, ldx, ldw, ld_g);
+    p.Out2 = Act; p.ldo2 = ld_act;
+    ProfScope prof(2.0 * (double)M * (double)(2 * I) * (double)K, (hipStream_t)stream);
+    return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_G, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
 // Out (M,N) bf16 = bf16(bf16(X W^T + bias) + Residual): a projection whose output feeds `x0 + residual -> LayerNorm`
 // (out_proj and fc2 of every block).  CX_ERR_SHAPE when the one-wave-per-SIMD kernel does not cover the shape.
 int cx_gemm_bf16_nt_residual(const uint16_t* X, const uint16_t* W, uint16_t* Out, const float* bias, const uint16_t* Residual,
@@ -236,6 +251,21 @@ int cx_gemm_bf16_swiglu_bwd(const uint16_t* dY, const uint16_t* W, const uint16_
     p.Out2 = const_cast<uint16_t*>(YG); p.ldo2 = ld_yg;
     ProfScope prof(2.0 * (double)M * (double)I * (double)K, (hipStream_t)stream);
     return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+// The same from the (activation, gate) pair cx_gemm_bf16_swiglu_gate leaves: Act, G: (M, I) bf16, leading dimension ld_ag.
+int cx_gemm_bf16_swiglu_bwd_gate(const uint16_t* dY, const uint16_t* W, const uint16_t* Act, const uint16_t* G, uint16_t* dYG,
+                                 int M, int I, int K, int ldx, int ldw, int ld_ag, int ld_dyg, void* stream) {
+    if (M <= 0 || I <= 0) return CX_OK;
+    if (!dY || !W || !Act || !G || !dYG) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (I % 256) != 0 || (ld_dyg % 8) != 0 || ld_dyg < 2 * I || (ld_ag % 8) != 0 || ld_ag < I)
+        return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    GemmParams p = base_params(dY, W, dYG, nullptr, M, I, K, ldx, ldw, ld_dyg);
+    p.Out2 = const_cast<uint16_t*>(Act); p.ldo2 = ld_ag;
+    p.In3 = G;
+    ProfScope prof(2.0 * (double)M * (double)I * (double)K, (hipStream_t)stream);
+    return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD_AG, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
 int cx_prof_gemm_config(int enable, int stride) {

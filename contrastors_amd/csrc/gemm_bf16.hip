@@ -991,3 +991,34 @@ int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_ti
 }
 
 }  // extern "C"
+
+// ---- round 3: compact save of the gated MLP (see gemm_api.hip for the product's entry points).  The dev library serves
+// them on the v6 kernel only (there is no A/B generation of these epilogues), without the launch profiler.
+int cx_gemm_bf16_swiglu_gate(const uint16_t* X, const uint16_t* W, uint16_t* G, uint16_t* Act, int M, int I, int K, int ldx,
+                             int ldw, int ld_g, int ld_act, void* stream) {
+    if (M <= 0 || I <= 0) return CX_OK;
+    if (K <= 0 || (K % BK) != 0 || (I % 32) != 0 || (ld_g % 8) != 0 || (ld_act % 8) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (!Act) return CX_ERR_ARG;
+    GemmParams p;
+    p.X = X; p.W = W; p.Out = G; p.bias = nullptr;
+    p.M = M; p.N = 2 * I; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ld_g;
+    p.tiles_m = p.tiles_n = 0; p.split_k = 1; p.alpha = 1.f; p.dbg = 0; p.act = 0;
+    p.Out2 = Act; p.ldo2 = ld_act; p.In3 = nullptr; p.sup_m = p.sup_n = 0; p.trace = nullptr;
+    return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_G, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+int cx_gemm_bf16_swiglu_bwd_gate(const uint16_t* dY, const uint16_t* W, const uint16_t* Act, const uint16_t* G, uint16_t* dYG,
+                                 int M, int I, int K, int ldx, int ldw, int ld_ag, int ld_dyg, void* stream) {
+    if (M <= 0 || I <= 0) return CX_OK;
+    if (!dY || !W || !Act || !G || !dYG) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (I % 256) != 0 || (ld_dyg % 8) != 0 || ld_dyg < 2 * I || (ld_ag % 8) != 0 || ld_ag < I)
+        return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    GemmParams p;
+    p.X = dY; p.W = W; p.Out = dYG; p.bias = nullptr;
+    p.M = M; p.N = I; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ld_dyg;
+    p.tiles_m = p.tiles_n = 0; p.split_k = 1; p.alpha = 1.f; p.dbg = 0; p.act = 0;
+    p.Out2 = const_cast<uint16_t*>(Act); p.ldo2 = ld_ag; p.In3 = G; p.sup_m = p.sup_n = 0; p.trace = nullptr;
+    return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD_AG, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}

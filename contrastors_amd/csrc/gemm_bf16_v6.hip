@@ -83,6 +83,9 @@ struct Frags6 {
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
+    constexpr bool IS_SWIGLU_BWD = EPI == GEMM_EPI_SWIGLU_BWD || EPI == GEMM_EPI_SWIGLU_BWD_AG;
+    constexpr bool AG = EPI == GEMM_EPI_SWIGLU_BWD_AG;      // the saved pair is (act, gate) instead of (y, gate)
+    constexpr bool SAVEG = EPI == GEMM_EPI_SWIGLU_G;        // the forward's optional save is the gate alone
     long long t_begin = 0, n_ktiles = 0;
     if constexpr (DBG != 0) t_begin = (long long)__builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x;
@@ -521,16 +524,31 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 } else {
                     store_tile(std::false_type{});
                 }
-            } else if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
+            } else if constexpr (IS_SWIGLU_BWD) {
                 // fc2 dgrad with the SwiGLU backward in the epilogue (sc/layers/mlp.py:75 swiglu, its autograd): the tile
                 // is d(act) for 128 activation columns of this wave = 256 columns [y0|g0|y1|g1|y2|g2|y3|g3] of the
                 // pre-activation tensor YG (p.Out2, input) and of its gradient dYG (p.Out).  d(act) is never written; the
                 // HBM-bound elementwise pass (read YG + d(act), write dYG) now overlaps other workgroups' MFMA phases.
                 // Per pass of 32 rows: YG block -> LDS (coalesced 16-B loads), every lane updates its (row, 4 columns)
                 // cells in place, dYG block LDS -> HBM (coalesced).  [32 rows][512 B], 16-B chunk index ^ row.
+                // AG form (round 3): the forward saved the gate alone, (M, I), next to the activation it writes anyway; the
+                // (y, gate) block is assembled from the two tensors -- y slots take act, gate slots take gate, the same 16
+                // row loads per pass, each lane picks its tensor -- and y is recovered inside the derivative:
+                //   d gate = d * y * silu'(g),  y = act / silu(g)   =>   d gate = d * act * (1 / g + 1 - sigmoid(g))
+                // (act is y * silu(g) rounded once to bf16, so the recovered y carries the same 2^-9 the saved bf16 y had).
                 const bf16_t* yg_in = reinterpret_cast<const bf16_t*>(p.Out2);
+                const bf16_t* g_in = reinterpret_cast<const bf16_t*>(p.In3);
                 bf16_t* dyg = reinterpret_cast<bf16_t*>(p.Out);
                 const int c0 = 2 * n0;  // first pre-activation column of this wave
+                // d(gate) coefficient per element: silu'(g) * y from (y, g)  |  act * (1/g + 1 - sg) from (act, g)
+                auto dgate_of = [&](float yv, float gv, float sg, float gs, float dv) {
+                    if constexpr (AG) {
+                        const float rg = __builtin_amdgcn_rcpf(__builtin_fabsf(gv) < 1e-30f ? 1.f : gv);  // (g = 0 <=> act = 0)
+                        return dv * yv * (rg + 1.f - sg);
+                    } else {
+                        return (sg + gs * (1.f - sg)) * dv * yv;
+                    }
+                };
                 auto cell = [&](int row, int colbyte) { return my + row * 512 + ((((colbyte >> 4) ^ row) & 31) << 4) + (colbyte & 15); };
                 // ---- fast path (interior tiles).  The first version ran its four 32-row passes strictly one after the
                 // other: the (y, gate) loads of pass b + 1 were issued after the dYG stores of pass b, and on gfx9 a load
@@ -541,7 +559,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 const bool fast_bwd = m0 + 128 <= p.M && n0 + 128 <= p.N;
                 if (fast_bwd) {
                     const int lrow = lane >> 5, lch = lane & 31;
-                    const bf16_t* src = yg_in + (size_t)(m0 + lrow) * p.ldo2 + c0 + lch * 8;
+                    // (AG: chunk lch of the 512-B row = columns [8 lch, 8 lch + 8) of [y0|g0|y1|g1|y2|g2|y3|g3]: 32-column group
+                    // lch >> 3 of this wave's 128 activation columns, from Act (y slot) or G (gate slot))
+                    const bf16_t* src = AG ? ((lch & 4) ? g_in : yg_in) + (size_t)(m0 + lrow) * p.ldo2 + n0 + (lch >> 3) * 32 + (lch & 3) * 8
+                                           : yg_in + (size_t)(m0 + lrow) * p.ldo2 + c0 + lch * 8;
                     bf16_t* dst = dyg + (size_t)(m0 + lrow) * p.ldo + c0 + lch * 8;
                     uint4 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
 #define CX_L(i, b_) t##i = gld(src + (size_t)((b_) * 32 + (i) * 2) * p.ldo2);
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                     const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
                                     const float gs = g[e] * sg;
                                     dy[e] = gs * d[e];
-                                    dg[e] = (sg + gs * (1.f - sg)) * d[e] * y[e];
+                                    dg[e] = dgate_of(y[e], g[e], sg, gs, d[e]);
                                 }
                                 uint2 o;
                                 o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);
@@ -621,7 +642,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     {                                                                                                 \
         int m_ = m0 + b * 32 + (i) * 2 + lrow;                                                        \
         m_ = m_ < p.M ? m_ : p.M - 1;                                                                 \
-        in##i = *reinterpret_cast<const uint4*>(yg_in + (size_t)m_ * p.ldo2 + c0 + lch * 8);          \
+        in##i = AG ? *reinterpret_cast<const uint4*>(((lch & 4) ? g_in : yg_in) + (size_t)m_ * p.ldo2 + n0 + (lch >> 3) * 32 + (lch & 3) * 8) \
+                   : *reinterpret_cast<const uint4*>(yg_in + (size_t)m_ * p.ldo2 + c0 + lch * 8);     \
     }
 #define CX_YG_STAGE(i) *reinterpret_cast<uint4*>(cell((i) * 2 + lrow, lch * 16)) = in##i;
                     {
@@ -657,7 +679,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
                                 const float gs = g[e] * sg;
                                 dy[e] = gs * d;
-                                dg[e] = (sg + gs * (1.f - sg)) * d * y[e];
+                                dg[e] = dgate_of(y[e], g[e], sg, gs, d);
                             }
                             uint2 o;
                             o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);
@@ -736,15 +758,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 // latency, unpredicated 16-byte stores -- instead of 12 serial LDS-read -> wait -> predicated-store steps.
                 auto fast_swiglu = [&](auto save_c) {
                     constexpr bool SAVE = decltype(save_c)::value;
+                    constexpr bool SAVE_YG = SAVE && !SAVEG;   // the interleaved (y, gate) pair, (M, 2I)
+                    constexpr bool SAVE_G = SAVE && SAVEG;     // the gate alone, (M, I): staged and stored like the activation
                     const int rrow = lane >> 4, rch = lane & 15;     // pre-activation rows: 16 lanes x 16 B
                     const int arow = lane >> 3, ach = lane & 7;      // activation rows: 8 lanes x 16 B
-                    bf16_t* ygp = SAVE ? reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8 : nullptr;
+                    bf16_t* ygp = SAVE_YG ? reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8 : nullptr;
+                    bf16_t* gp = SAVE_G ? reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + arow) * p.ldo + (n0 >> 1) + ach * 8 : nullptr;
                     bf16_t* actp = reinterpret_cast<bf16_t*>(p.Out2) + (size_t)(m0 + arow) * p.ldo2 + (n0 >> 1) + ach * 8;
                     const char* rdy = my + rrow * ROWB + rch * 16;
                     const char* rda = mya + arow * AROWB + ach * 16;
+                    const char* rdg = my + arow * AROWB + ach * 16;   // (SAVE_G: the (y, gate) staging region holds the gate rows)
                     char* wry = my + l31 * ROWB + hi * 8;
                     char* wra = mya + l31 * AROWB + hi * 8;
-                    uint2 pky[16], pka[8];
+                    char* wrg = my + l31 * AROWB + hi * 8;
+                    uint2 pky[SAVE_YG ? 16 : 1], pkg[SAVE_G ? 8 : 1], pka[8];
                     auto compute_pass = [&](int b) {
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {
@@ -759,10 +786,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 py.y = pack_bf16x2(yb[4 * q + 2], yb[4 * q + 3]);
                                 pg.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
                                 pg.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
-                                if constexpr (SAVE) {
+                                if constexpr (SAVE_YG) {
                                     pky[(2 * pr) * 4 + q] = py;
                                     pky[(2 * pr + 1) * 4 + q] = pg;
                                 }
+                                if constexpr (SAVE_G) pkg[pr * 4 + q] = pg;
                                 const float yy[4] = {bf16lo_to_f32(py.x), bf16hi_to_f32(py.x), bf16lo_to_f32(py.y), bf16hi_to_f32(py.y)};
                                 const float gg[4] = {bf16lo_to_f32(pg.x), bf16hi_to_f32(pg.x), bf16lo_to_f32(pg.y), bf16hi_to_f32(pg.y)};
                                 float o[4];
@@ -774,11 +802,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         }
                     };
                     auto stage = [&]() {
-                        if constexpr (SAVE) {
+                        if constexpr (SAVE_YG) {
 #pragma unroll
                             for (int a = 0; a < 4; ++a)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wry + (a * 32 + 8 * q) * 2) = pky[a * 4 + q];
+                        }
+                        if constexpr (SAVE_G) {
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wrg + (pr * 32 + 8 * q) * 2) = pkg[pr * 4 + q];
                         }
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr)
@@ -788,11 +822,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     auto one_pass = [&](auto bc) {
                         constexpr int b = decltype(bc)::value;
                         uint4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {};
-                        if constexpr (SAVE) {
+                        if constexpr (SAVE_YG) {
                             v0 = *reinterpret_cast<const uint4*>(rdy + 0 * ROWB); v1 = *reinterpret_cast<const uint4*>(rdy + 4 * ROWB);
                             v2 = *reinterpret_cast<const uint4*>(rdy + 8 * ROWB); v3 = *reinterpret_cast<const uint4*>(rdy + 12 * ROWB);
                             v4 = *reinterpret_cast<const uint4*>(rdy + 16 * ROWB); v5 = *reinterpret_cast<const uint4*>(rdy + 20 * ROWB);
                             v6 = *reinterpret_cast<const uint4*>(rdy + 24 * ROWB); v7 = *reinterpret_cast<const uint4*>(rdy + 28 * ROWB);
+                        }
+                        if constexpr (SAVE_G) {
+                            v0 = *reinterpret_cast<const uint4*>(rdg + 0 * AROWB); v1 = *reinterpret_cast<const uint4*>(rdg + 8 * AROWB);
+                            v2 = *reinterpret_cast<const uint4*>(rdg + 16 * AROWB); v3 = *reinterpret_cast<const uint4*>(rdg + 24 * AROWB);
                         }
                         const uint4 a0 = *reinterpret_cast<const uint4*>(rda + 0 * AROWB), a1 = *reinterpret_cast<const uint4*>(rda + 8 * AROWB),
                                     a2 = *reinterpret_cast<const uint4*>(rda + 16 * AROWB), a3 = *reinterpret_cast<const uint4*>(rda + 24 * AROWB);
@@ -800,7 +838,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         if constexpr (b < 3) compute_pass(b + 1);
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (b < 3) stage();  // the LDS executes a wave's operations in order: these follow the row reads
-                        if constexpr (SAVE) {
+                        if constexpr (SAVE_YG) {
                             bf16_t* o = ygp + (size_t)(b * 32) * p.ldo;
                             gst(o, v0);
                             gst(o + (size_t)4 * p.ldo, v1);
@@ -810,6 +848,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             gst(o + (size_t)20 * p.ldo, v5);
                             gst(o + (size_t)24 * p.ldo, v6);
                             gst(o + (size_t)28 * p.ldo, v7);
+                        }
+                        if constexpr (SAVE_G) {
+                            bf16_t* o = gp + (size_t)(b * 32) * p.ldo;
+                            gst(o, v0);
+                            gst(o + (size_t)8 * p.ldo, v1);
+                            gst(o + (size_t)16 * p.ldo, v2);
+                            gst(o + (size_t)24 * p.ldo, v3);
                         }
                         bf16_t* oa = actp + (size_t)(b * 32) * p.ldo2;
                         gst(oa, a0);
@@ -842,12 +887,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 uint2 pk;
-                                pk.x = pack_bf16x2(yb[4 * q], yb[4 * q + 1]);
-                                pk.y = pack_bf16x2(yb[4 * q + 2], yb[4 * q + 3]);
-                                *reinterpret_cast<uint2*>(my + l31 * ROWB + (2 * pr * 32 + 8 * q + 4 * hi) * 2) = pk;
-                                pk.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
-                                pk.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
-                                *reinterpret_cast<uint2*>(my + l31 * ROWB + ((2 * pr + 1) * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                if constexpr (SAVEG) {   // the gate alone, staged in the activation's row layout
+                                    pk.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
+                                    pk.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
+                                    *reinterpret_cast<uint2*>(my + l31 * AROWB + (pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                } else {
+                                    pk.x = pack_bf16x2(yb[4 * q], yb[4 * q + 1]);
+                                    pk.y = pack_bf16x2(yb[4 * q + 2], yb[4 * q + 3]);
+                                    *reinterpret_cast<uint2*>(my + l31 * ROWB + (2 * pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                    pk.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
+                                    pk.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
+                                    *reinterpret_cast<uint2*>(my + l31 * ROWB + ((2 * pr + 1) * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                }
                             }
                         }
 #pragma unroll
@@ -865,13 +916,25 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         }
                     }
                     if (p.Out) {
+                        if constexpr (SAVEG) {
 #pragma unroll
-                        for (int ps = 0; ps < 8; ++ps) {
-                            const int row = ps * 4 + (lane >> 4), ch = lane & 15;
-                            const int m = m0 + b * 32 + row, n = n0 + ch * 8;
-                            const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
-                            if (m < p.M && n < p.N)
-                                gst(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n, vv);
+                            for (int ps = 0; ps < 4; ++ps) {
+                                const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                                const int m = m0 + b * 32 + row;
+                                const int col = (n0 >> 1) + ch * 8;
+                                const uint4 vv = *reinterpret_cast<const uint4*>(my + row * AROWB + ch * 16);
+                                if (m < p.M && 2 * col < p.N)
+                                    gst(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + col, vv);
+                            }
+                        } else {
+#pragma unroll
+                            for (int ps = 0; ps < 8; ++ps) {
+                                const int row = ps * 4 + (lane >> 4), ch = lane & 15;
+                                const int m = m0 + b * 32 + row, n = n0 + ch * 8;
+                                const uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
+                                if (m < p.M && n < p.N)
+                                    gst(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m * p.ldo + n, vv);
+                            }
                         }
                     }
 #pragma unroll
@@ -892,9 +955,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             // above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead across the epilogue
             // (~150 cycles of exposed LDS latency per tile against 32 registers); the SwiGLU backward additionally rebuilds
             // its 16 DMA cursor offsets from (round, K-tile).
-            if constexpr (EPI == GEMM_EPI_NONE || EPI == GEMM_EPI_SWIGLU_BWD) {
+            if constexpr (EPI == GEMM_EPI_NONE || IS_SWIGLU_BWD) {
                 asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
-                if constexpr (EPI == GEMM_EPI_SWIGLU_BWD) {
+                if constexpr (IS_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
                     asm volatile("" : "=v"(woff[0]), "=v"(woff[1]), "=v"(woff[2]), "=v"(woff[3]), "=v"(woff[4]), "=v"(woff[5]), "=v"(woff[6]), "=v"(woff[7]));
                     x_clamped = w_clamped = true;  // (forces the re-computation)
@@ -1218,6 +1281,8 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     }
 #endif
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
+           : epi == GEMM_EPI_SWIGLU_G ? launch6<GEMM_EPI_SWIGLU_G>(p, stream)
+           : epi == GEMM_EPI_SWIGLU_BWD_AG ? launch6<GEMM_EPI_SWIGLU_BWD_AG>(p, stream)
            : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
            : epi == GEMM_EPI_QGELU ? launch6<GEMM_EPI_QGELU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD ? launch6<GEMM_EPI_SWIGLU_BWD>(p, stream)

@@ -5,7 +5,9 @@
 
 enum { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_F32_ATOMIC = 2, GEMM_OUT_F32_PARTIAL = 3 };
 enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1, GEMM_EPI_GELU = 2, GEMM_EPI_SWIGLU_BWD = 3,
-       GEMM_EPI_QGELU = 4 };  // GELU / QGELU: Out2 = act(acc + bias), Out (optional) = acc + bias; act = erf GELU / quick_gelu
+       GEMM_EPI_QGELU = 4,   // GELU / QGELU: Out2 = act(acc + bias), Out (optional) = acc + bias; act = erf GELU / quick_gelu
+       GEMM_EPI_SWIGLU_G = 5,        // SWIGLU whose optional save is the GATE alone: Out = G (M, N/2), Out2 = Act (M, N/2)
+       GEMM_EPI_SWIGLU_BWD_AG = 6 }; // SWIGLU_BWD from (Act, G): Out2 = Act, In3 = G (INPUTS, (M, N) each, ld = ldo2), Out = dYG
 // SWIGLU_BWD: acc = d(act); Out2 = YG (INPUT, (M, 2N) interleaved by 32), Out = dYG (same layout)
 
 struct GemmParams {
@@ -21,6 +23,7 @@ struct GemmParams {
     int act;    // cx_gemm_bf16_bias_act: CX_ACT_GELU (erf, default 0) or CX_ACT_QUICK_GELU -> GEMM_EPI_GELU / GEMM_EPI_QGELU
     void* Out2; // SwiGLU epilogue: activation output (M, N/2) bf16
     int ldo2;
+    const uint16_t* In3;  // SWIGLU_BWD_AG: the saved gate (M, N) bf16, leading dimension ldo2
     int sup_m, sup_n;  // v2: L2 super-tile (sup_m x sup_n tiles walked together); 0 = plain row-major order
     long long* trace;  // v5p only (set by its launcher): per-workgroup phase cycle counters, or nullptr
 };

@@ -158,7 +158,7 @@ class _ChunkArena:
             t[n] = torch.empty(n_layer_slots if n == kept else n_slots, T_cap, d, **bf)
         for n in ("mean1", "rstd1", "mean2", "rstd2"):
             t[n] = torch.empty(n_slots, T_cap, **f32)
-        t["yg"] = torch.empty(n_slots, T_cap, wfc1, **bf)
+        t["yg"] = torch.empty(n_slots, T_cap, I, **bf)   # plain MLP: biased pre-activation; gated MLP: the gate alone (ABI 6)
         t["act"] = torch.empty(n_slots, T_cap, I, **bf)
         t["pool_norm"] = torch.empty(B_cap, **f32)
         patch_dim = int(getattr(cfg, "patch_dim", 0) or 0)
@@ -210,8 +210,7 @@ class _ChunkArena:
         checkpointing): qkv, ctx, lse, three of z1 / h1 / z2 / h2 (the fourth is the per-layer input tensor a checkpointing
         arena holds anyway), the LayerNorm statistics, the fc1 pre-activation and the activation."""
         d, I, H = cfg.n_embd, cfg.n_inner, cfg.n_head
-        wfc1 = 2 * I if cfg.gated else I
-        return 2 * (3 * d + d + 3 * d + wfc1 + I) + 4 * (H + 4)
+        return 2 * (3 * d + d + 3 * d + I + I) + 4 * (H + 4)
 
 
 _FULL_CACHE: Dict[tuple, tuple] = {}

@@ -185,6 +185,19 @@ int cx_gemm_bf16_bias_act(const uint16_t* X, const uint16_t* W, const float* bia
  * CX_ERR_SHAPE = shape not covered (needs I % 256 == 0, K % 64 == 0): run cx_gemm_bf16_nt + cx_swiglu_bwd instead. */
 int cx_gemm_bf16_swiglu_bwd(const uint16_t* dY, const uint16_t* W, const uint16_t* YG, uint16_t* dYG, int M, int I, int K,
                             int ldx, int ldw, int ld_yg, void* stream);
+/* Round 3: the compact save of the gated MLP.  The reference's swiglu keeps y and gate for its backward (sc/layers/mlp.py:75,
+ * flash_attn.ops.activations.swiglu) and the activation for fc2's: three (M, I) tensors per layer.  y is redundant:
+ * act = y * silu(gate), so   d gate = d * y * silu'(g) = d * act * (1 / g + 1 - sigmoid(g)).   cx_gemm_bf16_swiglu_gate
+ * saves G: (M, I) = bf16(X Wg^T) in plain column order (may be NULL) next to Act; cx_gemm_bf16_swiglu_bwd_gate is
+ * cx_gemm_bf16_swiglu_bwd reading (Act, G) (both leading dimension ld_ag) and writing dYG (M, 2I) in the interleaved-by-32
+ * layout; cx_swiglu_bwd_gate is the standalone form for shapes the fused kernel does not cover (CX_ERR_SHAPE as there).
+ * The recovered y carries one bf16 rounding (of act), as the saved bf16 y did. */
+int cx_gemm_bf16_swiglu_gate(const uint16_t* X, const uint16_t* W, uint16_t* G, uint16_t* Act, int M, int I, int K, int ldx,
+                             int ldw, int ld_g, int ld_act, void* stream);
+int cx_gemm_bf16_swiglu_bwd_gate(const uint16_t* dY, const uint16_t* W, const uint16_t* Act, const uint16_t* G, uint16_t* dYG,
+                                 int M, int I, int K, int ldx, int ldw, int ld_ag, int ld_dyg, void* stream);
+int cx_swiglu_bwd_gate(const uint16_t* dact, const uint16_t* act, const uint16_t* gate, uint16_t* dyg, int T, int I,
+                       void* stream);
 /* act = gelu_erf(pre + bias); bias fp32[I] may be NULL.  backward: dpre = dact * gelu'(pre + bias). */
 int cx_bias_gelu_fwd(const uint16_t* pre, const float* bias, uint16_t* act, int T, int I, void* stream);
 int cx_bias_gelu_bwd(const uint16_t* dact, const uint16_t* pre, const float* bias, uint16_t* dpre, int T, int I,
@@ -369,7 +382,8 @@ typedef struct CxChunkBuffers {
     uint16_t* z1;               /* (T,d) attn_out + residual (LN1 input) */
     uint16_t* h1;               /* (T,d) LN1 output */
     float* mean1; float* rstd1;
-    uint16_t* yg;               /* (T,2I) or (T,I) fc1 output */
+    uint16_t* yg;               /* (T,I) per slot: what fc1 keeps for backward -- the biased pre-activation (plain MLP) or the
+                                 * gate alone (gated MLP, cx_abi_version >= 6; it was the (T,2I) (y, gate) pair before) */
     uint16_t* act;              /* (T,I) */
     uint16_t* z2;               /* (T,d) */
     uint16_t* h2;               /* (T,d) LN2 output = layer output */

@@ -87,10 +87,13 @@ if not a.shape and not a.only:
     dyg = torch.empty_like(yg)
     act = torch.randn(T, I, device=dev).bfloat16()
     out = torch.empty(T, d, device=dev, dtype=torch.bfloat16)
+    gsave = torch.randn(T, I, device=dev).bfloat16()
     fused = {
         "fc1+swiglu (save yg)": (2.0 * T * 2 * I * d, lambda: lib.cx_gemm_bf16_swiglu(x.data_ptr(), w1.data_ptr(), yg.data_ptr(), act.data_ptr(), T, I, d, d, d, 2 * I, I, s)),
         "fc1+swiglu (no save)": (2.0 * T * 2 * I * d, lambda: lib.cx_gemm_bf16_swiglu(x.data_ptr(), w1.data_ptr(), None, act.data_ptr(), T, I, d, d, d, 2 * I, I, s)),
         "fc2 dgrad+swiglu bwd": (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_swiglu_bwd(x.data_ptr(), w2t.data_ptr(), yg.data_ptr(), dyg.data_ptr(), T, I, d, d, d, 2 * I, s)),
+        "fc1+swiglu (save gate)": (2.0 * T * 2 * I * d, lambda: lib.cx_gemm_bf16_swiglu_gate(x.data_ptr(), w1.data_ptr(), gsave.data_ptr(), act.data_ptr(), T, I, d, d, d, I, I, s)),
+        "fc2 dgrad+swiglu bwd (act, gate)": (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_swiglu_bwd_gate(x.data_ptr(), w2t.data_ptr(), act.data_ptr(), gsave.data_ptr(), dyg.data_ptr(), T, I, d, d, d, I, 2 * I, s)),
         "fc2 fwd + residual": (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_nt_residual(act.data_ptr(), w2.data_ptr(), out.data_ptr(), None, res.data_ptr(), T, d, I, I, I, d, d, s)),
         "out_proj fwd + residual": (2.0 * T * d * d, lambda: lib.cx_gemm_bf16_nt_residual(x.data_ptr(), wo.data_ptr(), out.data_ptr(), None, res.data_ptr(), T, d, d, d, d, d, d, s)),
     }

@@ -18,10 +18,10 @@ def algorithmic_bytes(chunk, seq=128, d=768, inner=3072):
     Derivation, X = T x d x 2 B, per layer and chunk:
       forward x 2 (pass 1 no save, pass 2 save):
         qkv       X + W(3d x d) + out 3X                         out_proj  X + W(d x d) + residual X + out X
-        fc1+swiglu X + W(2I x d) + act T I 2 [+ (y, gate) T 2I 2 in pass 2]
+        fc1+swiglu X + W(2I x d) + act T I 2 [+ gate T I 2 in pass 2; rounds 1-2 saved (y, gate): T 2I 2]
         fc2       act + W(d x I) + residual X + out X
       dgrad:
-        fc2-dgrad + SwiGLU backward  X + W + (y, gate) read + d(y, gate) write      fc1-dgrad  d(y,gate) + W + add X + out X
+        fc2-dgrad + SwiGLU backward  X + W + (act, gate) read + d(y, gate) write    fc1-dgrad  d(y,gate) + W + add X + out X
         out_proj dgrad  X + W + out X                                               qkv dgrad  3X + W + add X + out X
       wgrad (natural layout, both operands streamed once):
         fc2  X + act      fc1  d(y,gate) + X      out_proj  X + X      qkv  3X + X"""
@@ -31,11 +31,11 @@ def algorithmic_bytes(chunk, seq=128, d=768, inner=3072):
     YG = 2 * A                   # (y, gate) / its gradient
     Wqkv, Wo, W1, W2 = 3 * d * d * 2.0, d * d * 2.0, 2 * inner * d * 2.0, d * inner * 2.0
     plain = [X + Wqkv + 3 * X, X + Wo + X + X, A + W2 + X + X] * 2 + [YG + W1 + X + X, X + Wo + X, 3 * X + Wqkv + X + X]
-    swiglu = [X + W1 + A, X + W1 + A + YG]
-    swiglu_bwd = [X + W2 + YG + YG]
+    swiglu = [X + W1 + A, X + W1 + A + A]      # (pass 2 saves the gate alone, T I 2)
+    swiglu_bwd = [X + W2 + YG + YG]            # (reads act + gate = the bytes of the (y, gate) pair it replaced)
     wgrad = [X + A, YG + X, X + X, 3 * X + X]
-    classes = {"gemm_bf16_v6_kernel<0": plain, "gemm_bf16_v6_kernel<1": swiglu, "gemm_bf16_v6_kernel<3": swiglu_bwd,
-               "gemm_bf16_v6tn_kernel": wgrad}
+    classes = {"gemm_bf16_v6_kernel<0": plain, "gemm_bf16_v6_kernel<5": swiglu, "gemm_bf16_v6_kernel<6": swiglu_bwd,
+               "gemm_bf16_v6tn_kernel": wgrad}   # <5> / <6>: the gate-save forms of <1> (SwiGLU) / <3> (SwiGLU backward)
     allb = sum(sum(v) for v in classes.values())
     n = sum(len(v) for v in classes.values())
     return {k: (len(v), sum(v) / len(v)) for k, v in classes.items()}, allb / n

@@ -82,6 +82,15 @@ def test_fp8_symmetric_loss_at_cfg5_shape():
         out[fp8] = (loss.item(), qq.grad.clone(), dd.grad.clone())
     l0, l1 = out[False][0], out[True][0]
     eq, ed = rel_err(out[True][1], out[False][1]), rel_err(out[True][2], out[False][2])
-    report("cfg5_fp8_loss", exact=l0, fp8=l1, rel_dq=eq, rel_dd=ed)
+    # an INDEPENDENT reference at the shape's own size (the fp8 path had only been held against fp64 up to
+    # 512 x 2048): plain torch in fp64 on the device -- the (4096, 32768) logit matrix is 1 GB there
+    qr, dr = q.to(DEV).double().requires_grad_(), docs.to(DEV).double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(qr @ dr.T * 50.0, torch.arange(N, device=DEV) * (G // N))
+    ref.backward()
+    e64 = {fp8: (abs(out[fp8][0] - ref.item()), rel_err(out[fp8][1], qr.grad), rel_err(out[fp8][2], dr.grad)) for fp8 in out}
+    report("cfg5_fp8_loss", exact=l0, fp8=l1, fp64=ref.item(), rel_dq=eq, rel_dd=ed, exact_vs_fp64=list(e64[False]),
+           fp8_vs_fp64=list(e64[True]))
     assert abs(l1 - l0) < 2e-2
     assert eq < 8e-2 and ed < 8e-2
+    assert e64[False][0] < 1e-5 * abs(ref.item()) + 1e-6 and e64[False][1] < 1e-4 and e64[False][2] < 1e-4, e64[False]
+    assert e64[True][0] < 2e-2 and e64[True][1] < 8e-2 and e64[True][2] < 8e-2, e64[True]

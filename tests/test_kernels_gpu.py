@@ -655,6 +655,69 @@ def test_gemm_swiglu_bwd_fused(M, I, K):
     assert rel_err(got.float(), ref.reshape(M, 2 * I)) < 6e-3
 
 
+# ---- round 3: the gated MLP keeps the gate alone; y is recovered from act = y * silu(gate) inside the derivative ---------
+@pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
+def test_gemm_swiglu_gate_save(M, I, K):
+    """cx_gemm_bf16_swiglu_gate: the SAME activation bit for bit as cx_gemm_bf16_swiglu (with or without the save), and G =
+    the gate columns of that kernel's interleaved (y, gate) pair, bit for bit, in plain column order."""
+    x = bf(_randn(M, K, seed=90))
+    w11, w12 = bf(_randn(I, K, seed=91, std=0.05)), bf(_randn(I, K, seed=92, std=0.05))
+    wi = torch.stack([w11.view(I // 32, 32, K), w12.view(I // 32, 32, K)], 1).reshape(2 * I, K).contiguous()
+    yg = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV)
+    act = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_gemm_bf16_swiglu(x.data_ptr(), wi.data_ptr(), yg.data_ptr(), act.data_ptr(), M, I, K, K, K, 2 * I, I, S()))
+    g = torch.full((M, I), 7.0, dtype=torch.bfloat16, device=DEV)
+    act_g = torch.empty_like(act)
+    _C.check(L().cx_gemm_bf16_swiglu_gate(x.data_ptr(), wi.data_ptr(), g.data_ptr(), act_g.data_ptr(), M, I, K, K, K, I, I, S()),
+             "cx_gemm_bf16_swiglu_gate")
+    assert torch.equal(act_g, act)
+    assert torch.equal(g, yg.view(M, I // 32, 2, 32)[:, :, 1].reshape(M, I))
+    act_n = torch.empty_like(act)
+    _C.check(L().cx_gemm_bf16_swiglu_gate(x.data_ptr(), wi.data_ptr(), None, act_n.data_ptr(), M, I, K, K, K, I, I, S()))
+    assert torch.equal(act_n, act), "no-grad variant (nothing saved) must give identical activations"
+
+
+@pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (1000, 512, 256), (257, 256, 64)])
+def test_gemm_swiglu_bwd_from_act_and_gate(M, I, K):
+    """cx_gemm_bf16_swiglu_bwd_gate (fc2 dgrad + SwiGLU backward from the saved (act, gate)) against: the standalone
+    cx_swiglu_bwd_gate on the bf16 d(act) of a separate GEMM (same arithmetic: 2e-3), the (y, gate)-based kernel it replaces
+    (one more bf16 rounding on the d(gate) half: 8e-3), and fp64 torch on the exact (y, gate) the activation came from."""
+    dy = bf(_randn(M, K, seed=80))
+    w = bf(_randn(I, K, seed=81, std=0.05))          # transposed fc2 weight: (I, d)
+    y, g = bf(_randn(M, I, seed=82)), bf(_randn(M, I, seed=83, std=2.0))
+    g[0, :8] = 0.0                                   # a zero gate: act = 0, d(gate) = 0 * (anything finite) = 0, no NaN
+    g[1, :8] = -120.0                                # silu underflows: act = 0 -> both gradients 0
+    g[2, :8] = 60.0
+    act = (torch.nn.functional.silu(g.float()) * y.float()).to(torch.bfloat16)
+    got = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV)
+    _C.check(L().cx_gemm_bf16_swiglu_bwd_gate(dy.data_ptr(), w.data_ptr(), act.data_ptr(), g.data_ptr(), got.data_ptr(), M, I, K,
+                                              K, K, I, 2 * I, S()), "cx_gemm_bf16_swiglu_bwd_gate")
+    assert torch.isfinite(got.float()).all()
+    dact = gemm(dy, w, out_mode=0)                   # (M, I) bf16
+    want = torch.empty_like(got)
+    _C.check(L().cx_swiglu_bwd_gate(dact.data_ptr(), act.data_ptr(), g.data_ptr(), want.data_ptr(), M, I, S()), "cx_swiglu_bwd_gate")
+    assert rel_err(got.float(), want.float()) < 2e-3
+    yg = torch.stack([y.view(M, I // 32, 32), g.view(M, I // 32, 32)], 2).reshape(M, 2 * I).contiguous()
+    old = torch.empty_like(got)
+    _C.check(L().cx_gemm_bf16_swiglu_bwd(dy.data_ptr(), w.data_ptr(), yg.data_ptr(), old.data_ptr(), M, I, K, K, K, 2 * I, S()))
+    gv, ov = got.view(M, I // 32, 2, 32).float(), old.view(M, I // 32, 2, 32).float()
+    assert torch.equal(gv[:, :, 0], ov[:, :, 0]), "d y = silu(gate) * d(act) does not involve y: identical"
+    e_gate = rel_err(gv[:, :, 1], ov[:, :, 1])
+    d64, y64, g64 = dact.double(), y.double(), g.double()
+    sg = torch.sigmoid(g64)
+    ref_dg = (sg * (1 + g64 * (1 - sg))) * d64 * y64
+    # (the planted exact-zero gates are where y is not recoverable -- act = 0 there -- and d(gate) comes out 0 instead of
+    # d * y / 2: a probability-zero event for a bf16-rounded fp32 accumulator, left out of the norm below)
+    ok = torch.ones(M, I, dtype=torch.bool, device=DEV)
+    ok[0, :8] = False
+    gn, on = gv[:, :, 1].reshape(M, I).double() * ok, ov[:, :, 1].reshape(M, I).double() * ok
+    e_new, e_old = rel_err(gn, ref_dg * ok), rel_err(on, ref_dg * ok)
+    report("swiglu_bwd_gate", M=M, I=I, K=K, rel_dgate_vs_yg_kernel=e_gate, rel_dgate_vs_fp64=e_new, yg_kernel_vs_fp64=e_old)
+    assert e_gate < 8e-3
+    assert e_new < 4e-3 and e_new < 2.0 * e_old + 1e-3   # (one more bf16 rounding than the (y, gate) kernel: sqrt(2) x)
+    assert float(got.view(M, I // 32, 2, 32)[0, 0, 1, :8].float().abs().max()) == 0.0   # zero gate -> zero d(gate)
+
+
 @pytest.mark.parametrize("with_bias", [False, True])
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1000, 768, 3072), (257, 264, 64)])
 def test_gemm_residual_fused(M, N, K, with_bias):
