@@ -409,7 +409,8 @@ def test_attention_prerotated_path_equals_rotate_on_load(lens):
 
 
 @pytest.mark.parametrize("rotary", [True, False])
-@pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8, [2048, 1531]])
+@pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8, [2048, 1531],
+                                  [256, 129, 225, 224, 96, 1]])   # max 256 without rotary: the all-keys-in-LDS forward
 def test_attention_fwd_bwd(rotary, lens):
     H, D = 3, 64
     T, B, mx = sum(lens), len(lens), max(lens)
