@@ -2015,168 +2015,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
     }
 }
 
-// ------------------------------------------------------------------ forward, 128 < sequences <= 256 (ViT-B/16: S = 197)
-// The streaming kernel above spends a 197-token problem on four stage -> barrier -> compute -> barrier rounds per query
-// tile, each behind its own global round trip (S = 197 ran at 226 TFLOP/s, below both S = 128 and S = 512).  Here a
-// workgroup owns one 128-query tile of a (sequence, head) problem and keeps ALL keys and values (<= 256) in LDS: every
-// global load is issued up front (66 KB in flight per workgroup, two workgroups per CU), there is ONE barrier, and the
-// two 128-key halves run back to back with one online-softmax rescale between them.  All-padding 32-key blocks (keys
-// 224 .. 255 at S = 197) are skipped wave-uniformly, and a wave whose 32 queries lie past the end leaves after the barrier.
-// No rotation at the loads: image towers have none, and the engine pre-rotates long text sequences in place.
-constexpr int FWD256_LDS = 16384 + 32768 + 32768;  // Q tile | K rows 0 .. 255 (tile64 layout) | V rows 0 .. 255 (v128 layout)
-
-__global__ __launch_bounds__(256, 2) void attn_fwd_s256_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem256[];
-    char* Qs = smem256;
-    char* Ks = smem256 + 16384;
-    char* Vs = smem256 + 16384 + 32768;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-    const int q0 = blockIdx.x * 128;
-    if (q0 >= len) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
-    const int nkb = (len + 31) >> 5;                 // 32-key blocks that hold at least one key (<= 8)
-    const int cp = tid & 3;
-    uint4 qlo[2], qhi[2], klo[4], khi[4], vv[8];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        int r = q0 + it * 64 + (tid >> 2);
-        r = r < len ? r : len - 1;
-        const bf16_t* qrow = qbase + (size_t)(t0 + r) * tok_stride;
-        qlo[it] = *reinterpret_cast<const uint4*>(qrow + cp * 8);
-        qhi[it] = *reinterpret_cast<const uint4*>(qrow + 32 + cp * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {   // K: row it*64 + tid/4, chunks cp and cp + 4.  Rows past the end re-read the last row
-        int r = it * 64 + (tid >> 2);  // (one cache line; conditional loads would turn these arrays into scratch memory)
-        r = r < len ? r : len - 1;
-        const bf16_t* krow = kbase + (size_t)(t0 + r) * tok_stride;
-        klo[it] = *reinterpret_cast<const uint4*>(krow + cp * 8);
-        khi[it] = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {   // V: key row it*32 + tid/8, 16-B chunk tid%8
-        int key = it * 32 + (tid >> 3);
-        key = key < len ? key : len - 1;
-        vv[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + key) * tok_stride + (tid & 7) * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int r = it * 64 + (tid >> 2);
-        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = qlo[it];
-        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = qhi[it];
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int r = it * 64 + (tid >> 2);
-        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = klo[it];
-        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = khi[it];
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it)
-        *reinterpret_cast<uint4*>(Vs + v128_off(it * 32 + (tid >> 3), (tid & 7) * 8)) = vv[it];
-    __syncthreads();
-    if (q0 + wave * 32 >= len) return;   // (no barrier below: a wave without a single query is done)
-
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
-    const float sc2 = p.scale * LOG2E;
-    float m_run = -1e30f, l_run = 0.f;
-    f32x16_t acc_o[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        if (kh * 4 >= nkb) break;          // (wave-uniform: sequences of at most 128 keys have no second half)
-        float s[4][16];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int kblk = kh * 4 + kb;
-            if (kblk < nkb) {
-                f32x16_t a;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kblk * 32 + l31, ks * 2 + hi)), qf[ks], a);
-                if (kblk * 32 + 32 > len) {   // the one block that straddles the end of the sequence
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] = kblk * 32 + acc_row(r, hi) < len ? a[r] : -INFINITY;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] = a[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = -INFINITY;
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc2;   // (softmax_scale > 0: the maximum commutes with the scale)
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], sc2, -m_new));
-                psum += s[kb][r];
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (kh > 0) {
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
-        }
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int kblk = kh * 4 + kb;
-            if (kblk < nkb) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const bf16x8_t pf = pack_frag(s[kb], half);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db)
-                        acc_o[db] = mfma_bf16_32x32x16(v128_tr_frag(Vs, db * 32, kblk * 32 + 16 * half, lane), pf, acc_o[db]);
-                }
-            }
-        }
-    }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    {   // output through this wave's own (dead) Q rows: full 128-byte rows leave, as in the S <= 128 kernel
-        const int qrow = wave * 32 + l31;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 pk;
-                pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
-                pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(Qs + tile64_off(qrow, db * 4 + qd) + hi * 8) = pk;
-            }
-        if (q0 + qrow < len && hi == 0) p.lse[(size_t)h * p.T + t0 + q0 + qrow] = (m_run + log2f(l_tot)) * LN2;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int q = wave * 32 + it * 8 + (lane >> 3), chunk = lane & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(Qs + tile64_off(q, chunk));
-            if (q0 + q < len) *reinterpret_cast<uint4*>(p.out + ((size_t)(t0 + q0 + q) * p.H + h) * DH + chunk * 8) = v;
-        }
-    }
-}
-
 #ifndef CX_PRODUCT
 int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
@@ -2214,11 +2052,6 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 #endif
     if (max_seqlen <= 128) {  // one workgroup per (sequence, head) problem, single pass
         hipLaunchKernelGGL(attn_fwd_s128v_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (max_seqlen <= 256 && !rot_cos) {  // all keys / values of a problem in LDS, one barrier (ViT-B/16: S = 197)
-        static CxLdsOptIn lds256;
-        if (!lds256.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel), FWD256_LDS)) return CX_ERR_LAUNCH;
-        hipLaunchKernelGGL(attn_fwd_s256_kernel, dim3((max_seqlen + 127) / 128, H, B), dim3(256), FWD256_LDS,
-                           (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
         hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);

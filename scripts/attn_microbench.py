@@ -15,6 +15,8 @@ ap.add_argument("--heads", type=int, default=12)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--bwd-mode", type=int, default=None, help="cx_attn_set_bwd_s128 (dev library): 4 fused3 (default), 3 fused2, ...")
 ap.add_argument("--seqs", type=str, default="128,197,512,2048,8192")
+ap.add_argument("--max-seqlen-pad", type=int, default=0, help="pass max_seqlen = S + this to the forward (A/B: > 256 selects the streaming kernel for S = 197)")
+ap.add_argument("--rotary", type=int, default=1, help="0: no rotation tables (image towers; what the engine passes for pre-rotated long sequences)")
 a = ap.parse_args()
 lib = _C.dev_lib()
 if a.bwd_mode is not None:
@@ -30,15 +32,16 @@ for S in [int(x) for x in a.seqs.split(",")]:
     inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
     fr = torch.outer(torch.arange(S, dtype=torch.float32), inv)
     cos, sin = torch.cos(fr).cuda().contiguous(), torch.sin(fr).cuda().contiguous()
+    cp, sp = (cos.data_ptr(), sin.data_ptr()) if a.rotary else (None, None)
     out = torch.empty(T, H * D, device="cuda", dtype=torch.bfloat16)
     lse = torch.empty(H * T, device="cuda")
     dout = torch.randn_like(out)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(H * T, device="cuda")
-    fwd = lambda: lib.cx_attn_varlen_fwd(qkv.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), out.data_ptr(),
-                                         lse.data_ptr(), B, H, T, S, 0.125, s)
+    fwd = lambda: lib.cx_attn_varlen_fwd(qkv.data_ptr(), cu.data_ptr(), cp, sp, out.data_ptr(),
+                                         lse.data_ptr(), B, H, T, S + a.max_seqlen_pad, 0.125, s)
     bwd = lambda: lib.cx_attn_varlen_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(),
-                                         cos.data_ptr(), sin.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, H, T, S,
+                                         cp, sp, delta.data_ptr(), dqkv.data_ptr(), B, H, T, S,
                                          0.125, s)
     res = []
     for fn in (fwd, bwd):
