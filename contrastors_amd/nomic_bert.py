@@ -643,6 +643,11 @@ class NomicBertEngine(torch.nn.Module):
         total = torch.cuda.get_device_properties(self.device_).total_memory
         peak = torch.cuda.max_memory_allocated(self.device_)
         budget = self.CKPT_HBM_FRACTION * total - peak - _hbm_grant(self.device_, 0)
+        # ... and never more than the device has free right now (another process on the same GPU does not show up in this
+        # process's peak): driver-level free memory + the allocator's cache + the arena that is about to be dropped
+        free_now, _ = torch.cuda.mem_get_info(self.device_)
+        free_now += torch.cuda.memory_reserved(self.device_) - torch.cuda.memory_allocated(self.device_) + arena.nbytes()
+        budget = min(budget, self.CKPT_HBM_FRACTION * free_now - arena.nbytes() - _hbm_grant(self.device_, 0))
         keep = int(max(0, min(L, budget // max(per_keep, 1))))
         self._keep_plan[T_cap] = keep
         if keep == 0:
