@@ -338,7 +338,8 @@ class NomicBertEngine(torch.nn.Module):
         self.checkpoint_keep: Union[int, str] = 0   # blocks that keep their activations under checkpointing: n | "auto"
         self._keep_logged: set = set()
         self._keep_suspended = 0   # > 0: "auto" keeps nothing (a caller that lines up MANY arenas budgets the HBM itself)
-        self._keep_plan: Dict[object, int] = {}   # T_cap -> blocks the next arena of that size keeps ("auto", measured)
+        self._keep_plan: Dict[int, int] = {}      # T_cap -> blocks the next arena of that size keeps ("auto", measured)
+        self._keep_granted: Dict[int, int] = {}   # T_cap -> ledger bytes promised to that arena, until it is built
         self.sync_shadows()
 
     # ------------------------------------------------------------------------------------------------ parameters
@@ -597,13 +598,13 @@ class NomicBertEngine(torch.nn.Module):
         if keep > 0:
             try:
                 a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=True, keep_layers=keep)
-                a.granted = self._keep_plan.pop(("granted", T_cap), 0)   # the ledger entry now belongs to the arena
+                a.granted = self._keep_granted.pop(T_cap, 0)   # the ledger entry now belongs to the arena
                 self._log_keep(T_cap, keep)
                 return a
             except torch.OutOfMemoryError:
                 # (fragmentation, another tenant of the device): nothing has been computed yet -> take the recipe literally
                 torch.cuda.empty_cache()
-                _hbm_grant(self.device_, -self._keep_plan.pop(("granted", T_cap), 0))
+                _hbm_grant(self.device_, -self._keep_granted.pop(T_cap, 0))
                 if self._keep_mode() != "auto":
                     raise   # an explicit number is a demand, not a hint
                 self._keep_plan[T_cap] = 0
@@ -653,7 +654,7 @@ class NomicBertEngine(torch.nn.Module):
         if keep == 0:
             return False
         _hbm_grant(self.device_, keep * per_keep)
-        self._keep_plan[("granted", T_cap)] = keep * per_keep   # handed to the successor arena when it is built
+        self._keep_granted[T_cap] = keep * per_keep   # handed to the successor arena when it is built
         return True
 
     @contextlib.contextmanager
