@@ -406,7 +406,7 @@ typedef struct CxChunkBuffers {
      * sc/models/vit/vit.py:200-231): != 0 -> a saving forward keeps ONE (T,d) tensor per block -- `h2` (post-norm: the
      * block's output = the next block's input) or `z1` (pre-norm: the residual stream at LN1) has n_layer slots, every
      * other per-layer buffer has a single slot -- and backward recomputes each block from it before differentiating
-     * it.  Results are bit-identical to checkpoint = 0; the arena shrinks from ~31 KB to ~1.5 KB per token and layer. */
+     * it.  Results are bit-identical to checkpoint = 0; the arena shrinks from ~25 KB to ~1.5 KB per token and layer. */
     int checkpoint;
     /* dropout state of the chunk, set by the host before the forward and read again by the backward: Philox (seed, offset)
      * drawn from the torch generator (so RandContext replays it), the on/off switch, and one more (T,d) gradient buffer

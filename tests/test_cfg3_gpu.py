@@ -123,7 +123,7 @@ def test_cfg3_checkpointed_step_matches_plain_step():
 
 def test_cfg3_baseline_per_gpu_shape_fits_with_checkpointing():
     """configs[2] per-GPU shape: 32 queries + 256 documents x 2048 tokens (590 k tokens), direct step, Matryoshka, hamming.
-    Saved activations without checkpointing would be ~369 KB/token = 217 GB; with it the step has to fit comfortably."""
+    Saved activations without checkpointing are ~296 KB/token = 175 GB (217 GB before the gate-only save); with it the step has to fit comfortably."""
     import gc
 
     gc.collect()
