@@ -202,3 +202,45 @@ def test_auto_keep_measures_the_first_use_then_keeps_what_fits():
         eng.abandon_arena(arena)
     finally:
         del os.environ["CX_CHECKPOINT_KEEP"]
+
+
+@pytest.mark.parametrize("attn_pdrop", [0.0, 0.1])
+def test_checkpointing_under_dropout_regenerates_the_same_masks(attn_pdrop):
+    """resid_pdrop / embd_pdrop (/ attn_pdrop) > 0: a recomputed block must draw the masks its first forward drew -- they are a
+    pure function of the chunk's Philox (seed, offset) in the arena, the dropout site and the indices -- so literal and
+    selective checkpointing give the embeddings and gradients of the non-checkpointed engine under the same generator state
+    (max_seqlen > 128 with attention dropout: the streaming kernels are the ones that carry the mask code)."""
+    L, S = 4, 160 if attn_pdrop > 0 else 96
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=1024, n_layer=L, resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=attn_pdrop)
+    ids, lens, g = _ragged(6, S, 1024, 21)
+    vb = VarlenBatch.from_lengths(ids, lens)
+    probe = torch.randn(6, cfg.n_embd, generator=g).to(DEV)
+    res = {}
+    p0 = None
+    for key, (ck, keep) in {"plain": (False, 0), "literal": (True, 0), "keep2": (True, 2)}.items():
+        eng = NomicBertEngine(cfg, device=DEV, seed=3)
+        if p0 is None:
+            p0 = eng.flat_param.clone()
+        eng.flat_param.copy_(p0)
+        eng.sync_shadows()
+        eng.train()
+        eng.gradient_checkpointing_enable(ck, keep_layers=keep)
+        torch.manual_seed(123)   # the device generator the engine draws (seed, offset) from
+        emb, arena = eng.forward_chunk(vb, True)
+        assert arena.desc.drop_active == 1 and arena.keep_layers == keep
+        eng.zero_grad()
+        eng.backward_chunk(vb, arena, probe)
+        torch.cuda.synchronize()
+        res[key] = (emb.clone(), {k: v.clone() for k, v in eng.reference_grad_dict().items()})   # (views of flat_grad)
+    torch.manual_seed(124)
+    emb_other, arena = eng.forward_chunk(vb, True)
+    eng.abandon_arena(arena)
+    assert not torch.equal(emb_other, res["plain"][0]), "another generator state must give other masks"
+    for key in ("literal", "keep2"):
+        assert torch.equal(res["plain"][0], res[key][0]), key
+        for name, a in res["plain"][1].items():
+            b = res[key][1][name]
+            if ".layers." in name and not name.endswith(".bias"):
+                assert torch.equal(a, b), (key, name, float((a - b).abs().max()))
+            else:
+                assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-30, (key, name)
