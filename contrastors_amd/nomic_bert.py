@@ -122,6 +122,7 @@ class _ChunkArena:
     """Device memory for one in-flight chunk (CxChunkBuffers).  `n_slots` = 1 for no-grad forwards, n_layer else."""
 
     probation = False   # "auto" selective checkpointing: first use, literal; its successor is sized from the measured peak
+    last_tick = 0       # the engine's saving-forward counter when this arena was last handed out (idle arenas are given back)
     granted = 0         # bytes of the per-device ledger this arena holds (returned when it is destroyed)
 
     def __del__(self):
@@ -340,6 +341,7 @@ class NomicBertEngine(torch.nn.Module):
         self._keep_suspended = 0   # > 0: "auto" keeps nothing (a caller that lines up MANY arenas budgets the HBM itself)
         self._keep_plan: Dict[int, int] = {}      # T_cap -> blocks the next arena of that size keeps ("auto", measured)
         self._keep_granted: Dict[int, int] = {}   # T_cap -> ledger bytes promised to that arena, until it is built
+        self._arena_tick = 0                      # saving forwards so far (ages the idle arenas)
         self.sync_shadows()
 
     # ------------------------------------------------------------------------------------------------ parameters
@@ -579,8 +581,16 @@ class NomicBertEngine(torch.nn.Module):
         self._desc = e
 
     # ------------------------------------------------------------------------------------------------ arenas
+    ARENA_IDLE_USES = 16   # a saving arena nobody has taken for this many saving forwards of its engine is given back
+
     def _get_arena(self, T: int, B: int, save: bool) -> _ChunkArena:
         T_cap = _round_up(max(T, 1), 128)
+        if save:
+            # ragged batches: an arena serves every batch up to its capacity, so a loader's batches ratchet it up to the
+            # largest one seen (~ln(steps) times per run); size classes (64 per octave, <= 1.6 % of slack) keep a record by
+            # a handful of tokens from costing a rebuild, and the arenas left behind are given back below once idle
+            T_cap = _round_up(T_cap, max(128, 1 << max(0, T_cap.bit_length() - 7)))
+            self._arena_tick += 1
         if not save:
             a = self._arena_nograd
             if a is None or a.T_cap < T_cap or a.B_cap < B:
@@ -592,13 +602,29 @@ class NomicBertEngine(torch.nn.Module):
         # chunk the big arena and then has to build a second big one
         fits = [i for i, a in enumerate(self._arena_free) if a.T_cap >= T_cap and a.B_cap >= B and a.checkpoint == ck]
         if fits:
-            return self._arena_free.pop(min(fits, key=lambda i: self._arena_free[i].T_cap))
+            a = self._arena_free.pop(min(fits, key=lambda i: self._arena_free[i].T_cap))
+            a.last_tick = self._arena_tick
+            return a
+        # nothing fits: before building a bigger arena, give back the ones that have sat idle (a batch size that no longer
+        # occurs; with selective checkpointing such an arena can hold most of the HBM).  Their plans are forgotten with them.
+        stale = [a for a in self._arena_free if self._arena_tick - a.last_tick >= self.ARENA_IDLE_USES]
+        if stale:
+            self._arena_free = [a for a in self._arena_free if a not in stale]
+            for a in stale:
+                self._keep_plan.pop(a.T_cap, None)
+            del stale, a
         L = self.config.n_layer
+        if ck and self._keep_mode() == "auto" and not self._keep_suspended:
+            # an arena that was measured and dropped for its rebuild is rebuilt at ITS size when a smaller batch comes first
+            pending = [t for t in self._keep_granted if t >= T_cap]
+            if pending:
+                T_cap = min(pending)
         keep = self._checkpoint_keep_for(T_cap) if ck else 0
         if keep > 0:
             try:
                 a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=True, keep_layers=keep)
                 a.granted = self._keep_granted.pop(T_cap, 0)   # the ledger entry now belongs to the arena
+                a.last_tick = self._arena_tick
                 self._log_keep(T_cap, keep)
                 return a
             except torch.OutOfMemoryError:
@@ -613,6 +639,7 @@ class NomicBertEngine(torch.nn.Module):
                     keep, L, T_cap)
         a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=ck)
         a.probation = ck and self._keep_mode() == "auto" and not self._keep_suspended and T_cap not in self._keep_plan
+        a.last_tick = self._arena_tick
         return a
 
     # ---- selective activation checkpointing (round 3): `gradient_checkpointing: true` is a memory knob sized for 80 GB ----

@@ -244,3 +244,53 @@ def test_checkpointing_under_dropout_regenerates_the_same_masks(attn_pdrop):
                 assert torch.equal(a, b), (key, name, float((a - b).abs().max()))
             else:
                 assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-30, (key, name)
+
+
+def test_ragged_batches_ratchet_one_arena_up_and_idle_arenas_are_given_back():
+    """Token counts change every step with ragged batches.  An arena serves every batch up to its capacity; a new record
+    builds a bigger one (one literal step, then its kept blocks); the arena left behind is given back once it has sat idle
+    for ARENA_IDLE_USES saving forwards, its ledger grant with it -- nothing accumulates."""
+    import gc
+
+    from contrastors_amd import nomic_bert as nb
+
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=1024, n_layer=2)
+    eng = NomicBertEngine(cfg, device=DEV, seed=2)
+    eng.train()
+    eng.gradient_checkpointing_enable(True, keep_layers="auto")
+    eng.ARENA_IDLE_USES = 4
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    ledger0 = nb._hbm_grant(eng.device_, 0)
+    g = torch.Generator().manual_seed(5)
+
+    def step(total_tokens):
+        B = 80   # (a fixed batch of 80 sequences whose lengths change: what a loader hands over)
+        lens = [total_tokens // B + (1 if i < total_tokens % B else 0) for i in range(B)]
+        ids = torch.randint(3, 1024, (B, 128), generator=g).to(DEV)
+        vb = VarlenBatch.from_lengths(ids, lens)
+        emb, arena = eng.forward_chunk(vb, True)
+        info = (arena.T_cap, arena.keep_layers, arena.probation)
+        eng.zero_grad()
+        eng.backward_chunk(vb, arena, torch.randn(len(lens), cfg.n_embd, generator=g).to(DEV))
+        del arena
+        return info
+
+    a = step(3000)                       # first batch: literal, measured
+    assert a[1:] == (0, True)
+    b = step(2500)                       # a smaller batch: the rebuilt arena (every block kept) serves it
+    assert b[0] == a[0] and b[1:] == (2, False)
+    c = step(5000)                       # a record: a bigger arena, literal once ...
+    assert c[0] > a[0] and c[1:] == (0, True)
+    d = step(4000)                       # ... then rebuilt with its kept blocks; the 3000-token arena idles in the free list
+    assert d[0] == c[0] and d[1:] == (2, False)
+    assert sorted(x.T_cap for x in eng._arena_free) == [a[0], c[0]]
+    for _ in range(3):
+        assert step(4500)[0] == c[0]
+    assert step(9000)[1:] == (0, True)   # the next record first gives the idle 3000-token arena back
+    torch.cuda.synchronize()
+    gc.collect()
+    assert a[0] not in [x.T_cap for x in eng._arena_free] and a[0] not in eng._keep_plan
+    held = sum(x.granted for x in eng._arena_free) + sum(eng._keep_granted.values())
+    assert nb._hbm_grant(eng.device_, 0) - ledger0 == held, (nb._hbm_grant(eng.device_, 0), ledger0, held)
