@@ -637,7 +637,19 @@ class NomicBertEngine(torch.nn.Module):
                 logging.getLogger("contrastors_amd").info(
                     "selective checkpointing: keeping %d of %d blocks ran out of memory at %d tokens; recomputing every block",
                     keep, L, T_cap)
-        a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=ck)
+        try:
+            a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=ck)
+        except torch.OutOfMemoryError:
+            # a record batch while the arena it outgrew (with its kept blocks) still sits in the free list: every idle arena
+            # goes back, whatever its age, and the allocation is tried once more
+            if not self._arena_free:
+                raise
+            for old_arena in self._arena_free:
+                self._keep_plan.pop(old_arena.T_cap, None)
+            self._arena_free = []
+            old_arena = None
+            torch.cuda.empty_cache()
+            a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=ck)
         a.probation = ck and self._keep_mode() == "auto" and not self._keep_suspended and T_cap not in self._keep_plan
         a.last_tick = self._arena_tick
         return a

@@ -294,3 +294,47 @@ def test_ragged_batches_ratchet_one_arena_up_and_idle_arenas_are_given_back():
     assert a[0] not in [x.T_cap for x in eng._arena_free] and a[0] not in eng._keep_plan
     held = sum(x.granted for x in eng._arena_free) + sum(eng._keep_granted.values())
     assert nb._hbm_grant(eng.device_, 0) - ledger0 == held, (nb._hbm_grant(eng.device_, 0), ledger0, held)
+
+
+def test_out_of_memory_on_a_record_batch_gives_the_idle_arenas_back_and_retries(monkeypatch):
+    """A batch larger than any arena so far, while the outgrown arena (with its kept blocks) still sits in the free list:
+    the first allocation attempt may not fit.  Every idle arena is given back and the allocation is tried once more."""
+    from contrastors_amd import nomic_bert as nb
+
+    cfg = NomicBertConfig.nomic_bert_2048(vocab_size=1024, n_layer=2)
+    eng = NomicBertEngine(cfg, device=DEV, seed=2)
+    eng.train()
+    eng.gradient_checkpointing_enable(True, keep_layers=0)
+    g = torch.Generator().manual_seed(6)
+
+    def batch(n):
+        ids = torch.randint(3, 1024, (n, 128), generator=g).to(DEV)
+        return VarlenBatch.from_lengths(ids, [128] * n), torch.randn(n, cfg.n_embd, generator=g).to(DEV)
+
+    vb, probe = batch(8)
+    _, arena = eng.forward_chunk(vb, True)
+    eng.backward_chunk(vb, arena, probe)
+    del arena
+    assert len(eng._arena_free) == 1
+    real, calls = nb._ChunkArena, []
+
+    class Flaky(real):
+        def __init__(self, *a, **k):
+            calls.append(1)
+            if len(calls) == 1:
+                raise torch.OutOfMemoryError("simulated")
+            super().__init__(*a, **k)
+
+    monkeypatch.setattr(nb, "_ChunkArena", Flaky)
+    vb2, probe2 = batch(16)
+    emb, arena = eng.forward_chunk(vb2, True)
+    assert len(calls) == 2 and eng._arena_free == []
+    eng.zero_grad()
+    eng.backward_chunk(vb2, arena, probe2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(emb).all() and torch.isfinite(eng.flat_grad).all() and float(eng.flat_grad.abs().max()) > 0
+    # with nothing idle to give back the error is the caller's
+    calls.clear()
+    eng._arena_free = []
+    with pytest.raises(torch.OutOfMemoryError):
+        eng.forward_chunk(batch(32)[0], True)
