@@ -99,6 +99,7 @@ _SIGS = {
     "cx_gemm_bf16_swiglu": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_nt_residual": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_swiglu_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "cx_gemm_bf16_nt_splitk": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_swiglu_gate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_gemm_bf16_swiglu_bwd_gate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_swiglu_bwd_gate": (i32, [vp, vp, vp, vp, i32, i32, vp]),

@@ -106,9 +106,17 @@ int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW,
 
 // out = x W^T + bias (+ residual when the fused epilogue covers the shape).  *folded tells the caller whether the
 // residual is already in `out` (then the LayerNorm that follows gets residual = NULL).
+// `buf` (optional): its split-K workspace serves the few-tile, long-K case (small batches: cx_gemm_bf16_nt_splitk).
 int proj_residual(const uint16_t* x, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* out, int T,
-                  int N, int K, bool* folded, void* stream) {
+                  int N, int K, bool* folded, void* stream, const CxChunkBuffers* buf = nullptr) {
     *folded = false;
+    if (buf && buf->ws_f32 && (long)((T + 255) / 256) * ((N + 255) / 256) <= 64 && K >= 1536) {
+        const int rc = cx_gemm_bf16_nt_splitk(x, W, out, bias, residual, buf->ws_f32, buf->ws_floats, T, N, K, K, K, N, N, stream);
+        if (rc != CX_ERR_SHAPE) {
+            *folded = residual != nullptr && rc == CX_OK;
+            return rc;
+        }
+    }
     if (residual) {
         const int rc = cx_gemm_bf16_nt_residual(x, W, out, bias, residual, T, N, K, K, K, N, N, stream);
         if (rc != CX_ERR_SHAPE) {
@@ -156,7 +164,7 @@ struct BlockRunner {
     int mlp(const CxLayerWeights& w, const uint16_t* x, int l, uint16_t* out, const uint16_t* residual, bool keep,
             bool* folded) const {
         CX_TRY(mlp_up(w, x, l, keep));
-        return proj_residual(s.act(l), w.Wfc2, w.bfc2, residual, out, T, enc->d, enc->d_inner, folded, stream);
+        return proj_residual(s.act(l), w.Wfc2, w.bfc2, residual, out, T, enc->d, enc->d_inner, folded, stream, buf);
     }
     int attn(const CxLayerWeights& w, const uint16_t* x, int l, uint16_t* out, const uint16_t* residual, bool* folded) const {
         const int d = enc->d;
@@ -334,7 +342,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                                           w.gbfc1, T, I, enc->mlp_act, stream));
         }
         CX_TRY(wgrad(buf->g_wide, s.wfc1, mlp_in, d, w.gWfc1, buf, T, stream));
-        return proj_residual(buf->g_wide, w.Wfc1T, nullptr, add, buf->g_b, T, d, s.wfc1, folded, stream);
+        return proj_residual(buf->g_wide, w.Wfc1T, nullptr, add, buf->g_b, T, d, s.wfc1, folded, stream, buf);
     };
     // attention backward: dx (grad of the out_proj output) -> parameter gradients, d(attention input) into buf->g_b
     auto attn_bwd = [&](const CxLayerWeights& w, int l, const uint16_t* dx, const uint16_t* attn_in, const uint16_t* add,
@@ -356,7 +364,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         }
         if (w.gbqkv) CX_TRY(cx_bias_grad(buf->g_wide, w.gbqkv, T, 3 * d, 3 * d, stream));
         CX_TRY(wgrad(buf->g_wide, 3 * d, attn_in, d, w.gWqkv, buf, T, stream));
-        return proj_residual(buf->g_wide, w.WqkvT, nullptr, add, buf->g_b, T, d, 3 * d, folded, stream);
+        return proj_residual(buf->g_wide, w.WqkvT, nullptr, add, buf->g_b, T, d, 3 * d, folded, stream, buf);
     };
     // LayerNorm backward whose dz is the gradient of (Linear output + residual): `gbias` (the Linear's bias gradient, may be
     // NULL) rides along as the column sums of dz when the kernel has its workspace; *done says whether it did

@@ -295,3 +295,5 @@ int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_ti
 }
 
 }  // extern "C"
+
+#include "gemm_splitk_small.inc"

@@ -1022,3 +1022,5 @@ int cx_gemm_bf16_swiglu_bwd_gate(const uint16_t* dY, const uint16_t* W, const ui
     p.Out2 = const_cast<uint16_t*>(Act); p.ldo2 = ld_ag; p.In3 = G; p.sup_m = p.sup_n = 0; p.trace = nullptr;
     return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD_AG, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
+
+#include "gemm_splitk_small.inc"

@@ -173,6 +173,10 @@ class _ChunkArena:
             t["patch_proj"] = torch.empty(T_cap, d, **bf)
         if getattr(cfg, "prepre_layernom", False):  # CLIP flavour: the pre-LayerNorm's input, kept for its backward
             t["zpre"] = torch.empty(T_cap, d, **bf)
+        # split-K workspace (fp32 partial slabs): 8 slabs of the largest weight, 16 of the smallest, for the wgrad GEMMs; every
+        # arena has it, because the few-tile long-K projections of SMALL chunks take a split-K route too
+        # (cx_gemm_bf16_nt_splitk) and a no-grad forward must round exactly like the saving forward of the same chunk
+        t["ws_f32"] = torch.empty(max(8 * max(3 * d, wfc1, patch_dim) * d, 16 * d * d), **f32)
         if with_backward:
             wide = max(3 * d, wfc1, patch_dim)
             for n in ("g_a", "g_b", "g_c"):
@@ -182,8 +186,6 @@ class _ChunkArena:
             t["tr_a"] = torch.empty(wide, T_cap, **bf)
             t["tr_b"] = torch.empty(wide, T_cap, **bf)
             t["delta"] = torch.empty(T_cap * H, **f32)
-            # split-K workspace of the wgrad GEMMs (fp32 partial slabs): 8 slabs of the largest weight, 16 of the smallest
-            t["ws_f32"] = torch.empty(max(8 * wide * d, 16 * d * d), **f32)
             if getattr(cfg, "resid_pdrop", 0.0) > 0:  # dropout: the LayerNorm backward returns a second gradient
                 t["g_d"] = torch.empty(T_cap, d, **bf)
         self.tensors = t

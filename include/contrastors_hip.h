@@ -167,6 +167,14 @@ int cx_swiglu_bwd(const uint16_t* dact, const uint16_t* yg, uint16_t* dyg, int T
 int cx_gemm_bf16_nt_residual(const uint16_t* X, const uint16_t* W, uint16_t* Out, const float* bias,
                              const uint16_t* Residual, int M, int N, int K, int ldx, int ldw, int ldo, int ldr,
                              void* stream);
+/* The same projection for FEW output tiles and a LONG K (sc/trainers at small batches: BASELINE configs[0], B = 32, S = 64 is
+ * 2048 token rows -- fc2 is 24 tiles of 256 x 256 with 48 K-tiles each): the K range is split into K / 384 slices (at most
+ * 16; a function of K alone, so the summation order does not depend on M), fp32 partial slabs go to `ws` (>= slices * M * N
+ * floats) and one fixed-order pass writes Out = bf16(bf16(sum + bias) + Residual) (bias, Residual optional).  Deterministic.
+ * CX_ERR_SHAPE = not the case this route is for (more than 64 tiles, K < 1536, no room for the slabs): use
+ * cx_gemm_bf16_nt / cx_gemm_bf16_nt_residual. */
+int cx_gemm_bf16_nt_splitk(const uint16_t* X, const uint16_t* W, uint16_t* Out, const float* bias, const uint16_t* Residual,
+                           float* ws, long ws_floats, int M, int N, int K, int ldx, int ldw, int ldo, int ldr, void* stream);
 int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint16_t* Act, int M, int I, int K, int ldx,
                         int ldw, int ld_yg, int ld_act, void* stream);
 /* fc1 of the plain MLP (sc/layers/mlp.py:30-34: fc2(gelu(fc1 x)), erf GELU, block.py:181-189) with bias + GELU fused

@@ -656,6 +656,50 @@ def test_gemm_swiglu_bwd_fused(M, I, K):
     assert rel_err(got.float(), ref.reshape(M, 2 * I)) < 6e-3
 
 
+# ---- round 3: few output tiles, long K (small batches): split-K over the chip + one fixed-order fold ---------------------
+@pytest.mark.parametrize("M,N,K,with_bias,with_res", [(2048, 768, 3072, True, True), (300, 768, 2304, False, True),
+                                                       (1000, 264, 1536, True, False)])
+def test_gemm_splitk_small_matches_the_one_pass_projection(M, N, K, with_bias, with_res):
+    x, w = bf(_randn(M, K, seed=70)), bf(_randn(N, K, seed=71, std=0.05))
+    bias = _randn(N, seed=72) if with_bias else None
+    res = bf(_randn(M, N, seed=73)) if with_res else None
+    ws = torch.empty(8 * M * N, device=DEV)
+    got = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    args = (x.data_ptr(), w.data_ptr(), got.data_ptr(), _C.ptr(bias), _C.ptr(res), ws.data_ptr(), ws.numel(), M, N, K, K, K, N, N, S())
+    _C.check(L().cx_gemm_bf16_nt_splitk(*args), "cx_gemm_bf16_nt_splitk")
+    ref = x.float() @ w.float().T
+    if with_bias:
+        ref = ref + bias
+    ref = ref.to(torch.bfloat16).float()
+    if with_res:
+        ref = ref + res.float()
+    assert torch.isfinite(got.float()).all()
+    assert rel_err(got.float(), ref) < 4e-3     # one bf16 rounding of the result (two with the residual)
+    if with_res and N % 8 == 0:                 # the fused-epilogue kernel it stands in for: same rounding points
+        one = torch.empty_like(got)
+        _C.check(L().cx_gemm_bf16_nt_residual(x.data_ptr(), w.data_ptr(), one.data_ptr(), _C.ptr(bias), res.data_ptr(), M, N, K, K,
+                                              K, N, N, S()))
+        assert rel_err(got.float(), one.float()) < 3e-3
+        assert float((got.float() - one.float()).abs().max()) <= 2 ** -6 * float(one.float().abs().max())  # a few 1-ulp flips
+    again = torch.empty_like(got)
+    _C.check(L().cx_gemm_bf16_nt_splitk(x.data_ptr(), w.data_ptr(), again.data_ptr(), _C.ptr(bias), _C.ptr(res), ws.data_ptr(),
+                                        ws.numel(), M, N, K, K, K, N, N, S()))
+    assert torch.equal(got, again), "fixed-order reduction: deterministic"
+
+
+def test_gemm_splitk_small_declines_what_the_one_pass_kernels_do_better():
+    """More than 64 output tiles, a short K, or no room for two slabs: CX_ERR_SHAPE (-1), the caller takes the one-pass kernel."""
+    x, w = bf(_randn(20000, 3072, seed=70)), bf(_randn(768, 3072, seed=71))
+    out = torch.empty(20000, 768, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(8 * 2048 * 768, device=DEV)
+    f = L().cx_gemm_bf16_nt_splitk
+    base = (x.data_ptr(), w.data_ptr(), out.data_ptr(), None, None, ws.data_ptr())
+    assert f(*base, ws.numel(), 20000, 768, 3072, 3072, 3072, 768, 768, S()) == -1     # 79 x 3 tiles
+    assert f(*base, ws.numel(), 2048, 768, 768, 3072, 3072, 768, 768, S()) == -1       # K = 768: 12 K-tiles
+    assert f(*base, 7 * 2048 * 768, 2048, 768, 3072, 3072, 3072, 768, 768, S()) == -1  # K = 3072 wants 8 slabs, never fewer
+    assert f(*base, ws.numel(), 2048, 768, 3072, 3072, 3072, 768, 768, S()) == 0
+
+
 # ---- round 3: the gated MLP keeps the gate alone; y is recovered from act = y * silu(gate) inside the derivative ---------
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
 def test_gemm_swiglu_gate_save(M, I, K):
