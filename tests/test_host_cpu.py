@@ -145,3 +145,65 @@ def test_selective_checkpointing_arena_and_config():
     for bad in (-1, "some"):
         with _pt.raises(ValueError):
             TrainArgs(checkpoint_keep_layers=bad)
+
+
+def test_selective_checkpointing_planner_budgets_the_measured_headroom_once(monkeypatch):
+    """checkpoint_keep_layers = 'auto', host arithmetic only (torch.cuda.* mocked): after an arena's first, literal use the
+    planner keeps as many blocks as 90 % of the device minus the step's measured peak pays for; a second arena of the same
+    step sees what the first one was promised (per-device ledger), never more than the device has free right now; a
+    suspended engine and an explicit keep count plan nothing; the ledger is settled when an arena dies."""
+    import gc
+    from types import SimpleNamespace
+
+    from contrastors_amd import nomic_bert as nb
+
+    GB = 1 << 30
+    cfg = nb.NomicBertConfig.nomic_bert_2048(vocab_size=512, n_layer=12)
+    per_tok = nb._ChunkArena.slot_bytes_per_token(cfg)
+    assert per_tok == 2 * (3 * 768 + 768 + 3 * 768 + 3072 + 3072) + 4 * 16
+    state = {"total": 288 * GB, "peak": 60 * GB, "free": 220 * GB, "reserved": 70 * GB, "allocated": 62 * GB}
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: SimpleNamespace(total_memory=state["total"]))
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda d=None: state["peak"])
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (state["free"], state["total"]))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda d=None: state["reserved"])
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: state["allocated"])
+    dev = SimpleNamespace(index=7)   # a device index no other test touches
+    eng = SimpleNamespace(config=cfg, device_=dev, CKPT_HBM_FRACTION=0.9, checkpoint_keep="auto", _keep_suspended=0,
+                          _keep_plan={}, _keep_granted={})
+    eng._keep_mode = lambda: nb.NomicBertEngine._keep_mode(eng)
+    plan = lambda arena: nb.NomicBertEngine._plan_keep(eng, arena)
+    arena = lambda T, nbytes: SimpleNamespace(T_cap=T, probation=True, nbytes=lambda: nbytes)
+    base = nb._hbm_grant(dev, 0)
+
+    docs = arena(524288, 50 * GB)
+    assert plan(docs) is True and docs.probation is False
+    # 0.9 * 288 - 60 = 199.2 GB of headroom >= 12 blocks of 524288 tokens (12.0 GB each): everything is kept
+    assert eng._keep_plan[524288] == 12 and eng._keep_granted[524288] == 12 * 524288 * per_tok
+    queries = arena(65536, 6 * GB)
+    assert plan(queries) is True and eng._keep_plan[65536] == 12          # 18 GB more still fit
+    big = arena(1048576, 100 * GB)
+    assert plan(big) is True
+    granted = 12 * (524288 + 65536) * per_tok
+    left = min(0.9 * 288 * GB - 60 * GB - granted,                        # what the ledger leaves of the measured headroom
+               0.9 * (220 + 8 + 100) * GB - 100 * GB - granted)           # ... and of what the device has free right now
+    assert eng._keep_plan[1048576] == int(left // (1048576 * per_tok)) == 1
+    assert nb._hbm_grant(dev, 0) - base == sum(eng._keep_granted.values())
+    # another process on the same GPU: the device's free memory, not this process's peak, is the binding bound
+    state.update(free=20 * GB, reserved=62 * GB)
+    eng._keep_plan.clear()
+    tight = arena(262144, 25 * GB)
+    assert plan(tight) is False and eng._keep_plan[262144] == 0           # 0.9 * (20 + 25) - 25 - grants < one block
+    # suspended (resident GradCache) and explicit counts never plan
+    eng._keep_suspended = 1
+    assert plan(arena(131072, 10 * GB)) is False and 131072 not in eng._keep_plan
+    eng._keep_suspended, eng.checkpoint_keep = 0, 3
+    assert plan(arena(131072, 10 * GB)) is False and 131072 not in eng._keep_plan
+    # an arena that dies returns its grant
+    a = nb._ChunkArena(nb.NomicBertConfig.nomic_bert_2048(vocab_size=512, n_layer=2, n_embd=128, n_head=2, n_inner=256), 128, 2,
+                       True, 2, torch.device("cpu"), checkpoint=True, keep_layers=1)
+    a._device, a.granted = dev, 5 * GB
+    before = nb._hbm_grant(dev, 5 * GB)
+    del a
+    gc.collect()
+    assert nb._hbm_grant(dev, 0) == before - 5 * GB
+    nb._HBM_GRANTED.pop(7, None)
