@@ -207,3 +207,71 @@ def test_selective_checkpointing_planner_budgets_the_measured_headroom_once(monk
     gc.collect()
     assert nb._hbm_grant(dev, 0) == before - 5 * GB
     nb._HBM_GRANTED.pop(7, None)
+
+
+def test_arena_pool_host_logic_on_cpu(monkeypatch):
+    """NomicBertEngine._get_arena / release_arena without a GPU (arenas on the CPU device, planner mocked): size classes,
+    best fit, a measured-and-dropped arena rebuilt at its own size, idle arenas given back, out-of-memory retry."""
+    from types import SimpleNamespace
+
+    from contrastors_amd import nomic_bert as nb
+
+    E = nb.NomicBertEngine
+    cfg = nb.NomicBertConfig.nomic_bert_2048(vocab_size=512, n_layer=2, n_embd=128, n_head=2, n_inner=256)
+    eng = SimpleNamespace(config=cfg, device_=torch.device("cpu"), gradient_checkpointing=True, checkpoint_keep="auto",
+                          _arena_free=[], _arena_nograd=None, _arena_tick=0, _keep_plan={}, _keep_granted={}, _keep_suspended=0,
+                          _keep_logged=set(), ARENA_IDLE_USES=4)
+    for name in ("_keep_mode", "_checkpoint_keep_for", "_log_keep"):
+        setattr(eng, name, (lambda n: lambda *a: getattr(E, n)(eng, *a))(name))
+
+    def plan(arena):   # stands in for the measuring planner: every block fits
+        arena.probation = False
+        eng._keep_plan[arena.T_cap] = 2
+        eng._keep_granted[arena.T_cap] = 1
+        return True
+
+    eng._plan_keep = plan
+    get = lambda T: E._get_arena(eng, T, 4, True)
+    rel = lambda a: E.release_arena(eng, a)
+
+    a = get(3000)
+    cap0 = a.T_cap
+    assert cap0 == 3072 and a.probation and a.keep_layers == 0         # 128-token granules, then 64 size classes per octave
+    rel(a)
+    assert eng._arena_free == [] and eng._keep_plan == {cap0: 2}       # measured, dropped for its rebuild
+    b = get(2500)
+    assert b.T_cap == cap0 and b.keep_layers == 2 and not b.probation  # the smaller batch rebuilds the planned arena, at ITS size
+    rel(b)
+    c = get(5000)
+    assert c.T_cap > cap0 and c.probation
+    rel(c)
+    d = get(4000)
+    assert d.T_cap == c.T_cap and d.keep_layers == 2
+    rel(d)
+    assert sorted(x.T_cap for x in eng._arena_free) == [cap0, d.T_cap]
+    assert get(2000) is b                                             # best fit, not first fit
+    rel(b)
+    eng._arena_tick += 10                                             # nobody took either arena for a while ...
+    e = get(9000)                                                     # ... and a record batch comes: both are given back first
+    assert e.probation and eng._arena_free == [] and cap0 not in eng._keep_plan and d.T_cap not in eng._keep_plan
+    rel(e)
+    # out of memory with an idle arena in the pool: the pool is emptied and the allocation tried again
+    f = get(9000)
+    rel(f)
+    real, calls = nb._ChunkArena, []
+
+    class Flaky(real):
+        def __init__(self, *a, **k):
+            calls.append(1)
+            if len(calls) == 1:
+                raise torch.OutOfMemoryError("simulated")
+            super().__init__(*a, **k)
+
+    monkeypatch.setattr(nb, "_ChunkArena", Flaky)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    eng.checkpoint_keep = 0
+    g = get(20000)
+    assert len(calls) == 2 and eng._arena_free == [] and g.T_cap >= 20000
+    calls.clear()
+    with pytest.raises(torch.OutOfMemoryError):
+        get(40000)                                                    # nothing idle to give back: the caller's error
