@@ -275,3 +275,25 @@ def test_arena_pool_host_logic_on_cpu(monkeypatch):
     calls.clear()
     with pytest.raises(torch.OutOfMemoryError):
         get(40000)                                                    # nothing idle to give back: the caller's error
+
+
+def test_compact_swiglu_backward_identity():
+    """The algebra behind cx_gemm_bf16_swiglu_bwd_gate (the gated MLP keeps the gate alone): with act = y * silu(g),
+    d gate = d * y * silu'(g) = d * act * (1 / g + 1 - sigmoid(g)).  Exact in fp64 against autograd of the reference's
+    formula (flash_attn.ops.activations.swiglu: silu(x) * y, sc/layers/mlp.py:75); with act rounded to bf16 the recovered
+    gradient carries that one rounding (2^-9 relative), as a saved bf16 y would."""
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn(4096, 64, generator=g, dtype=torch.float64)
+    gate = (torch.randn(4096, 64, generator=g, dtype=torch.float64) * 3).requires_grad_()
+    d = torch.randn(4096, 64, generator=g, dtype=torch.float64)
+    yv = y.clone().requires_grad_()
+    act = torch.nn.functional.silu(gate) * yv
+    act.backward(d)
+    sg = torch.sigmoid(gate.detach())
+    dgate = d * act.detach() * (1.0 / gate.detach() + 1.0 - sg)
+    dy = d * gate.detach() * sg
+    assert float((dgate - gate.grad).abs().max()) < 1e-11 and float((dy - yv.grad).abs().max()) < 1e-12
+    act16 = act.detach().to(torch.bfloat16).double()
+    dgate16 = d * act16 * (1.0 / gate.detach() + 1.0 - sg)
+    rel = (dgate16 - gate.grad).abs() / gate.grad.abs().clamp_min(1e-300)
+    assert float(rel.max()) <= 2.0 ** -8 and float(rel.mean()) < 2.0 ** -9
