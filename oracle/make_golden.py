@@ -436,6 +436,60 @@ def gen_clip_loss_single():
     print("clip_loss_w1 done")
 
 
+def gen_matryoshka_step():
+    """tests/golden/matryoshka_step.npz: the reference trainer's direct step (sc/trainers/text_text.py:324-378 `_forward_step`:
+    both sides through the model with normalize = False, gather_with_grad, one clip_loss per Matryoshka prefix on re-normalised
+    prefixes, weighted sum; hard negatives folded into the document side) -- the REFERENCE'S OWN FUNCTION, compiled from its
+    source file (the module itself imports deepspeed / sentence_transformers / megablocks, absent here, so the FunctionDef is
+    lifted out of the file with `ast` and executed against the reference's own clip_loss / gather_with_grad).  The model is a
+    stand-in that returns fixed embeddings: what is pinned is the loss composition of SURVEY row a20, not the encoder."""
+    import ast
+    from types import SimpleNamespace
+
+    ref_loss, _, _ = ref_import.load()
+    ref_dist = __import__("importlib").import_module("contrastors.distributed")
+    src = (ref_import.REF_ROOT / "trainers" / "text_text.py").read_text()
+    fn = next(n for c in ast.parse(src).body if isinstance(c, ast.ClassDef) and c.name == "TextTextTrainer"
+              for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "_forward_step")
+    ns = {"F": torch.nn.functional, "torch": torch, "gather_with_grad": ref_dist.gather_with_grad, "clip_loss": ref_loss.clip_loss,
+          "moe": SimpleNamespace(clear_load_balancing_loss=lambda: None), "calculate_auxiliary_loss": None}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), str(ref_import.REF_ROOT / "trainers" / "text_text.py"), "exec"), ns)
+    forward_step = ns["_forward_step"]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29614", rank=0, world_size=1)
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    # (query and document counts are multiples of 4: the product's fused InfoNCE backward contracts over them)
+    for tag, nq, negs, dims, weights in (("m4", 8, 7, [64, 32, 16, 8], [1.0, 1.0, 1.0, 1.0]), ("w3", 4, 2, [48, 24, 8], [1.0, 0.5, 0.25]),
+                                         ("plain", 8, 7, None, None)):
+        q = (torch.randn(nq, 64, generator=g) * 1.5).requires_grad_()
+        d = (torch.randn(nq * (1 + negs), 64, generator=g) * 1.5).requires_grad_()
+
+        class _Model:   # BiEncoder's output contract; `normalize` as the trainer passes it
+            device = torch.device("cpu")
+
+            def __call__(self, input_ids, attention_mask=None, normalize=True):
+                e = q if input_ids.shape[0] == nq else d
+                return {"embedding": torch.nn.functional.normalize(e, dim=-1) if normalize else e, "router_loss": None}
+
+        trainer = SimpleNamespace(config=SimpleNamespace(model_args=SimpleNamespace(num_experts=0),
+                                                         train_args=SimpleNamespace(router_aux_loss_coef=0.0, wandb=False)),
+                                  tracker=None)
+        batch = {"dataset_name": "golden", "query_input_ids": torch.zeros(nq, 4, dtype=torch.long),
+                 "query_attention_mask": torch.ones(nq, 4, dtype=torch.long),
+                 "document_input_ids": torch.zeros(nq * (1 + negs), 4, dtype=torch.long),
+                 "document_attention_mask": torch.ones(nq * (1 + negs), 4, dtype=torch.long)}
+        res = forward_step(trainer, _Model(), batch, _Scale(50.0), matryoshka_dims=dims, matroyshka_loss_weights=weights)
+        loss = res["loss"] if isinstance(res, dict) else res
+        loss.backward()
+        out.update({f"{tag}/q": q.detach().numpy(), f"{tag}/d": d.detach().numpy(), f"{tag}/loss": loss.detach().numpy(),
+                    f"{tag}/dq": q.grad.numpy(), f"{tag}/dd": d.grad.numpy(),
+                    f"{tag}/dims": np.array(dims if dims else [], dtype=np.int64),
+                    f"{tag}/weights": np.array(weights if weights else [], dtype=np.float64)})
+    np.savez_compressed(GOLD / "matryoshka_step.npz", **out)
+    dist.destroy_process_group()
+    print("matryoshka_step done")
+
+
 def _rank_clip(rank, world, tmp):
     ref_loss, _, _ = ref_import.load()
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29612", rank=rank, world_size=world)
@@ -520,6 +574,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "local_loader":
         gen_local_loader()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "matryoshka":
+        gen_matryoshka_step()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hf_remap":
         gen_hf_remap()
         sys.exit(0)
@@ -528,6 +585,7 @@ if __name__ == "__main__":
     # Dynamic-NTK rotary (modeling_hf_nomic_bert.py:1215-1235): sequences (32) longer than max_trained_positions (16)
     gen_encoder("encoder_nomic_ntk_tiny", dict(TINY_NOMIC, rotary_scaling_factor=2.0, max_trained_positions=16), 5)
     gen_clip_loss_single()
+    gen_matryoshka_step()
     gen_multirank()
     gen_vit("vit_tiny", TINY_VIT, 5)
     gen_vit("vit_clip_tiny", TINY_VIT_CLIP, 6)

@@ -65,11 +65,9 @@ def _oracle_loss(sd, ns, batch, scale, bf16):
         return torch.cat(rows)
 
     q, d = embed("query"), embed("document")
-    loss = 0.0
-    labels = torch.from_numpy(infonce_ref.labels_for(q.shape[0], d.shape[0], 0, 1)).to(DEV)   # stride 8: 1 pos + 7 neg
-    for dim in DIMS:  # sc/trainers/text_text.py:352-369, unit weights; sc/loss.py:108-125 at world size 1
-        sim = F.normalize(q[:, :dim], dim=-1) @ F.normalize(d[:, :dim], dim=-1).T * scale
-        loss = loss + F.cross_entropy(sim, labels)
+    # sc/trainers/text_text.py:352-369, unit weights; sc/loss.py:108-125 at world size 1 (label stride 8: 1 pos + 7 neg):
+    # the restatement pinned to the reference trainer's own function by tests/golden/matryoshka_step.npz
+    loss = infonce_ref.matryoshka_step_loss_ref(q, d, scale, DIMS)
     loss.backward()
     return loss.detach(), {k: v.grad for k, v in sdd.items()}
 
@@ -170,3 +168,38 @@ def test_cfg3_baseline_per_gpu_shape_fits_with_checkpointing():
     assert losses[0] == loss_lit and losses[1] == loss_lit, (losses, loss_lit)
     assert kept and all(k > 0 for _, k in kept), kept
     assert peak < peak_auto < 0.93 * total, (peak, peak_auto, total)
+
+
+@pytest.mark.parametrize("tag", ["m4", "w3", "plain"])
+def test_forward_step_loss_composition_vs_reference_golden(tag):
+    """The product's TextTextTrainer.forward_step (direct step, Matryoshka prefixes + weights, folded hard negatives) against
+    tests/golden/matryoshka_step.npz = the reference trainer's OWN `_forward_step` run on fixed embeddings
+    (oracle/make_golden.py gen_matryoshka_step).  The tower is a stand-in returning those embeddings, so what is compared is
+    the loss composition on the fused InfoNCE kernel: loss 1e-5, embedding gradients 1e-4 relative."""
+    from pathlib import Path
+    from types import SimpleNamespace
+
+    from contrastors_amd.biencoder import LogitScale
+
+    g = np.load(Path(__file__).parent / "golden" / "matryoshka_step.npz")
+    q = torch.from_numpy(g[f"{tag}/q"]).to(DEV).requires_grad_()
+    d = torch.from_numpy(g[f"{tag}/d"]).to(DEV).requires_grad_()
+    dims, weights = [int(x) for x in g[f"{tag}/dims"]], [float(x) for x in g[f"{tag}/weights"]]
+
+    def tower(input_ids, attention_mask=None, seqlens=None, normalize=True):
+        e = q if input_ids.shape[0] == q.shape[0] else d
+        return {"embedding": F.normalize(e, dim=-1) if normalize else e}
+
+    scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(DEV)
+    fake = SimpleNamespace(config=SimpleNamespace(train_args=SimpleNamespace(grad_cache=False, matryoshka_dims=dims or None,
+                                                                             matryoshka_loss_weights=weights or None,
+                                                                             use_fp8=False)),
+                           model={"model": tower, "logit_scale": scale}, device=DEV)
+    fake._inputs = lambda batch, prefix: TextTextTrainer._inputs(fake, batch, prefix)
+    batch = {"query_input_ids": torch.zeros(q.shape[0], 4, dtype=torch.long), "document_input_ids": torch.zeros(d.shape[0], 4, dtype=torch.long)}
+    loss = TextTextTrainer.forward_step(fake, batch)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}/loss"])) <= 1e-5 * abs(float(g[f"{tag}/loss"]))
+    for got, want in ((q.grad, g[f"{tag}/dq"]), (d.grad, g[f"{tag}/dd"])):
+        want = torch.from_numpy(want).to(DEV)
+        assert float((got - want).norm() / want.norm()) < 1e-4

@@ -58,6 +58,21 @@ def test_clip_loss_restatement_w1(gold, tag, bid):
     np.testing.assert_allclose(d.grad.numpy(), g[f"{tag}/dd"], atol=1e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["m4", "w3", "plain"])
+def test_matryoshka_step_restatement(gold, tag):
+    """The reference trainer's own `_forward_step` (sc/trainers/text_text.py:324-378, lifted from its source file by
+    oracle/make_golden.py) on fixed embeddings: 1 positive + 7 (or 2) hard negatives per query, Matryoshka prefixes with unit
+    and non-unit weights, and the plain (normalised, single-loss) case."""
+    g = gold("matryoshka_step")
+    q = torch.from_numpy(g[f"{tag}/q"]).requires_grad_()
+    d = torch.from_numpy(g[f"{tag}/d"]).requires_grad_()
+    loss = infonce_ref.matryoshka_step_loss_ref(q, d, 50.0, [int(x) for x in g[f"{tag}/dims"]], list(g[f"{tag}/weights"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"{tag}/loss"], rtol=1e-5)
+    np.testing.assert_allclose(q.grad.numpy(), g[f"{tag}/dq"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(d.grad.numpy(), g[f"{tag}/dd"], atol=1e-6, rtol=1e-4)
+
+
 def test_reference_kat_toy_infonce(gold):
     """tests/test_loss.py:5-17 of the reference: clip_loss == -mean log softmax on the diagonal labels."""
     g = gold("clip_loss_w1")
