@@ -27,17 +27,29 @@ from .optimizer import FusedAdamW
 
 
 def _lr_lambda(schedule: str, warmup: int, total: int):
+    """The multiplier `transformers.get_scheduler(name=schedule_type, optimizer, num_warmup_steps, num_training_steps)` puts on
+    the base learning rate at scheduler step `step` -- the scheduler the reference builds (sc/trainers/base.py:258-263) --
+    restated so that the trainers do not depend on the library; pinned to it step by step in tests/test_host_cpu.py.
+    Note what that means: the warm-up starts AT ZERO (the first optimizer step of a run with warmup_steps > 0 moves nothing)
+    and reaches the base rate at step == warmup, and the cosine is not clamped past `total`.  (Rounds 1-3 had the warm-up one
+    step early: (step + 1) / warmup.)"""
+    if schedule not in ("cosine", "linear", "constant", "constant_with_warmup", "inverse_sqrt"):
+        raise ValueError(f"schedule_type {schedule!r} is not served (cosine, linear, constant, constant_with_warmup, inverse_sqrt)")
+
     def f(step: int) -> float:
-        if warmup and step < warmup:
-            return (step + 1) / warmup
-        if total <= warmup:
+        if schedule == "constant":
             return 1.0
-        p = min(1.0, (step - warmup) / max(1, total - warmup))
-        if schedule == "cosine":
-            return 0.5 * (1.0 + math.cos(math.pi * p))
+        if step < warmup:
+            return float(step) / float(max(1, warmup))
+        if schedule == "constant_with_warmup":
+            return 1.0
+        if schedule == "inverse_sqrt":   # (sc/trainers/base.py:262 passes no horizon; timescale = warmup or 10000)
+            timescale = warmup or 10_000
+            return 1.0 / math.sqrt((step + timescale - warmup) / timescale)
         if schedule == "linear":
-            return 1.0 - p
-        return 1.0  # constant
+            return max(0.0, float(total - step) / float(max(1, total - warmup)))
+        progress = float(step - warmup) / float(max(1, total - warmup))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
 
     return f
 

@@ -23,7 +23,7 @@ DIMS = [768, 512, 256, 128]
 
 
 def _trainer(n_layer, vocab, checkpointing=False, batch=4, keep=0):
-    cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=1, grad_cache=False,
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-5, weight_decay=0.01, warmup_steps=0, grad_cache=False,
                                       schedule_type="linear", max_grad_norm=1.0, clamp_logits=False,
                                       matryoshka_dims=DIMS, checkpoint_keep_layers=keep),
                  data_args=DataArgs(batch_size=batch, seed=3),

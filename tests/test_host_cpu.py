@@ -34,9 +34,28 @@ def test_validators_match_reference():
 
 def test_scheduler_shapes():
     f = _lr_lambda("cosine", 700, 10000)
-    assert f(0) == pytest.approx(1 / 700) and f(699) == pytest.approx(1.0) and f(10000) == pytest.approx(0.0, abs=1e-9)
+    assert f(0) == 0.0 and f(1) == pytest.approx(1 / 700) and f(700) == pytest.approx(1.0) and f(10000) == pytest.approx(0.0, abs=1e-9)
     g = _lr_lambda("linear", 10, 110)
     assert g(60) == pytest.approx(0.5)
+    with pytest.raises(ValueError):
+        _lr_lambda("polynomial", 1, 10)
+
+
+@pytest.mark.parametrize("name", ["cosine", "linear", "constant", "constant_with_warmup", "inverse_sqrt"])
+@pytest.mark.parametrize("warmup,total", [(0, 12), (4, 12), (700, 3000)])
+def test_lr_schedule_is_the_one_the_reference_builds(name, warmup, total):
+    """sc/trainers/base.py:258-263 calls transformers.get_scheduler(name=schedule_type, num_warmup_steps, num_training_steps
+    (None for inverse_sqrt)): our LambdaLR must produce the same learning rate at every step, past the horizon included."""
+    transformers = pytest.importorskip("transformers")
+    ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=3e-4)
+    ref = transformers.get_scheduler(name=name, optimizer=ref_opt, num_warmup_steps=warmup,
+                                     num_training_steps=(total if name != "inverse_sqrt" else None))
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=3e-4)
+    ours = torch.optim.lr_scheduler.LambdaLR(opt, _lr_lambda(name, warmup, total))
+    for step in range(min(total + 5, 900)):
+        assert opt.param_groups[0]["lr"] == pytest.approx(ref_opt.param_groups[0]["lr"], rel=1e-12, abs=1e-18), (name, step)
+        opt.step(); ref_opt.step()
+        ours.step(); ref.step()
 
 
 def test_varlen_batch_from_lengths_matches_mask_path():
@@ -112,7 +131,7 @@ def test_lr_horizon_follows_set_total_steps():
         lrs.append(t.scheduler.get_last_lr()[0])
         t.optimizer.step()
         t.scheduler.step()
-    assert abs(lrs[9] - 1.0) < 1e-6 and lrs[0] == pytest.approx(0.1) and lrs[99] < 0.02
+    assert lrs[0] == 0.0 and lrs[1] == pytest.approx(0.1) and abs(lrs[10] - 1.0) < 1e-6 and lrs[99] < 0.02
 
 
 def test_selective_checkpointing_arena_and_config():
@@ -297,3 +316,46 @@ def test_compact_swiglu_backward_identity():
     dgate16 = d * act16 * (1.0 / gate.detach() + 1.0 - sg)
     rel = (dgate16 - gate.grad).abs() / gate.grad.abs().clamp_min(1e-300)
     assert float(rel.max()) <= 2.0 ** -8 and float(rel.mean()) < 2.0 ** -9
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("arch", ["nomic", "bert", "vit", "vit_clip"])
+def test_decay_grouping_equals_the_reference_configure_optimizer(arch):
+    """The engines lay their parameters out as [decay | no-decay] flat buffers (fused AdamW).  Which parameter
+    goes where is the reference's rule (sc/optimizer.py:7-47: squeeze().ndim < 2, 'bias' in the name, logit_scale -> no
+    decay): run the reference's OWN configure_optimizer on a module carrying the engine's parameter names and shapes and
+    compare the two groups."""
+    from types import SimpleNamespace
+
+    from contrastors_amd import nomic_bert as nb
+    from contrastors_amd.vit import ViTConfig, ViTEngine
+    from oracle import ref_import
+
+    ref_import.load()
+    import importlib
+
+    ref_opt = importlib.import_module("contrastors.optimizer")
+    if arch in ("nomic", "bert"):
+        cfg = (nb.NomicBertConfig.nomic_bert_2048(vocab_size=128, n_layer=2) if arch == "nomic"
+               else nb.NomicBertConfig.bert_base_uncased(vocab_size=128, n_layer=2))
+        cls = nb.NomicBertEngine
+    else:
+        cfg = ViTConfig(n_layer=2) if arch == "vit" else ViTConfig.clip_vit_base_patch16(n_layer=2)
+        cls = ViTEngine
+    fake = SimpleNamespace(config=cfg, _LAYER_PREFIX=cls._LAYER_PREFIX)
+    fake._layer_specs = lambda l: cls._layer_specs(fake, l)
+    decay, nodecay = cls._param_specs(fake)
+    mod = torch.nn.Module()
+    back = {}
+    for name, shape in decay + nodecay:
+        key = name.replace(".", "__")
+        back[key] = name
+        mod.register_parameter(key, torch.nn.Parameter(torch.zeros(*shape)))
+    args = SimpleNamespace(weight_decay=0.01, learning_rate=1e-3, adam_beta1=0.9, adam_beta2=0.999, eps=1e-8)
+    opt = ref_opt.configure_optimizer([mod], args)
+    ids = {id(p): back[k] for k, p in mod.named_parameters()}
+    ref_decay = {ids[id(p)] for p in opt.param_groups[0]["params"]}
+    ref_nodecay = {ids[id(p)] for p in opt.param_groups[1]["params"]}
+    assert opt.param_groups[0]["weight_decay"] == 0.01 and opt.param_groups[1]["weight_decay"] == 0.0
+    assert ref_decay == {n for n, _ in decay}, ref_decay ^ {n for n, _ in decay}
+    assert ref_nodecay == {n for n, _ in nodecay}, ref_nodecay ^ {n for n, _ in nodecay}

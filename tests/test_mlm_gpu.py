@@ -121,7 +121,7 @@ def test_mask_tokens_statistics():
 
 
 def _trainer(accum=1, max_grad_norm=1.0):
-    cfg = Config(train_args=TrainArgs(learning_rate=2e-3, weight_decay=1e-5, warmup_steps=1, schedule_type="linear",
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-3, weight_decay=1e-5, warmup_steps=0, schedule_type="linear",
                                       max_grad_norm=max_grad_norm, gradient_accumulation_steps=accum, adam_beta2=0.98,
                                       eps=1e-6, clamp_logits=False),
                  data_args=DataArgs(batch_size=16, seed=3), model_args=ModelArgs(model_type="mlm", seq_len=64))

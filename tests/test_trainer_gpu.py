@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _trainer(grad_cache: bool, trainable_scale: bool = False):
-    cfg = Config(train_args=TrainArgs(learning_rate=1e-3, weight_decay=0.01, warmup_steps=1, grad_cache=grad_cache,
+    cfg = Config(train_args=TrainArgs(learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, grad_cache=grad_cache,
                                       chunk_size=4, schedule_type="linear", max_grad_norm=1.0, clamp_logits=False),
                  data_args=DataArgs(batch_size=16, seed=7),
                  model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny",
@@ -46,7 +46,7 @@ def test_image_text_trainer_clip_and_lit(lit):
     from contrastors_amd.trainers import ImageTextTrainer
     from contrastors_amd.vit import ViTConfig
 
-    cfg = Config(train_args=TrainArgs(learning_rate=2e-3, weight_decay=0.01, warmup_steps=1, grad_cache=False,
+    cfg = Config(train_args=TrainArgs(learning_rate=2e-3, weight_decay=0.01, warmup_steps=0, grad_cache=False,
                                       schedule_type="linear", max_grad_norm=1.0, clamp_logits=True),
                  data_args=DataArgs(batch_size=16, seed=7),
                  text_model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny-text"),
@@ -105,7 +105,7 @@ def test_train_cli_runs_reference_recipe_shape(tmp_path):
     import numpy as np
     import yaml
 
-    cfg = {"train_args": {"num_epochs": 1, "learning_rate": 2.0e-4, "weight_decay": 0.01, "warmup_steps": 1,
+    cfg = {"train_args": {"num_epochs": 1, "learning_rate": 2.0e-4, "weight_decay": 0.01, "warmup_steps": 0,
                           "chunk_size": 64, "schedule_type": "cosine", "max_grad_norm": 1.0, "adam_beta1": 0.9,
                           "adam_beta2": 0.999, "grad_cache": True, "loss_fn": "clip", "clamp_logits": False,
                           "logit_max": 100, "wandb": False},
