@@ -96,11 +96,23 @@ def _load_initial_weights(model: BiEncoder, ma, explicit_arch: bool):
         "checkpoint at local weights, or set pretrained: false to train from a random init")
 
 
+def _check_accumulation(ta):
+    """The contrastive trainers take one optimizer step per batch, as every contrastive recipe of the reference does
+    (`gradient_accumulation_steps` is 1 or absent in configs/train/contrastive_*.yaml; the global batch is what GradCache is
+    for).  sc/trainers/base.py:366-393 would accumulate: say so instead of silently stepping every batch.  (The MLM trainer,
+    whose recipes do accumulate, implements the reference's micro-step schedule: mlm.py.)"""
+    n = getattr(ta, "gradient_accumulation_steps", 1)
+    if n is not None and int(n) > 1:
+        raise NotImplementedError(f"gradient_accumulation_steps = {n}: the contrastive trainers step once per batch "
+                                  "(raise the batch size -- GradCache bounds the activations); the MLM trainer accumulates")
+
+
 class TextTextTrainer:
     def __init__(self, config: Config, dtype=torch.bfloat16, device=None, trunk_config: Optional[NomicBertConfig] = None,
                  total_steps: Optional[int] = None):
         if dtype != torch.bfloat16:
             raise NotImplementedError("the native path computes in bf16 with fp32 master weights (--dtype=bf16)")
+        _check_accumulation(config.train_args)
         self.config = config
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.distributed = dist.is_available() and dist.is_initialized()

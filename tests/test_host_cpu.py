@@ -359,3 +359,12 @@ def test_decay_grouping_equals_the_reference_configure_optimizer(arch):
     assert opt.param_groups[0]["weight_decay"] == 0.01 and opt.param_groups[1]["weight_decay"] == 0.0
     assert ref_decay == {n for n, _ in decay}, ref_decay ^ {n for n, _ in decay}
     assert ref_nodecay == {n for n, _ in nodecay}, ref_nodecay ^ {n for n, _ in nodecay}
+
+
+def test_contrastive_trainers_refuse_silent_accumulation():
+    from contrastors_amd.trainers import _check_accumulation
+
+    _check_accumulation(TrainArgs())
+    _check_accumulation(TrainArgs(gradient_accumulation_steps=1))
+    with pytest.raises(NotImplementedError):
+        _check_accumulation(TrainArgs(gradient_accumulation_steps=4))
