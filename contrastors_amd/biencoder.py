@@ -39,6 +39,8 @@ class BiEncoderConfig:
     # (not a reference field) selective checkpointing on a 288 GB part: how many blocks keep their activations although
     # gradient_checkpointing is on -- "auto" = as many as the free HBM takes, 0 = the reference's behaviour (all recomputed)
     checkpoint_keep_layers: Union[int, str] = "auto"
+    # model_args.resid_pdrop (sc/config.py:187; modeling_biencoder.py:237 hands it to the nomic text trunk): None = as configured
+    resid_pdrop: Optional[float] = None
     encoder: bool = True
     seq_len: int = 2048
     trunk_config: Optional[object] = None  # NomicBertConfig or ViTConfig: no hub access, the architecture is explicit
@@ -71,6 +73,17 @@ def _default_trunk_config(name: str) -> NomicBertConfig:
     raise ValueError(f"no offline architecture table entry for {name!r}; pass BiEncoderConfig.trunk_config")
 
 
+def trunk_config_with_overrides(config: BiEncoderConfig, trunk_cfg):
+    """The architecture the tower is built with: the named / given trunk configuration with the overrides the reference's
+    BiEncoder applies on top (modeling_biencoder.py:222-240: `resid_pdrop` of a text trunk)."""
+    rp = getattr(config, "resid_pdrop", None)
+    if rp is not None and isinstance(trunk_cfg, NomicBertConfig):
+        import dataclasses
+
+        trunk_cfg = dataclasses.replace(trunk_cfg, resid_pdrop=float(rp))
+    return trunk_cfg
+
+
 class BiEncoder(torch.nn.Module):
     def __init__(self, config: BiEncoderConfig, device="cuda", seed: Optional[int] = None):
         super().__init__()
@@ -80,7 +93,7 @@ class BiEncoder(torch.nn.Module):
         if config.pooling not in ("mean", "cls", "map"):
             # "last" (modeling_biencoder.py:52-77) picks a decoder trunk's eos token; decoder trunks are out of scope
             raise NotImplementedError(f"pooling={config.pooling!r}")
-        trunk_cfg = config.trunk_config or _default_trunk_config(config.model_name)
+        trunk_cfg = trunk_config_with_overrides(config, config.trunk_config or _default_trunk_config(config.model_name))
         self.is_vision = isinstance(trunk_cfg, ViTConfig)  # image tower: `input_ids` carries the pixel tensor
         if config.pooling == "map" and not self.is_vision:
             raise NotImplementedError("pooling='map' serves the image tower: the reference's masked (text) branch of "

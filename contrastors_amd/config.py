@@ -107,7 +107,7 @@ class ModelArgs(BaseModel):
     model_name: Optional[str] = "nomic-ai/nomic-bert-2048"
     tokenizer_name: Optional[str] = "bert-base-uncased"
     seq_len: int = 2048
-    logit_scale: float = 1 / 0.07
+    logit_scale: Optional[float] = 1 / 0.07   # (None, as nomic_embed_vision_v1.5.yaml writes it, is the default: sc/config.py:193-197)
     trainable_logit_scale: bool = False
     pooling: str = "mean"
     nomic_encoder: bool = True
@@ -130,11 +130,29 @@ class ModelArgs(BaseModel):
     projection_dim: Optional[int] = None
     freeze: bool = False
     hamming: bool = False
+    # sc/config.py:187 -> NomicBertModel.from_pretrained(..., resid_pdrop=) (modeling_biencoder.py:237): residual dropout of a
+    # PRETRAINED nomic text trunk (None = the checkpoint's own value); served by the engine's Philox dropout
+    resid_pdrop: Optional[float] = None
+    # keys of the reference schema this path does not serve: accepted at their inert defaults, refused otherwise (a recipe
+    # that sets them must not train as if it had not)
+    ema: bool = False
+    patch_dropout: float = 0.0
+    num_experts: int = 0
 
     @model_validator(mode="after")
     def _model_type(self):
-        if self.model_type not in ("encoder", "mlm", "glue", "locked_text", "image_text", "distill"):
+        if self.model_type not in ("encoder", "mlm", "glue", "locked_text", "image_text", "mmlm", "distill"):   # sc/config.py:198-203
             raise ValueError(f"Model type {self.model_type} not found in model registry")
+        if not self.logit_scale:   # sc/config.py:193-196: `scale or 1 / 0.07`
+            self.logit_scale = 1 / 0.07
+        if self.ema:
+            raise ValueError("model_args.ema: an EMA copy of the weights (sc/trainers/base.py:387-391) is not served")
+        if self.patch_dropout and self.patch_dropout > 0:
+            raise ValueError("model_args.patch_dropout > 0 (sc/layers/embedding.py:415-418) is not served by the image tower")
+        if self.num_experts and self.num_experts > 0:
+            raise ValueError("model_args.num_experts > 0: mixture-of-experts trunks (megablocks) are out of scope")
+        if self.resid_pdrop is not None and not (0.0 <= self.resid_pdrop < 1.0):
+            raise ValueError(f"model_args.resid_pdrop must be in [0, 1), got {self.resid_pdrop}")
         return self
 
 

@@ -55,6 +55,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     config = apply_overrides(read_config(args.config), overrides)
+    if config.model_args.model_type not in TRAINER_REGISTRY:   # glue / mmlm / distill: valid reference types, not on this path
+        raise NotImplementedError(f"model_type {config.model_args.model_type!r}: this build serves {sorted(TRAINER_REGISTRY)} "
+                                  "(the contrastive, image-text and MLM trainers of the hot path)")
     trainer = TRAINER_REGISTRY[config.model_args.model_type](config, torch.bfloat16, total_steps=args.synthetic_steps)
     per_rank = config.data_args.batch_size // world
     if args.synthetic_steps <= 0 and config.data_args.input_shards:

@@ -146,6 +146,7 @@ class TextTextTrainer:
                              freeze=ma.freeze, hamming=ma.hamming, gradient_checkpointing=ma.gradient_checkpointing,
                              checkpoint_keep_layers=_parse_keep(config.train_args.checkpoint_keep_layers, "train_args.checkpoint_keep_layers"),
                              nomic_encoder=ma.nomic_encoder, seq_len=ma.seq_len,
+                             resid_pdrop=ma.resid_pdrop if ma.pretrained else None,   # (the reference overrides a PRETRAINED trunk only)
                              trunk_config=trunk_config)
         model = BiEncoder(bc, device=self.device).train()
         model.overlap_reduce = bool(config.train_args.overlap_grad_reduce)
@@ -341,6 +342,7 @@ class ImageTextTrainer(TextTextTrainer):
                                  freeze=ma.freeze, hamming=ma.hamming, gradient_checkpointing=ma.gradient_checkpointing,
                                  checkpoint_keep_layers=_parse_keep(config.train_args.checkpoint_keep_layers, "train_args.checkpoint_keep_layers"),
                                  nomic_encoder=ma.nomic_encoder,
+                                 resid_pdrop=ma.resid_pdrop if ma.pretrained else None,
                                  seq_len=ma.seq_len, trunk_config=trunk)
             tower = BiEncoder(bc, device=self.device).train()
             tower.overlap_reduce = bool(config.train_args.overlap_grad_reduce)

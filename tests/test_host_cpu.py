@@ -368,3 +368,45 @@ def test_contrastive_trainers_refuse_silent_accumulation():
     _check_accumulation(TrainArgs(gradient_accumulation_steps=1))
     with pytest.raises(NotImplementedError):
         _check_accumulation(TrainArgs(gradient_accumulation_steps=4))
+
+
+def test_reference_schema_keys_are_served_or_refused_never_dropped():
+    """model_args.resid_pdrop reaches the text trunk's configuration (sc/config.py:187, modeling_biencoder.py:237); the keys of
+    the reference schema this path does not serve are accepted at their inert defaults and refused otherwise."""
+    from contrastors_amd.biencoder import BiEncoderConfig, trunk_config_with_overrides
+    from contrastors_amd.config import ModelArgs
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from contrastors_amd.vit import ViTConfig
+
+    ma = ModelArgs(resid_pdrop=0.1, ema=False, patch_dropout=0.0, num_experts=0)
+    base = NomicBertConfig.nomic_bert_2048()
+    got = trunk_config_with_overrides(BiEncoderConfig(resid_pdrop=ma.resid_pdrop), base)
+    assert got.resid_pdrop == 0.1 and base.resid_pdrop == 0.0 and got.n_layer == base.n_layer
+    assert trunk_config_with_overrides(BiEncoderConfig(), base) is base
+    v = ViTConfig.vit_base_patch16_224()
+    assert trunk_config_with_overrides(BiEncoderConfig(resid_pdrop=0.1), v) is v      # (image towers: not a text trunk)
+    for bad in (dict(ema=True), dict(patch_dropout=0.5), dict(num_experts=8), dict(resid_pdrop=1.5)):
+        with pytest.raises(ValueError):
+            ModelArgs(**bad)
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_every_reference_recipe_parses_or_is_refused_for_a_stated_reason():
+    """All 17 recipes of sc/configs/train: the ones on the path parse unchanged; mixture-of-experts recipes are refused when the
+    YAML is read (they used to parse with `num_experts` silently dropped, i.e. would have trained a dense model)."""
+    import glob
+
+    ok, refused = [], {}
+    for f in sorted(glob.glob(str(REF_YAML.parent / "*.yaml"))):
+        try:
+            read_config(f)
+            ok.append(Path(f).name)
+        except ValueError as e:
+            refused[Path(f).name] = str(e)
+    assert set(refused) == {"contrastive_finetune_moe.yaml", "contrastive_pretrain_multilingual.yaml",
+                            "contrastive_pretrain_multilingual_full.yaml", "contrastive_pretrain_tk2.yaml"}, refused
+    assert all("num_experts" in v for v in refused.values())
+    assert {"contrastive_pretrain.yaml", "contrastive_matryoshka.yaml", "mlm.yaml", "mmlm.yaml", "nomic_embed_vision_v1.5.yaml",
+            "contrastive_finetune.yaml"} <= set(ok) and len(ok) == 13
+    vis = read_config(str(REF_YAML.parent / "nomic_embed_vision_v1.5.yaml"))
+    assert vis.vision_model_args.logit_scale == pytest.approx(1 / 0.07)   # `logit_scale: null` -> the default (sc/config.py:193-196)
