@@ -410,3 +410,32 @@ def test_every_reference_recipe_parses_or_is_refused_for_a_stated_reason():
             "contrastive_finetune.yaml"} <= set(ok) and len(ok) == 13
     vis = read_config(str(REF_YAML.parent / "nomic_embed_vision_v1.5.yaml"))
     assert vis.vision_model_args.logit_scale == pytest.approx(1 / 0.07)   # `logit_scale: null` -> the default (sc/config.py:193-196)
+
+
+@pytest.mark.parametrize("p", [0.15, 0.3])
+def test_mask_tokens_is_the_collator_the_reference_uses(p):
+    """sc/trainers/mlm.py:70,84 collates with transformers.DataCollatorForLanguageModeling: under the same torch RNG state
+    mlm.mask_tokens must pick the same targets, the same [MASK] / random / kept split and the same random words -- bit for bit."""
+    transformers = pytest.importorskip("transformers")
+    from contrastors_amd.mlm import mask_tokens
+
+    class Tok:   # the three things torch_mask_tokens asks its tokenizer
+        mask_token, pad_token = "[MASK]", "[PAD]"
+
+        def convert_tokens_to_ids(self, t):
+            return 103
+
+        def __len__(self):
+            return 30522
+
+    coll = transformers.DataCollatorForLanguageModeling(tokenizer=Tok(), mlm=True, mlm_probability=p)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1000, 30000, (32, 128), generator=g)
+    special = torch.zeros_like(ids, dtype=torch.bool)
+    special[:, 0] = True
+    special[:, 100:] = True
+    torch.manual_seed(5)
+    want_ids, want_labels = coll.torch_mask_tokens(ids.clone(), special_tokens_mask=special.clone())
+    torch.manual_seed(5)
+    got_ids, got_labels = mask_tokens(ids, special, p, 103, 30522, None)
+    assert torch.equal(got_labels, want_labels) and torch.equal(got_ids, want_ids)
