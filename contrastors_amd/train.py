@@ -18,31 +18,75 @@ from .config import read_config
 from .trainers import TRAINER_REGISTRY, synthetic_batches
 
 
-def parse_args():
+def _str2bool(v):
+    """sc/train.py:39-47."""
+    if isinstance(v, bool):
+        return v
+    t = str(v).lower()
+    if t in ("yes", "true", "t", "y", "1"):
+        return True
+    if t in ("no", "false", "f", "n", "0"):
+        return False
+    raise ValueError(f"Boolean value expected, got {v!r}")
+
+
+def split_overrides(extra):
+    """`--key value`, `--key=value` and a bare `--flag` (= true, as the reference's `nargs='?', const=True` flags) -> dict."""
+    out, i = {}, 0
+    while i < len(extra):
+        tok = extra[i]
+        if not tok.startswith("--"):
+            raise SystemExit(f"unexpected argument {tok!r}")
+        key = tok[2:]
+        if "=" in key:
+            key, val = key.split("=", 1)
+        elif i + 1 < len(extra) and not extra[i + 1].startswith("--"):
+            val = extra[i + 1]
+            i += 1
+        else:
+            val = True
+        out[key.replace("-", "_")] = val
+        i += 1
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bfloat16"])   # sc/train.py:29-36: the names of bf16 there
+    ap.add_argument("--local_rank", type=int, default=-1)                      # sc/train.py:54 (launchers that still pass it)
     ap.add_argument("--synthetic-steps", type=int, default=10)
     ap.add_argument("--seq-len", type=int, default=128)
-    args, extra = ap.parse_known_args()
-    overrides = {}
-    for k, v in zip(extra[::2], extra[1::2]):
-        overrides[k.lstrip("-").replace("-", "_")] = v
-    return args, overrides
+    args, extra = ap.parse_known_args(argv)
+    return args, split_overrides(extra)
 
 
 def apply_overrides(config, overrides):
-    for section in (config.train_args, config.model_args, config.data_args):
-        for k, v in overrides.items():
-            if k in type(section).model_fields:
-                cur = getattr(section, k)
-                if isinstance(cur, bool):
-                    v = str(v).lower() in ("1", "true", "yes")
-                elif isinstance(cur, int):
-                    v = int(v)
-                elif isinstance(cur, float):
-                    v = float(v)
-                setattr(section, k, v)
+    """sc/train.py:87-94 `update_config_with_args`: a key is written into every section that has it.  The reference declares a
+    fixed list of flags; here any field of the three sections can be overridden, typed by its current value / annotation --
+    and a key no section has is an error, not a silent no-op."""
+    sections = [s for s in (config.train_args, config.model_args, config.data_args) if s is not None]
+    for k, v in overrides.items():
+        hit = False
+        for section in sections:
+            if k not in type(section).model_fields:
+                continue
+            hit = True
+            cur = getattr(section, k)
+            ann = str(type(section).model_fields[k].annotation)
+            if isinstance(cur, bool) or (cur is None and "bool" in ann):
+                val = _str2bool(v)
+            elif isinstance(cur, int) and not isinstance(v, bool):
+                val = int(v)
+            elif isinstance(cur, float) or (cur is None and "float" in ann and "str" not in ann):
+                val = float(v)
+            elif cur is None and "int" in ann and "str" not in ann:
+                val = int(v)
+            else:
+                val = v
+            setattr(section, k, val)
+        if not hit:
+            raise SystemExit(f"--{k}: no such key in train_args / model_args / data_args")
     return config
 
 

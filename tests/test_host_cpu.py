@@ -439,3 +439,26 @@ def test_mask_tokens_is_the_collator_the_reference_uses(p):
     torch.manual_seed(5)
     got_ids, got_labels = mask_tokens(ids, special, p, 103, 30522, None)
     assert torch.equal(got_labels, want_labels) and torch.equal(got_ids, want_ids)
+
+
+def test_train_cli_overrides():
+    """sc/train.py:50-94: `--key value` / `--key=value` / bare boolean flags land in every section that has the key, typed;
+    unknown keys are an error (the reference's argparse rejects them; a typo must not train the YAML's value)."""
+    from contrastors_amd.train import apply_overrides, parse_args, split_overrides
+
+    args, ov = parse_args(["--config", "x.yaml", "--dtype", "bfloat16", "--local_rank", "3", "--learning_rate", "1e-3",
+                           "--batch_size=64", "--gradient_checkpointing", "--seq_len", "512", "--weighted_sampling", "no",
+                           "--resid_pdrop", "0.1", "--checkpoint-keep-layers", "auto", "--num_train_steps", "7"])
+    assert args.config == "x.yaml" and args.dtype == "bfloat16" and args.local_rank == 3
+    assert ov == {"learning_rate": "1e-3", "batch_size": "64", "gradient_checkpointing": True, "seq_len": "512",
+                  "weighted_sampling": "no", "resid_pdrop": "0.1", "checkpoint_keep_layers": "auto", "num_train_steps": "7"}
+    cfg = apply_overrides(Config(train_args=TrainArgs()), ov)
+    assert cfg.train_args.learning_rate == 1e-3 and cfg.data_args.batch_size == 64 and cfg.model_args.seq_len == 512
+    assert cfg.model_args.gradient_checkpointing is True and cfg.data_args.weighted_sampling is False
+    assert cfg.model_args.resid_pdrop == 0.1 and cfg.train_args.checkpoint_keep_layers == "auto" and cfg.train_args.num_train_steps == 7
+    with pytest.raises(SystemExit):
+        apply_overrides(Config(train_args=TrainArgs()), {"learning_rte": "1"})
+    with pytest.raises(ValueError):
+        apply_overrides(Config(train_args=TrainArgs()), {"gradient_checkpointing": "maybe"})
+    with pytest.raises(SystemExit):
+        split_overrides(["stray"])
