@@ -1,6 +1,7 @@
 """Host logic that needs no GPU: the reference's own recipe YAML parses into our Config, validators, scheduler shape,
 varlen index construction, label arithmetic, synthetic batch contract."""
 from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -462,3 +463,26 @@ def test_train_cli_overrides():
         apply_overrides(Config(train_args=TrainArgs()), {"gradient_checkpointing": "maybe"})
     with pytest.raises(SystemExit):
         split_overrides(["stray"])
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_oracle_pooling_head_equals_the_reference_modules():
+    """oracle.encoder_ref.pool / the hamming LayerNorm / normalisation of `biencoder_embedding` against the reference's OWN
+    modules (sc/models/biencoder/modeling_biencoder.py:44-49 ClsSelector, :79-90 MeanPooling incl. its mask-free ViT branch,
+    :283 nn.LayerNorm(elementwise_affine=False), :317 F.normalize), imported by oracle/ref_import.load_biencoder()."""
+    from oracle import encoder_ref, ref_import
+
+    bi = ref_import.load_biencoder()
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(5, 9, 32, generator=g)
+    lens = torch.tensor([9, 1, 4, 7, 2])
+    mask = (torch.arange(9)[None] < lens[:, None]).long()
+    ids = torch.zeros(5, 9, dtype=torch.long)
+    assert torch.equal(encoder_ref.pool(h, mask, "cls"), bi.ClsSelector()(h, ids, mask))
+    torch.testing.assert_close(encoder_ref.pool(h, mask, "mean"), bi.MeanPooling()(h, ids, mask), rtol=0, atol=0)
+    torch.testing.assert_close(encoder_ref.pool(h, None, "mean"), bi.MeanPooling()(h, ids, None), rtol=0, atol=0)
+    e = encoder_ref.pool(h, mask, "mean")
+    ham = torch.nn.LayerNorm(32, elementwise_affine=False)
+    torch.testing.assert_close(torch.nn.functional.layer_norm(e, (32,)), ham(e), rtol=0, atol=0)
+    ls = bi.LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=True))
+    assert float(ls(torch.ones(1)).detach()) == pytest.approx(20.0, rel=1e-6) and ls.logit_scale.requires_grad
