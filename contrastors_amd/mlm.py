@@ -235,7 +235,7 @@ class MLMTrainer:
         loss.backward()
         model.fold_tied_grad()
         clip = ta.max_grad_norm is not None and ta.max_grad_norm > 0
-        fire = (self.step + 1) % self.accum == 0
+        fire = (self.step + 1) % self.accum == 0 or self.step == self.total_steps - 1   # (base.py:381: the run's last micro-step steps too)
         if fire:
             model.sync_gradients()  # DDP reduces on the micro-step that ends the window
         if clip and self.accum > 1 and self.step % self.accum == 0:
