@@ -486,3 +486,36 @@ def test_oracle_pooling_head_equals_the_reference_modules():
     torch.testing.assert_close(torch.nn.functional.layer_norm(e, (32,)), ham(e), rtol=0, atol=0)
     ls = bi.LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=True))
     assert float(ls(torch.ones(1)).detach()) == pytest.approx(20.0, rel=1e-6) and ls.logit_scale.requires_grad
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_rand_context_behaves_like_the_reference_class_on_the_cpu_generator():
+    """rand_state.RandContext against sc/rand_state.py:6-22 (the reference's own class, loaded from its file): numbers drawn
+    inside `with ctx:` replay the stream that followed the snapshot, and the outer stream continues afterwards as if the
+    block had not run; `needed=False` (dropout 0: the saving this port makes) leaves the generator alone entirely."""
+    import importlib.util
+
+    from contrastors_amd.rand_state import RandContext
+
+    spec = importlib.util.spec_from_file_location("ref_rand_state", str(REF_YAML.parents[2] / "rand_state.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    def run(cls, **kw):
+        torch.manual_seed(11)
+        chunk = {"input_ids": torch.zeros(2, 3, dtype=torch.long)}
+        torch.rand(3)                       # something before the snapshot
+        ctx = cls(chunk, **kw)
+        first = torch.rand(4)               # "pass 1" consumes numbers after the snapshot
+        between = torch.rand(2)             # ... and the program goes on
+        with ctx:
+            replay = torch.rand(4)          # "pass 2" under the snapshot
+        after = torch.rand(2)
+        return first, between, replay, after
+
+    a, b = run(ref.RandContext), run(RandContext)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(b[0], b[2])          # the replay IS pass 1's stream
+    off = run(RandContext, needed=False)
+    assert torch.equal(off[0], a[0]) and not torch.equal(off[2], off[0])   # no snapshot, no replay: the stream just continues
