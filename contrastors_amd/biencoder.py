@@ -73,6 +73,18 @@ def _default_trunk_config(name: str) -> NomicBertConfig:
     raise ValueError(f"no offline architecture table entry for {name!r}; pass BiEncoderConfig.trunk_config")
 
 
+def config_json(config: "BiEncoderConfig", trunk_config) -> dict:
+    """What save_pretrained writes as config.json: the reference's BiEncoderConfig fields under their own names (its
+    PretrainedConfig.from_pretrained reads them back: tests/test_host_cpu.py), plus the explicit trunk architecture this
+    build needs because it cannot ask a hub for it."""
+    import dataclasses
+
+    cfg = {k: v for k, v in dataclasses.asdict(config).items() if k != "trunk_config"}
+    cfg["trunk_config"] = dataclasses.asdict(trunk_config)
+    cfg["trunk_type"] = type(trunk_config).__name__
+    return cfg
+
+
 def trunk_config_with_overrides(config: BiEncoderConfig, trunk_cfg):
     """The architecture the tower is built with: the named / given trunk configuration with the overrides the reference's
     BiEncoder applies on top (modeling_biencoder.py:222-240: `resid_pdrop` of a text trunk)."""
@@ -227,11 +239,8 @@ class BiEncoder(torch.nn.Module):
         if self.selector is not None:
             sd.update({f"selector.{k}": v.detach().cpu().contiguous() for k, v in self.selector.state_dict().items()})
         save_file(sd, os.path.join(output_dir, "model.safetensors"))
-        cfg = {k: v for k, v in dataclasses.asdict(self.config).items() if k != "trunk_config"}
-        cfg["trunk_config"] = dataclasses.asdict(self.trunk.config)
-        cfg["trunk_type"] = type(self.trunk.config).__name__
         with open(os.path.join(output_dir, "config.json"), "w") as f:
-            json.dump(cfg, f, indent=1)
+            json.dump(config_json(self.config, self.trunk.config), f, indent=1)
 
     def load_pretrained(self, model_path: str, strict: bool = True):
         import os

@@ -519,3 +519,27 @@ def test_rand_context_behaves_like_the_reference_class_on_the_cpu_generator():
     assert torch.equal(b[0], b[2])          # the replay IS pass 1's stream
     off = run(RandContext, needed=False)
     assert torch.equal(off[0], a[0]) and not torch.equal(off[2], off[0])   # no snapshot, no replay: the stream just continues
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_saved_config_json_loads_with_the_reference_biencoder_config(tmp_path):
+    """BiEncoder.save_pretrained's config.json through the reference's own BiEncoderConfig.from_pretrained
+    (sc/models/biencoder/configuration_biencoder.py:4-31; what sc/trainers/text_text.py:148-159 does with `checkpoint:`)."""
+    import importlib.util
+    import json
+
+    from contrastors_amd.biencoder import BiEncoderConfig, config_json
+    from contrastors_amd.nomic_bert import NomicBertConfig
+
+    spec = importlib.util.spec_from_file_location(
+        "ref_bi_cfg", str(REF_YAML.parents[2] / "models" / "biencoder" / "configuration_biencoder.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    ours = BiEncoderConfig(model_name="nomic-ai/nomic-bert-2048", pooling="mean", logit_scale=50.0, hamming=True,
+                           gradient_checkpointing=True, projection_dim=256, nomic_encoder=True, trainable_logit_scale=True)
+    (tmp_path / "config.json").write_text(json.dumps(config_json(ours, NomicBertConfig.nomic_bert_2048())))
+    got = ref.BiEncoderConfig.from_pretrained(str(tmp_path))
+    for k in ("model_name", "pooling", "logit_scale", "hamming", "gradient_checkpointing", "projection_dim", "nomic_encoder",
+              "trainable_logit_scale", "freeze", "pretrained", "use_fused_kernels"):
+        assert getattr(got, k) == getattr(ours, k), k
+    assert got.trunk_config["n_layer"] == 12 and got.trunk_type == "NomicBertConfig"
