@@ -224,7 +224,9 @@ def leg_cfg1(torch, dev, steps):
     return {"workload": "configs[0]: bert-base-uncased bi-encoder, paired InfoNCE, B = 32, S = 64, direct step (HIP path)",
             "value": B / (med * 1e-3), "unit": "pairs/s", "ms_per_step": med, "p10_ms": _pct(ms, 0.1), "p90_ms": _pct(ms, 0.9),
             "steps": len(ms), "frac_of_mfma_peak": flop / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-            "note": "2048 token rows per GEMM launch: far below one round of 256 x 256 tiles on 256 CUs"}
+            "note": "2048 token rows per GEMM launch: far below one round of 256 x 256 tiles on 256 CUs; the tower is the "
+                    "BERT-base ARCHITECTURE with dropout 0 (a reference run on the hub model trains it with p = 0.1, "
+                    "sc/models/encoder/bert.py:19-21: NomicBertConfig.bert_base_uncased(hf_dropout=True))"}
 
 
 def _selective(rec):
@@ -352,7 +354,8 @@ def leg_image_text(torch, dev, steps, clip: bool, keep=0):
            "roofline": {"bound": "mfma", "achieved": flop / (med * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": flop / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                         "note": "algorithmic encoder FLOPs: image 35.1 GFLOP x " + ("3" if clip else "1 (frozen)") +
-                                ", text 13.4 GFLOP x 3 per pair"},
+                                ", text 13.4 GFLOP x 3 per pair; towers run without dropout (the reference's hub-config "
+                                "conversion gives the BERT-base text tower p = 0.1)"},
            "loss_forward": {"ms": loss_fwd_ms, "flop": loss_flop, "achieved": loss_flop / (loss_fwd_ms * 1e-3) / 1e12,
                             "peak": PEAK_FP8_TFLOPS if clip else 157.3, "unit": "TFLOP/s",
                             "frac": loss_flop / (loss_fwd_ms * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if clip else 157.3),

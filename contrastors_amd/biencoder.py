@@ -67,7 +67,9 @@ def _default_trunk_config(name: str) -> NomicBertConfig:
     if "nomic" in name:
         return NomicBertConfig.nomic_bert_2048()
     if "bert-base" in name:
-        return NomicBertConfig.bert_base_uncased()
+        # a recipe that names the model gets what the reference builds from its hub config: dropout 0.1 included
+        # (sc/models/encoder/bert.py:19-21); an explicit BiEncoderConfig.trunk_config is taken as given
+        return NomicBertConfig.bert_base_uncased(hf_dropout=True)
     if "vit-base-patch16-224" in name or "vit_base_patch16_224" in name:
         return ViTConfig.vit_base_patch16_224()
     raise ValueError(f"no offline architecture table entry for {name!r}; pass BiEncoderConfig.trunk_config")

@@ -90,10 +90,17 @@ class NomicBertConfig:
         return cls(**kw)
 
     @classmethod
-    def bert_base_uncased(cls, **kw) -> "NomicBertConfig":
-        """cfg 1: bert_config_to_nomic_config of the standard HF BertConfig (sc/models/encoder/bert.py:11-50)."""
+    def bert_base_uncased(cls, hf_dropout: bool = False, **kw) -> "NomicBertConfig":
+        """cfg 1: bert_config_to_nomic_config of the standard HF BertConfig (sc/models/encoder/bert.py:11-50).
+        `hf_dropout`: that conversion carries BertConfig's hidden_dropout_prob / attention_probs_dropout_prob = 0.1 into
+        resid_pdrop / embd_pdrop / attn_pdrop (bert.py:19-21), so a reference run on bert-base-uncased TRAINS WITH DROPOUT
+        0.1; True reproduces that (what a recipe naming the model gets, biencoder._default_trunk_config), False is the
+        architecture alone (parity tests against the oracle, throughput legs; pinned to the reference function in
+        tests/test_host_cpu.py)."""
         base = dict(vocab_size=30522, n_positions=512, max_position_embeddings=512, activation_function="gelu",
                     rotary_emb_fraction=0.0, qkv_proj_bias=True, mlp_fc1_bias=True, mlp_fc2_bias=True)
+        if hf_dropout:
+            base.update(resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.1)
         base.update(kw)
         return cls(**base)
 

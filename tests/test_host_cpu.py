@@ -543,3 +543,40 @@ def test_saved_config_json_loads_with_the_reference_biencoder_config(tmp_path):
               "trainable_logit_scale", "freeze", "pretrained", "use_fused_kernels"):
         assert getattr(got, k) == getattr(ours, k), k
     assert got.trunk_config["n_layer"] == 12 and got.trunk_type == "NomicBertConfig"
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_bert_base_architecture_equals_the_reference_conversion_of_the_hf_config():
+    """NomicBertConfig.bert_base_uncased(hf_dropout=True) against sc/models/encoder/bert.py:11-50 bert_config_to_nomic_config
+    applied to transformers.BertConfig() (= bert-base-uncased's hub config): every field the engine reads, the dropout
+    probabilities 0.1 the conversion carries over included; without the flag only those three differ."""
+    import dataclasses
+    import importlib.util
+    import sys
+    import types
+
+    transformers = pytest.importorskip("transformers")
+    from contrastors_amd.biencoder import _default_trunk_config
+    from contrastors_amd.nomic_bert import NomicBertConfig
+
+    enc = REF_YAML.parents[2] / "models" / "encoder"
+    pkg = types.ModuleType("ref_enc_pkg")
+    pkg.__path__ = [str(enc)]
+    sys.modules["ref_enc_pkg"] = pkg
+    mods = {}
+    for n in ("configuration_nomic_bert", "bert"):
+        spec = importlib.util.spec_from_file_location(f"ref_enc_pkg.{n}", str(enc / f"{n}.py"))
+        mods[n] = importlib.util.module_from_spec(spec)
+        sys.modules[f"ref_enc_pkg.{n}"] = mods[n]
+        spec.loader.exec_module(mods[n])
+    ref = mods["bert"].bert_config_to_nomic_config(transformers.BertConfig())
+    ours = NomicBertConfig.bert_base_uncased(hf_dropout=True)
+    skip = {"rotary_emb_base", "max_position_embeddings", "rotary_scaling_factor", "max_trained_positions"}  # (no rotary in BERT)
+    diff = {f.name for f in dataclasses.fields(ours) if f.name not in skip and hasattr(ref, f.name)
+            and getattr(ref, f.name) != getattr(ours, f.name)}
+    assert diff == set(), diff
+    assert (ours.resid_pdrop, ours.embd_pdrop, ours.attn_pdrop) == (0.1, 0.1, 0.1)
+    plain = NomicBertConfig.bert_base_uncased()
+    assert {f.name for f in dataclasses.fields(plain) if getattr(plain, f.name) != getattr(ours, f.name)} == {
+        "resid_pdrop", "embd_pdrop", "attn_pdrop"}
+    assert _default_trunk_config("bert-base-uncased") == ours
