@@ -580,3 +580,28 @@ def test_bert_base_architecture_equals_the_reference_conversion_of_the_hf_config
     assert {f.name for f in dataclasses.fields(plain) if getattr(plain, f.name) != getattr(ours, f.name)} == {
         "resid_pdrop", "embd_pdrop", "attn_pdrop"}
     assert _default_trunk_config("bert-base-uncased") == ours
+
+
+@pytest.mark.skipif(not REF_YAML.exists(), reason="reference tree only exists in the build container")
+def test_vit_architectures_equal_the_reference_conversions_of_the_hf_configs():
+    """ViTConfig.vit_base_patch16_224() against sc/models/vit/hf_vit.py:9-53 applied to transformers.ViTConfig()
+    (google/vit-base-patch16-224) and ViTConfig.clip_vit_base_patch16() against sc/models/vit/clip.py:9-55 applied to the
+    vision half of transformers.CLIPConfig with patch 16 (openai/clip-vit-base-patch16): every field of ours, equal."""
+    import dataclasses
+    import importlib.util
+
+    transformers = pytest.importorskip("transformers")
+    from contrastors_amd.vit import ViTConfig
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(f"ref_vit_{name}", str(REF_YAML.parents[2] / "models" / "vit" / f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    for ours, ref in ((ViTConfig.vit_base_patch16_224(), load("hf_vit").hf_vit_config_to_vit_config(transformers.ViTConfig())),
+                      (ViTConfig.clip_vit_base_patch16(),
+                       load("clip").clip_config_to_vit_config(transformers.CLIPConfig(vision_config={"patch_size": 16})))):
+        diff = {f.name: (getattr(ref, f.name, "<absent>"), getattr(ours, f.name)) for f in dataclasses.fields(ours)
+                if getattr(ref, f.name, "<absent>") != getattr(ours, f.name)}
+        assert diff == {}, diff
