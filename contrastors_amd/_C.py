@@ -172,6 +172,12 @@ _DEV_SIGS = {
     "cx_gemm_set_trace": (None, [vp]),
     "cx_gemm_v6_ablate": (None, [i32]),
     "cx_gemm_v6_trace": (None, [vp]),
+    "cx_gemm_v7_mode": (None, [i32]),
+    "cx_gemm_v7_trace": (None, [vp]),
+    "cx_gemm_v7_occupancy": (i32, []),
+    "cx_gemm_v7_ablate": (None, [i32]),
+    "cx_gemm_v7_flags": (None, [i32]),
+    "cx_gemm_v7_period": (None, [i32]),
     "cx_gemm_set_glds": (None, [i32]),
     "cx_gemm_get_glds": (i32, []),
     "cx_attn_set_bwd_s128": (None, [i32]),

@@ -82,8 +82,9 @@ def build(verbose: bool = False, dev: bool = True) -> Path:
     if dev:
         jobs += [(s, False) for s in srcs if s.name not in PRODUCT_ONLY]
     v6 = CSRC / "gemm_bf16_v6.hip"
+    v7 = CSRC / "gemm_bf16_v7.hip"
     audit_needed = [prod for prod in ((True, False) if dev else (True,))
-                    if _stale(OBJDIR / ("product" if prod else "dev") / "gemm_bf16_v6.o", [v6, CSRC / "gemm_v6_acc.inc", Path(__file__)])]
+                    if _stale(OBJDIR / ("product" if prod else "dev") / "gemm_bf16_v6.o", [v6, v7, CSRC / "gemm_v6_acc.inc", Path(__file__)])]
     with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         audits = [ex.submit(_audit_v6, prod) for prod in audit_needed]
         objs = list(ex.map(lambda j: _compile(*j), jobs))

@@ -645,6 +645,12 @@ extern "C" {
 void cx_gemm_set_trace(void* buf) { cx_gemm_v5_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_v6_trace(void* buf) { cx_gemm_v6_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_v6_ablate(int mask) { cx_gemm_v6_set_ablate(mask); }
+void cx_gemm_v7_mode(int mode) { cx_gemm_v7_set_mode(mode); }
+void cx_gemm_v7_trace(void* buf) { cx_gemm_v7_set_trace(static_cast<long long*>(buf)); }
+int cx_gemm_v7_occupancy(void) { return cx_gemm_v7_occupancy_query(); }
+void cx_gemm_v7_ablate(int mask) { cx_gemm_v7_set_ablate(mask); }
+void cx_gemm_v7_flags(int f) { cx_gemm_v7_set_flags(f); }
+void cx_gemm_v7_period(int cycles) { cx_gemm_v7_set_period(cycles); }
 void cx_gemm_set_debug(int d) {
     g_dbg = d;
     cx_gemm_v5_set_persistent((d & 4) == 0);

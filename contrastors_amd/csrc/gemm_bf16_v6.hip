@@ -1207,6 +1207,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
+// Routing between this kernel and the two-workgroups-per-CU kernel (gemm_bf16_v7.hip).  CX_V7_POLICY (build-time, for whole-
+// step A/B builds through CX_EXTRA_HIPCC_FLAGS): 0 = never, 1 = the shipped policy below, 2 = every launch v7 covers.
+#ifndef CX_V7_POLICY
+#define CX_V7_POLICY 0   // round 4 A/B (profiles/r4_gemm_v7_*.txt): v7 ties v6 on the SwiGLU-backward launch and loses 6-36 % elsewhere
+#endif
+#ifndef CX_PRODUCT
+int g_v7_mode = -1;            // cx_gemm_v7_set_mode: -1 = CX_V7_POLICY, 0 = never, 1 = every launch v7 covers
+#else
+constexpr int g_v7_mode = -1;
+#endif
+bool v7_takes(const GemmParams& p, int epi) {
+    const int mode = g_v7_mode >= 0 ? (g_v7_mode ? 2 : 0) : CX_V7_POLICY;
+    if (mode == 0 || !cx_gemm_v7_covers(p, epi)) return false;
+    if (mode == 2) return true;
+    // shipped policy: the launches whose epilogue stream v6's lone wave cannot hide behind its own main loop
+    if (p.M < 4096) return false;                        // few tiles: v6's 256 workgroups fill the chip better than 512 half-tiles
+    if (epi == GEMM_EPI_SWIGLU_BWD_AG) return p.K <= 1024;
+    if (epi == GEMM_EPI_SWIGLU_G) return p.K <= 1024;
+    return p.K <= 1024;                                  // plain / residual: short-K only (the epilogue is a quarter of a K = 768 tile)
+}
+
 #ifndef CX_PRODUCT
 int g_v6_dbg = 0;              // ablation mask (cx_gemm_v6_ablate)
 long long* g_v6_trace = nullptr;  // ablation builds only: 2 x int64 per workgroup {cycles, K-tiles}
@@ -1241,6 +1262,7 @@ int cx_gemm_v6_groups(int tiles_m, int tiles_n, int K) {
 void cx_gemm_v6_set_trace(long long* buf) { g_v6_trace = buf; }
 void cx_gemm_v6_set_ablate(int mask) { g_v6_dbg = mask; }
 void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
+void cx_gemm_v7_set_mode(int mode) { g_v7_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
 #endif
 
 // TN wgrad form: p.X = dY (T, M), p.W = A (T, N), p.K = tokens, p.Out = fp32 partial slabs [split_k][M][ldo];
@@ -1256,6 +1278,7 @@ hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream) {
 
 // NT forms with bf16 output (plain / bias / alpha, or fused SwiGLU), K % 64 == 0, N % 8 == 0, split_k == 1.
 hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
+    if (v7_takes(p, epi)) return cx_launch_gemm_v7(p, epi, g_v6_force_gn, stream);
     p.tiles_m = (p.M + BM6 - 1) / BM6;
     p.tiles_n = (p.N + BN6 - 1) / BN6;
     if (p.tiles_n > 256) return hipErrorInvalidValue;  // tile ids are (tm << 8) | tn: N <= 65536

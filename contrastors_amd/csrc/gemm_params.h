@@ -36,6 +36,16 @@ void cx_gemm_v6_force_groups(int gn);
 void cx_gemm_v6_set_trace(long long* buf);
 void cx_gemm_v6_set_ablate(int mask);
 hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream);
+// gemm_bf16_v7.hip: two resident workgroups per CU, 256x128x64 tiles (plain / residual, SwiGLU with gate save, SwiGLU backward
+// from (act, gate)); cx_launch_gemm_v6 routes to it (policy there).  force_gn: 0 = heuristic XCD grid.
+bool cx_gemm_v7_covers(const GemmParams& p, int epi);
+hipError_t cx_launch_gemm_v7(GemmParams p, int epi, int force_gn, hipStream_t stream);
+void cx_gemm_v7_set_trace(long long* buf);   // dev: int64[grid][4] = {start, end, HW_ID, XCC_ID} per workgroup
+int cx_gemm_v7_occupancy_query(void);
+void cx_gemm_v7_set_ablate(int mask);
+void cx_gemm_v7_set_flags(int f);   // dev: bit 0 = K loop at s_setprio 1
+void cx_gemm_v7_set_period(int cycles);   // dev: tile period for the start stagger (-1 estimate, 0 off)
+void cx_gemm_v7_set_mode(int mode);   // dev library only: -1 = shipped policy, 0 = never, 1 = every launch v7 covers
 void cx_gemm_v5_set_persistent(bool on);
 void cx_gemm_v5_set_use_v6(bool on);
 bool cx_gemm_v5_get_use_v6(void);

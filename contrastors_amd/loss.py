@@ -421,10 +421,13 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
     if resident:
         q_out = d_out = None
         try:
+            # ONLY the forwards sit inside the try: they run before any collective, so a rank that falls back here issues
+            # exactly the collectives its peers issue (one gather + one reduce-scatter inside cache_loss, one gradient
+            # reduction).  An out-of-memory error inside cache_loss -- after gather_with_grad has run -- must propagate:
+            # retrying it on this rank alone would issue one more all-gather than the peers and hang or desynchronise
+            # the one-shot exchange's epochs.
             q_out = _resident_forward(tower1, q_chunks)
             d_out = _resident_forward(tower2, d_chunks)
-            q_cache, d_cache, loss = cache_loss(torch.cat([o.detach() for o in q_out]), torch.cat([o.detach() for o in d_out]),
-                                                logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
         except torch.OutOfMemoryError:
             # the estimate of resident_activations_fit was wrong (fragmentation, another tenant of the allocator): no
             # parameter gradient has been touched yet (the encoder backward starts below), so drop what pass 1 kept,
@@ -438,6 +441,13 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")
         else:
+            try:
+                q_cache, d_cache, loss = cache_loss(torch.cat([o.detach() for o in q_out]), torch.cat([o.detach() for o in d_out]),
+                                                    logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
+            except torch.OutOfMemoryError:
+                _release_resident(tower1, q_out)   # nothing leaks, and nothing is retried: the error is the caller's
+                _release_resident(tower2, d_out)
+                raise
             _resident_backward(tower1, q_out, q_cache.split(sizes_q), final=tower1 is not tower2 or not was_training2)
             _resident_backward(tower2, d_out, d_cache.split(sizes_d), final=True)
             del q_out, d_out

@@ -29,6 +29,22 @@ void cx_gemm_set_trace(void* buf);
 void cx_gemm_v6_ablate(int mask);
 void cx_gemm_v6_trace(void* buf);
 
+/* routing between the one-wave-per-SIMD kernel (gemm_bf16_v6.hip) and the two-workgroups-per-CU kernel
+   (gemm_bf16_v7.hip): -1 = the shipped policy (default), 0 = never v7, 1 = every launch v7 covers (A/B, parity tests) */
+void cx_gemm_v7_mode(int mode);
+/* residency census of the v7 kernel: buf = int64[grid][4] {s_memtime at entry, at exit, HW_REG_HW_ID, HW_REG_XCC_ID} per
+   workgroup (NULL = off); cx_gemm_v7_occupancy = the occupancy API's workgroups per CU at its LDS / register budget */
+void cx_gemm_v7_trace(void* buf);
+int cx_gemm_v7_occupancy(void);
+/* ablation instantiations of the v7 kernel (plain and SwiGLU-backward forms; mask bits: 1 no LDS-DMA in the K loop, 2 no
+   barrier, 4 no W fragment reads, 8 no MFMA, 16 no epilogue, 32 no X fragment reads, 64 no vmcnt waits; a mask that is not
+   instantiated runs the real kernel; results are garbage) */
+void cx_gemm_v7_ablate(int mask);
+void cx_gemm_v7_flags(int flags); /* experiments: bit 0 = the K loop runs at s_setprio 1, the epilogue at 0 */
+/* start stagger of the v7 kernel: tile period in shader cycles over which the workgroups' starts are spread (-1 = the
+   launcher's estimate, 0 = no stagger: every workgroup starts at once) */
+void cx_gemm_v7_period(int cycles);
+
 void cx_gemm_set_glds(int enable); /* 1 (default): operand tiles via global_load_lds DMA; 0: register staging */
 int cx_gemm_get_glds(void);
 

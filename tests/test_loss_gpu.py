@@ -352,6 +352,23 @@ def test_resident_schedule_falls_back_to_two_pass_on_out_of_memory(monkeypatch, 
     with pytest.raises(torch.OutOfMemoryError):
         grad_cache_loss(tower, q, tower, d, 8, scale, policy=GradCachePolicy(chunk="exact", resident=True))
     assert tower.trunk._outstanding == 0
+    # an out-of-memory error INSIDE cache_loss (after gather_with_grad has run its collective) is not retried on this rank
+    # alone -- that would issue one more all-gather than the peers: it propagates, and nothing is leaked
+    monkeypatch.setattr(tower.trunk, "forward_chunk", real)
+    real_cache_loss = L_.cache_loss
+    seen = {"n": 0}
+
+    def oom_cache_loss(*a, **k):
+        seen["n"] += 1
+        raise torch.OutOfMemoryError("simulated: inside cache_loss")
+
+    monkeypatch.setattr(L_, "cache_loss", oom_cache_loss)
+    tower.trunk.zero_grad()
+    with pytest.raises(torch.OutOfMemoryError, match="inside cache_loss"):
+        grad_cache_loss(tower, q, tower, d, 8, scale, policy=GradCachePolicy(chunk="exact", resident="auto"))
+    assert seen["n"] == 1, "cache_loss (and its collectives) ran once, not once per schedule"
+    monkeypatch.setattr(L_, "cache_loss", real_cache_loss)
+    assert tower.trunk._outstanding == 0
     # the environment variable is an operator override on top of the config
     monkeypatch.setenv("CX_GRADCACHE_RESIDENT", "0")
     assert GradCachePolicy(resident=True).with_env().resident is False
