@@ -200,9 +200,11 @@ def _pct(sorted_ms, q):
     return sorted_ms[min(len(sorted_ms) - 1, max(0, int(round(q * (len(sorted_ms) - 1)))))]
 
 
-def leg_cfg1(torch, dev, steps):
+def leg_cfg1(torch, dev, steps, hf_dropout=True):
     """configs[0] on the HIP path (its CPU twin is cpu_baseline.cfg1_full_step): bert-base bi-encoder, B = 32, S = 64, direct
-    step.  M = 2048 token rows per GEMM launch: the launch-bound end of the design, reported so that it is on record."""
+    step.  M = 2048 token rows per GEMM launch: the launch-bound end of the design, reported so that it is on record.
+    hf_dropout = True (the record): the tower the reference trains -- its conversion of the hub config carries
+    hidden_dropout_prob = attention_probs_dropout_prob = 0.1 (sc/models/encoder/bert.py:19-21); False: the architecture alone."""
     from contrastors_amd.config import Config, DataArgs, ModelArgs, TrainArgs
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.trainers import TextTextTrainer
@@ -211,7 +213,8 @@ def leg_cfg1(torch, dev, steps):
                                       schedule_type="linear", max_grad_norm=1.0, clamp_logits=False),
                  data_args=DataArgs(batch_size=32, seed=3),
                  model_args=ModelArgs(logit_scale=50.0, pooling="mean", model_name="bert-base-uncased", seq_len=64))
-    tr = TextTextTrainer(cfg, torch.bfloat16, device=dev, trunk_config=NomicBertConfig.bert_base_uncased(), total_steps=1000)
+    tr = TextTextTrainer(cfg, torch.bfloat16, device=dev, trunk_config=NomicBertConfig.bert_base_uncased(hf_dropout=hf_dropout),
+                         total_steps=1000)
     g = torch.Generator().manual_seed(7)
     B, S = 32, 64
     batch = {}
@@ -224,9 +227,11 @@ def leg_cfg1(torch, dev, steps):
     return {"workload": "configs[0]: bert-base-uncased bi-encoder, paired InfoNCE, B = 32, S = 64, direct step (HIP path)",
             "value": B / (med * 1e-3), "unit": "pairs/s", "ms_per_step": med, "p10_ms": _pct(ms, 0.1), "p90_ms": _pct(ms, 0.9),
             "steps": len(ms), "frac_of_mfma_peak": flop / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-            "note": "2048 token rows per GEMM launch: far below one round of 256 x 256 tiles on 256 CUs; the tower is the "
-                    "BERT-base ARCHITECTURE with dropout 0 (a reference run on the hub model trains it with p = 0.1, "
-                    "sc/models/encoder/bert.py:19-21: NomicBertConfig.bert_base_uncased(hf_dropout=True))"}
+            "dropout": 0.1 if hf_dropout else 0.0,
+            "note": "2048 token rows per GEMM launch: far below one round of 256 x 256 tiles on 256 CUs; the tower is "
+                    + ("bert-base-uncased as the reference converts its hub config: residual, embedding and attention dropout 0.1 "
+                       "(sc/models/encoder/bert.py:19-21), Philox masks regenerated in backward"
+                       if hf_dropout else "the BERT-base ARCHITECTURE with dropout 0")}
 
 
 def _selective(rec):
@@ -263,7 +268,9 @@ def leg_cfg3(torch, dev, steps, keep=0):
         batch[f"{side}_input_ids"] = torch.randint(1000, 30522, (n, S), generator=g).to(dev)
         batch[f"{side}_seqlens"] = [S] * n
     torch.cuda.reset_peak_memory_stats(dev)
-    ms = _time_steps(torch, lambda: tr.training_step(batch), 1, max(2, min(steps, 5)))
+    # (selective checkpointing: step 1 takes the recipe literally and measures, step 2 rebuilds the arenas with their kept
+    # blocks -- both stay outside the timed window)
+    ms = _time_steps(torch, lambda: tr.training_step(batch), 3 if keep == "auto" else 1, max(2, min(steps, 5)))
     tokens = (nq + nd) * S
     fwd = tokens * 12 * _fwd_flop_per_token(768, 2 * 3072 + 3072, S)
     med = _pct(ms, 0.5)
@@ -281,7 +288,7 @@ def leg_cfg3(torch, dev, steps, keep=0):
             "kept_blocks": [{"arena_tokens": t, "kept": k, "of": 12} for t, k in sorted(tr.model["model"].trunk._keep_logged)]}
 
 
-def leg_image_text(torch, dev, steps, clip: bool, keep=0):
+def leg_image_text(torch, dev, steps, clip: bool, keep=0, hf_dropout=True):
     """configs[3] (LiT: frozen ViT-B/16 image tower, trainable BERT-base text tower) and configs[4] (CLIP: both trained, fp8
     similarity, global batch 32768) at the per-GPU shape of an 8-GPU job: 4096 (image, text) pairs, text seq 77.  On one GPU
     the other seven ranks' gathered embeddings are stand-ins (28672 random unit vectors), so the loss has its real
@@ -299,8 +306,10 @@ def leg_image_text(torch, dev, steps, clip: bool, keep=0):
                                     gradient_checkpointing=clip, checkpoint_keep_layers=keep,
                                     trunk_config=ViTConfig.vit_base_patch16_224()),
                     device=dev, seed=1).train()
+    # the text tower as the reference converts bert-base-uncased's hub config: dropout 0.1 on residuals, embeddings and
+    # attention probabilities (sc/models/encoder/bert.py:19-21); hf_dropout = False: the architecture alone (sub-record)
     txt = BiEncoder(BiEncoderConfig(model_name="bert-base-uncased", pooling="mean",
-                                    trunk_config=NomicBertConfig.bert_base_uncased()), device=dev, seed=2).train()
+                                    trunk_config=NomicBertConfig.bert_base_uncased(hf_dropout=hf_dropout)), device=dev, seed=2).train()
     scale = LogitScale(SimpleNamespace(logit_scale=1 / 0.07, trainable_logit_scale=False)).to(dev)
     towers = [txt] + ([vis] if clip else [])
     groups = [{"params": [], "weight_decay": 0.01}, {"params": [], "weight_decay": 0.0}]
@@ -337,7 +346,7 @@ def leg_image_text(torch, dev, steps, clip: bool, keep=0):
         return loss
 
     torch.cuda.reset_peak_memory_stats(dev)
-    ms = _time_steps(torch, step, 1, max(2, min(steps, 5)))
+    ms = _time_steps(torch, step, 3 if keep == "auto" else 1, max(2, min(steps, 5)))
     med = _pct(ms, 0.5)
     f_img = n * 197 * 12 * _fwd_flop_per_token(768, 2 * 3072, 197) + n * 196 * 2.0 * 768 * 768
     f_txt = n * S_t * 12 * _fwd_flop_per_token(768, 2 * 3072, S_t)
@@ -354,14 +363,15 @@ def leg_image_text(torch, dev, steps, clip: bool, keep=0):
            "roofline": {"bound": "mfma", "achieved": flop / (med * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": flop / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                         "note": "algorithmic encoder FLOPs: image 35.1 GFLOP x " + ("3" if clip else "1 (frozen)") +
-                                ", text 13.4 GFLOP x 3 per pair; towers run without dropout (the reference's hub-config "
-                                "conversion gives the BERT-base text tower p = 0.1)"},
+                                ", text 13.4 GFLOP x 3 per pair; text tower dropout " + ("0.1 (the reference's "
+                                "conversion of the hub config)" if hf_dropout else "0 (architecture only)")},
            "loss_forward": {"ms": loss_fwd_ms, "flop": loss_flop, "achieved": loss_flop / (loss_fwd_ms * 1e-3) / 1e12,
                             "peak": PEAK_FP8_TFLOPS if clip else 157.3, "unit": "TFLOP/s",
                             "frac": loss_flop / (loss_fwd_ms * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if clip else 157.3),
                             "kernel": "infonce_fp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4) + row quantisation" if clip else
                                       "sgemm_nt_kernel<LSE> (v_mfma_f32_32x32x2_f32, exact)",
                             "note": "both directions of the 4096 x 32768 x 768 similarity + online log-sum-exp"},
+           "text_tower_dropout": 0.1 if hf_dropout else 0.0,
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
     if clip:
         rec["checkpoint_keep_layers"] = keep
@@ -382,6 +392,21 @@ def run_config_legs(torch, dev, steps):
             out[name] = f"failed: {type(e).__name__}: {e}"[:300]
         gc.collect()
         torch.cuda.empty_cache()
+    # the three legs with a BERT-base tower once more with dropout 0 (rounds 1-3 reported only this; the records above are the
+    # reference's recipe): what the Philox masks cost
+    for name, fn in (("cfg1", lambda: leg_cfg1(torch, dev, steps, hf_dropout=False)),
+                     ("lit", lambda: leg_image_text(torch, dev, steps, clip=False, hf_dropout=False)),
+                     ("clip", lambda: leg_image_text(torch, dev, steps, clip=True, hf_dropout=False))):
+        if not isinstance(out.get(name), dict):
+            continue
+        try:
+            r = fn()
+            out[name]["dropout_0"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "p10_ms", "p90_ms", "steps") if k in r}
+            out[name]["dropout_0"]["frac_of_mfma_peak"] = r["roofline"]["frac"] if "roofline" in r else r.get("frac_of_mfma_peak")
+        except Exception as e:  # noqa: BLE001
+            out[name]["dropout_0"] = f"failed: {type(e).__name__}: {e}"[:300]
+        gc.collect()
+        torch.cuda.empty_cache()
     # the two legs whose recipes switch activation checkpointing on, once more with selective checkpointing ("auto")
     for name, fn in (("cfg3", lambda: leg_cfg3(torch, dev, steps, keep="auto")),
                      ("clip", lambda: leg_image_text(torch, dev, steps, clip=True, keep="auto"))):
@@ -394,6 +419,38 @@ def run_config_legs(torch, dev, steps):
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def flat_scalars(extra: dict) -> dict:
+    """The secondary records once more as flat scalar keys: the driver's `parsed` view of the JSON line keeps scalars, the
+    nested records only by name."""
+    f = {}
+
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d if isinstance(d, (int, float)) else None
+
+    for leg, unit_key in (("cfg1", "cfg1_pairs_s"), ("cfg3", "cfg3_query_examples_s"), ("lit", "lit_pairs_s_per_gpu"),
+                          ("clip", "clip_pairs_s_per_gpu")):
+        f[unit_key] = get(extra, leg, "value")
+        f[f"{leg}_frac"] = get(extra, leg, "roofline", "frac") if leg != "cfg1" else get(extra, leg, "frac_of_mfma_peak")
+        f[f"{leg}_ms_per_step"] = get(extra, leg, "ms_per_step")
+    for leg in ("cfg1", "lit", "clip"):
+        f[f"{leg}_dropout0_value"] = get(extra, leg, "dropout_0", "value")
+    for leg in ("cfg3", "clip"):
+        f[f"{leg}_selective_value"] = get(extra, leg, "selective_checkpointing", "value")
+        f[f"{leg}_selective_frac"] = get(extra, leg, "selective_checkpointing", "frac_of_mfma_peak")
+        f[f"{leg}_selective_p10_ms"] = get(extra, leg, "selective_checkpointing", "p10_ms")
+        f[f"{leg}_selective_p90_ms"] = get(extra, leg, "selective_checkpointing", "p90_ms")
+    f["fp8_loss_frac_of_fp8_peak"] = get(extra, "clip", "loss_forward", "frac")
+    f["weak_pairs_s"] = get(extra, "weak", "value")
+    f["resident_pairs_s"] = get(extra, "resident", "value")
+    f["dropin_chunk64_pairs_s"] = get(extra, "dropin_chunk64", "value")
+    f["exact_chunk64_pairs_s"] = get(extra, "dropin_chunk64", "exact_chunk64", "value")
+    return {k: v for k, v in f.items() if v is not None}
 
 
 
@@ -451,7 +508,9 @@ def main():
 
     if args.only_config_legs:   # (rocprofv3 of one secondary leg: scripts/gpu_r3_final.sh)
         want = set(args.only_config_legs.split(","))
-        fns = {"cfg1": lambda: leg_cfg1(torch, dev, args.steps), "cfg3": lambda: leg_cfg3(torch, dev, args.steps),
+        fns = {"cfg1": lambda: leg_cfg1(torch, dev, args.steps), "cfg1_nodrop": lambda: leg_cfg1(torch, dev, args.steps, hf_dropout=False),
+               "lit_nodrop": lambda: leg_image_text(torch, dev, args.steps, False, hf_dropout=False),
+               "cfg3": lambda: leg_cfg3(torch, dev, args.steps),
                "lit": lambda: leg_image_text(torch, dev, args.steps, False), "clip": lambda: leg_image_text(torch, dev, args.steps, True),
                "cfg3_selective": lambda: leg_cfg3(torch, dev, args.steps, keep="auto"),
                "clip_selective": lambda: leg_image_text(torch, dev, args.steps, True, keep="auto")}
@@ -647,7 +706,7 @@ def main():
         # passes of this same command line (scripts/gpu_round.sh PMC=1 -> scripts/pmc_traffic.py) when they were
         # collected at the same launch sizes (same GradCache chunk), else null.
         traffic, traffic_src = None, None
-        for name in ("r3_pmc_gemm_traffic.json", "r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
+        for name in ("r4_pmc_gemm_traffic.json", "r3_pmc_gemm_traffic.json", "r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
             try:
                 tj = json.load(open(ROOT / "profiles" / name))
                 if tj.get("grad_cache_chunk") == min(args.chunk_size, b):
@@ -683,6 +742,8 @@ def main():
                          "whole_step_frac_of_mfma_peak": pairs_per_s / world * GFLOP_PER_PAIR / 1e3 / PEAK_BF16_TFLOPS},
         }
         out.update(extra)
+        out.update(flat_scalars(extra))
+        out["whole_step_frac_of_mfma_peak"] = out["roofline"]["whole_step_frac_of_mfma_peak"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(S)
         print(json.dumps(out), flush=True)

@@ -174,6 +174,39 @@ CX_DEVICE float attn_keep1(const AttnParams& p, uint32_t unit, int q, int key) {
     return e == 0 ? k4[0] : e == 1 ? k4[1] : e == 2 ? k4[2] : k4[3];
 }
 
+// keep-scales of ONE key (`key`, this lane's) for the four consecutive queries q0 .. q0 + 3.  The lanes of a quad (lane & ~3)
+// hold the keys 4m .. 4m + 3 of one Philox key group: lane j = lane & 3 draws the four words of query q0 + j (keys 4m .. 4m + 3)
+// and the quad transposes the 4 x 4 block with DPP quad permutes: out[e] = word (key & 3) of the lane that drew query q0 + e.
+template <int E>
+CX_DEVICE float quad_bcast(float x) {   // lane (quad base + E)'s value in every lane of the quad (DPP quad_perm [E, E, E, E])
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), E * 0x55, 0xf, 0xf, true));
+}
+CX_DEVICE void quad_keep4(const AttnParams& p, uint32_t unit, int q0, int key, int lane, float (&out)[4]) {
+    float w[4];
+    attn_keep4(p, unit, q0 + (lane & 3), key & ~3, w);
+    const int j = key & 3;   // (= lane & 3: the lane's key is wave * 32 + (lane & 31))
+    // out[e] = word j of the lane that drew query q0 + e: the word index depends on the READER, so every word of lane e is
+    // broadcast and the reader picks its own
+#define CX_QK(e) (j == 0 ? quad_bcast<e>(w[0]) : j == 1 ? quad_bcast<e>(w[1]) : j == 2 ? quad_bcast<e>(w[2]) : quad_bcast<e>(w[3]))
+    {
+        const float a0 = quad_bcast<0>(w[0]), a1 = quad_bcast<0>(w[1]), a2 = quad_bcast<0>(w[2]), a3 = quad_bcast<0>(w[3]);
+        out[0] = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+    }
+    {
+        const float a0 = quad_bcast<1>(w[0]), a1 = quad_bcast<1>(w[1]), a2 = quad_bcast<1>(w[2]), a3 = quad_bcast<1>(w[3]);
+        out[1] = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+    }
+    {
+        const float a0 = quad_bcast<2>(w[0]), a1 = quad_bcast<2>(w[1]), a2 = quad_bcast<2>(w[2]), a3 = quad_bcast<2>(w[3]);
+        out[2] = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+    }
+    {
+        const float a0 = quad_bcast<3>(w[0]), a1 = quad_bcast<3>(w[1]), a2 = quad_bcast<3>(w[2]), a3 = quad_bcast<3>(w[3]);
+        out[3] = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+    }
+#undef CX_QK
+}
+
 // Where a (sequence, head) problem's rows live.  X = false: packed qkv, one set of lengths (self-attention).
 struct AttnView {
     const bf16_t *q, *k, *v;
@@ -1652,6 +1685,11 @@ constexpr int FUSED2_LDS = 16384 * 3 + 32768;  // 80 KiB
 #define CX_STAMP(i) do {} while (0)
 #endif
 
+// DROP: dP reaches P only through the kept entries -- dV = (P * keep / (1 - p))^T dO, dS = P * (dP * keep / (1 - p) - delta);
+// a lane holds ONE key and four consecutive queries per accumulator quad.  The four lanes of a key group (keys 4m .. 4m + 3)
+// would each draw the same four Philox words per query; instead lane j draws the word quadruple of query q0 + j and the 4 x 4
+// block is transposed across the quad with DPP (one Philox call per four mask values, as in the forward).
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams p, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
@@ -1779,12 +1817,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qrow);
                 const float4 d4 = *reinterpret_cast<const float4*>(dl_s + qrow);
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                float kq[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (DROP) kq[0] = 0.f, quad_keep4(p, (uint32_t)u, qrow, row, lane, kq);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
                     const float pv = row_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
-                    pr[r] = pv;
-                    ds[r] = pv * (a_dp[r] - dd[e]);
+                    if constexpr (DROP) {
+                        pr[r] = pv * kq[e];
+                        ds[r] = pv * (a_dp[r] * kq[e] - dd[e]);
+                    } else {
+                        pr[r] = pv;
+                        ds[r] = pv * (a_dp[r] - dd[e]);
+                    }
                 }
                 uint2 pk;  // dS[key = row][queries qrow .. qrow+3]
                 pk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
@@ -1882,6 +1927,11 @@ CX_DEVICE bf16x8_t v128_tr_frag(const char* tile, int d0, int kbase, int lane) {
     return u.v;
 }
 
+//  * DROP (attn_pdrop > 0, the reference's bert-base-uncased recipes: sc/models/encoder/bert.py:19-21 carries the hub config's
+//    attention_probs_dropout_prob = 0.1): O accumulates P * keep / (1 - p), the normaliser is the undropped row sum; the lane
+//    holds 4 consecutive keys of ONE query per accumulator quad = one Philox call (round 4; before, p > 0 fell to the general
+//    streaming kernels at 1.6 x the attention time).
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[16384 * 3];
     char* Qs = smem;
@@ -1975,6 +2025,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
             s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], sc2, -mxs));
             psum += s[kb][r];
         }
+    if constexpr (DROP) {
+        const int qi = wave * 32 + l31;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float k4[4];
+                attn_keep4(p, (uint32_t)(b * p.H + h), qi, kb * 32 + 8 * qd + 4 * hi, k4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[kb][4 * qd + e] *= k4[e];
+            }
+    }
     f32x16_t acc_o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -2051,7 +2113,7 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     }
 #endif
     if (max_seqlen <= 128) {  // one workgroup per (sequence, head) problem, single pass
-        hipLaunchKernelGGL(attn_fwd_s128v_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_fwd_s128v_kernel<false>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
         hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -2077,9 +2139,9 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
 #endif
     if (max_seqlen <= 128 && bwd_mode == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
         static CxLdsOptIn lds2;
-        if (!lds2.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel), FUSED2_LDS)) return CX_ERR_LAUNCH;
+        if (!lds2.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false>), FUSED2_LDS)) return CX_ERR_LAUNCH;
         const int n_units = B * H;
-        hipLaunchKernelGGL(attn_bwd_fused2_s128_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
+        hipLaunchKernelGGL(attn_bwd_fused2_s128_kernel<false>, dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
                            (hipStream_t)stream, p, B);
         return done();
     }
@@ -2134,8 +2196,10 @@ int cx_attn_varlen_bwd_prerotated(const uint16_t* dout, const uint16_t* qkv_rota
     return done();
 }
 
-// attention dropout > 0: the general kernels at every length (the S <= 128 single-pass kernels have no mask code: attn_pdrop is
-// 0 in every shipped recipe, and the hot path keeps its registers).
+// attention dropout > 0 (the reference's bert-base-uncased recipes train with attention_probs_dropout_prob = 0.1,
+// sc/models/encoder/bert.py:19-21): max_seqlen <= 128 runs the <DROP> instantiations of the single-pass forward and of the
+// fused persistent backward (round 4: separate instantiations, the p = 0 hot path keeps its registers), longer sequences the
+// general streaming kernels.
 int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
                                uint16_t* out, float* lse, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
                                unsigned long long seed, unsigned long long offset, unsigned int site, void* stream) {
@@ -2147,6 +2211,15 @@ int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, c
     p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = rot_cos; p.lsin = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
     p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
+#ifndef CX_PRODUCT
+    const bool single_pass = g_fwd_s128 != 0;   // (dev library: cx_attn_set_fwd_s128(0) keeps the general kernel for A/B)
+#else
+    constexpr bool single_pass = true;
+#endif
+    if (max_seqlen <= 128 && single_pass) {   // the single-pass kernel with the mask (round 4)
+        hipLaunchKernelGGL(attn_fwd_s128v_kernel<true>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+        return done();
+    }
     dim3 grid((max_seqlen + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return done();
@@ -2166,6 +2239,19 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
     p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
+#ifndef CX_PRODUCT
+    const bool fused = g_bwd_s128 != 0;         // (dev library: cx_attn_set_bwd_s128(0) keeps the general kernels for A/B)
+#else
+    constexpr bool fused = true;
+#endif
+    if (max_seqlen <= 128 && fused) {   // fused persistent kernel with the mask (delta inline: `delta` is not written)
+        static CxLdsOptIn lds2d;
+        if (!lds2d.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<true>), FUSED2_LDS)) return CX_ERR_LAUNCH;
+        const int n_units = B * H;
+        hipLaunchKernelGGL(attn_bwd_fused2_s128_kernel<true>, dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
+                           (hipStream_t)stream, p, B);
+        return done();
+    }
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;

@@ -16,11 +16,15 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--bwd-mode", type=int, default=None, help="cx_attn_set_bwd_s128 (dev library): 4 fused3 (default), 3 fused2, ...")
 ap.add_argument("--seqs", type=str, default="128,197,512,2048,8192")
 ap.add_argument("--max-seqlen-pad", type=int, default=0, help="pass max_seqlen = S + this to the forward (A/B: > 256 selects the streaming kernel for S = 197)")
+ap.add_argument("--pdrop", type=float, default=0.0, help="> 0: the attention-dropout entry points (cx_attn_varlen_dropout_fwd / _bwd)")
+ap.add_argument("--fwd-mode", type=int, default=None, help="cx_attn_set_fwd_s128 (dev library); with --pdrop: 0 = general kernel")
 ap.add_argument("--rotary", type=int, default=1, help="0: no rotation tables (image towers; what the engine passes for pre-rotated long sequences)")
 a = ap.parse_args()
 lib = _C.dev_lib()
 if a.bwd_mode is not None:
     lib.cx_attn_set_bwd_s128(a.bwd_mode)
+if a.fwd_mode is not None:
+    lib.cx_attn_set_fwd_s128(a.fwd_mode)
 s = torch.cuda.current_stream().cuda_stream
 H, D = a.heads, 64
 print("S      B     fwd us   fwd TF    bwd us   bwd TF   (FLOP: fwd 4*S*S*D per seq-head, bwd 2.5x)")
@@ -43,6 +47,11 @@ for S in [int(x) for x in a.seqs.split(",")]:
     bwd = lambda: lib.cx_attn_varlen_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(),
                                          cp, sp, delta.data_ptr(), dqkv.data_ptr(), B, H, T, S,
                                          0.125, s)
+    if a.pdrop > 0:
+        fwd = lambda: lib.cx_attn_varlen_dropout_fwd(qkv.data_ptr(), cu.data_ptr(), cp, sp, out.data_ptr(), lse.data_ptr(), B, H, T,
+                                                     S + a.max_seqlen_pad, 0.125, a.pdrop, 1234, 0, 0, s)
+        bwd = lambda: lib.cx_attn_varlen_dropout_bwd(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(), cp, sp,
+                                                     delta.data_ptr(), dqkv.data_ptr(), B, H, T, S, 0.125, a.pdrop, 1234, 0, 0, s)
     res = []
     for fn in (fwd, bwd):
         assert fn() == 0
