@@ -144,6 +144,7 @@ _SIGS = {
     "cx_xent_bwd": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i64, i64, f32, i64, vp]),
     "cx_grad_sq_norm": (i32, [vp, i64, vp, vp]),
     "cx_adamw_clip_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, f32, vp]),
+    "cx_ema_update": (i32, [vp, vp, i64, f32, vp]),
     "cx_infonce_ws_floats": (i64, [i32, i32]),
     "cx_infonce_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_infonce_bwd": (i32, [vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -133,9 +133,10 @@ class ModelArgs(BaseModel):
     # sc/config.py:187 -> NomicBertModel.from_pretrained(..., resid_pdrop=) (modeling_biencoder.py:237): residual dropout of a
     # PRETRAINED nomic text trunk (None = the checkpoint's own value); served by the engine's Philox dropout
     resid_pdrop: Optional[float] = None
+    ema: bool = False          # sc/config.py:179 + sc/trainers/base.py:387-391: an EMA copy of the weights, updated every step
+    ema_decay: float = 0.9999  # (this path's key: the reference leaves the weighting as a TODO)
     # keys of the reference schema this path does not serve: accepted at their inert defaults, refused otherwise (a recipe
     # that sets them must not train as if it had not)
-    ema: bool = False
     patch_dropout: float = 0.0
     num_experts: int = 0
 
@@ -145,8 +146,8 @@ class ModelArgs(BaseModel):
             raise ValueError(f"Model type {self.model_type} not found in model registry")
         if not self.logit_scale:   # sc/config.py:193-196: `scale or 1 / 0.07`
             self.logit_scale = 1 / 0.07
-        if self.ema:
-            raise ValueError("model_args.ema: an EMA copy of the weights (sc/trainers/base.py:387-391) is not served")
+        if not 0.0 <= self.ema_decay <= 1.0:
+            raise ValueError(f"model_args.ema_decay must be in [0, 1], got {self.ema_decay}")
         if self.patch_dropout and self.patch_dropout > 0:
             raise ValueError("model_args.patch_dropout > 0 (sc/layers/embedding.py:415-418) is not served by the image tower")
         if self.num_experts and self.num_experts > 0:

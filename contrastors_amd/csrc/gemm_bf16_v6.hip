@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 // Routing between this kernel and the two-workgroups-per-CU kernel (gemm_bf16_v7.hip).  CX_V7_POLICY (build-time, for whole-
 // step A/B builds through CX_EXTRA_HIPCC_FLAGS): 0 = never, 1 = the shipped policy below, 2 = every launch v7 covers.
 #ifndef CX_V7_POLICY
-#define CX_V7_POLICY 0   // round 4 A/B (profiles/r4_gemm_v7_*.txt): v7 ties v6 on the SwiGLU-backward launch and loses 6-36 % elsewhere
+#define CX_V7_POLICY 1
 #endif
 #ifndef CX_PRODUCT
 int g_v7_mode = -1;            // cx_gemm_v7_set_mode: -1 = CX_V7_POLICY, 0 = never, 1 = every launch v7 covers
@@ -1221,11 +1221,13 @@ bool v7_takes(const GemmParams& p, int epi) {
     const int mode = g_v7_mode >= 0 ? (g_v7_mode ? 2 : 0) : CX_V7_POLICY;
     if (mode == 0 || !cx_gemm_v7_covers(p, epi)) return false;
     if (mode == 2) return true;
-    // shipped policy: the launches whose epilogue stream v6's lone wave cannot hide behind its own main loop
-    if (p.M < 4096) return false;                        // few tiles: v6's 256 workgroups fill the chip better than 512 half-tiles
-    if (epi == GEMM_EPI_SWIGLU_BWD_AG) return p.K <= 1024;
-    if (epi == GEMM_EPI_SWIGLU_G) return p.K <= 1024;
-    return p.K <= 1024;                                  // plain / residual: short-K only (the epilogue is a quarter of a K = 768 tile)
+    // shipped policy (round 4 A/B, profiles/r4_gemm_v7_ab.txt, r4_gemm_v7_small.txt): v7's half-size tiles and two resident
+    // workgroups per CU win 7 - 37 % while the launch is at most ~1.5 rounds of v6's 256 x 256 tiles on 256 CUs (literal
+    // chunk_size 64: 8192 token rows; cfg 1: 2048) -- there a launch lasts as long as its slowest tile and half the CUs idle --
+    // and lose 1 - 36 % on the metric-sized launches (1.5 x the operand traffic per FLOP), fc1 + SwiGLU at every size measured.
+    if (epi == GEMM_EPI_SWIGLU_G) return false;
+    const long tiles256 = (long)((p.M + BM6 - 1) / BM6) * ((p.N + BN6 - 1) / BN6);
+    return tiles256 <= 400;
 }
 
 #ifndef CX_PRODUCT

@@ -62,6 +62,10 @@ __device__ __forceinline__ uint4 bld7(__amdgpu_buffer_rsrc_t r, uint32_t voff, u
     const v4u7 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, (CX_V7_NT & 2) ? 2 : 0);
     return make_uint4(t.x, t.y, t.z, t.w);
 }
+__device__ __forceinline__ float4 bldf7(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {   // (cached: the bias is re-read by every tile)
+    const v4u7 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
 __device__ __forceinline__ void bst7(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint4 v) {
     const v4u7 t = {v.x, v.y, v.z, v.w};
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, (CX_V7_NT & 1) ? 2 : 0);
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             // ablation: no epilogue
         } else if constexpr (EPI == GEMM_EPI_NONE) {
             // Out = bf16(acc) [+ residual, added in fp32 and rounded once more: the x0 + residual of dropout_add_layer_norm].
-            // alpha == 1 and no bias (the launcher sends everything else to v6).
+            // optional fp32 bias; alpha == 1 (the launcher sends everything else to v6).
             const bf16_t* resid = reinterpret_cast<const bf16_t*>(p.Out2);
             const __amdgpu_buffer_rsrc_t rs_out = rsrc7(reinterpret_cast<bf16_t*>(p.Out) + (size_t)m0 * p.ldo + n0, rows_here * (uint32_t)p.ldo * 2u);
             const uint32_t vo = ((uint32_t)lrow * (uint32_t)p.ldo + lch * 8) * 2u;
@@ -396,8 +400,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 v.z = pack_bf16x2(bf16lo_to_f32(v.z) + bf16lo_to_f32(r.z), bf16hi_to_f32(v.z) + bf16hi_to_f32(r.z));
                 v.w = pack_bf16x2(bf16lo_to_f32(v.w) + bf16lo_to_f32(r.w), bf16hi_to_f32(v.w) + bf16hi_to_f32(r.w));
             };
-            auto tile_epi = [&](auto with_resid) {
+            auto tile_epi = [&](auto with_resid, auto with_bias) {
                 constexpr bool RES = decltype(with_resid)::value;
+                constexpr bool BIAS = decltype(with_bias)::value;
+                // bias (fp32[N], FusedDense of the biased towers): added in fp32 before the bf16 rounding, as v6 does
+                const __amdgpu_buffer_rsrc_t rs_bias = rsrc7(BIAS ? p.bias + n0 : nullptr, BIAS ? (uint32_t)BN7 * 4u : 0u);
                 const __amdgpu_buffer_rsrc_t rs_res = rsrc7(RES ? resid + (size_t)m0 * p.ldo2 + n0 : nullptr, RES ? rows_here * (uint32_t)p.ldo2 * 2u : 0u);
                 const uint32_t vr = ((uint32_t)lrow * (uint32_t)p.ldo2 + lch * 8) * 2u;
                 const uint32_t sr = (uint32_t)p.ldo2 * 8u;
@@ -411,10 +418,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         uint2 pk[4];
+                        float4 bq[4] = {};
+                        if constexpr (BIAS) {   // columns a * 32 + 8 q + 4 hi .. + 3 of the tile
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) bq[q] = bldf7(rs_bias, (uint32_t)hi * 16u, (uint32_t)(a * 128 + q * 32));
+                        }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            pk[q].x = pack_bf16x2(acc[4 * b + a][4 * q], acc[4 * b + a][4 * q + 1]);
-                            pk[q].y = pack_bf16x2(acc[4 * b + a][4 * q + 2], acc[4 * b + a][4 * q + 3]);
+                            pk[q].x = pack_bf16x2(acc[4 * b + a][4 * q] + bq[q].x, acc[4 * b + a][4 * q + 1] + bq[q].y);
+                            pk[q].y = pack_bf16x2(acc[4 * b + a][4 * q + 2] + bq[q].z, acc[4 * b + a][4 * q + 3] + bq[q].w);
                         }
                         if (a == 0) { *reinterpret_cast<uint2*>(V7_CELL(0)) = pk[0]; *reinterpret_cast<uint2*>(V7_CELL(1)) = pk[1]; *reinterpret_cast<uint2*>(V7_CELL(2)) = pk[2]; *reinterpret_cast<uint2*>(V7_CELL(3)) = pk[3]; }
                         if (a == 1) { *reinterpret_cast<uint2*>(V7_CELL(4)) = pk[0]; *reinterpret_cast<uint2*>(V7_CELL(5)) = pk[1]; *reinterpret_cast<uint2*>(V7_CELL(6)) = pk[2]; *reinterpret_cast<uint2*>(V7_CELL(7)) = pk[3]; }
@@ -453,8 +465,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 one_pass(std::integral_constant<int, 1>{});
 #undef V7_RES_ROWS
             };
-            if (resid) tile_epi(std::true_type{});
-            else tile_epi(std::false_type{});
+            if (p.bias) {
+                if (resid) tile_epi(std::true_type{}, std::true_type{});
+                else tile_epi(std::false_type{}, std::true_type{});
+            } else {
+                if (resid) tile_epi(std::true_type{}, std::false_type{});
+                else tile_epi(std::false_type{}, std::false_type{});
+            }
         } else if constexpr (IS_SWIGLU) {
             // fc1 + SwiGLU: weight rows interleaved by 32, so the tile's 128 fused columns are [y0 | g0 | y1 | g1] = 64
             // activation columns (one 128-B line per row).  Act = silu(g) * y on the bf16-rounded y / g (what the standalone
@@ -700,11 +717,11 @@ int v7_groups(int tiles_m, int tiles_n, int K) {
 }  // namespace
 
 // Shapes the two-workgroups-per-CU kernel covers: N a multiple of 128, K of 64, 16-B aligned leading dimensions (checked by
-// the C entry points), alpha == 1 and no bias for the plain form.
+// the C entry points), alpha == 1 for the plain / bias / residual form.
 bool cx_gemm_v7_covers(const GemmParams& p, int epi) {
     if (epi != GEMM_EPI_NONE && epi != GEMM_EPI_SWIGLU_G && epi != GEMM_EPI_SWIGLU_BWD_AG) return false;
     if ((p.N % BN7) != 0 || (p.K % BK7) != 0 || p.K < 2 * BK7) return false;
-    if (epi == GEMM_EPI_NONE && (p.alpha != 1.f || p.bias != nullptr)) return false;
+    if (epi == GEMM_EPI_NONE && p.alpha != 1.f) return false;
     if ((p.N / BN7) > 256) return false;
     return true;
 }
@@ -729,7 +746,7 @@ static int v7_stagger_unit(const GemmParams& p, int epi) {
 #ifndef CX_PRODUCT
 static long long* g_v7_trace = nullptr;
 static int g_v7_dbg = 0;
-static int g_v7_flags = 0;
+static int g_v7_flags = 1;   // bit 0: K loop at s_setprio 1 (measured +1 .. 2.5 %, profiles/r4_gemm_v7_ab.txt)
 void cx_gemm_v7_set_flags(int f) { g_v7_flags = f; }
 void cx_gemm_v7_set_trace(long long* buf) { g_v7_trace = buf; }
 void cx_gemm_v7_set_ablate(int mask) { g_v7_dbg = mask; }
@@ -748,6 +765,7 @@ hipError_t cx_launch_gemm_v7(GemmParams p, int epi, int force_gn, hipStream_t st
     p.dbg = g_v7_flags;
 #else
     p.trace = nullptr;
+    p.dbg = 1;   // the K loop runs at s_setprio 1 (see the kernel)
 #endif
 #ifndef CX_PRODUCT
     if (g_v7_dbg) {   // ablation builds (scripts/gemm_v7_ablate.py): timing only

@@ -75,6 +75,23 @@ __global__ __launch_bounds__(256) void adamw_clip_step_kernel(float* __restrict_
     }
 }
 
+// ema = decay * ema + (1 - decay) * param over a flat fp32 buffer (sc/trainers/base.py:387-391: `self.model["ema"].update`)
+__global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float decay) {
+    const long n4 = n / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float w = 1.f - decay;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 e = reinterpret_cast<float4*>(ema)[i];
+        const float4 q = reinterpret_cast<const float4*>(p)[i];
+        e.x = decay * e.x + w * q.x; e.y = decay * e.y + w * q.y; e.z = decay * e.z + w * q.z; e.w = decay * e.w + w * q.w;
+        reinterpret_cast<float4*>(ema)[i] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        ema[i] = decay * ema[i] + w * p[i];
+    }
+}
+
 inline int grid_for(long n) {
     long blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -109,6 +126,14 @@ int cx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* e
     a.max_norm = max_norm;
     hipLaunchKernelGGL(adamw_clip_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, a, sq_norm);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
+
+int cx_ema_update(float* ema, const float* param, long n, float decay, void* stream) {
+    if (n <= 0) return CX_OK;
+    if (!ema || !param || !(decay >= 0.f) || decay > 1.f) return CX_ERR_ARG;
+    if (!aligned16(ema) || !aligned16(param)) return CX_ERR_SHAPE;
+    hipLaunchKernelGGL(ema_update_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, param, n, decay);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 

@@ -92,3 +92,43 @@ def configure_optimizer(modules: Iterable[torch.nn.Module], args, fused: bool = 
               {"params": no_decay, "weight_decay": 0.0, "lr": args.learning_rate}]
     cls = FusedAdamW if fused else torch.optim.AdamW
     return cls(groups, betas=(args.adam_beta1, args.adam_beta2), eps=args.eps)
+
+
+class EmaWeights:
+    """Exponential moving average of a set of fp32 parameter tensors (sc/trainers/base.py:387-391: the trainer calls
+    `self.model["ema"].update(model)` after every training step when an EMA model is configured).  The engines keep their
+    parameters in two flat buffers per tower, so the whole update is one `cx_ema_update` pass per buffer; shadows live in fp32
+    next to the masters.  `decay` is the per-update weight of the running average (the `beta` of ema_pytorch-style wrappers,
+    which is the API the reference's call assumes)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], decay: float = 0.9999):
+        if not 0.0 <= decay <= 1.0:
+            raise ValueError(f"ema decay must be in [0, 1], got {decay}")
+        self.decay = float(decay)
+        self.params = [p for p in params]
+        self.shadow = [p.detach().clone() for p in self.params]
+        self.num_updates = 0
+
+    @torch.no_grad()
+    def update(self, *_):
+        lib, stream = _C.lib(), _C.cur_stream()
+        for sh, p in zip(self.shadow, self.params):
+            if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0 and sh.data_ptr() % 16 == 0:
+                _C.check(lib.cx_ema_update(sh.data_ptr(), p.data_ptr(), p.numel(), self.decay, stream), "cx_ema_update")
+            else:   # (small head parameters that are not 16-byte aligned views)
+                sh.mul_(self.decay).add_(p.detach(), alpha=1.0 - self.decay)
+        self.num_updates += 1
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow": [s.detach().cpu() for s in self.shadow]}
+
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = float(sd["decay"]), int(sd["num_updates"])
+        for s, v in zip(self.shadow, sd["shadow"]):
+            s.copy_(v)
+
+    @torch.no_grad()
+    def copy_to(self, params: Optional[Iterable[torch.Tensor]] = None):
+        """Write the averaged weights into `params` (default: the tracked parameters themselves, e.g. before an export)."""
+        for s, p in zip(self.shadow, self.params if params is None else params):
+            p.copy_(s)

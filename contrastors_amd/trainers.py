@@ -96,15 +96,14 @@ def _load_initial_weights(model: BiEncoder, ma, explicit_arch: bool):
         "checkpoint at local weights, or set pretrained: false to train from a random init")
 
 
-def _check_accumulation(ta):
-    """The contrastive trainers take one optimizer step per batch, as every contrastive recipe of the reference does
-    (`gradient_accumulation_steps` is 1 or absent in configs/train/contrastive_*.yaml; the global batch is what GradCache is
-    for).  sc/trainers/base.py:366-393 would accumulate: say so instead of silently stepping every batch.  (The MLM trainer,
-    whose recipes do accumulate, implements the reference's micro-step schedule: mlm.py.)"""
+def _accumulation_steps(ta) -> int:
+    """gradient_accumulation_steps of the recipe (sc/trainers/base.py:366-393).  Every contrastive recipe of the reference
+    leaves it at 1 (the global batch is what GradCache is for); > 1 runs the reference's micro-step schedule below."""
     n = getattr(ta, "gradient_accumulation_steps", 1)
-    if n is not None and int(n) > 1:
-        raise NotImplementedError(f"gradient_accumulation_steps = {n}: the contrastive trainers step once per batch "
-                                  "(raise the batch size -- GradCache bounds the activations); the MLM trainer accumulates")
+    n = 1 if n is None else int(n)
+    if n < 1:
+        raise ValueError(f"gradient_accumulation_steps must be >= 1, got {n}")
+    return n
 
 
 class TextTextTrainer:
@@ -112,7 +111,7 @@ class TextTextTrainer:
                  total_steps: Optional[int] = None):
         if dtype != torch.bfloat16:
             raise NotImplementedError("the native path computes in bf16 with fp32 master weights (--dtype=bf16)")
-        _check_accumulation(config.train_args)
+        self.accum = _accumulation_steps(config.train_args)
         self.config = config
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.distributed = dist.is_available() and dist.is_initialized()
@@ -129,6 +128,19 @@ class TextTextTrainer:
         self.optimizer = self.get_optimizer(config)
         self.scheduler = self.get_scheduler(config, self.optimizer)
         self.step = 0
+        self._need_zero = True      # (gradient accumulation: the buffers are zeroed on the micro-step after an optimizer step)
+        # sc/trainers/base.py:387-391: an EMA copy of the weights, updated after every training step
+        if self._wants_ema(config):
+            from .optimizer import EmaWeights
+
+            self.model["ema"] = EmaWeights([p for g in self.optimizer.param_groups for p in g["params"]], self._ema_decay(config))
+            self.model["ema_gettr"] = lambda m: m
+
+    def _wants_ema(self, config) -> bool:
+        return bool(getattr(config.model_args, "ema", False)) if config.model_args is not None else False
+
+    def _ema_decay(self, config) -> float:
+        return float(config.model_args.ema_decay)
 
     def set_total_steps(self, total_steps: int):
         """The schedule horizon is baked into the LR lambda: derive it from the dataloader BEFORE training starts
@@ -230,16 +242,51 @@ class TextTextTrainer:
         self._sync_logit_scale_grad()
 
     # sc/trainers/base.py:366-393
-    def training_step(self, batch) -> torch.Tensor:
-        ta = self.config.train_args
-        model = self.model["model"]
-        model.trunk.zero_grad()
+    def _zero_grads(self):
+        self.model["model"].trunk.zero_grad()
         self.optimizer.zero_grad(set_to_none=False)
-        loss = self.forward_step(batch)
-        self.backward(loss)
-        self._clip_and_step()
-        self.scheduler.step()
-        model.trunk.sync_shadows()
+
+    def _after_optimizer_step(self):
+        self.model["model"].trunk.sync_shadows()
+
+    def _micro_step(self, batch):
+        """One call = one micro-batch (sc/trainers/base.py:366-393).  gradient_accumulation_steps == 1 (every shipped
+        contrastive recipe): zero, forward, backward, fused clip + AdamW, scheduler.  > 1: the reference's schedule with its
+        quirks kept -- `backward` sums the micro-batches' gradients (no averaging), the clip fires on micro-step
+        `step % accum == 0` (on whatever has been accumulated by then), optimizer and scheduler on `(step + 1) % accum == 0` or
+        on the run's last micro-step, gradients are zeroed right after the optimizer step.  Under data parallelism every
+        micro-step's reduction averages the whole gradient buffer: the part accumulated by earlier micro-steps is already
+        identical on every rank, so averaging it again leaves it unchanged -- the sum over micro-steps of the averaged
+        gradients, which is what DDP produces."""
+        ta = self.config.train_args
+        if self.accum == 1:
+            self._zero_grads()
+            out = self.forward_step(batch)
+            self.backward(out)
+            self._clip_and_step()
+            self.scheduler.step()
+            self._after_optimizer_step()
+        else:
+            if self._need_zero:
+                self._zero_grads()
+                self._need_zero = False
+            out = self.forward_step(batch)
+            self.backward(out)
+            clip = ta.max_grad_norm is not None and ta.max_grad_norm > 0
+            if clip and self.step % self.accum == 0:
+                params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+                torch.nn.utils.clip_grad_norm_(params, ta.max_grad_norm)
+            if (self.step + 1) % self.accum == 0 or self.step == self.total_steps - 1:
+                self.optimizer.step(max_grad_norm=None)
+                self.scheduler.step()
+                self._after_optimizer_step()
+                self._need_zero = True
+        if self.model.get("ema") is not None:   # (every micro-step, as the reference does)
+            self.model["ema"].update(self.model["ema_gettr"](self.model["model"]))
+        return out
+
+    def training_step(self, batch) -> torch.Tensor:
+        loss = self._micro_step(batch)
         self.step += 1
         if self.world > 1:
             check_exchange(sync=True)   # a peer that never signalled stops this step, not the next one
@@ -273,6 +320,8 @@ class TextTextTrainer:
             # travels in its own file
             torch.save(self.scheduler.state_dict(), os.path.join(output_dir, "scheduler.pt"))
             torch.save({"step": self.step}, os.path.join(output_dir, "trainer_state.pt"))
+            if self.model.get("ema") is not None:
+                torch.save(self.model["ema"].state_dict(), os.path.join(output_dir, "ema.pt"))
         torch.save({"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "random": random.getstate(),
                     "cuda": torch.cuda.get_rng_state_all()}, os.path.join(output_dir, f"random_states_{self.rank}.pt"))
         if self.world > 1:   # rank 0 wrote ~2 GB: nobody runs ahead into the next step's exchange meanwhile
@@ -300,6 +349,8 @@ class TextTextTrainer:
             self.scheduler.load_state_dict(sch)
             st = os.path.join(input_dir, "trainer_state.pt")
             self.step = int(torch.load(st)["step"]) if os.path.exists(st) else int(sch.get("last_epoch", 0))
+        if self.model.get("ema") is not None and os.path.exists(os.path.join(input_dir, "ema.pt")):
+            self.model["ema"].load_state_dict(torch.load(os.path.join(input_dir, "ema.pt")))
         rs = torch.load(os.path.join(input_dir, f"random_states_{self.rank}.pt"), weights_only=False)
         torch.set_rng_state(rs["torch"])
         np.random.set_state(rs["numpy"])
@@ -391,22 +442,29 @@ class ImageTextTrainer(TextTextTrainer):
             dist.all_reduce(ls.grad)
             ls.grad.div_(self.world)
 
-    # sc/trainers/base.py:366-393 + image_text.py:180-196 (logit clamp)
-    def training_step(self, batch) -> torch.Tensor:
-        ta = self.config.train_args
+    def _zero_grads(self):
         for t in self._trainable_towers():
             t.trunk.zero_grad()
         self.optimizer.zero_grad(set_to_none=False)
-        out = self.forward_step(batch)
-        self.backward(out)
-        self._clip_and_step()
-        self.scheduler.step()
+
+    def _after_optimizer_step(self):
         for t in self._trainable_towers():
             t.trunk.sync_shadows()
+        ta = self.config.train_args
         ls = self.model["model"].logit_scale.logit_scale
         if ta.clamp_logits and ls.requires_grad:
             with torch.no_grad():
                 ls.clamp_(0, float(np.log(ta.logit_max)))
+
+    def _wants_ema(self, config) -> bool:
+        return any(bool(getattr(ma, "ema", False)) for ma in (config.text_model_args, config.vision_model_args) if ma is not None)
+
+    def _ema_decay(self, config) -> float:
+        return float((config.vision_model_args or config.text_model_args).ema_decay)
+
+    # sc/trainers/base.py:366-393 + image_text.py:180-196 (logit clamp)
+    def training_step(self, batch) -> torch.Tensor:
+        out = self._micro_step(batch)
         self.step += 1
         if self.world > 1:
             check_exchange(sync=True)

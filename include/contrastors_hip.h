@@ -510,6 +510,9 @@ int cx_grad_sq_norm(const float* grad, long n, double* sq_norm_accum, void* stre
 int cx_adamw_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, long step, const double* sq_norm, float max_norm,
                        void* stream);
+/* EMA copy of the weights (sc/trainers/base.py:387-391 `self.model["ema"].update(model)`): ema = decay * ema + (1 - decay) *
+ * param over a flat fp32 buffer, one pass; 16-B aligned, 0 <= decay <= 1. */
+int cx_ema_update(float* ema, const float* param, long n, float decay, void* stream);
 
 
 /* ---- one-shot exchange over xGMI (sc/distributed.py:5-12 gather_with_grad): receive buffers shared between the

