@@ -182,6 +182,7 @@ _DEV_SIGS = {
     "cx_gemm_set_glds": (None, [i32]),
     "cx_gemm_get_glds": (i32, []),
     "cx_attn_set_bwd_s128": (None, [i32]),
+    "cx_attn_set_prio": (None, [i32]),
     "cx_attn_set_fwd_s128": (None, [i32]),
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),

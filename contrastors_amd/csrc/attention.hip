@@ -160,6 +160,7 @@ struct AttnParams {
     // forward, dQ and dK/dV kernels (and a GradCache re-forward under RandContext) regenerate it, nothing is stored.
     CxDropout drop;
     uint32_t drop_site;
+    int prio;   // experiments (dev library, cx_attn_set_prio): 1 = MFMA loops of the S <= 128 backward run at s_setprio 1
 };
 
 // keep-scale (0 or 1 / (1 - p)) of P[q][key .. key + 3] of problem `unit` = b * H + h; key % 4 == 0
@@ -1689,7 +1690,12 @@ constexpr int FUSED2_LDS = 16384 * 3 + 32768;  // 80 KiB
 // a lane holds ONE key and four consecutive queries per accumulator quad.  The four lanes of a key group (keys 4m .. 4m + 3)
 // would each draw the same four Philox words per query; instead lane j draws the word quadruple of query q0 + j and the 4 x 4
 // block is transposed across the quad with DPP (one Philox call per four mask values, as in the forward).
-template <bool DROP>
+// PIPE (round 4): the NEXT problem's rows (Q, K, V, dO, O, rotation table, lse) are requested after the dQ products, ahead of the
+// dQ store phase, into the registers the current problem no longer needs: their flight overlaps the store phase, the barrier
+// and the loop overhead instead of starting behind the stores (one in-order vmcnt: a load issued after a store cannot be
+// waited for without waiting for the store).  s_setprio 1 around the S / dP / dV / dK loop: the SIMD's other wave belongs to
+// the CU's other workgroup and is usually in a load / store phase.
+template <bool DROP, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams p, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
@@ -1724,7 +1730,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
     long long* tr = reinterpret_cast<long long*>(p.delta);
     int it = -1;
 #endif
+    RowPairLoads qo, ko, vo, dOo, oo;   // (PIPE only: loop-carried; the serial form keeps its loads inside the loop body)
+    CosSin cso;
+    float lseo = 0.f;
+    // every global load of problem `un` (skipping empty sequences); returns the unit it loaded, or n_units when there is none
+    auto request = [&](int un, RowPairLoads& q, RowPairLoads& k, RowPairLoads& v, RowPairLoads& dO, RowPairLoads& o, CosSin& cs,
+                       float& lse_v) {
+        for (; un < n_units; un += gridDim.x) {
+            const int b = un / p.H;
+            if (p.cu[b + 1] - p.cu[b] > 0) break;
+        }
+        if (un >= n_units) return n_units;
+        const int b = un / p.H, h = un - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        int ra = 2 * kp, rb = ra + 1;
+        ra = ra < len ? ra : len - 1;
+        rb = rb < len ? rb : len - 1;
+        const bf16_t* qbase = p.qkv + (size_t)h * DH;
+        load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, k);
+        load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, v);
+        load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
+        load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dO);
+        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
+        if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
+        lse_v = 0.f;
+        if (tid < 128) {
+            const bool ok = tid < len;
+            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
+            lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
+        }
+        return un;
+    };
+    int u_next = n_units;
+    if constexpr (PIPE) u_next = request(blockIdx.x, qo, ko, vo, dOo, oo, cso, lseo);
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        if constexpr (PIPE) {
+            u = u_next;              // (the problem whose rows are in flight; empty sequences were skipped by `request`)
+            if (u >= n_units) break;
+        }
         const int b = u / p.H, h = u - b * p.H;
         const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
         if (len <= 0) continue;  // (uniform per workgroup)
@@ -1732,24 +1775,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         ++it;
 #endif
         CX_STAMP(0);
-        int ra = 2 * kp, rb = ra + 1;
-        ra = ra < len ? ra : len - 1;
-        rb = rb < len ? rb : len - 1;
-        const bf16_t* qbase = p.qkv + (size_t)h * DH;
-        RowPairLoads q, k, v, dO, o;
-        CosSin cs;
-        load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, k);
-        load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, v);
-        load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
-        load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dO);
-        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
-        if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
-        float lse_v = 0.f;
-        if (tid < 128) {
-            const bool ok = tid < len;
-            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
-            lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
+        RowPairLoads ql, kl, vl, dOl, ol;
+        CosSin csl;
+        float lsel = 0.f;
+        if constexpr (!PIPE) {   // (the serial form, exactly as it shipped in round 3: its register allocation is a fragile optimum)
+            int ra = 2 * kp, rb = ra + 1;
+            ra = ra < len ? ra : len - 1;
+            rb = rb < len ? rb : len - 1;
+            const bf16_t* qbase = p.qkv + (size_t)h * DH;
+            load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, kl);
+            load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, vl);
+            load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, ql);
+            load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dOl);
+            load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, ol);
+            if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
+            if (tid < 128) {
+                const bool ok = tid < len;
+                // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
+                lsel = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
+            }
         }
+        RowPairLoads &q = PIPE ? qo : ql, &k = PIPE ? ko : kl, &v = PIPE ? vo : vl, &dO = PIPE ? dOo : dOl, &o = PIPE ? oo : ol;
+        CosSin& cs = PIPE ? cso : csl;
+        const float lse_v = PIPE ? lseo : lsel;
         CX_STAMP(1);  // loads landed
         // ---- K, V row-major (for this wave's key fragments), then everything that depends on dO / O / Q ----
         if (p.cosv) rotate_pair(k, cs);
@@ -1778,7 +1826,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         }
         if (tid < 128) lse_s[tid] = lse_v;
 #if CX_ATTN_PF
-        if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
+        if constexpr (PIPE) {
+            if (u + 2 * (int)gridDim.x < n_units) l2_prefetch(u + 2 * gridDim.x);
+        } else {
+            if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
+        }
 #endif
         CX_STAMP(2);  // staged
         __syncthreads();
@@ -1800,6 +1852,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
+        if (PIPE || p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1  // (rolled: unrolling makes the compiler hoist ~100 loop-invariant LDS addresses and spill)
         for (int qb = 0; qb < 4; ++qb) {
             f32x16_t a_s, a_dp;
@@ -1846,6 +1899,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 }
             }
         }
+        if (PIPE || p.prio) __builtin_amdgcn_s_setprio(0);
         CX_STAMP(5);  // main loop
         __syncthreads();  // the dS tile is complete; lse / delta, Q^T and dO^T are dead: R2 becomes Kt
         CX_STAMP(6);  // barrier
@@ -1877,6 +1931,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 acc_dq[db] = mfma_bf16_32x32x16(sw_linear_frag(R2, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
         }
         CX_STAMP(10);  // dQ products
+        if constexpr (PIPE) u_next = request(u + gridDim.x, qo, ko, vo, dOo, oo, cso, lseo);   // q, k, v, dO, o, cs are dead: the next problem's rows fly under the dQ store
         store_unrotated_rows(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
                              len - wave * 32, acc_dq, p.scale, p.cosv, p.sinv, row_ok ? row : len - 1, hi, lane);
         CX_STAMP(11);  // dQ stored
@@ -2087,7 +2142,9 @@ int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 wo
 extern "C" {
 
 #ifndef CX_PRODUCT
-void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 3) ? mode : 3; }
+int g_attn_prio = 0;
+void cx_attn_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
+void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 4) ? mode : 3; }
 void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
 #endif
 
@@ -2133,10 +2190,19 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
 #ifndef CX_PRODUCT
+    p.prio = g_attn_prio;
     const int bwd_mode = g_bwd_s128;
 #else
     constexpr int bwd_mode = 3;
 #endif
+    if (max_seqlen <= 128 && bwd_mode == 4) {  // the same with the next problem's loads ahead of the dQ store (A/B; round 4)
+        static CxLdsOptIn lds2p;
+        if (!lds2p.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false, true>), FUSED2_LDS)) return CX_ERR_LAUNCH;
+        const int n_units = B * H;
+        hipLaunchKernelGGL((attn_bwd_fused2_s128_kernel<false, true>), dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
+                           (hipStream_t)stream, p, B);
+        return done();
+    }
     if (max_seqlen <= 128 && bwd_mode == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
         static CxLdsOptIn lds2;
         if (!lds2.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false>), FUSED2_LDS)) return CX_ERR_LAUNCH;

@@ -51,7 +51,8 @@ int cx_gemm_get_glds(void);
 /* backward kernel choice for max_seqlen <= 128: 3 = fused persistent kernel with an 80 KiB LDS layout, two workgroups
  * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
  * 0 = the general kernels */
-void cx_attn_set_bwd_s128(int mode);
+void cx_attn_set_bwd_s128(int mode);   /* 4 (round 4, A/B): mode 3 with the next problem's rows requested ahead of the dQ store */
+void cx_attn_set_prio(int on);         /* experiments: the MFMA loop of the fused S <= 128 backward at s_setprio 1 */
 
 /* forward kernel for max_seqlen <= 128: 2 (default) lean-VALU form with full-row output stores (V fragments through
  * the transposing LDS read, mask skipped for full sequences, scale folded into the exponent, output staged in LDS),
