@@ -63,7 +63,7 @@ class CxChunkBuffers(C.Structure):
             "h2", "mean2", "rstd2", "pool_norm", "g_a", "g_b", "g_c", "g_wide", "g_act", "tr_a", "tr_b", "delta",
             "ws_f32",
         )
-    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp), ("layer_events", C.POINTER(vp)), ("zpre", vp), ("ckpt_keep", i32)]
+    ] + [("ws_floats", i64)] + [(n, vp) for n in ("zf", "hf", "meanf", "rstdf", "patch_in", "patch_proj")] + [("checkpoint", i32), ("drop_active", i32), ("drop_seed", C.c_ulonglong), ("drop_offset", C.c_ulonglong), ("g_d", vp), ("layer_events", C.POINTER(vp)), ("zpre", vp), ("ckpt_keep", i32), ("patch_keep", vp), ("patch_inv", vp), ("n_keep", i32), ("n_patch_all", i32)]
 
 
 # name -> (restype, argtypes).  Keep in the order of include/contrastors_hip.h.
@@ -134,6 +134,9 @@ _SIGS = {
     "cx_vit_patchify": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "cx_vit_assemble_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "cx_vit_assemble_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cx_vit_patchify_gather": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "cx_vit_assemble_fwd_gather": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "cx_vit_assemble_bwd_gather": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
     "cx_vit_forward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, vp, i32, i32, i32, i32, i32,
                              i32, vp, vp]),
     "cx_vit_backward": (i32, [C.POINTER(CxEncoderDesc), C.POINTER(CxChunkBuffers), vp, i32, i32, vp, vp, vp]),

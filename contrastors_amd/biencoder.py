@@ -41,6 +41,9 @@ class BiEncoderConfig:
     checkpoint_keep_layers: Union[int, str] = "auto"
     # model_args.resid_pdrop (sc/config.py:187; modeling_biencoder.py:237 hands it to the nomic text trunk): None = as configured
     resid_pdrop: Optional[float] = None
+    # model_args.patch_dropout (sc/config.py:180; modeling_biencoder.py:174,187 sets it on the image trunk's config): fraction of
+    # the patch tokens an image tower drops per image in training
+    patch_dropout: float = 0.0
     encoder: bool = True
     seq_len: int = 2048
     trunk_config: Optional[object] = None  # NomicBertConfig or ViTConfig: no hub access, the architecture is explicit
@@ -95,6 +98,11 @@ def trunk_config_with_overrides(config: BiEncoderConfig, trunk_cfg):
         import dataclasses
 
         trunk_cfg = dataclasses.replace(trunk_cfg, resid_pdrop=float(rp))
+    pd = float(getattr(config, "patch_dropout", 0.0) or 0.0)
+    if pd > 0.0 and hasattr(trunk_cfg, "patch_dropout"):   # image towers only (modeling_biencoder.py:174,187)
+        import dataclasses
+
+        trunk_cfg = dataclasses.replace(trunk_cfg, patch_dropout=pd)
     return trunk_cfg
 
 

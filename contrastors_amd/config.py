@@ -135,9 +135,9 @@ class ModelArgs(BaseModel):
     resid_pdrop: Optional[float] = None
     ema: bool = False          # sc/config.py:179 + sc/trainers/base.py:387-391: an EMA copy of the weights, updated every step
     ema_decay: float = 0.9999  # (this path's key: the reference leaves the weighting as a TODO)
+    patch_dropout: float = 0.0   # sc/config.py:180 -> PatchEmbedding's PatchDropout (image towers; sc/layers/embedding.py:415-418)
     # keys of the reference schema this path does not serve: accepted at their inert defaults, refused otherwise (a recipe
     # that sets them must not train as if it had not)
-    patch_dropout: float = 0.0
     num_experts: int = 0
 
     @model_validator(mode="after")
@@ -148,8 +148,8 @@ class ModelArgs(BaseModel):
             self.logit_scale = 1 / 0.07
         if not 0.0 <= self.ema_decay <= 1.0:
             raise ValueError(f"model_args.ema_decay must be in [0, 1], got {self.ema_decay}")
-        if self.patch_dropout and self.patch_dropout > 0:
-            raise ValueError("model_args.patch_dropout > 0 (sc/layers/embedding.py:415-418) is not served by the image tower")
+        if not 0.0 <= float(self.patch_dropout or 0.0) < 1.0:
+            raise ValueError(f"model_args.patch_dropout must be in [0, 1), got {self.patch_dropout}")
         if self.num_experts and self.num_experts > 0:
             raise ValueError("model_args.num_experts > 0: mixture-of-experts trunks (megablocks) are out of scope")
         if self.resid_pdrop is not None and not (0.0 <= self.resid_pdrop < 1.0):

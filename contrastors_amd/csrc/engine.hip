@@ -487,23 +487,27 @@ int vit_forward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const 
                      uint16_t* hidden_out, void* stream) {
     if (Bc <= 0) return CX_OK;
     if (!enc || !buf || patch <= 0 || (H % patch) || (W % patch)) return CX_ERR_ARG;
-    const int P = (H / patch) * (W / patch), S = P + 1, T = Bc * S;
+    // PatchDropout (CxChunkBuffers.patch_keep): only the kept patches of every image exist from here on
+    const int P_all = (H / patch) * (W / patch);
+    const int32_t* keep = buf ? buf->patch_keep : nullptr;
+    if (keep && (buf->n_keep <= 0 || buf->n_keep > P_all || buf->n_patch_all != P_all)) return CX_ERR_ARG;
+    const int P = keep ? buf->n_keep : P_all, S = P + 1, T = Bc * S;
     CX_TRY(check_desc(enc, buf, T));
     if (!enc->Wpatch || !enc->cls_token || !enc->vit_pos || !buf->patch_in || !buf->patch_proj) return CX_ERR_ARG;
     if (enc->patch_dim != Cc * patch * patch || (enc->patch_dim % 64) != 0) return CX_ERR_SHAPE;
     (void)hipGetLastError();
     const int d = enc->d, I = enc->d_inner;
     const Slots s = make_slots(enc, buf, save_for_backward);
-    CX_TRY(cx_vit_patchify(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, stream));
+    CX_TRY(cx_vit_patchify_gather(pixels, pixels_bf16, buf->patch_in, Bc, Cc, H, W, patch, keep, P, stream));
     CX_TRY(cx_gemm_bf16_nt(buf->patch_in, enc->Wpatch, buf->patch_proj, enc->bpatch, Bc * P, d, enc->patch_dim,
                            enc->patch_dim, enc->patch_dim, d, 0, 1, 1.f, stream));
     if (enc->lnpre_g) {   // CLIP flavour (sc/models/vit/vit.py:180): LayerNorm on [cls | patches] + pos before the first block
         if (!enc->lnpre_b || !buf->zpre) return CX_ERR_ARG;
-        CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->zpre, Bc, P, d, stream));
+        CX_TRY(cx_vit_assemble_fwd_gather(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->zpre, Bc, P, d, keep, stream));
         CX_TRY(cx_layernorm_fwd(buf->zpre, nullptr, enc->lnpre_g, enc->lnpre_b, buf->h0, nullptr, buf->emb_mean, buf->emb_rstd, T, d,
                                 enc->ln_eps, stream));
     } else {
-        CX_TRY(cx_vit_assemble_fwd(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, stream));
+        CX_TRY(cx_vit_assemble_fwd_gather(buf->patch_proj, enc->cls_token, enc->vit_pos, buf->h0, Bc, P, d, keep, stream));
     }
     const uint16_t* h_final = nullptr;
     CX_TRY(blocks_forward(enc, buf, s, buf->h0, cu_seqlens, Bc, T, S, s.mode, &h_final, stream));
@@ -555,7 +559,13 @@ int vit_backward_impl(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const
                            (hipStream_t)stream) != hipSuccess)
             return CX_ERR_LAUNCH;
     }
-    CX_TRY(cx_vit_assemble_bwd(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, stream));
+    if (buf->patch_keep) {   // PatchDropout: n_patch is the kept count; position gradients land on the ORIGINAL positions
+        if (!buf->patch_inv || buf->n_keep != P || buf->n_patch_all < P) return CX_ERR_ARG;
+        CX_TRY(cx_vit_assemble_bwd_gather(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, buf->patch_inv,
+                                          buf->n_patch_all, stream));
+    } else {
+        CX_TRY(cx_vit_assemble_bwd(da, buf->patch_proj, enc->gcls_token, enc->gvit_pos, Bc, P, d, stream));
+    }
     if (enc->gbpatch) CX_TRY(cx_bias_grad(buf->patch_proj, enc->gbpatch, Tp, d, d, stream));
     CX_TRY(wgrad(buf->patch_proj, d, buf->patch_in, enc->patch_dim, enc->gWpatch, buf, Tp, stream));
     return mark_grads_done(buf, enc->n_layer, stream);
@@ -714,7 +724,7 @@ int cx_vit_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, 
     return vit_backward_impl(enc, buf, cu_seqlens, Bc, n_patch, nullptr, nullptr, dhidden, stream);
 }
 
-int cx_abi_version(void) { return 6; }  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
+int cx_abi_version(void) { return 7; }  // 7: CxChunkBuffers.patch_keep / patch_inv / n_keep (PatchDropout);  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

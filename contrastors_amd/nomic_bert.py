@@ -205,7 +205,7 @@ class _ChunkArena:
                 self.desc.checkpoint = int(self.checkpoint)
             elif name == "ckpt_keep":
                 self.desc.ckpt_keep = int(self.keep_layers)
-            elif name in ("drop_active", "drop_seed", "drop_offset"):
+            elif name in ("drop_active", "drop_seed", "drop_offset", "n_keep", "n_patch_all"):
                 setattr(self.desc, name, 0)
             else:
                 setattr(self.desc, name, t[name].data_ptr() if name in t else None)

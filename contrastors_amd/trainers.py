@@ -394,6 +394,7 @@ class ImageTextTrainer(TextTextTrainer):
                                  checkpoint_keep_layers=_parse_keep(config.train_args.checkpoint_keep_layers, "train_args.checkpoint_keep_layers"),
                                  nomic_encoder=ma.nomic_encoder,
                                  resid_pdrop=ma.resid_pdrop if ma.pretrained else None,
+                                 patch_dropout=float(ma.patch_dropout or 0.0),
                                  seq_len=ma.seq_len, trunk_config=trunk)
             tower = BiEncoder(bc, device=self.device).train()
             tower.overlap_reduce = bool(config.train_args.overlap_grad_reduce)

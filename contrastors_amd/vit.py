@@ -52,6 +52,9 @@ class ViTConfig:
     embd_pdrop: float = 0.0
     attn_pdrop: float = 0.0
     drop_path_rate: float = 0.0
+    # PatchDropout (sc/layers/embedding.py:415-418, 519-557): fraction of the patch tokens dropped per image in TRAINING
+    # (the [cls] token is always kept); 0 = off
+    patch_dropout: float = 0.0
 
     def __post_init__(self):
         if self.n_embd != self.n_head * 64:
@@ -64,6 +67,8 @@ class ViTConfig:
             raise NotImplementedError("dropout / drop-path > 0")
         if self.rotary_emb_fraction != 0:
             raise NotImplementedError("rotary ViT (eva02)")
+        if not 0.0 <= self.patch_dropout < 1.0:
+            raise ValueError(f"patch_dropout must be in [0, 1), got {self.patch_dropout}")
         if self.img_size % self.patch_size or self.patch_size % 4:
             raise NotImplementedError("img_size must be a multiple of patch_size, patch_size of 4")
         if self.patch_dim % 64:
@@ -173,11 +178,11 @@ class ViTEngine(NomicBertEngine):
         e.glnpre_g, e.glnpre_b = G("prepre_layernom.weight"), G("prepre_layernom.bias")
 
     # ---- compute --------------------------------------------------------------------------------------------------
-    def _cu_seqlens(self, B: int) -> torch.Tensor:
-        key = ("vit_cu", B)
+    def _cu_seqlens(self, B: int, S: Optional[int] = None) -> torch.Tensor:
+        S = self.config.n_patch + 1 if S is None else S
+        key = ("vit_cu", B, S)
         hit = getattr(self, "_cu_cache", {}).get(key)
         if hit is None:
-            S = self.config.n_patch + 1
             hit = torch.arange(0, (B + 1) * S, S, dtype=torch.int32).to(self.device_)
             self._cu_cache = getattr(self, "_cu_cache", {})
             self._cu_cache[key] = hit
@@ -193,18 +198,47 @@ class ViTEngine(NomicBertEngine):
             pixels = pixels.float()
         return pixels.contiguous()
 
+    def _patch_subset(self, B: int):
+        """PatchDropout (sc/layers/embedding.py:531-557), training only: every image keeps max(1, int(n_patch * (1 - p))) patch
+        tokens -- the top-k of a standard-normal draw per patch, taken from torch's CPU generator exactly as the reference does
+        (`torch.randn(batch, num_tokens)` then `.topk(k).indices`), in top-k order.  Under GradCache the re-forward replays the
+        draw because RandContext restores the CPU generator too.  Returns (keep (B, K) int32, inverse (B, n_patch) int32, K) on
+        the device, or None when nothing is dropped."""
+        p = float(getattr(self.config, "patch_dropout", 0.0) or 0.0)
+        if p <= 0.0 or not self.training:
+            return None
+        P = self.config.n_patch
+        K = max(1, int(P * (1.0 - p)))
+        keep = torch.randn(B, P).topk(K, dim=-1).indices
+        inv = torch.full((B, P), -1, dtype=torch.int32)
+        inv.scatter_(1, keep, torch.arange(K, dtype=torch.int32).expand(B, K))
+        return keep.to(torch.int32).to(self.device_), inv.to(self.device_), K
+
+    def _set_patch_subset(self, arena: _ChunkArena, subset):
+        d = arena.desc
+        if subset is None:
+            d.patch_keep, d.patch_inv, d.n_keep, d.n_patch_all = None, None, 0, 0
+            arena.patch_subset = None
+        else:
+            keep, inv, K = subset
+            d.patch_keep, d.patch_inv, d.n_keep, d.n_patch_all = keep.data_ptr(), inv.data_ptr(), K, self.config.n_patch
+            arena.patch_subset = subset   # (keeps the index tensors alive until the backward has run)
+
     def forward_chunk(self, pixels: torch.Tensor, save_for_backward: bool, normalize: Optional[bool] = None,
                       out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[_ChunkArena]]:
         cfg = self.config
         pixels = self._check_pixels(pixels)
         B = pixels.shape[0]
-        T = B * (cfg.n_patch + 1)
+        subset = self._patch_subset(B)
+        S = (subset[2] if subset else cfg.n_patch) + 1
+        T = B * S
         if out is None:
             out = torch.empty(B, cfg.n_embd, dtype=torch.float32, device=self.device_)
         arena = self._get_arena(T, B, save_for_backward)
+        self._set_patch_subset(arena, subset)
         self._desc.normalize = int(self.normalize_default if normalize is None else normalize)
         rc = self.lib.cx_vit_forward(C.byref(self._desc), C.byref(arena.desc), pixels.data_ptr(),
-                                     int(pixels.dtype == torch.bfloat16), self._cu_seqlens(B).data_ptr(), B,
+                                     int(pixels.dtype == torch.bfloat16), self._cu_seqlens(B, S).data_ptr(), B,
                                      cfg.num_channels, cfg.img_size, cfg.img_size, cfg.patch_size,
                                      int(save_for_backward), out.data_ptr(), _C.cur_stream())
         _C.check(rc, "cx_vit_forward")
@@ -221,9 +255,12 @@ class ViTEngine(NomicBertEngine):
         demb = demb.to(torch.float32).contiguous()
         self._desc.normalize = arena.normalize
         fires = self._begin_backward(arena)
-        rc = self.lib.cx_vit_backward(C.byref(self._desc), C.byref(arena.desc), self._cu_seqlens(B).data_ptr(), B,
-                                      self.config.n_patch, demb.data_ptr(), arena.emb_out.data_ptr(), _C.cur_stream())
+        sub = getattr(arena, "patch_subset", None)
+        P = sub[2] if sub else self.config.n_patch
+        rc = self.lib.cx_vit_backward(C.byref(self._desc), C.byref(arena.desc), self._cu_seqlens(B, P + 1).data_ptr(), B,
+                                      P, demb.data_ptr(), arena.emb_out.data_ptr(), _C.cur_stream())
         _C.check(rc, "cx_vit_backward")
+        arena.patch_subset = None
         self._end_backward(arena, fires)
 
     # ---- token-level outputs (poolers above the C-ABI: `pooling: map`): (B, n_patch + 1, d) bf16 after ln_f ------------
@@ -231,11 +268,13 @@ class ViTEngine(NomicBertEngine):
         cfg = self.config
         pixels = self._check_pixels(pixels)
         B = pixels.shape[0]
-        S = cfg.n_patch + 1
+        subset = self._patch_subset(B)
+        S = (subset[2] if subset else cfg.n_patch) + 1
         hidden = torch.empty(B, S, cfg.n_embd, dtype=torch.bfloat16, device=self.device_)
         arena = self._get_arena(B * S, B, save_for_backward)
+        self._set_patch_subset(arena, subset)
         rc = self.lib.cx_vit_forward_hidden(C.byref(self._desc), C.byref(arena.desc), pixels.data_ptr(),
-                                            int(pixels.dtype == torch.bfloat16), self._cu_seqlens(B).data_ptr(), B,
+                                            int(pixels.dtype == torch.bfloat16), self._cu_seqlens(B, S).data_ptr(), B,
                                             cfg.num_channels, cfg.img_size, cfg.img_size, cfg.patch_size,
                                             int(save_for_backward), hidden.data_ptr(), _C.cur_stream())
         _C.check(rc, "cx_vit_forward_hidden")
@@ -248,9 +287,12 @@ class ViTEngine(NomicBertEngine):
     def backward_hidden_chunk(self, B: int, arena: _ChunkArena, dhidden: torch.Tensor):
         dh = dhidden.to(torch.bfloat16).contiguous()
         fires = self._begin_backward(arena)
-        rc = self.lib.cx_vit_backward_hidden(C.byref(self._desc), C.byref(arena.desc), self._cu_seqlens(B).data_ptr(), B,
-                                             self.config.n_patch, dh.data_ptr(), _C.cur_stream())
+        sub = getattr(arena, "patch_subset", None)
+        P = sub[2] if sub else self.config.n_patch
+        rc = self.lib.cx_vit_backward_hidden(C.byref(self._desc), C.byref(arena.desc), self._cu_seqlens(B, P + 1).data_ptr(), B,
+                                             P, dh.data_ptr(), _C.cur_stream())
         _C.check(rc, "cx_vit_backward_hidden")
+        arena.patch_subset = None
         self._end_backward(arena, fires)
 
     def hidden_states(self, pixels: torch.Tensor) -> torch.Tensor:

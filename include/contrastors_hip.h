@@ -438,6 +438,16 @@ typedef struct CxChunkBuffers {
      * only the blocks below them.  0 = the reference's behaviour (every block recomputed).  A memory knob like
      * `checkpoint` itself: results are bit-identical for every value (tests/test_checkpoint_gpu.py). */
     int ckpt_keep;
+    /* PatchDropout of the image tower (cx_abi_version >= 7; sc/layers/embedding.py:415-418, 519-557): NULL = every patch.
+     * patch_keep: (Bc, n_keep) int32 device array, the patch indices (0 .. n_patch - 1) each image keeps, in the order their
+     * tokens take in the sequence ([cls] first, then patch_keep[b][0 .. n_keep - 1]); patch_inv: (Bc, n_patch) int32, position
+     * of a patch among its image's kept ones or -1.  Only the kept patches are gathered, projected and run through the blocks:
+     * sequences have n_keep + 1 tokens, cu_seqlens = multiples of n_keep + 1, cx_vit_backward takes n_patch = n_keep;
+     * n_patch_all = (H / patch) * (W / patch), the row count of patch_inv (the backward does not see the image size). */
+    const int32_t* patch_keep;
+    const int32_t* patch_inv;
+    int n_keep;
+    int n_patch_all;
 } CxChunkBuffers;
 
 /* input_ids:(Bc,S) int64 padded batch rows of this chunk; indices:(T) int32; cu_seqlens:(Bc+1) int32.
@@ -476,6 +486,14 @@ int cx_vit_assemble_fwd(const uint16_t* proj, const float* cls_token, const floa
                         int P, int d, void* stream);
 int cx_vit_assemble_bwd(const uint16_t* dz, uint16_t* dproj, float* gcls, float* gpos, int B, int P, int d,
                         void* stream);
+/* the same three with a patch subset (PatchDropout, see CxChunkBuffers.patch_keep): keep (B, n_keep) / inv (B, P_all) int32
+ * device arrays, NULL = the plain forms above; with keep, P = n_keep in the assemble calls */
+int cx_vit_patchify_gather(const void* pixels, int pixels_bf16, uint16_t* patches, int B, int C, int H, int W, int patch,
+                           const int32_t* keep, int n_keep, void* stream);
+int cx_vit_assemble_fwd_gather(const uint16_t* proj, const float* cls_token, const float* pos_embed, uint16_t* out, int B,
+                               int P, int d, const int32_t* keep, void* stream);
+int cx_vit_assemble_bwd_gather(const uint16_t* dz, uint16_t* dproj, float* gcls, float* gpos, int B, int P, int d,
+                               const int32_t* inv, int P_all, void* stream);
 int cx_vit_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const void* pixels, int pixels_bf16,
                    const int32_t* cu_seqlens, int Bc, int C, int H, int W, int patch, int save_for_backward,
                    float* emb_out, void* stream);

@@ -108,8 +108,10 @@ TINY_VIT_CLIP = dict(TINY_VIT, layer_norm_epsilon=1e-5, activation_function="qui
                      patch_embed_bias=False)
 
 
-def gen_vit(name, cfgd, seed):
-    """tests/golden/vit_tiny.npz: the reference ViTModel (sc/models/vit/vit.py) run on CPU in fp32."""
+def gen_vit(name, cfgd, seed, patch_dropout=0.0):
+    """tests/golden/vit_tiny.npz: the reference ViTModel (sc/models/vit/vit.py) run on CPU in fp32.
+    patch_dropout > 0 (vit_patchdrop_tiny.npz): the model in TRAINING mode with the reference's PatchDropout
+    (sc/layers/embedding.py:415-418, 519-557) drawing from torch's CPU generator seeded with `rng_seed` right before the forward."""
     from transformers import GPT2Config
 
     vit = ref_import.load_vit()
@@ -125,7 +127,7 @@ def gen_vit(name, cfgd, seed):
         parallel_block_tied_norm=False, rotary_emb_fraction=0, tie_word_embeddings=False, fused_dropout_add_ln=False,
         fused_bias_fc=False, patch_embed_bias=bool(getattr(cfg, "patch_embed_bias", True)), use_flash_attn=False, qkv_proj_bias=True, mlp_fc1_bias=True,
         mlp_fc2_bias=True, use_rms_norm=False, causal=False, hidden_features_scaling_factor=1.0, mask_token=False,
-        learned_pos_embedding=False, patch_dropout=0, sinusoidal_pos_embedding=False)
+        learned_pos_embedding=False, patch_dropout=patch_dropout, sinusoidal_pos_embedding=False)
     m = vit.ViTModel(c).float()
     sd = vit_ref.random_state_dict(cfg, seed)
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -133,8 +135,19 @@ def gen_vit(name, cfgd, seed):
     m.eval()
     g = torch.Generator().manual_seed(seed + 1)
     pixels = torch.randn(5, cfg.num_channels, cfg.img_size, cfg.img_size, generator=g)
-    hid = m(pixels).last_hidden_state
     out = {}
+    if patch_dropout > 0:
+        m.train()
+        rng_seed = seed + 3
+        P = (cfg.img_size // cfg.patch_size) ** 2
+        K = max(1, int(P * (1 - patch_dropout)))
+        torch.manual_seed(rng_seed)
+        out["keep"] = torch.randn(5, P).topk(K, dim=-1).indices.numpy()   # (what PatchDropout.forward is about to draw)
+        out["rng_seed"] = np.array(rng_seed)
+        torch.manual_seed(rng_seed)
+    hid = m(pixels).last_hidden_state
+    if patch_dropout > 0:
+        assert hid.shape[1] == 1 + out["keep"].shape[1], hid.shape
     for pooling in ("cls", "mean"):
         m.zero_grad()
         # BiEncoder pooling restated (modeling_biencoder.py:44-49,79-90,317) on the REFERENCE hidden states
@@ -560,6 +573,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "vit":  # regenerate only the ViT fixtures
         gen_vit("vit_tiny", TINY_VIT, 5)
         gen_vit("vit_clip_tiny", TINY_VIT_CLIP, 6)
+        gen_vit("vit_patchdrop_tiny", TINY_VIT, 7, patch_dropout=0.5)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "map_pool":
         gen_map_pool("map_pool_tiny", 9)
@@ -589,6 +603,7 @@ if __name__ == "__main__":
     gen_multirank()
     gen_vit("vit_tiny", TINY_VIT, 5)
     gen_vit("vit_clip_tiny", TINY_VIT_CLIP, 6)
+    gen_vit("vit_patchdrop_tiny", TINY_VIT, 7, patch_dropout=0.5)
     gen_map_pool("map_pool_tiny", 9)
     gen_hf_remap()
     gen_mlm("mlm_nomic_tiny", TINY_NOMIC, 21)

@@ -56,8 +56,9 @@ def patchify(pixels: torch.Tensor, p: int) -> torch.Tensor:
     return x.reshape(B, (H // p) * (W // p), C * p * p)
 
 
-def vit_hidden(sd: Dict[str, torch.Tensor], cfg, pixels: torch.Tensor) -> torch.Tensor:
-    """-> (B, P+1, d) output of ln_f."""
+def vit_hidden(sd: Dict[str, torch.Tensor], cfg, pixels: torch.Tensor, keep=None) -> torch.Tensor:
+    """-> (B, P+1, d) output of ln_f.  keep (B, K) int64: PatchDropout (sc/layers/embedding.py:531-557) -- after the position
+    embeddings every image keeps the [cls] token and its patch tokens keep[b], in that order: (B, K+1, d)."""
     d, H = cfg.n_embd, cfg.n_head
     eps = cfg.layer_norm_epsilon
     x = patchify(pixels.float(), cfg.patch_size) @ sd["embeddings.proj.weight"].T
@@ -65,6 +66,9 @@ def vit_hidden(sd: Dict[str, torch.Tensor], cfg, pixels: torch.Tensor) -> torch.
         x = x + sd["embeddings.proj.bias"]
     B = x.shape[0]
     x = torch.cat([sd["embeddings.cls_token"].expand(B, 1, d), x], 1) + sd["embeddings.pos_embed"]
+    if keep is not None:
+        keep = torch.as_tensor(keep, dtype=torch.long, device=x.device)
+        x = torch.cat([x[:, :1], x[:, 1:][torch.arange(B, device=x.device)[:, None], keep]], 1)
     if "prepre_layernom.weight" in sd:   # sc/models/vit/vit.py:128-132,180
         x = F.layer_norm(x, (d,), sd["prepre_layernom.weight"], sd["prepre_layernom.bias"], eps)
     quick = getattr(cfg, "activation_function", "gelu") == "quick_gelu"   # sc/layers/activations.py:4-5
@@ -86,7 +90,7 @@ def vit_hidden(sd: Dict[str, torch.Tensor], cfg, pixels: torch.Tensor) -> torch.
     return F.layer_norm(hidden + residual, (d,), sd["ln_f.weight"], sd["ln_f.bias"], eps)
 
 
-def vit_embedding(sd, cfg, pixels, pooling: str = "cls", normalize: bool = True) -> torch.Tensor:
-    h = vit_hidden(sd, cfg, pixels)
+def vit_embedding(sd, cfg, pixels, pooling: str = "cls", normalize: bool = True, keep=None) -> torch.Tensor:
+    h = vit_hidden(sd, cfg, pixels, keep)
     e = h[:, 0] if pooling == "cls" else h.mean(1)
     return F.normalize(e, dim=-1) if normalize else e

@@ -29,7 +29,7 @@ def test_header_symbols_exported(built):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_C.EXPORTED_SYMBOLS), declared ^ set(_C.EXPORTED_SYMBOLS)
-    assert lib.cx_abi_version() == 6  # 2: CxChunkBuffers.checkpoint; 3: dropout state + sorted embedding backward; 4: attn_pdrop; 5: layer_events; 6: ckpt_keep
+    assert lib.cx_abi_version() == 7  # 7: PatchDropout fields; 2: CxChunkBuffers.checkpoint; 3: dropout state + sorted embedding backward; 4: attn_pdrop; 5: layer_events; 6: ckpt_keep
     assert b"gfx950" in lib.cx_build_info()
     assert lib.cx_error_string(-1) == b"unsupported shape"
     assert lib.cx_infonce_ws_floats(2048, 16384) == 2048 * (2 * 2 * 128 + 1)
@@ -58,14 +58,14 @@ def test_ctypes_struct_layout_matches_c(tmp_path, built):
         "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(CxLayerWeights), sizeof(CxEncoderDesc),"
         " sizeof(CxChunkBuffers), offsetof(CxEncoderDesc, layers), offsetof(CxEncoderDesc, word_emb),"
         " offsetof(CxChunkBuffers, delta), offsetof(CxEncoderDesc, patch_dim), offsetof(CxEncoderDesc, Wpatch),"
-        " offsetof(CxChunkBuffers, patch_proj), offsetof(CxChunkBuffers, ckpt_keep)); return 0;}\n")
+        " offsetof(CxChunkBuffers, patch_proj), offsetof(CxChunkBuffers, ckpt_keep)); printf(\"%zu %zu\\n\", offsetof(CxChunkBuffers, patch_keep), offsetof(CxChunkBuffers, n_patch_all)); return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     want = [C.sizeof(_C.CxLayerWeights), C.sizeof(_C.CxEncoderDesc), C.sizeof(_C.CxChunkBuffers),
             _C.CxEncoderDesc.layers.offset, _C.CxEncoderDesc.word_emb.offset, _C.CxChunkBuffers.delta.offset,
             _C.CxEncoderDesc.patch_dim.offset, _C.CxEncoderDesc.Wpatch.offset, _C.CxChunkBuffers.patch_proj.offset,
-            _C.CxChunkBuffers.ckpt_keep.offset]
+            _C.CxChunkBuffers.ckpt_keep.offset, _C.CxChunkBuffers.patch_keep.offset, _C.CxChunkBuffers.n_patch_all.offset]
     assert got == want
 
 

@@ -390,7 +390,10 @@ def test_reference_schema_keys_are_served_or_refused_never_dropped():
     v = ViTConfig.vit_base_patch16_224()
     assert trunk_config_with_overrides(BiEncoderConfig(resid_pdrop=0.1), v) is v      # (image towers: not a text trunk)
     assert ModelArgs(ema=True).ema and ModelArgs(ema=True).ema_decay == 0.9999   # (round 4: served, sc/trainers/base.py:387-391)
-    for bad in (dict(ema_decay=1.5), dict(patch_dropout=0.5), dict(num_experts=8), dict(resid_pdrop=1.5)):
+    # (round 4: patch_dropout reaches the image trunk's configuration, modeling_biencoder.py:174,187; text trunks ignore it)
+    assert trunk_config_with_overrides(BiEncoderConfig(patch_dropout=0.5), v).patch_dropout == 0.5 and v.patch_dropout == 0.0
+    assert trunk_config_with_overrides(BiEncoderConfig(patch_dropout=0.5), base) is base
+    for bad in (dict(ema_decay=1.5), dict(patch_dropout=1.0), dict(num_experts=8), dict(resid_pdrop=1.5)):
         with pytest.raises(ValueError):
             ModelArgs(**bad)
 

@@ -130,7 +130,7 @@ def test_gradcache_ddp_two_ranks(gold):
             assert abs(float(sd[n].grad.norm()) - float(g[k])) <= 2e-3 * max(1e-3, float(g[k])), n
 
 
-@pytest.mark.parametrize("name", ["vit_tiny", "vit_clip_tiny"])
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_clip_tiny", "vit_patchdrop_tiny"])
 def test_vit_restatement_matches_reference(gold, name):
     """oracle/vit_ref.py vs the reference's own ViTModel python (sc/models/vit/vit.py) on CPU fp32: hidden states,
     pooled embeddings for both poolings, every parameter-gradient norm and five gradient slices.  vit_clip_tiny = the
@@ -144,11 +144,13 @@ def test_vit_restatement_matches_reference(gold, name):
     for v in sd.values():
         v.requires_grad_(True)
     pix = torch.from_numpy(g["pixels"])
-    np.testing.assert_allclose(vit_ref.vit_hidden(sd, cfg, pix).detach().numpy(), g["hidden"], atol=2e-5, rtol=1e-4)
+    # vit_patchdrop_tiny: the reference model in training mode with PatchDropout 0.5; `keep` = what its CPU draw selected
+    keep = torch.from_numpy(g["keep"]) if "keep" in g.files else None
+    np.testing.assert_allclose(vit_ref.vit_hidden(sd, cfg, pix, keep).detach().numpy(), g["hidden"], atol=2e-5, rtol=1e-4)
     for pooling in ("cls", "mean"):
         for v in sd.values():
             v.grad = None
-        emb = vit_ref.vit_embedding(sd, cfg, pix, pooling)
+        emb = vit_ref.vit_embedding(sd, cfg, pix, pooling, keep=keep)
         np.testing.assert_allclose(emb.detach().numpy(), g[f"{pooling}/embedding"], atol=2e-6)
         (emb * torch.from_numpy(g[f"{pooling}/probe"])).sum().backward()
         for k in g.files:

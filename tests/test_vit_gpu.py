@@ -273,3 +273,56 @@ def test_map_pooling_head_on_the_vit_tower_matches_the_oracle(gold):
         BiEncoder(BiEncoderConfig(model_name="t", pooling="map", trunk_config=NomicBertConfig.nomic_bert_2048(n_layer=1)), device=DEV)
     with pytest.raises(NotImplementedError):
         BiEncoder(BiEncoderConfig(model_name="t", pooling="last", trunk_config=cfg), device=DEV)
+
+
+@pytest.mark.parametrize("pooling", ["cls", "mean"])
+def test_vit_patch_dropout_matches_reference_golden(gold, pooling):
+    """PatchDropout (sc/layers/embedding.py:415-418, 519-557; round 4): in training every image keeps [cls] + the top-k of a CPU
+    standard-normal draw over its patches.  The engine draws from the same generator in the same way, gathers ONLY the kept
+    patches (patchify -> projection -> blocks on K + 1 tokens) and scatters the position gradients back to the original
+    positions.  Judged against vit_patchdrop_tiny.npz = the reference's own ViTModel in training mode with patch_dropout 0.5."""
+    g = gold("vit_patchdrop_tiny")
+    d = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg/")}
+    cfg, ns = ViTConfig(**d, patch_dropout=0.5), SimpleNamespace(**d)
+    sd = vit_ref.random_state_dict(ns, int(g["seed"]))
+    pix = torch.from_numpy(g["pixels"]).to(DEV)
+    probe = torch.from_numpy(g[f"{pooling}/probe"]).to(DEV)
+    keep = torch.from_numpy(g["keep"])
+    eng = ViTEngine(cfg, device=DEV, pooling=pooling)
+    eng.load_reference_state_dict(sd)
+    eng.train()
+    torch.manual_seed(int(g["rng_seed"]))
+    emb, arena = eng.forward_chunk(pix, True)
+    assert torch.equal(arena.patch_subset[0].cpu().long(), keep), "the engine's draw must select the reference's patches"
+    eng.zero_grad()
+    eng.backward_chunk(pix, arena, probe)
+    grads = eng.reference_grad_dict()
+    gold_emb = torch.from_numpy(g[f"{pooling}/embedding"]).to(DEV)
+    sdd = {k: v.detach().to(DEV).requires_grad_() for k, v in sd.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        emb16 = vit_ref.vit_embedding(sdd, ns, pix, pooling, keep=keep).float()
+    (emb16 * probe).sum().backward()
+    e_hip, e_b = max_err(emb, gold_emb), max_err(emb16, gold_emb)
+    for k in g.files:
+        if not k.startswith(f"{pooling}/gnorm/"):
+            continue
+        n = k[len(pooling) + 7:]
+        want, got, bf = float(g[k]), float(grads[n].norm()), float(sdd[n].grad.norm())
+        assert abs(got - want) <= 3 * abs(bf - want) + 2e-2 * want + 1e-5, f"{n}: |grad| {got} vs reference {want} (bf16 {bf})"
+    e_pos = rel_err(grads["embeddings.pos_embed"].reshape(-1), torch.from_numpy(g[f"{pooling}/g/embeddings.pos_embed"]).to(DEV).reshape(-1))
+    e_cls = rel_err(grads["embeddings.cls_token"].reshape(-1), torch.from_numpy(g[f"{pooling}/g/embeddings.cls_token"]).to(DEV).reshape(-1))
+    report("vit_patch_dropout", pooling=pooling, e_emb_hip=e_hip, e_emb_bf16=e_b, e_pos=e_pos, e_cls=e_cls)
+    assert e_hip <= 5e-3 and e_hip <= 3 * e_b + 1e-4
+    assert e_pos < 5e-2 and e_cls < 5e-2
+    # a dropped patch's position receives no gradient from the images that dropped it: positions nobody kept are exactly zero
+    gp = grads["embeddings.pos_embed"].reshape(-1, cfg.n_embd)
+    kept_any = torch.zeros(cfg.n_patch, dtype=torch.bool)
+    kept_any[keep.reshape(-1)] = True
+    for pi in range(cfg.n_patch):
+        if not kept_any[pi]:
+            assert float(gp[1 + pi].abs().max()) == 0.0
+    # eval mode: no dropout, the full sequence
+    eng.eval()
+    full, _ = eng.forward_chunk(pix, False)
+    ref_full = vit_ref.vit_embedding({k: v.to(DEV) for k, v in sd.items()}, ns, pix, pooling)
+    assert max_err(full, ref_full) <= 5e-3
