@@ -346,6 +346,11 @@ def _select_exchange(shard: torch.Tensor) -> Optional[OneShotExchange]:
                       "using the process group's collectives")
         _EXCHANGE_CHOICE = "pg"
         _EXCHANGE_REPORT.update(choice="pg", verified=False, reason=f"verification failed: {why or 'on another rank'}")
+        try:   #  the IPC buffers of an exchange that will never be used are given back
+            ex.close()
+        except Exception:  # noqa: BLE001
+            pass
+        _ONESHOT = None
         return None
     _EXCHANGE_REPORT.update(verified=True)
     if mode == "oneshot":
@@ -373,15 +378,33 @@ def _select_exchange(shard: torch.Tensor) -> Optional[OneShotExchange]:
 
 def _oneshot_for(shard: torch.Tensor) -> Optional[OneShotExchange]:
     """The one-shot exchange when it carries this process's gather_with_grad, else None (the process group does)."""
-    global _ONESHOT
+    global _ONESHOT, _EXCHANGE_CHOICE
     if _EXCHANGE_CHOICE is None:
         return _select_exchange(shard)
     if _EXCHANGE_CHOICE != "oneshot" or _ONESHOT is None:
         return None
     need = dist.get_world_size() * shard.numel() * 4
     if _ONESHOT.cap < need:   # a larger batch than the one the buffers were sized for: same on every rank -> collective
-        _ONESHOT.close()
-        _ONESHOT = OneShotExchange(need, device=shard.device)
+        # (ADVICE r3) the regrow can fail like the first set-up (IPC handle exchange, allocation): agree on the outcome across
+        # ranks and fall back to the process group for the rest of the run instead of raising out of an autograd forward
+        err = None
+        try:
+            _ONESHOT.close()
+            _ONESHOT = None
+            _ONESHOT = OneShotExchange(need, device=shard.device)
+        except Exception as e:  # noqa: BLE001
+            err = str(e)
+        if not _agree(err is None, shard.device):
+            warnings.warn(f"one-shot xGMI exchange could not be resized to {need} B ({err or 'failed on another rank'}); "
+                          "using the process group's collectives from here on")
+            try:
+                if _ONESHOT is not None:
+                    _ONESHOT.close()
+            except Exception:  # noqa: BLE001
+                pass
+            _ONESHOT, _EXCHANGE_CHOICE = None, "pg"
+            _EXCHANGE_REPORT.update(choice="pg", reason=f"resize failed: {err or 'on another rank'}")
+            return None
     return _ONESHOT
 
 

@@ -350,6 +350,7 @@ class NomicBertEngine(torch.nn.Module):
         self._keep_suspended = 0   # > 0: "auto" keeps nothing (a caller that lines up MANY arenas budgets the HBM itself)
         self._keep_plan: Dict[int, int] = {}      # T_cap -> blocks the next arena of that size keeps ("auto", measured)
         self._keep_granted: Dict[int, int] = {}   # T_cap -> ledger bytes promised to that arena, until it is built
+        self._keep_granted_B: Dict[int, int] = {}  # T_cap -> sequence capacity of the measured arena (its successor keeps it)
         self._arena_tick = 0                      # saving forwards so far (ages the idle arenas)
         self.sync_shadows()
 
@@ -628,11 +629,16 @@ class NomicBertEngine(torch.nn.Module):
             pending = [t for t in self._keep_granted if t >= T_cap]
             if pending:
                 T_cap = min(pending)
+                #  ... with the SEQUENCE capacity of the arena that was measured too: sized from the smaller batch that
+                # happens to come first, the rebuilt arena would fail the `B_cap >= B` fit test when the batch it was planned for
+                # arrives, and a second kept arena of the same T_cap would be built outside the ledger
+                B = max(B, self._keep_granted_B.get(T_cap, 0))
         keep = self._checkpoint_keep_for(T_cap) if ck else 0
         if keep > 0:
             try:
                 a = _ChunkArena(self.config, T_cap, L, True, max(B, 1), self.device_, checkpoint=True, keep_layers=keep)
                 a.granted = self._keep_granted.pop(T_cap, 0)   # the ledger entry now belongs to the arena
+                self._keep_granted_B.pop(T_cap, None)
                 a.last_tick = self._arena_tick
                 self._log_keep(T_cap, keep)
                 return a
@@ -640,6 +646,7 @@ class NomicBertEngine(torch.nn.Module):
                 # (fragmentation, another tenant of the device): nothing has been computed yet -> take the recipe literally
                 torch.cuda.empty_cache()
                 _hbm_grant(self.device_, -self._keep_granted.pop(T_cap, 0))
+                self._keep_granted_B.pop(T_cap, None)
                 if self._keep_mode() != "auto":
                     raise   # an explicit number is a demand, not a hint
                 self._keep_plan[T_cap] = 0
@@ -703,6 +710,7 @@ class NomicBertEngine(torch.nn.Module):
             return False
         _hbm_grant(self.device_, keep * per_keep)
         self._keep_granted[T_cap] = keep * per_keep   # handed to the successor arena when it is built
+        self._keep_granted_B[T_cap] = int(arena.B_cap)
         return True
 
     @contextlib.contextmanager
