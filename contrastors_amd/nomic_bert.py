@@ -710,7 +710,7 @@ class NomicBertEngine(torch.nn.Module):
             return False
         _hbm_grant(self.device_, keep * per_keep)
         self._keep_granted[T_cap] = keep * per_keep   # handed to the successor arena when it is built
-        self._keep_granted_B[T_cap] = int(arena.B_cap)
+        self._keep_granted_B[T_cap] = int(getattr(arena, "B_cap", 0))
         return True
 
     @contextlib.contextmanager
