@@ -189,7 +189,7 @@ def test_selective_checkpointing_planner_budgets_the_measured_headroom_once(monk
     monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: state["allocated"])
     dev = SimpleNamespace(index=7)   # a device index no other test touches
     eng = SimpleNamespace(config=cfg, device_=dev, CKPT_HBM_FRACTION=0.9, checkpoint_keep="auto", _keep_suspended=0,
-                          _keep_plan={}, _keep_granted={})
+                          _keep_plan={}, _keep_granted={}, _keep_granted_B={})
     eng._keep_mode = lambda: nb.NomicBertEngine._keep_mode(eng)
     plan = lambda arena: nb.NomicBertEngine._plan_keep(eng, arena)
     arena = lambda T, nbytes: SimpleNamespace(T_cap=T, probation=True, nbytes=lambda: nbytes)
@@ -239,7 +239,7 @@ def test_arena_pool_host_logic_on_cpu(monkeypatch):
     E = nb.NomicBertEngine
     cfg = nb.NomicBertConfig.nomic_bert_2048(vocab_size=512, n_layer=2, n_embd=128, n_head=2, n_inner=256)
     eng = SimpleNamespace(config=cfg, device_=torch.device("cpu"), gradient_checkpointing=True, checkpoint_keep="auto",
-                          _arena_free=[], _arena_nograd=None, _arena_tick=0, _keep_plan={}, _keep_granted={}, _keep_suspended=0,
+                          _arena_free=[], _arena_nograd=None, _arena_tick=0, _keep_plan={}, _keep_granted={}, _keep_granted_B={}, _keep_suspended=0,
                           _keep_logged=set(), ARENA_IDLE_USES=4)
     for name in ("_keep_mode", "_checkpoint_keep_for", "_log_keep"):
         setattr(eng, name, (lambda n: lambda *a: getattr(E, n)(eng, *a))(name))
