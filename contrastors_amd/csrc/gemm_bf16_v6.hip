@@ -27,6 +27,12 @@ namespace {
 // Epilogue traffic is touched once: outputs are not re-read by this launch and the streamed epilogue inputs (residual,
 // saved (y, gate)) are read once.  CX_V6_NT (bit 0 stores, bit 1 loads) marks them non-temporal so that they do not evict
 // the operand panels the XCD's other workgroups are about to re-use from L2.
+#ifndef CX_V6_DEFER_NT
+#define CX_V6_DEFER_NT 0      // the deferred register stores (DEFER) non-temporal?  measured: nt 1.55-1.70 x the staged kernel, plain 1.08-1.15 x
+#endif
+#ifndef CX_V6_DEFER_SPREAD
+#define CX_V6_DEFER_SPREAD 1  // K-tiles of the next tile the 32 deferred stores of a tile are spread over (8, 4, 2 or 1; 1 measured best)
+#endif
 #ifndef CX_V6_NT
 #define CX_V6_NT 3   // measured on the whole step (scripts/gpu_variant_bench.sh): 0 -> 3861..3873, 1 -> 3895, 3 -> 3907 pairs/s
 #endif
@@ -80,8 +86,15 @@ struct Frags6 {
 // DBG (ablation builds only, scripts/gemm_ablate.py; results are garbage, timing is the point): bit0 no DMA in the main
 // loop, bit1 no barrier, bit2 no fragment reads, bit3 no MFMA, bit4 no epilogue, bit5 no vmcnt wait.  With p.trace set,
 // wave 0 of every workgroup stores its s_memtime span and K-tile count.
-template <int EPI, int DBG = 0>
+// DEFER (round 4, plain bf16 output only: alpha 1, no bias, no residual, every tile whole, K >= 512): the tile's results do
+// not leave through the LDS at the tile end.  They are rounded to bf16 into 128 VGPRs (v6_pack_block), put into 16-byte row
+// pieces with v_permlane32_swap (lanes l and l + 32 hold the two 8-byte halves of the same row piece), and stored straight
+// from the registers in the MFMA shadow of the NEXT tile's first K-tiles (CX_V6_DEFER_SPREAD of them): the idea was that the
+// 7.8 k cycles of a K = 768 tile's epilogue (22 % of the tile, profiles/r2_gemm_v6_ablation.txt) shrink to the register copy.
+// Bit-identical to the staged epilogue (tests/test_kernels_gpu.py), measured slower (see CX_V6_DEFER below): not routed.
+template <int EPI, int DBG = 0, bool DEFER = false>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6_kernel(GemmParams p) {
+    static_assert(!DEFER || EPI == GEMM_EPI_NONE, "deferred stores: plain epilogue only");
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr bool IS_SWIGLU_BWD = EPI == GEMM_EPI_SWIGLU_BWD || EPI == GEMM_EPI_SWIGLU_BWD_AG;
     constexpr bool AG = EPI == GEMM_EPI_SWIGLU_BWD_AG;      // the saved pair is (act, gate) instead of (y, gate)
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // a[16i : 16i+15] and invisible to the compiler: written only by the MFMA asm (the first k-step of a tile uses the
     // C = 0 form, so nothing is ever zeroed), read only by v6_read_block in the epilogue.
 
-    int cp_round = 0, cp_kt = 0;
+    int cp_round = 0;
     int cp_tile = first_tile;
     lx_live = lw_live = cp_tile >= 0;
     if (cp_tile < 0) return;  // (only when the grid is larger than the tile count: never with launch6's grid)
@@ -240,12 +253,58 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         if constexpr ((DBG & 8) != 0) return;
         v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]);
     };
+    // ---- DEFER state: the previous tile as 32 x 16 bytes per lane.  Pd[2i + h] = block i (a = i & 3 n-block, b = i >> 2
+    // m-block), column half h: after the swaps lane (l31, hi) holds columns a*32 + 16h + 8hi .. +7 of row b*32 + l31 of the
+    // wave's 128 x 128 sub-tile.  All indices are literals (switch cases): the array must stay in registers.
+    // There is no "is there a previous tile" test in the K loop: until its first tile is complete a workgroup's stores write
+    // zeros over that same tile (dbase starts there), and the tile's real stores follow them in the wave's in-order stream.
+    cx_u32x4 Pd[DEFER ? 32 : 1];
+    const char* dbase = nullptr;                   // wave-uniform: row m0, column n0 of the tile held in Pd
+    if constexpr (DEFER) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) Pd[j] = cx_u32x4{0u, 0u, 0u, 0u};
+        dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)((cp_tile >> 8) * BM6 + wm * 128) * p.ldo + (cp_tile & 255) * BN6 + wn * 128) * 2;
+    }
+    long long drowblk = (long long)p.ldo * 64;   // bytes per 32 output rows
+    uint32_t dvoff = (uint32_t)l31 * (uint32_t)p.ldo * 2u + (uint32_t)hi * 16u;
+    auto dstore = [&](auto jc) {   // one store: 32 rows x 32 contiguous bytes
+        constexpr int J = decltype(jc)::value, I = J >> 1, H = J & 1, A = I & 3, B = I >> 2;
+        const char* bb = dbase + B * drowblk;
+        const uint32_t vo = dvoff;                      // (locals: asm operands alone do not capture in a generic lambda)
+        const cx_u32x4 v = Pd[DEFER ? J : 0];
+#if CX_V6_DEFER_NT
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" ::"v"(vo), "v"(v), "s"(bb), "n"((A * 32 + 16 * H) * 2) : "memory");
+#else
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(vo), "v"(v), "s"(bb), "n"((A * 32 + 16 * H) * 2) : "memory");
+#endif
+    };
+    int cp_kt = 0;
+    auto drain_all = [&]() {
+#define CX_D4(k_) dstore(std::integral_constant<int, 4 * (k_)>{}); dstore(std::integral_constant<int, 4 * (k_) + 1>{}); \
+                  dstore(std::integral_constant<int, 4 * (k_) + 2>{}); dstore(std::integral_constant<int, 4 * (k_) + 3>{});
+        CX_D4(0) CX_D4(1) CX_D4(2) CX_D4(3) CX_D4(4) CX_D4(5) CX_D4(6) CX_D4(7)
+#undef CX_D4
+    };
+    // accumulator block I -> Pd[2I], Pd[2I + 1]
+    auto pack_block = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        uint32_t pk[8];
+        v6_pack_block(I, pk);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // column groups (2h, 2h + 1): vdst = group 2h, src = group 2h + 1 (T21 of the guide)
+            const auto rx = __builtin_amdgcn_permlane32_swap(pk[4 * h], pk[4 * h + 2], false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(pk[4 * h + 1], pk[4 * h + 3], false, false);
+            Pd[DEFER ? 2 * I + h : 0] = cx_u32x4{rx[0], ry[0], rx[1], ry[1]};
+        }
+    };
+
     // One k-step: 16 MFMAs on `cur`; after the first one, the 8 reads of the next k-step (into `nxt`) and up to 4 DMA
     // instructions are interleaved one per MFMA, the rest of the MFMAs follow back to back.
     // dma_kind: 0 none, 1 W instructions j0..j0+3, 2 X instructions j0..j0+3 (M0 write | MFMA | load, see the cursors)
-#define CX_KSTEP(MMA, cur, nxt, rxs, rws, rks, dma_kind, j0)                                           \
+#define CX_KSTEP(MMA, cur, nxt, rxs, rws, rks, dma_kind, j0, HK)                                       \
     do {                                                                                              \
         MMA(cur, 0);                                                                                  \
+        HK(0);                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                            \
             read_one(nxt, rxs, rws, rks, i_);                                                         \
@@ -266,8 +325,28 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         CX_DMA_LD(dma_kind, (j0) + 3);                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         MMA(cur, 13);                                                                                 \
+        HK(1);                                                                                        \
         MMA(cur, 14);                                                                                 \
+        HK(2);                                                                                        \
         MMA(cur, 15);                                                                                 \
+        HK(3);                                                                                        \
+    } while (0)
+#define CX_NOHOOK(s_) do {} while (0)
+    // DEFER: one deferred store of the previous tile behind an MFMA (its issue hides in the MFMA's pipe time); all four sit in
+    // the K-tile's LAST k-step, behind the vmcnt wait + barrier, so that a store has a whole K-tile to retire before the next
+    // K-tile's counted wait (which, on gfx9's one in-order vmcnt, waits for it along with the operands)
+#define CX_DRAINHOOK(s_)                                                      \
+    do {                                                                      \
+        if constexpr (DEFER && DRK >= 0 && DRK < CX_V6_DEFER_SPREAD) {        \
+            constexpr int PER_ = 8 / CX_V6_DEFER_SPREAD;   /* stores per hook */ \
+            constexpr int J0_ = ((DRK < 0 ? 0 : DRK) * 4 + (s_)) * PER_;      \
+            dstore(std::integral_constant<int, J0_>{});                       \
+            if constexpr (PER_ > 1) dstore(std::integral_constant<int, J0_ + (PER_ > 1 ? 1 : 0)>{}); \
+            if constexpr (PER_ > 2) { dstore(std::integral_constant<int, J0_ + (PER_ > 2 ? 2 : 0)>{}); dstore(std::integral_constant<int, J0_ + (PER_ > 2 ? 3 : 0)>{}); } \
+            if constexpr (PER_ > 4) { dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 4 : 0)>{}); dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 5 : 0)>{}); \
+                                      dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 6 : 0)>{}); dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 7 : 0)>{}); } \
+            __builtin_amdgcn_sched_barrier(0);                                \
+        }                                                                     \
     } while (0)
 #define CX_DMA_M0(kind, J)                                                       \
     do {                                                                         \
@@ -292,7 +371,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // the first K-tile of every output tile is a peeled copy of this body, so the accumulators are DEFINED there and
     // only ever updated in place afterwards (no zeroing, no conditional definitions for the register allocator).
     int pxs_slot = 0, pws_slot = 0;  // slots consumed by the K-tile just finished (the epilogue's staging space)
-    auto kt_body = [&](auto first) {
+    auto kt_body = [&](auto first, auto drk) {
+        constexpr int DRK = decltype(drk)::value;   // DEFER: this K-tile issues stores 4 DRK .. 4 DRK + 3 of the tile in Pd (-1: none)
         // DMA of this iteration: W of iteration +1 (k-steps 0,1), X of iteration +2 (k-steps 2,3); both target slots
         // consumed in iteration -1.
         if constexpr (DBG != 0) ++n_ktiles;
@@ -300,13 +380,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const char* ws = dsm + (3 + ws_slot) * XS6;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
         if constexpr (decltype(first)::value) {
-            CX_KSTEP(mma1z, F0, F1, xs, ws, 1, 1, 0);
+            CX_KSTEP(mma1z, F0, F1, xs, ws, 1, 1, 0, CX_NOHOOK);
         } else {
-            CX_KSTEP(mma1, F0, F1, xs, ws, 1, 1, 0);
+            CX_KSTEP(mma1, F0, F1, xs, ws, 1, 1, 0, CX_NOHOOK);
         }
-        CX_KSTEP(mma1, F1, F0, xs, ws, 2, 1, 4);
+        CX_KSTEP(mma1, F1, F0, xs, ws, 2, 1, 4, CX_NOHOOK);
         w_advance();
-        CX_KSTEP(mma1, F0, F1, xs, ws, 3, 2, 0);
+        CX_KSTEP(mma1, F0, F1, xs, ws, 3, 2, 0, CX_NOHOOK);
         // this wave's reads of the current slots are complete (F1 has landed) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ... and so are its DMA writes of the next iteration's operands: everything but the 4 X instructions issued in
@@ -318,7 +398,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const char* nxs = dsm + nxs_slot * XS6;
         const char* nws = dsm + (3 + nws_slot) * XS6;
         // (at a tile end these reads fetch the first fragments of the next tile: its operands have landed too)
-        CX_KSTEP(mma1, F1, F0, nxs, nws, 0, 2, 4);
+        CX_KSTEP(mma1, F1, F0, nxs, nws, 0, 2, 4, CX_DRAINHOOK);
         x_advance();
         ++cp_kt;
         pxs_slot = xs_slot;
@@ -330,9 +410,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll 1
     while (cp_tile >= 0) {
         cp_kt = 0;
-        kt_body(std::true_type{});
+        if constexpr (DEFER) {
+            kt_body(std::true_type{}, std::integral_constant<int, 0>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 1>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 2>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 3>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 4>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 5>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 6>{});
+            kt_body(std::false_type{}, std::integral_constant<int, 7>{});
+        } else {
+            kt_body(std::true_type{}, std::integral_constant<int, -1>{});
+        }
 #pragma unroll 1
-        while (cp_kt < nk) kt_body(std::false_type{});
+        while (cp_kt < nk) kt_body(std::false_type{}, std::integral_constant<int, -1>{});
 
         {
             // MFMA results are read by VALU below; the hazard recogniser does not see through the inline asm
@@ -345,6 +436,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
             if constexpr ((DBG & 16) != 0) {
                 // ablation: no epilogue
+            } else if constexpr (DEFER) {
+                // (the previous tile's 32 stores were issued during this tile's K-tiles 0 .. 7: Pd is free)
+                pack_block(std::integral_constant<int, 0>{}); pack_block(std::integral_constant<int, 1>{});
+                pack_block(std::integral_constant<int, 2>{}); pack_block(std::integral_constant<int, 3>{});
+                pack_block(std::integral_constant<int, 4>{}); pack_block(std::integral_constant<int, 5>{});
+                pack_block(std::integral_constant<int, 6>{}); pack_block(std::integral_constant<int, 7>{});
+                pack_block(std::integral_constant<int, 8>{}); pack_block(std::integral_constant<int, 9>{});
+                pack_block(std::integral_constant<int, 10>{}); pack_block(std::integral_constant<int, 11>{});
+                pack_block(std::integral_constant<int, 12>{}); pack_block(std::integral_constant<int, 13>{});
+                pack_block(std::integral_constant<int, 14>{}); pack_block(std::integral_constant<int, 15>{});
+                dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)m0 * p.ldo + n0) * 2;
             } else if constexpr (EPI == GEMM_EPI_NONE) {
                 const bool add_bias = p.bias != nullptr;
                 // `plain` (compile time): alpha == 1 and no bias -- the forward / dgrad launches of bias-free models;
@@ -955,7 +1057,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             // above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead across the epilogue
             // (~150 cycles of exposed LDS latency per tile against 32 registers); the SwiGLU backward additionally rebuilds
             // its 16 DMA cursor offsets from (round, K-tile).
-            if constexpr (EPI == GEMM_EPI_NONE || IS_SWIGLU_BWD) {
+            if constexpr ((EPI == GEMM_EPI_NONE || IS_SWIGLU_BWD) && !DEFER) {
                 asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
                 if constexpr (IS_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
@@ -972,12 +1074,16 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
             }
             // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
-            __builtin_amdgcn_s_barrier();
+            // (DEFER stages nothing: a tile boundary is an ordinary K-tile boundary)
+            if constexpr (!DEFER) __builtin_amdgcn_s_barrier();
         }
     }
 #undef CX_KSTEP
+#undef CX_NOHOOK
+#undef CX_DRAINHOOK
 #undef CX_DMA_M0
 #undef CX_DMA_LD
+    if constexpr (DEFER) drain_all();   // the workgroup's last tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cursors' dummy DMAs must land before the LDS is handed on
     if constexpr (DBG != 0) {
         if (p.trace && tid == 0) {
@@ -987,13 +1093,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, bool DEFER = false>
 hipError_t launch6(const GemmParams& p, hipStream_t stream) {
     static CxLdsOptIn lds;
-    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG>), LDS6)) return hipErrorInvalidValue;
+    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG, DEFER>), LDS6)) return hipErrorInvalidValue;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, DBG>), dim3(grid), dim3(256), LDS6, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, DBG, DEFER>), dim3(grid), dim3(256), LDS6, stream, p);
     return hipGetLastError();
 }
 
@@ -1230,6 +1336,26 @@ bool v7_takes(const GemmParams& p, int epi) {
     return tiles256 <= 400;
 }
 
+// Deferred register stores (the DEFER instantiation): CX_V6_DEFER (build-time) 1 = every plain launch it covers, 0 = never.
+// Measured SLOWER than the staged epilogue at every shape (profiles/r4_gemm_deferred_stores_ab.txt: 1.08-1.10 x at K = 768 in its
+// best form, 1.6 x with non-temporal stores spread over 8 K-tiles): a store instruction of this layout writes 32 rows x 32
+// contiguous bytes, and the CU's write path takes ~2 cycles per 32-byte row piece (16 B/clk against 64 B/clk for whole lines) --
+// the 32 stores of a tile cost more than the LDS round trip they replace.  Routed off; kept as a dev-library A/B.
+#ifndef CX_V6_DEFER
+#define CX_V6_DEFER 0
+#endif
+#ifndef CX_PRODUCT
+int g_v6_defer = -1;           // cx_gemm_v6_set_defer: -1 = CX_V6_DEFER, 0 = never, 1 = every launch it covers
+#else
+constexpr int g_v6_defer = -1;
+#endif
+// plain bf16 output (alpha 1, no bias, no residual), whole tiles only, at least the 8 K-tiles the 32 stores are spread over
+bool defer_takes(const GemmParams& p, int epi) {
+    if (!(g_v6_defer >= 0 ? g_v6_defer != 0 : CX_V6_DEFER != 0)) return false;
+    return epi == GEMM_EPI_NONE && !p.bias && p.alpha == 1.f && !p.Out2 && (p.M % BM6) == 0 && (p.N % BN6) == 0 && p.K >= 8 * BK6 &&
+           (reinterpret_cast<uintptr_t>(p.Out) & 15) == 0 && (p.ldo % 8) == 0;
+}
+
 #ifndef CX_PRODUCT
 int g_v6_dbg = 0;              // ablation mask (cx_gemm_v6_ablate)
 long long* g_v6_trace = nullptr;  // ablation builds only: 2 x int64 per workgroup {cycles, K-tiles}
@@ -1265,6 +1391,7 @@ void cx_gemm_v6_set_trace(long long* buf) { g_v6_trace = buf; }
 void cx_gemm_v6_set_ablate(int mask) { g_v6_dbg = mask; }
 void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
 void cx_gemm_v7_set_mode(int mode) { g_v7_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
+void cx_gemm_v6_set_defer(int mode) { g_v6_defer = mode < 0 ? -1 : (mode ? 1 : 0); }
 #endif
 
 // TN wgrad form: p.X = dY (T, M), p.W = A (T, N), p.K = tokens, p.Out = fp32 partial slabs [split_k][M][ldo];
@@ -1305,6 +1432,7 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
         }
     }
 #endif
+    if (defer_takes(p, epi)) return launch6<GEMM_EPI_NONE, 0, true>(p, stream);
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_G ? launch6<GEMM_EPI_SWIGLU_G>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD_AG ? launch6<GEMM_EPI_SWIGLU_BWD_AG>(p, stream)

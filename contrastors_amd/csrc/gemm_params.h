@@ -35,6 +35,7 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream);
 void cx_gemm_v6_force_groups(int gn);
 void cx_gemm_v6_set_trace(long long* buf);
 void cx_gemm_v6_set_ablate(int mask);
+void cx_gemm_v6_set_defer(int mode);   // dev library only: -1 = CX_V6_DEFER, 0 = never, 1 = every launch the deferred-store form covers
 hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream);
 // gemm_bf16_v7.hip: two resident workgroups per CU, 256x128x64 tiles (plain / residual, SwiGLU with gate save, SwiGLU backward
 // from (act, gate)); cx_launch_gemm_v6 routes to it (policy there).  force_gn: 0 = heuristic XCD grid.
