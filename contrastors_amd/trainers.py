@@ -106,6 +106,40 @@ def _accumulation_steps(ta) -> int:
     return n
 
 
+# Below this many token rows per side a direct step's two tower calls (sc/trainers/text_text.py:330-345: model(query),
+# model(document)) are ONE call on the concatenated batch: every launch of BASELINE configs[0] (B = 32, S = 64) is 2048
+# token rows = 8 row panels of 256 on 256 CUs, its duration is latency, and two such launches back to back take twice as
+# long as one of 4096 rows.  Every op of the trunk is per token or per sequence, so embeddings are the same numbers; the
+# weight gradients sum the two sides' tokens in one reduction instead of two accumulating ones (summation order only).
+PAIR_FUSE_MAX_TOKENS = 32768
+
+
+def encode_pair(model, q, d, normalize):
+    """(query embeddings, document embeddings) from one tower call, or None when the two-call form applies: other tower
+    types (image towers, wrapped models), towers called without a mask-free length list AND without masks of equal
+    layout, or sides big enough to fill the chip on their own."""
+    if not isinstance(model, BiEncoder) or model.is_vision or model.selector is not None:
+        return None
+    qi, di = q["input_ids"], d["input_ids"]
+    if qi.dim() != 2 or di.dim() != 2 or set(q) != set(d):
+        return None
+    if max(qi.shape[0] * qi.shape[1], di.shape[0] * di.shape[1]) > PAIR_FUSE_MAX_TOKENS:
+        return None
+    S = max(qi.shape[1], di.shape[1])
+
+    def widen(t, fill=0):   # right-pad to the common width (pad positions are masked out / beyond the lengths)
+        return t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]), value=fill)
+
+    both = {"input_ids": torch.cat([widen(qi), widen(di)], 0)}
+    if "attention_mask" in q:
+        both["attention_mask"] = torch.cat([widen(q["attention_mask"]), widen(d["attention_mask"])], 0)
+    if "seqlens" in q:
+        both["seqlens"] = list(np.asarray(q["seqlens"]).reshape(-1)) + list(np.asarray(d["seqlens"]).reshape(-1))
+    emb = model(**both, normalize=normalize)["embedding"]
+    nq = qi.shape[0]
+    return emb[:nq], emb[nq:]
+
+
 class TextTextTrainer:
     def __init__(self, config: Config, dtype=torch.bfloat16, device=None, trunk_config: Optional[NomicBertConfig] = None,
                  total_steps: Optional[int] = None):
@@ -217,8 +251,13 @@ class TextTextTrainer:
             return loss
         dims = ta.matryoshka_dims
         normalize = dims is None  # sc/trainers/text_text.py:325
-        queries = model(**q, normalize=normalize)["embedding"]
-        all_documents = gather_with_grad(model(**d, normalize=normalize)["embedding"])
+        pair = encode_pair(model, q, d, normalize)
+        if pair is not None:
+            queries, documents = pair
+        else:
+            queries = model(**q, normalize=normalize)["embedding"]
+            documents = model(**d, normalize=normalize)["embedding"]
+        all_documents = gather_with_grad(documents)
         if not dims:
             return clip_loss(queries, all_documents, scale, use_fp8=bool(ta.use_fp8))
         # Matryoshka (text_text.py:352-369): one InfoNCE per prefix width on re-normalised prefixes, weighted sum.

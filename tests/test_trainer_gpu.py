@@ -39,6 +39,39 @@ def test_gradcache_and_direct_steps_agree_and_learn():
     assert last < first - 0.05
 
 
+def test_direct_step_one_tower_call_equals_two(monkeypatch):
+    """Round 4: a direct step encodes query and document side in ONE call on the concatenated batch while a side is small
+    (trainers.encode_pair; the reference calls the tower twice, sc/trainers/text_text.py:330-345).  Same loss and same
+    gradients as the two-call form on ragged sides of different widths (queries 16 x 24, documents 16 x 32, masks) -- only the
+    summation order of the weight gradients differs (one reduction over both sides' tokens instead of two accumulating ones)."""
+    from contrastors_amd import trainers as T
+
+    g = torch.Generator().manual_seed(11)
+    batch = {}
+    for side, S in (("query", 24), ("document", 32)):
+        ids = torch.randint(3, 512, (16, S), generator=g)
+        lens = torch.randint(S // 2, S + 1, (16,), generator=g)
+        mask = (torch.arange(S)[None] < lens[:, None]).long()
+        batch[f"{side}_input_ids"], batch[f"{side}_attention_mask"] = ids * mask, mask
+    a, b = _trainer(False), _trainer(False)
+    b.model["model"].trunk.flat_param.copy_(a.model["model"].trunk.flat_param)
+    b.model["model"].trunk.sync_shadows()
+    calls = []
+    fwd = type(a.model["model"]).forward
+    monkeypatch.setattr(type(a.model["model"]), "forward", lambda self, *x, **k: (calls.append(k["input_ids"].shape[0]), fwd(self, *x, **k))[1])
+    for tr, limit in ((a, T.PAIR_FUSE_MAX_TOKENS), (b, 0)):
+        monkeypatch.setattr(T, "PAIR_FUSE_MAX_TOKENS", limit)
+        tr._zero_grads()
+        tr.loss_value = tr.forward_step(batch)
+        tr.backward(tr.loss_value)
+    torch.cuda.synchronize()
+    assert calls == [32, 16, 16], calls     # one call of 16 + 16 sequences, then one per side
+    la, lb = float(a.loss_value.detach()), float(b.loss_value.detach())
+    assert abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
+    ga, gb = a.model["model"].trunk.flat_grad, b.model["model"].trunk.flat_grad
+    assert float((ga - gb).norm() / gb.norm()) < 2e-3
+
+
 @pytest.mark.parametrize("lit", [False, True])
 def test_image_text_trainer_clip_and_lit(lit):
     """BASELINE configs 5 (CLIP: both towers trained) and 4 (LiT: frozen image tower) in miniature on the native towers:
