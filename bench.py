@@ -448,6 +448,7 @@ def flat_scalars(extra: dict) -> dict:
     f["fp8_loss_frac_of_fp8_peak"] = get(extra, "clip", "loss_forward", "frac")
     f["weak_pairs_s"] = get(extra, "weak", "value")
     f["resident_pairs_s"] = get(extra, "resident", "value")
+    f["auto_policy_pairs_s"] = get(extra, "auto_policy", "value")
     f["dropin_chunk64_pairs_s"] = get(extra, "dropin_chunk64", "value")
     f["exact_chunk64_pairs_s"] = get(extra, "dropin_chunk64", "exact_chunk64", "value")
     return {k: v for k, v in f.items() if v is not None}
@@ -530,7 +531,7 @@ def main():
     # --chunk-size is taken literally in every leg but the drop-in one; the metric is the two-pass GradCache step (the
     # `resident` record is separate)
     POL = {"metric": GradCachePolicy(chunk="exact", resident=False), "resident": GradCachePolicy(chunk="exact", resident=True),
-           "dropin": GradCachePolicy(chunk="auto", resident=False)}
+           "dropin": GradCachePolicy(chunk="auto", resident=False), "auto": GradCachePolicy(chunk="exact", resident="auto")}
     lib = _C.lib()
     G, S = args.global_batch, args.seq_len
     assert G % world == 0
@@ -643,6 +644,30 @@ def main():
                                                "an unmodified YAML gets (train_args.gradcache_chunk: auto raises the chunk to ~262144 "
                                                "tokens, results unchanged), exact_chunk64 = the literal 64 (gradcache_chunk: "
                                                "exact); loss rows x 2048 documents, encoder work per pair unchanged"}
+        # the metric's own step under the library's DEFAULT policy (train_args.gradcache_resident: auto): the whole batch does
+        # not fit at N = 1 (1.26 TB of saved activations), so the tail of the batch that does fit keeps its activations and
+        # skips the re-forward (loss.resident_tail_plan; same loss bit for bit, gradients to fp32 summation order).  Runs
+        # LAST among this tower's legs: it leaves ~250 GB of arenas in the engine's pool.
+        if world == 1 and b >= 4 * args.chunk_size:
+            try:
+                tower.trunk.drop_idle_arenas()   # (a training run with this schedule only ever holds ITS arenas)
+                torch.cuda.reset_peak_memory_stats(dev)
+                a_ms = []
+                adt2, _ = run_leg(b, args.chunk_size, max(2, args.steps // 2), 1, prof=False, policy=POL["auto"], step_ms=a_ms)
+                n_chunks = (b + args.chunk_size - 1) // args.chunk_size
+                extra["auto_policy"] = {"value": b * len(a_ms) / adt2, "unit": "pairs/s", "global_batch": b,
+                                        "ms_per_step": 1e3 * adt2 / len(a_ms), "steps": len(a_ms),
+                                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                                        "chunks_per_side": n_chunks,
+                                        "note": "same step, train_args.gradcache_resident: auto (the library default) instead of the "
+                                                "headline's literal two-pass schedule: the document-side tail chunks that fit in "
+                                                "HBM beside the no-grad arena keep their activations in pass 1 and are "
+                                                "back-propagated first in pass 2 without a re-forward (their arenas then serve "
+                                                "the re-forwards); identical loss, gradients to fp32 summation order "
+                                                "(tests/test_loss_gpu.py::test_partially_resident_gradcache_equals_two_pass). "
+                                                "NOT the headline: `value` stays the reference's two passes for every chunk"}
+            except torch.OutOfMemoryError:
+                extra["auto_policy"] = "the kept tail did not fit beside this run's other buffers"
         # the loss path's one exchange step on its own: all-gather of (16384 / N, 768) fp32 embeddings per rank, through the
         # process group (RCCL) and through the one-shot peer-store path (csrc/xgmi.hip), against 7 x 153 GB/s of xGMI per GPU
         if world > 1:

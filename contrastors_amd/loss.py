@@ -16,6 +16,7 @@ import contextlib
 import logging
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -219,8 +220,10 @@ def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tra
 
 
 # ----------------------------------------------------------------------------------------------------- GradCache
-def _split_inputs(inputs: Dict[str, torch.Tensor], chunk_size: int) -> List[Dict]:
-    """Chunk a tower's input dict along the batch axis and attach host-side sequence lengths (one sync per tower)."""
+def _split_inputs(inputs: Dict[str, torch.Tensor], chunk_size: int, tail_seqs: int = 0) -> List[Dict]:
+    """Chunk a tower's input dict along the batch axis and attach host-side sequence lengths (one sync per tower).
+    tail_seqs (resident_tail_plan): the last tail_seqs sequences are chunked on their own, counted from the END, so that the
+    kept region is whole chunks plus one shorter chunk at its front; the region before it is chunked as usual."""
     total = inputs["input_ids"].shape[0]
     lens = None
     mask = inputs.get("attention_mask")
@@ -232,11 +235,20 @@ def _split_inputs(inputs: Dict[str, torch.Tensor], chunk_size: int) -> List[Dict
         right_padded = (mask[:, 1:] <= mask[:, :-1]).all()
         host = torch.stack([lens_t.max(), right_padded.to(lens_t.dtype)]).cpu()  # the one sync
         lens = lens_t.cpu().numpy() if bool(host[1]) else None
+    tail_seqs = max(0, min(int(tail_seqs), total))
+    head = total - tail_seqs
+    bounds = [(a, min(a + chunk_size, head)) for a in range(0, head, chunk_size)]
+    tail = []
+    e = total
+    while e > head:
+        tail.append((max(head, e - chunk_size), e))
+        e -= chunk_size
+    bounds += tail[::-1]
     chunks = []
-    for s in range(0, total, chunk_size):
-        c = {k: v[s: s + chunk_size] for k, v in inputs.items() if torch.is_tensor(v) and v.shape[0] == total}
+    for a, b in bounds:
+        c = {k: v[a:b] for k, v in inputs.items() if torch.is_tensor(v) and v.shape[0] == total}
         if lens is not None:
-            c["seqlens"] = lens[s: s + chunk_size]
+            c["seqlens"] = lens[a:b]
         chunks.append(c)
     return chunks
 
@@ -248,28 +260,48 @@ def _uses_rng(model) -> bool:
     return bool(getattr(trunk, "uses_rng", False)) if trunk is not None else bool(getattr(model, "training", False))
 
 
-def get_chunked_embeddings(model, chunks, rand_states=None):
+def get_chunked_embeddings(model, chunks, rand_states=None, keep_tail: int = 0, kept: Optional[dict] = None):
     """Pass 1 (sc/loss.py:135-146): no-grad chunk forwards; returns (N,d) embeddings.  `rand_states` (a list) receives one
-    RandContext snapshot per chunk, taken right before the chunk's forward (loss.py:141-143)."""
+    RandContext snapshot per chunk, taken right before the chunk's forward (loss.py:141-143).
+    keep_tail / kept (beyond the reference's signature; resident_tail_plan): the LAST keep_tail chunks run as saving forwards
+    and their outputs (autograd holds the activation arenas) go to kept[chunk index] -- pass 2 back-propagates them without a
+    re-forward.  A saving forward that runs out of memory turns itself and the rest of the tail into plain no-grad forwards."""
     embs = []
     needed = rand_states is not None and _uses_rng(model)
-    with torch.no_grad():
-        for c in chunks:
-            if rand_states is not None:
-                rand_states.append(RandContext(c, needed=needed))
+    n = len(chunks)
+    trainable = kept is not None and keep_tail > 0 and model.training and not getattr(model, "frozen_trunk", False)
+    first_kept = n - keep_tail if trainable else n
+    trunk = getattr(model, "trunk", None)
+    for i, c in enumerate(chunks):
+        if rand_states is not None:
+            rand_states.append(RandContext(c, needed=needed))
+        if i >= first_kept:
+            suspended = (trunk.selective_checkpointing_suspended() if hasattr(trunk, "selective_checkpointing_suspended")
+                         else contextlib.nullcontext())
+            try:
+                with torch.enable_grad(), suspended:
+                    out = model(**c)["embedding"]
+                kept[i] = out
+                embs.append(out.detach())
+                continue
+            except torch.OutOfMemoryError:
+                first_kept = n   # the estimate was too generous: what is kept so far stays, the rest is recomputed in pass 2
+                _log_once(("gradcache-tail-oom",), "GradCache: a kept chunk ran out of memory; the rest of the step re-forwards")
+        with torch.no_grad():
             embs.append(model(**c)["embedding"])
     return torch.cat(embs, dim=0)
 
 
-def accumulate_gradients(model, chunks, cache, rand_states=None, final: bool = False):
+def accumulate_gradients(model, chunks, cache, rand_states=None, final: bool = False, skip=()):
     """Pass 2 (sc/loss.py:149-161): re-forward under the chunk's saved RNG state, back-propagate the cached embedding
     gradient through it.  `final`: this call's last chunk completes the tower's gradients for the step -- its backward
     starts the data-parallel reduction block by block (the reference's DDP does the same on the chunk it does not wrap in
-    no_sync, sc/loss.py:151)."""
-    n = len(chunks)
-    for i, (c, g) in enumerate(zip(chunks, cache)):
+    no_sync, sc/loss.py:151).  `skip`: chunk indices whose backward has already run (kept chunks, resident_tail_plan)."""
+    todo = [i for i in range(len(chunks)) if i not in skip]
+    for i in todo:
+        c, g = chunks[i], cache[i]
         state = rand_states[i] if rand_states is not None else RandContext(c, needed=False)
-        if final and i == n - 1 and hasattr(model, "arm_overlapped_reduce"):
+        if final and i == todo[-1] and hasattr(model, "arm_overlapped_reduce"):
             model.arm_overlapped_reduce()
         with state:
             out = model(**c)["embedding"]
@@ -374,6 +406,64 @@ def resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs, policy: Optio
     return need <= 0.8 * free
 
 
+def _pool_free_bytes(dev, towers) -> float:
+    free, _ = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # the allocator's own cache
+    for tw in {id(t): t for t in towers}.values():
+        free += sum(a.nbytes() for a in getattr(getattr(tw, "trunk", None), "_arena_free", []))   # arenas the engine re-uses
+    return float(free)
+
+
+def resident_tail_plan(tower1, t1_inputs, cq: int, tower2, t2_inputs, cd: int, policy: Optional[GradCachePolicy] = None):
+    """(query sequences, document sequences) at the END of each side whose activations pass 1 keeps when the whole batch does
+    not fit (resident_activations_fit said no): the two-pass schedule with as much of the re-forward removed as the HBM pays
+    for.  The kept chunks are back-propagated FIRST in pass 2, so their arenas are back in the engine's pool when the
+    re-forwards need a saving arena -- the budget is everything but the no-grad arena and the loss buffers: 85 % of (free +
+    pooled) bytes.  Whole chunks from the end of the document side (then of the query side), plus a last shorter chunk in
+    multiples of 64 sequences.  At the metric's single-GPU shape (2 x 16384 sequences of 128 tokens, 44 MB of saved
+    activations each) that is ~5600 sequences: 17 % of pass 2's forward, ~4 % of the step; the same kernels on the same
+    data, gradients accumulated in a different chunk order (fp32 summation order, as between any two chunk sizes).
+    policy.resident: "auto" only (False: the reference's schedule literally; True asked for everything resident)."""
+    mode = (policy or GradCachePolicy()).with_env().resident
+    if mode != "auto":
+        return 0, 0
+    sides = []
+    dev = None
+    for tw, inp, chunk in ((tower1, t1_inputs, cq), (tower2, t2_inputs, cd)):
+        cfg = getattr(getattr(tw, "trunk", None), "config", None)
+        ids = inp.get("input_ids") if isinstance(inp, dict) else None
+        ok = (cfg is not None and hasattr(cfg, "n_inner") and ids is not None and ids.is_cuda and ids.ndim == 2 and tw.training
+              and not getattr(tw, "frozen_trunk", False) and hasattr(tw.trunk, "_arena_free") and chunk and chunk > 0)
+        if not ok:
+            sides.append(None)
+            continue
+        dev = ids.device
+        lens = inp.get("seqlens")
+        per_seq = (float(np.max(lens)) if lens is not None and len(lens) else float(ids.shape[1]))   # (an upper bound is enough)
+        sides.append((ids.shape[0], int(chunk), per_seq * _arena_bytes_per_token(tw) * 1.03))
+    if dev is None:
+        return 0, 0
+    towers = [t for t, sd_ in zip((tower1, tower2), sides) if sd_ is not None]
+    budget = 0.85 * _pool_free_bytes(dev, towers)
+    biggest = max(sd_[1] * sd_[2] for sd_ in sides if sd_ is not None)
+    budget -= 0.09 * biggest + 3e9     # the no-grad arena (one slot instead of L: ~8 % of a saving arena) and the loss buffers
+    keep = [0, 0]
+    for side in (1, 0):                # document tail first, then the query tail
+        if sides[side] is None:
+            continue
+        total, chunk, per_seq = sides[side]
+        fit = int(max(0.0, budget) // per_seq)
+        if fit >= total:
+            keep[side] = total
+            budget -= total * per_seq
+            continue
+        whole = fit // chunk * chunk
+        part = (fit - whole) // 64 * 64      # one shorter chunk in front of the whole ones
+        keep[side] = whole + (part if part >= 256 else 0)
+        break
+    return keep[0], keep[1]
+
+
 def _resident_forward(model, chunks):
     """Forward of every chunk with its activations kept (autograd holds the arenas until the chunk's backward)."""
     if not model.training or getattr(model, "frozen_trunk", False):
@@ -406,18 +496,21 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
     (keyword-only, beyond the reference's signature) carries the MI355X scheduling decisions; see GradCachePolicy."""
     pol = (policy or GradCachePolicy()).with_env()
     cq, cd = effective_chunk(tower1, t1_inputs, chunk_size, pol), effective_chunk(tower2, t2_inputs, chunk_size, pol)
-    q_chunks = _split_inputs(t1_inputs, cq)
-    d_chunks = _split_inputs(t2_inputs, cd)
     was_training1, was_training2 = tower1.training, tower2.training
+    resident = resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs, pol)
+    # when the whole batch cannot stay resident, the tail of it that can is chunked on its own (resident_tail_plan)
+    kq_seqs, kd_seqs = (0, 0) if resident else resident_tail_plan(tower1, t1_inputs, cq, tower2, t2_inputs, cd, pol)
+    q_chunks = _split_inputs(t1_inputs, cq, kq_seqs)
+    d_chunks = _split_inputs(t2_inputs, cd, kd_seqs)
     sizes_q = [c["input_ids"].shape[0] for c in q_chunks]
     sizes_d = [c["input_ids"].shape[0] for c in d_chunks]
-    resident = resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs, pol)
     _log_once(("gradcache", chunk_size, cq, cd, resident, pol.use_fp8),
               f"GradCache schedule: recipe chunk_size {chunk_size} -> {cq} queries / {cd} documents per chunk "
               f"({len(q_chunks)} + {len(d_chunks)} chunks; policy.chunk = {pol.chunk!r}); "
               f"{'pass 1 keeps its activations, no re-forward' if resident else 'two passes (re-forward)'} "
               f"(policy.resident = {pol.resident!r}); similarity GEMM {'fp8' if pol.use_fp8 else 'fp32'}")
     done = False
+    fell_back = False   # the all-resident attempt ran out of memory: this step takes the reference's schedule literally
     if resident:
         q_out = d_out = None
         try:
@@ -437,6 +530,7 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             q_out = d_out = None
             if pol.resident is True:
                 raise
+            fell_back = True
             torch.cuda.empty_cache()
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")
@@ -453,14 +547,48 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             del q_out, d_out
             done = True
     if not done:
+        # two passes; under policy.resident = "auto" the tail of the batch that fits keeps its activations (resident_tail_plan)
+        nq_keep = 0 if fell_back else (kq_seqs + cq - 1) // cq if kq_seqs else 0    # (chunks: the kept region was split on its own)
+        nd_keep = 0 if fell_back else (kd_seqs + cd - 1) // cd if kd_seqs else 0
+        if nq_keep or nd_keep:
+            _log_once(("gradcache-tail", len(q_chunks), len(d_chunks), kq_seqs, kd_seqs),
+                      f"GradCache schedule: the last {kq_seqs} query and {kd_seqs} document sequences ({nq_keep} + {nd_keep} chunks of "
+                      f"{len(q_chunks)} + {len(d_chunks)}) keep their activations (no re-forward for them)")
         q_rnd, d_rnd = [], []
-        q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd)
-        d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd)
-        q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
+        q_kept, d_kept = {}, {}
+        try:
+            q_embs = get_chunked_embeddings(tower1, q_chunks, q_rnd, keep_tail=nq_keep, kept=q_kept)
+            d_embs = get_chunked_embeddings(tower2, d_chunks, d_rnd, keep_tail=nd_keep, kept=d_kept)
+            q_cache, d_cache, loss = cache_loss(q_embs, d_embs, logit_scale, bidirectional=bidirectional, use_fp8=pol.use_fp8)
+        except BaseException:
+            _release_resident(tower1, list(q_kept.values()))   # (nothing leaks when the loss, or a later forward, fails)
+            _release_resident(tower2, list(d_kept.values()))
+            raise
+        q_grads, d_grads = q_cache.split(sizes_q), d_cache.split(sizes_d)
+        done_q, done_d = set(q_kept), set(d_kept)       # (what pass 1 actually kept: an out-of-memory error may have cut the tail)
+        re_q = len(done_q) < len(q_chunks)                                  # "the query side has chunks to re-forward"
+        re_d = was_training2 and len(done_d) < len(d_chunks)
+        # Kept chunks first: their arenas go back to the engine's pool and serve the re-forwards below.  The backward that
+        # completes a tower's gradients starts their data-parallel reduction (arm_overlapped_reduce): the last re-forwarded
+        # chunk where there is one (accumulate_gradients' `final`), else the last kept chunk of that tower.
+        shared = tower1 is tower2
+        for i in sorted(done_q):
+            o = q_kept.pop(i)
+            last_of_tower1 = not re_q and not q_kept and (not shared or (not done_d and not re_d))
+            if last_of_tower1 and hasattr(tower1, "arm_overlapped_reduce"):
+                tower1.arm_overlapped_reduce()
+            o.backward(q_grads[i].to(o.dtype))
+        for i in sorted(done_d):
+            o = d_kept.pop(i)
+            last_of_tower2 = not re_d and not d_kept and not (shared and re_q)
+            if last_of_tower2 and hasattr(tower2, "arm_overlapped_reduce"):
+                tower2.arm_overlapped_reduce()
+            o.backward(d_grads[i].to(o.dtype))
         # (a tower shared by both sides has its gradients complete only after the document pass)
-        accumulate_gradients(tower1, q_chunks, q_cache.split(sizes_q), q_rnd, final=tower1 is not tower2 or not was_training2)
-        if was_training2:
-            accumulate_gradients(tower2, d_chunks, d_cache.split(sizes_d), d_rnd, final=True)
+        if re_q:
+            accumulate_gradients(tower1, q_chunks, q_grads, q_rnd, final=(not shared) or not re_d, skip=done_q)
+        if re_d:
+            accumulate_gradients(tower2, d_chunks, d_grads, d_rnd, final=True, skip=done_d)
     # data-parallel reduction of the accumulated gradients: once per step, one flat buffer per distinct tower
     seen = set()
     for tw, active in ((tower1, was_training1), (tower2, was_training2)):

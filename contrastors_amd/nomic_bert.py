@@ -890,6 +890,15 @@ class NomicBertEngine(torch.nn.Module):
             return out, arena
         return out, None
 
+    def drop_idle_arenas(self):
+        """Give every pooled (idle) activation arena back to the allocator: a schedule change (another batch shape, another
+        GradCache policy) then starts from exactly-sized arenas instead of best-fitting into the previous schedule's."""
+        for a in self._arena_free:
+            self._keep_plan.pop(a.T_cap, None)
+        self._arena_free = []
+        self._arena_nograd = None
+        torch.cuda.empty_cache()
+
     def backward_chunk(self, vb: VarlenBatch, arena: _ChunkArena, demb: torch.Tensor):
         """Accumulate every parameter gradient for the chunk whose activations are in `arena`."""
         assert arena.emb_out is not None, "backward_chunk needs a forward with save_for_backward=True"

@@ -302,6 +302,80 @@ def test_resident_activation_gradcache_equals_two_pass(monkeypatch):
     assert not resident_activations_fit(tower, {"input_ids": ids}, tower, {"input_ids": ids})
 
 
+def test_partially_resident_gradcache_equals_two_pass(monkeypatch):
+    """Round 4: when the whole batch does not fit, policy.resident = "auto" keeps the TAIL of the batch that does
+    (loss.resident_tail_plan): those chunks are back-propagated first in pass 2 without a re-forward, the rest takes the
+    reference's two passes.  Same embeddings -> the same loss bit for bit; the same per-chunk gradients accumulated in another
+    order -> gradients to fp32 summation order.  With dropout the kept chunks draw their masks in pass 1 exactly where the
+    no-grad forward would have (same generator states).  A kept forward that runs out of memory turns the rest of the tail
+    into plain no-grad forwards; the planner's arithmetic is checked on a fake budget."""
+    import contrastors_amd.loss as L_
+    from contrastors_amd.policy import GradCachePolicy
+
+    scale = LogitScale(SimpleNamespace(logit_scale=50.0, trainable_logit_scale=False)).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    B, S = 160, 64
+    q = {"input_ids": torch.randint(1000, 8192, (B, S), generator=g).to(DEV), "seqlens": [S] * B}
+    d = {"input_ids": torch.randint(1000, 8192, (B, S), generator=g).to(DEV), "seqlens": [S - 5] * B}
+    monkeypatch.delenv("CX_GRADCACHE_RESIDENT", raising=False)
+    monkeypatch.delenv("CX_GRADCACHE_CHUNK", raising=False)
+    monkeypatch.setattr(L_, "resident_activations_fit", lambda *a, **k: False)   # "the whole batch does not fit"
+    for p_drop in (0.0, 0.1):
+        cfg = NomicBertConfig.nomic_bert_2048(vocab_size=8192, n_layer=3, resid_pdrop=p_drop, embd_pdrop=p_drop)
+        tower = BiEncoder(BiEncoderConfig(model_name="nomic", pooling="mean", trunk_config=cfg), device=DEV, seed=13).train()
+        res = {}
+        # kept SEQUENCES per side (chunks of 32): none ... all; (0, 48) moves the chunk boundaries (112 = 32 + 32 + 32 + 16 | 16 + 32):
+        # without dropout nothing depends on them, with dropout a chunk's masks are keyed by its own generator offset (as any
+        # change of chunk_size re-draws them, here and in the reference)
+        for plan in ((0, 0), (0, 64), (32, 160), (160, 160)) + (((0, 48),) if p_drop == 0.0 else ()):
+            monkeypatch.setattr(L_, "resident_tail_plan", lambda *a, _p=plan, **k: _p)
+            torch.manual_seed(321)
+            tower.trunk.zero_grad()
+            loss = grad_cache_loss(tower, q, tower, d, 32, scale, policy=GradCachePolicy(chunk="exact", resident="auto"))
+            torch.cuda.synchronize()
+            res[plan] = (float(loss), tower.trunk.flat_grad.clone())
+            assert tower.trunk._outstanding == 0
+        gn = float(res[(0, 0)][1].norm())
+        for plan, (l, gr) in res.items():
+            assert l == res[(0, 0)][0], plan
+            assert float((gr - res[(0, 0)][1]).norm()) <= 2e-5 * gn, plan
+    # a kept forward runs out of memory: what is kept so far stays kept, the rest of the tail is recomputed
+    real = tower.trunk.forward_chunk
+    calls = {"n": 0}
+
+    def flaky(vb, save_for_backward, *a, **k):
+        if save_for_backward:
+            calls["n"] += 1
+            if calls["n"] == 2:
+                raise torch.OutOfMemoryError("simulated: HIP out of memory")
+        return real(vb, save_for_backward, *a, **k)
+
+    monkeypatch.setattr(L_, "resident_tail_plan", lambda *a, **k: (0, 128))
+    monkeypatch.setattr(tower.trunk, "forward_chunk", flaky)
+    torch.manual_seed(321)
+    tower.trunk.zero_grad()
+    loss = grad_cache_loss(tower, q, tower, d, 32, scale, policy=GradCachePolicy(chunk="exact", resident="auto"))
+    assert float(loss) == res[(0, 0)][0] and tower.trunk._outstanding == 0
+    assert float((tower.trunk.flat_grad - res[(0, 0)][1]).norm()) <= 2e-5 * gn
+    monkeypatch.undo()
+    # the planner: document tail first, whole chunks (+ a shorter one in multiples of 64 sequences when it is worth >= 256),
+    # 85 % of the pooled free bytes minus the no-grad arena and the loss buffers
+    monkeypatch.delenv("CX_GRADCACHE_RESIDENT", raising=False)
+    per = L_._arena_bytes_per_token(tower) * 1.03
+    s_q, s_d = S * per, (S - 5) * per                       # bytes per sequence
+    fixed = 3e9 + 0.09 * 32 * s_q
+    for free, want in ((0.0, (0, 0)), ((fixed + 80.5 * s_d) / 0.85, (0, 64)), ((fixed + 160 * s_d + 38.5 * s_q) / 0.85, (32, 160)),
+                       (1e15, (160, 160))):
+        monkeypatch.setattr(L_, "_pool_free_bytes", lambda *a, _f=free, **k: _f)
+        assert L_.resident_tail_plan(tower, q, 32, tower, d, 32, GradCachePolicy(resident="auto")) == want, (free, want)
+    monkeypatch.setattr(L_, "_pool_free_bytes", lambda *a, **k: (3e9 + 0.09 * 2048 * s_d + (4096 + 700) * s_d) / 0.85)
+    big = {"input_ids": d["input_ids"][:1].expand(16384, S), "seqlens": [S - 5] * 16384}
+    assert L_.resident_tail_plan(tower, big, 2048, tower, big, 2048, GradCachePolicy(resident="auto")) == (0, 4096 + 640)
+    assert L_.resident_tail_plan(tower, q, 32, tower, d, 32, GradCachePolicy(resident=False)) == (0, 0)
+    chunks = L_._split_inputs(big, 2048, 4096 + 640)
+    assert [c["input_ids"].shape[0] for c in chunks] == [2048] * 5 + [1408, 640, 2048, 2048]
+
+
 def test_resident_schedule_falls_back_to_two_pass_on_out_of_memory(monkeypatch, caplog):
     """ADVICE r2 / VERDICT r2 item 3: if keeping pass 1's activations runs out of memory (the estimate of
     resident_activations_fit cannot see fragmentation), the step must not die: no parameter gradient has been touched at
