@@ -79,6 +79,7 @@ _SIGS = {
     "cx_transpose_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "cx_cast_transpose_f32_to_bf16": (i32, [vp, vp, i32, i32, vp]),
+    "cx_cast_transpose_f32_to_bf16_batched": (i32, [vp, i32, i32, vp]),
     "cx_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "cx_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "cx_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

@@ -70,6 +70,27 @@ __global__ __launch_bounds__(256) void cast_transpose_f32_bf16_kernel(const floa
     }
 }
 
+// blockIdx.y = matrix, blockIdx.x = 64 x 64 tile of it (blocks past a matrix's tile count leave at once)
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CxCastJob* __restrict__ jobs) {
+    __shared__ float tile[64][65];
+    const CxCastJob j = jobs[blockIdx.y];
+    const int tiles_c = (j.cols + 63) / 64, tiles_r = (j.rows + 63) / 64;
+    if ((int)blockIdx.x >= tiles_c * tiles_r) return;
+    const int tid = threadIdx.x;
+    const int r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int gr = r0 + r, gc = c0 + c;
+        tile[r][c] = (gr < j.rows && gc < j.cols) ? j.in[(size_t)gr * j.cols + gc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        const int gr = r0 + r, gc = c0 + c;
+        if (gr < j.rows && gc < j.cols) j.out_t[(size_t)gc * j.rows + gr] = f32_to_bf16(tile[r][c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             int rows, int cols, int ld_in, int ld_out) {
     __shared__ float tile[64][65];
@@ -469,6 +490,14 @@ int cx_cast_transpose_f32_to_bf16(const float* In, uint16_t* OutT, int rows, int
     if (rows <= 0 || cols <= 0) return CX_OK;
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     hipLaunchKernelGGL(cast_transpose_f32_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, In, OutT, rows, cols);
+    return done();
+}
+
+int cx_cast_transpose_f32_to_bf16_batched(const CxCastJob* jobs, int n_jobs, int max_tiles, void* stream) {
+    if (n_jobs <= 0 || max_tiles <= 0) return CX_OK;
+    if (!jobs) return CX_ERR_ARG;
+    if (n_jobs > 65535) return CX_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(max_tiles, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
     return done();
 }
 

@@ -495,11 +495,18 @@ class NomicBertEngine(torch.nn.Module):
         n = self._lin_end - self._lin_begin
         _C.check(self.lib.cx_cast_f32_to_bf16(self.flat_param.data_ptr() + 4 * self._lin_begin, self.w16.data_ptr(),
                                                n, s), "cast")
-        for name in self._linear_names:
-            off, shape = self._layout[name]
-            _C.check(self.lib.cx_cast_transpose_f32_to_bf16(self.flat_param.data_ptr() + 4 * off,
-                                                             self._w16(name, True).data_ptr(), shape[0], shape[1],
-                                                             s), "cast_transpose")
+        jobs = getattr(self, "_cast_jobs", None)
+        if jobs is None:   # one launch for every transposed shadow (CxCastJob table in device memory; the buffers never move)
+            tab = np.zeros(len(self._linear_names), dtype=np.dtype([("in", "u8"), ("out", "u8"), ("rows", "i4"), ("cols", "i4")]))
+            tiles = 0
+            for i, name in enumerate(self._linear_names):
+                off, shape = self._layout[name]
+                tab[i] = (self.flat_param.data_ptr() + 4 * off, self._w16(name, True).data_ptr(), shape[0], shape[1])
+                tiles = max(tiles, ((shape[0] + 63) // 64) * ((shape[1] + 63) // 64))
+            dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device_)
+            jobs = self._cast_jobs = (dev_tab, len(self._linear_names), tiles, self.flat_param.data_ptr(), self.w16_t.data_ptr())
+        assert jobs[3] == self.flat_param.data_ptr() and jobs[4] == self.w16_t.data_ptr(), "parameter buffers moved"
+        _C.check(self.lib.cx_cast_transpose_f32_to_bf16_batched(jobs[0].data_ptr(), jobs[1], jobs[2], s), "cast_transpose")
 
     def zero_grad(self, set_to_none: bool = False):  # noqa: D401 - torch signature
         self.flat_grad.zero_()

@@ -61,6 +61,15 @@ int cx_transpose_bf16(const uint16_t* In, uint16_t* Out, int rows, int cols, int
 /* fp32 master weights -> bf16 shadow (row-major copy) and optional transposed bf16 shadow (for dgrad). */
 int cx_cast_f32_to_bf16(const float* In, uint16_t* Out, long n, void* stream);
 int cx_cast_transpose_f32_to_bf16(const float* In, uint16_t* OutT, int rows, int cols, void* stream);
+/* The same for n_jobs matrices in ONE launch (cx_abi_version >= 8): `jobs` is a DEVICE array; max_tiles = the largest
+ * ceil(rows / 64) * ceil(cols / 64) among them.  The optimizer step's refresh of the transposed bf16 weight shadows was 48
+ * launches of ~11 us each -- 5 % of BASELINE configs[0]'s 11 ms step. */
+typedef struct {
+    const float* in;    /* (rows, cols) fp32, row-major */
+    uint16_t* out_t;    /* (cols, rows) bf16 */
+    int rows, cols;
+} CxCastJob;
+int cx_cast_transpose_f32_to_bf16_batched(const CxCastJob* jobs, int n_jobs, int max_tiles, void* stream);
 int cx_cast_bf16_to_f32(const uint16_t* In, float* Out, long n, void* stream);
 
 /* ---- K5/K6  dropout_add_layer_norm / layer_norm  (flash_attn.ops.layer_norm; sc/layers/block.py:309-319,

@@ -195,6 +195,17 @@ def test_transpose_and_casts():
     ot = torch.empty(200, 300, dtype=torch.bfloat16, device=DEV)
     _C.check(L().cx_cast_transpose_f32_to_bf16(w.data_ptr(), ot.data_ptr(), 300, 200, S()))
     assert torch.equal(ot, w.T.to(torch.bfloat16))
+    # the batched form (one launch for every weight shadow of an optimizer step): a device table of CxCastJob
+    mats = [_randn(300, 200, seed=8), _randn(64, 768, seed=18), _randn(770, 65, seed=19)]
+    outs = [torch.full((m.shape[1], m.shape[0]), 7.0, dtype=torch.bfloat16, device=DEV) for m in mats]
+    tab = np.zeros(3, dtype=np.dtype([("in", "u8"), ("out", "u8"), ("rows", "i4"), ("cols", "i4")]))
+    for i, (m, o) in enumerate(zip(mats, outs)):
+        tab[i] = (m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1])
+    dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(DEV)
+    tiles = max(((m.shape[0] + 63) // 64) * ((m.shape[1] + 63) // 64) for m in mats)
+    _C.check(L().cx_cast_transpose_f32_to_bf16_batched(dev_tab.data_ptr(), 3, tiles, S()))
+    for m, o in zip(mats, outs):
+        assert torch.equal(o, m.T.to(torch.bfloat16))
     back = torch.empty(300 * 200, dtype=torch.float32, device=DEV)
     _C.check(L().cx_cast_bf16_to_f32(o16.data_ptr(), back.data_ptr(), w.numel(), S()))
     assert torch.equal(back, o16.float())
