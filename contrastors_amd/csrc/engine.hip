@@ -98,6 +98,7 @@ int wgrad(const uint16_t* dY, int out_f, const uint16_t* X, int in_f, float* gW,
     if (!gW) return CX_OK;
     const int rc = cx_gemm_bf16_tn_accum(dY, X, gW, b->ws_f32, b->ws_floats, T, out_f, in_f, out_f, in_f, stream);
     if (rc != CX_ERR_SHAPE) return rc;
+    if (!b->tr_a || !b->tr_b) return CX_ERR_ARG;   // (optional since ABI 8: arenas of towers whose feature counts tile by 256 omit them)
     const int Tp = (int)round_up(T, 64);
     CX_TRY(cx_transpose_bf16(dY, b->tr_a, T, out_f, out_f, Tp, Tp, stream));
     CX_TRY(cx_transpose_bf16(X, b->tr_b, T, in_f, in_f, Tp, Tp, stream));
@@ -272,7 +273,7 @@ int blocks_forward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const Sl
 }
 
 int check_bwd_buffers(const CxChunkBuffers* buf) {
-    return (!buf->g_a || !buf->g_b || !buf->g_c || !buf->g_wide || !buf->g_act || !buf->tr_a || !buf->tr_b || !buf->delta ||
+    return (!buf->g_a || !buf->g_b || !buf->g_c || !buf->g_wide || !buf->g_act || !buf->delta ||
             !buf->ws_f32) ? CX_ERR_ARG : CX_OK;
 }
 

@@ -363,7 +363,8 @@ def _arena_bytes_per_token(tower) -> float:
     wfc1 = 2 * I if getattr(cfg, "gated", False) else I
     per_layer = 2 * (3 * d + 5 * d + I + I) + 4 * (cfg.n_head + 4)   # (the gated MLP keeps the gate alone: (T, I), not (T, 2I))
     kept = 1 if getattr(tower.trunk, "gradient_checkpointing", False) else L
-    scratch = 2 * (3 * d + 3 * max(3 * d, wfc1) + I)
+    needs_tr = any(f % 256 for f in (d, 3 * d, I, wfc1))   # (the transposed wgrad operands: nomic_bert._ChunkArena)
+    scratch = 2 * (3 * d + (3 if needs_tr else 1) * max(3 * d, wfc1) + I)
     return kept * per_layer + (L - kept) * 2 * d + scratch
 
 

@@ -190,8 +190,11 @@ class _ChunkArena:
                 t[n] = torch.empty(T_cap, d, **bf)
             t["g_wide"] = torch.empty(T_cap, wide, **bf)
             t["g_act"] = torch.empty(T_cap, I, **bf)
-            t["tr_a"] = torch.empty(wide, T_cap, **bf)
-            t["tr_b"] = torch.empty(wide, T_cap, **bf)
+            # transposed operands of the wgrad FALLBACK: the natural-layout kernel covers feature counts that tile by 256 (every
+            # BASELINE tower); only other widths (the tiny test trunks) transpose -- 2 x wide x 2 B per token not allocated
+            if any(f % 256 for f in (d, 3 * d, I, wfc1) + ((patch_dim,) if patch_dim else ())):
+                t["tr_a"] = torch.empty(wide, T_cap, **bf)
+                t["tr_b"] = torch.empty(wide, T_cap, **bf)
             t["delta"] = torch.empty(T_cap * H, **f32)
             if getattr(cfg, "resid_pdrop", 0.0) > 0:  # dropout: the LayerNorm backward returns a second gradient
                 t["g_d"] = torch.empty(T_cap, d, **bf)

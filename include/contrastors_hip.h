@@ -410,7 +410,9 @@ typedef struct CxChunkBuffers {
     uint16_t* g_a; uint16_t* g_b; uint16_t* g_c;   /* (T,d) gradient ping-pong buffers */
     uint16_t* g_wide;           /* (T, max(3d, 2I)) */
     uint16_t* g_act;            /* (T, I) */
-    uint16_t* tr_a; uint16_t* tr_b; /* transposed operands for wgrad: (max(3d,2I), T_cap) each */
+    uint16_t* tr_a; uint16_t* tr_b; /* transposed operands for wgrad: (max(3d,2I), T_cap) each.  Only the fallback for feature
+                                     * counts that are not multiples of 256 uses them (cx_gemm_bf16_tn_accum declines those
+                                     * shapes); may be NULL otherwise (cx_abi_version >= 8) -- 24.6 KB per token at d = 768 */
     float* delta;               /* (H,T) */
     float* ws_f32;              /* split-K workspace for the wgrad GEMMs */
     long ws_floats;
