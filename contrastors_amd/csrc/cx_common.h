@@ -35,6 +35,37 @@ CX_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
 }
 CX_DEVICE bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
+// a * b with the DX9 rule 0 * anything = 0 (v_mul_legacy_f32: also 0 * inf and 0 * NaN)
+CX_DEVICE float mul_legacy_f32(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Backward of act = y * silu(g) from the saved (act, gate) pair (round 3's compact save: y = act / silu(g) is recovered
+// inside the derivative):  d y = d * g * s,  d gate = d * y * silu'(g) = d * act * (1 / g + 1 - s),  s = sigmoid(g).
+// An exactly-zero gate (or a silu that underflowed) means act = 0, y is not recoverable and d gate comes out 0: the last
+// product is a legacy multiply, 0 * (1/0 = inf) = 0 -- no compare / select per element (round 4: the fc2-dgrad + SwiGLU-backward
+// epilogue spends ~4500 VALU instructions per tile and wave, 15.5 per element, in the one wave that also issues the MFMAs).
+CX_DEVICE void swiglu_bwd_from_act(float d, float act, float g, float& dy, float& dg) {
+    const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+    dy = g * s * d;
+    dg = mul_legacy_f32(d * act, __builtin_amdgcn_rcpf(g) + 1.f - s);
+}
+// The same on element PAIRS (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per instruction; the transcendental and
+// legacy-multiply instructions have no packed form).  Same operations in the same order per element: bit-identical to the
+// scalar form.
+typedef float cx_f2 __attribute__((ext_vector_type(2)));
+CX_DEVICE void swiglu_bwd_from_act2(cx_f2 d, cx_f2 act, cx_f2 g, cx_f2& dy, cx_f2& dg) {
+    const cx_f2 m = g * -1.4426950408889634f;
+    const cx_f2 t = cx_f2{__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)} + 1.f;
+    const cx_f2 s = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
+    dy = g * s * d;
+    const cx_f2 w = cx_f2{__builtin_amdgcn_rcpf(g.x), __builtin_amdgcn_rcpf(g.y)} + 1.f - s;
+    const cx_f2 da = d * act;
+    dg = cx_f2{mul_legacy_f32(da.x, w.x), mul_legacy_f32(da.y, w.y)};
+}
+
 // erf-GELU pieces on v_exp_f32 / v_rcp_f32: erf(x) = sign(x) (1 - poly(t) exp(-x^2)), t = 1 / (1 + 0.3275911 |x|)
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- two orders below a bf16 ulp).  libm's erff costs ~40 VALU ops per
 // element and made both GELU kernels VALU-bound at a third of HBM speed.  For gelu the argument is v / sqrt(2), so

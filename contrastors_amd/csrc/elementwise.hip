@@ -205,12 +205,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_gate_kernel(const bf16_t* __re
         unpack8(*reinterpret_cast<const uint4*>(gate + t * (long)I + c), g);
         unpack8(*reinterpret_cast<const uint4*>(dact + t * (long)I + c), d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float s = sigmoidf_(g[e]);
-            dy[e] = g[e] * s * d[e];
-            const float rg = __builtin_amdgcn_rcpf(fabsf(g[e]) < 1e-30f ? 1.f : g[e]);   // (g = 0 <=> act = 0)
-            dg[e] = d[e] * a[e] * (rg + 1.f - s);
-        }
+        for (int e = 0; e < 8; ++e) swiglu_bwd_from_act(d[e], a[e], g[e], dy[e], dg[e]);   // (g = 0 <=> act = 0 -> d gate = 0)
         bf16_t* orow = dyg + t * (2L * I);
         *reinterpret_cast<uint4*>(orow + ycol(c, I, 1)) = pack8(dy);
         *reinterpret_cast<uint4*>(orow + gcol(c, I, 1)) = pack8(dg);

@@ -643,12 +643,33 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 bf16_t* dyg = reinterpret_cast<bf16_t*>(p.Out);
                 const int c0 = 2 * n0;  // first pre-activation column of this wave
                 // d(gate) coefficient per element: silu'(g) * y from (y, g)  |  act * (1/g + 1 - sg) from (act, g)
-                auto dgate_of = [&](float yv, float gv, float sg, float gs, float dv) {
+                // one element: d(act) dv (fp32, straight from the accumulator -- round 4: the bf16 round trip the standalone op
+                // implies cost 1.5 instructions per element of an epilogue that is VALU-issue-bound, and fp32 is the better
+                // number), saved (y | act) yv and gate gv -> d y, d gate
+                auto bwd_elem = [&](float yv, float gv, float dv, float& dyo, float& dgo) {
                     if constexpr (AG) {
-                        const float rg = __builtin_amdgcn_rcpf(__builtin_fabsf(gv) < 1e-30f ? 1.f : gv);  // (g = 0 <=> act = 0)
-                        return dv * yv * (rg + 1.f - sg);
+                        swiglu_bwd_from_act(dv, yv, gv, dyo, dgo);
                     } else {
-                        return (sg + gs * (1.f - sg)) * dv * yv;
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gv));
+                        const float gs = gv * sg;
+                        dyo = gs * dv;
+                        dgo = (sg + gs * (1.f - sg)) * dv * yv;
+                    }
+                };
+                // four elements of a lane's (row, 4 columns) cell: the (act, gate) form on explicit pairs
+                auto bwd_quad = [&](const float (&yv)[4], const float (&gv)[4], const float* dv, float (&dyo)[4], float (&dgo)[4]) {
+                    if constexpr (AG) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            cx_f2 y2, g2;
+                            swiglu_bwd_from_act2(cx_f2{dv[2 * h], dv[2 * h + 1]}, cx_f2{yv[2 * h], yv[2 * h + 1]},
+                                                 cx_f2{gv[2 * h], gv[2 * h + 1]}, y2, g2);
+                            dyo[2 * h] = y2.x; dyo[2 * h + 1] = y2.y;
+                            dgo[2 * h] = g2.x; dgo[2 * h + 1] = g2.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bwd_elem(yv[e], gv[e], dv[e], dyo[e], dgo[e]);
                     }
                 };
                 auto cell = [&](int row, int colbyte) { return my + row * 512 + ((((colbyte >> 4) ^ row) & 31) << 4) + (colbyte & 15); };
@@ -690,17 +711,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 const uint2 gg = *reinterpret_cast<const uint2*>(pg);
                                 const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
                                 const float g[4] = {bf16lo_to_f32(gg.x), bf16hi_to_f32(gg.x), bf16lo_to_f32(gg.y), bf16hi_to_f32(gg.y)};
-                                // the standalone op sees bf16 d(act): round pairwise with the hardware convert
-                                const uint32_t d01 = pack_bf16x2(da[4 * q], da[4 * q + 1]), d23 = pack_bf16x2(da[4 * q + 2], da[4 * q + 3]);
-                                const float d[4] = {bf16lo_to_f32(d01), bf16hi_to_f32(d01), bf16lo_to_f32(d23), bf16hi_to_f32(d23)};
                                 float dy[4], dg[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
-                                    const float gs = g[e] * sg;
-                                    dy[e] = gs * d[e];
-                                    dg[e] = dgate_of(y[e], g[e], sg, gs, d[e]);
-                                }
+                                bwd_quad(y, g, &da[4 * q], dy, dg);
                                 uint2 o;
                                 o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);
                                 *reinterpret_cast<uint2*>(py) = o;
@@ -775,14 +787,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
                             const float g[4] = {bf16lo_to_f32(gg.x), bf16hi_to_f32(gg.x), bf16lo_to_f32(gg.y), bf16hi_to_f32(gg.y)};
                             float dy[4], dg[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float d = bf16_to_f32(f32_to_bf16(da[4 * q + e]));  // the standalone op sees bf16 d(act)
-                                const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
-                                const float gs = g[e] * sg;
-                                dy[e] = gs * d;
-                                dg[e] = dgate_of(y[e], g[e], sg, gs, d);
-                            }
+                            bwd_quad(y, g, &da[4 * q], dy, dg);
                             uint2 o;
                             o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);
                             *reinterpret_cast<uint2*>(py) = o;

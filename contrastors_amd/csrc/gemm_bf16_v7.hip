@@ -579,18 +579,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const uint2 gg = *reinterpret_cast<const uint2*>(pg);
                 const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
                 const float g[4] = {bf16lo_to_f32(gg.x), bf16hi_to_f32(gg.x), bf16lo_to_f32(gg.y), bf16hi_to_f32(gg.y)};
-                // the standalone op sees bf16 d(act): round pairwise with the hardware convert
-                const uint32_t d01 = pack_bf16x2(acc[blk + aa][4 * q], acc[blk + aa][4 * q + 1]);
-                const uint32_t d23 = pack_bf16x2(acc[blk + aa][4 * q + 2], acc[blk + aa][4 * q + 3]);
-                const float d[4] = {bf16lo_to_f32(d01), bf16hi_to_f32(d01), bf16lo_to_f32(d23), bf16hi_to_f32(d23)};
+                // (d(act) stays in fp32: as in gemm_bf16_v6.hip, round 4)
+                const float d[4] = {acc[blk + aa][4 * q], acc[blk + aa][4 * q + 1], acc[blk + aa][4 * q + 2], acc[blk + aa][4 * q + 3]};
                 float dy[4], dg[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g[e]));
-                    const float gs = g[e] * sg;
-                    dy[e] = gs * d[e];
-                    const float rg = __builtin_amdgcn_rcpf(__builtin_fabsf(g[e]) < 1e-30f ? 1.f : g[e]);  // (g = 0 <=> act = 0)
-                    dg[e] = d[e] * y[e] * (rg + 1.f - sg);
+                for (int h = 0; h < 2; ++h) {
+                    cx_f2 y2, g2;
+                    swiglu_bwd_from_act2(cx_f2{d[2 * h], d[2 * h + 1]}, cx_f2{y[2 * h], y[2 * h + 1]}, cx_f2{g[2 * h], g[2 * h + 1]}, y2, g2);
+                    dy[2 * h] = y2.x; dy[2 * h + 1] = y2.y;
+                    dg[2 * h] = g2.x; dg[2 * h + 1] = g2.y;
                 }
                 uint2 o;
                 o.x = pack_bf16x2(dy[0], dy[1]); o.y = pack_bf16x2(dy[2], dy[3]);

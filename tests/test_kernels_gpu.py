@@ -657,7 +657,9 @@ def test_gemm_swiglu_bwd_fused(M, I, K):
     dact = gemm(dy, w, out_mode=0)                   # (M, I) bf16
     want = torch.empty_like(got)
     _C.check(L().cx_swiglu_bwd(dact.data_ptr(), yg.data_ptr(), want.data_ptr(), M, I, 1, S()), "cx_swiglu_bwd")
-    assert rel_err(got.float(), want.float()) < 2e-3
+    # (round 4: the fused epilogue keeps d(act) in fp32, the two-kernel route rounds it to bf16 in between -- one bf16 rounding
+    # of an input on top of the two independent output roundings: sqrt(3) x 2^-9 / sqrt(3) ...)
+    assert rel_err(got.float(), want.float()) < 4e-3
     # and against plain torch on the bf16 inputs
     v = yg.view(M, I // 32, 2, 32).float()
     y, g = v[:, :, 0].reshape(M, I), v[:, :, 1].reshape(M, I)
@@ -752,7 +754,7 @@ def test_gemm_swiglu_bwd_from_act_and_gate(M, I, K):
     dact = gemm(dy, w, out_mode=0)                   # (M, I) bf16
     want = torch.empty_like(got)
     _C.check(L().cx_swiglu_bwd_gate(dact.data_ptr(), act.data_ptr(), g.data_ptr(), want.data_ptr(), M, I, S()), "cx_swiglu_bwd_gate")
-    assert rel_err(got.float(), want.float()) < 2e-3
+    assert rel_err(got.float(), want.float()) < 4e-3   # (the standalone op reads a bf16 d(act), the epilogue keeps it in fp32)
     yg = torch.stack([y.view(M, I // 32, 32), g.view(M, I // 32, 32)], 2).reshape(M, 2 * I).contiguous()
     old = torch.empty_like(got)
     _C.check(L().cx_gemm_bf16_swiglu_bwd(dy.data_ptr(), w.data_ptr(), yg.data_ptr(), old.data_ptr(), M, I, K, K, K, 2 * I, S()))
