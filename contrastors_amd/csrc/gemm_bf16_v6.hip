@@ -1140,11 +1140,25 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int hi = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    // An XCD runs a contiguous range of logical ids (xcd_remap), normally one K slice's tiles: the index that varies FASTEST is
+    // the one with fewer tiles, so that the workgroups sharing a panel of the BIGGER operand are neighbours and land on one
+    // XCD's L2.  fc2's wgrad (3 x 12 tiles, the activation operand four times the size of dY) walked tn fastest and put the
+    // three sharers of an activation panel 12 ids apart -- across an XCD boundary for a good part of them: 3.60 GB of L2 misses
+    // per launch against 2.01 GB algorithmic (profiles/r4_wgrad_traffic_by_shape.txt).
     int lid = xcd_remap(blockIdx.x, nwg);
-    const int tn = lid % p.tiles_n;
-    lid /= p.tiles_n;
-    const int tm = lid % p.tiles_m;
-    const int sk = lid / p.tiles_m;
+    int tm, tn;
+    if (p.tiles_m < p.tiles_n) {
+        tm = lid % p.tiles_m;
+        lid /= p.tiles_m;
+        tn = lid % p.tiles_n;
+        lid /= p.tiles_n;
+    } else {
+        tn = lid % p.tiles_n;
+        lid /= p.tiles_n;
+        tm = lid % p.tiles_m;
+        lid /= p.tiles_m;
+    }
+    const int sk = lid;
     const int m0 = tm * BM6, n0 = tn * BN6;
     const int nk_total = p.K / BK6;
     const int kt_begin = (int)(((long)nk_total * sk) / p.split_k);
