@@ -612,3 +612,30 @@ def test_vit_architectures_equal_the_reference_conversions_of_the_hf_configs():
         diff = {f.name: (getattr(ref, f.name, "<absent>"), getattr(ours, f.name)) for f in dataclasses.fields(ours)
                 if getattr(ref, f.name, "<absent>") != getattr(ours, f.name)}
         assert diff == {}, diff
+
+
+def test_split_inputs_chunks_a_kept_tail_on_its_own():
+    """loss._split_inputs(inputs, chunk, tail_seqs) (round 4, the partially resident GradCache schedule): the last tail_seqs
+    sequences are chunked from the END -- whole chunks last, the shorter one in front of them -- and the region before them as
+    usual; every sequence appears exactly once, in order, with its length."""
+    import numpy as np
+    import torch
+
+    from contrastors_amd.loss import _split_inputs
+
+    n, S = 1000, 8
+    ids = torch.arange(n * S).view(n, S)
+    lens = np.arange(n) % S + 1
+    for chunk, tail in ((128, 0), (128, 300), (128, 1000), (128, 64), (300, 301), (64, 5000)):
+        chunks = _split_inputs({"input_ids": ids, "seqlens": lens}, chunk, tail)
+        sizes = [c["input_ids"].shape[0] for c in chunks]
+        assert sum(sizes) == n and all(0 < z <= chunk for z in sizes)
+        assert torch.equal(torch.cat([c["input_ids"] for c in chunks]), ids)
+        assert np.array_equal(np.concatenate([c["seqlens"] for c in chunks]), lens)
+        t = min(tail, n)
+        k = (t + chunk - 1) // chunk                      # chunks of the kept region
+        if k:
+            assert sum(sizes[-k:]) == t
+            assert all(z == chunk for z in sizes[len(sizes) - k + 1:]), (chunk, tail, sizes)   # whole chunks behind the short one
+        head = sizes[: len(sizes) - k]
+        assert all(z == chunk for z in head[:-1])          # the region before the tail: the usual chunking
