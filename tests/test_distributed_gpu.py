@@ -64,7 +64,12 @@ def _worker(rank, world, port, out_dir, backend="gloo", exchange="rccl", residen
     sys.path.insert(0, str(ROOT))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["CX_EXCHANGE"] = exchange
-    os.environ["CX_GRADCACHE_RESIDENT"] = resident
+    os.environ["CX_GRADCACHE_RESIDENT"] = "auto" if resident == "tail" else resident
+    if resident == "tail":   # the partially resident schedule (round 4): the last 4 of this rank's 8 document sequences + the
+        import contrastors_amd.loss as L_   # last 6 query sequences keep their activations (a whole chunk + a shorter one)
+
+        L_.resident_activations_fit = lambda *a, **k: False
+        L_.resident_tail_plan = lambda *a, **k: (6, 4)
     local = rank if backend == "nccl" else 0   # RCCL: one rank per GPU; gloo: the ranks share the test box's one GPU
     torch.cuda.set_device(local)
     if backend == "nccl":
@@ -175,13 +180,14 @@ def test_two_rank_exchange_is_verified_and_chosen_by_measurement(tmp_path):
         assert np.abs(a[r]["grad"] - b[r]["grad"]).max() <= 1e-5 * np.abs(b[r]["grad"]).max()
 
 
-@pytest.mark.parametrize("resident", ["0", "1"])
+@pytest.mark.parametrize("resident", ["0", "1", "tail"])
 def test_overlapped_gradient_reduce_is_bit_identical_to_the_blocking_one(tmp_path, resident):
     """the step's last backward records one event per block (CxChunkBuffers.layer_events) and the flat
     gradient is all-reduced block by block on a side stream while the remaining blocks are still being differentiated;
     sync_gradients() only waits and rescales.  Same bits as one blocking all-reduce of the whole buffer, on both the
-    two-pass and the resident GradCache schedules."""
-    port = 29200 + (os.getpid() % 90) + (100 if resident == "1" else 0)
+    two-pass, the resident and the partially resident ("tail": kept chunks are back-propagated first, the last re-forwarded
+    chunk arms the reduction) GradCache schedules."""
+    port = 29200 + (os.getpid() % 90) + (100 if resident == "1" else 200 if resident == "tail" else 0)
     ov, bl = tmp_path / "ov", tmp_path / "bl"
     ov.mkdir()
     bl.mkdir()
