@@ -919,8 +919,11 @@ int ln_bwd_launch(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t
     const long per_block = (dz_colsum ? 3L : 2L) * d;
     if (ws && ws_floats >= per_block * 256) {
         long cap = ws_floats / per_block;
-        grid = (rows + 3) / 4;
-        if (grid > 768) grid = 768;  // 3 blocks per CU = the kernel's occupancy (130 VGPRs): one resident round, few partials
+        // 3 blocks per CU = the kernel's occupancy (130 VGPRs): one resident round, few partials; small inputs get at least 32
+        // rows per block (round 4: 8192 rows used to leave 768 partials of ~10 rows each, and the fold below -- 19 us for 768
+        // partials whatever the input -- was 4 % of a literal chunk_size-64 step)
+        grid = (rows + 31) / 32;
+        if (grid > 768) grid = 768;
         if (grid > cap) grid = (int)cap;
         part = ws;
     }
@@ -1014,7 +1017,7 @@ int cx_dropout_add_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b,
     float* part = nullptr;
     if (ws && ws_floats >= (long)2 * d * 256) {
         long cap = ws_floats / (2L * d);
-        grid = (rows + 3) / 4;
+        grid = (rows + 31) / 32;   // (as in ln_bwd_launch)
         if (grid > 768) grid = 768;
         if (grid > cap) grid = (int)cap;
         part = ws;
