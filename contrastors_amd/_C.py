@@ -151,6 +151,8 @@ _SIGS = {
     "cx_ema_update": (i32, [vp, vp, i64, f32, vp]),
     "cx_infonce_ws_floats": (i64, [i32, i32]),
     "cx_infonce_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "cx_infonce_argmax_ws_floats": (i64, [i32, i32]),
+    "cx_infonce_fwd_argmax": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_infonce_bwd": (i32, [vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_infonce_fp8_ws_floats": (i64, [i32, i32]),
     "cx_infonce_fp8_fwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -140,7 +140,16 @@ class BiEncoder(torch.nn.Module):
             for p in self.trunk.parameters():
                 p.requires_grad = False
         d = trunk_cfg.n_embd
-        self.proj = torch.nn.Linear(d, config.projection_dim).to(device) if config.projection_dim else torch.nn.Identity()
+        # modeling_biencoder.py:264-267 `proj`: an nn.Linear-compatible module (same `proj.weight` / `proj.bias` keys, same init)
+        # whose forward / backward are the HIP bf16 MFMA GEMMs (flash_attn_api FusedDense) -- no vendor BLAS on the product path
+        if config.projection_dim:
+            from .flash_attn_api.ops.fused_dense import FusedDense
+
+            if int(config.projection_dim) % 4:
+                raise NotImplementedError("projection_dim must be a multiple of 4 (row alignment of the GEMM's bf16 output)")
+            self.proj = FusedDense(d, int(config.projection_dim), device=device)
+        else:
+            self.proj = torch.nn.Identity()
         self.hamming = bool(config.hamming)
 
     @property

@@ -44,16 +44,19 @@ CX_DEVICE float mul_legacy_f32(float a, float b) {
 
 // Backward of act = y * silu(g) from the saved (act, gate) pair (round 3's compact save: y = act / silu(g) is recovered
 // inside the derivative):  d y = d * g * s,  d gate = d * y * silu'(g) = d * act * (1 / g + 1 - s),  s = sigmoid(g).
-// An exactly-zero gate (or a silu that underflowed) means act = 0, y is not recoverable and d gate comes out 0: the last
-// product is a legacy multiply, 0 * (1/0 = inf) = 0 -- no compare / select per element (round 4: the fc2-dgrad + SwiGLU-backward
-// epilogue spends ~4500 VALU instructions per tile and wave, 15.5 per element, in the one wave that also issues the MFMAs).
+// An exactly-zero gate (or a silu that underflowed) means act = 0, y is not recoverable and d gate comes out 0.  1 / g is
+// clamped to +-1e30 (one v_med3_f32: round 5): 0 * (clamped 1/0) = 0 with an ordinary multiply, and a denormal gate
+// next to a non-zero (denormal) act gives a finite d gate instead of inf * x -- round 4's legacy multiply covered act == 0 only.
+// No compare / select per element (the fc2-dgrad + SwiGLU-backward epilogue spends ~3200 VALU instructions per tile and wave in
+// the one wave that also issues the MFMAs).  Every |g| >= 1e-30 is untouched by the clamp: same bits as round 4 there.
+CX_DEVICE float rcp_clamped(float g) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(g), -1e30f, 1e30f); }
 CX_DEVICE void swiglu_bwd_from_act(float d, float act, float g, float& dy, float& dg) {
     const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
     dy = g * s * d;
-    dg = mul_legacy_f32(d * act, __builtin_amdgcn_rcpf(g) + 1.f - s);
+    dg = (d * act) * (rcp_clamped(g) + 1.f - s);
 }
 // The same on element PAIRS (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per instruction; the transcendental and
-// legacy-multiply instructions have no packed form).  Same operations in the same order per element: bit-identical to the
+// median instructions have no packed form).  Same operations in the same order per element: bit-identical to the
 // scalar form.
 typedef float cx_f2 __attribute__((ext_vector_type(2)));
 CX_DEVICE void swiglu_bwd_from_act2(cx_f2 d, cx_f2 act, cx_f2 g, cx_f2& dy, cx_f2& dg) {
@@ -61,9 +64,8 @@ CX_DEVICE void swiglu_bwd_from_act2(cx_f2 d, cx_f2 act, cx_f2 g, cx_f2& dy, cx_f
     const cx_f2 t = cx_f2{__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)} + 1.f;
     const cx_f2 s = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
     dy = g * s * d;
-    const cx_f2 w = cx_f2{__builtin_amdgcn_rcpf(g.x), __builtin_amdgcn_rcpf(g.y)} + 1.f - s;
-    const cx_f2 da = d * act;
-    dg = cx_f2{mul_legacy_f32(da.x, w.x), mul_legacy_f32(da.y, w.y)};
+    const cx_f2 w = cx_f2{rcp_clamped(g.x), rcp_clamped(g.y)} + 1.f - s;
+    dg = (d * act) * w;
 }
 
 // erf-GELU pieces on v_exp_f32 / v_rcp_f32: erf(x) = sign(x) (1 - poly(t) exp(-x^2)), t = 1 / (1 + 0.3275911 |x|)

@@ -725,7 +725,7 @@ int cx_vit_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, 
     return vit_backward_impl(enc, buf, cu_seqlens, Bc, n_patch, nullptr, nullptr, dhidden, stream);
 }
 
-int cx_abi_version(void) { return 8; }  // 8: cx_cast_transpose_f32_to_bf16_batched / CxCastJob; 7: CxChunkBuffers.patch_keep / patch_inv / n_keep (PatchDropout);  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
+int cx_abi_version(void) { return 9; }  // 9: cx_infonce_fwd_argmax; 8: cx_cast_transpose_f32_to_bf16_batched / CxCastJob; 7: CxChunkBuffers.patch_keep / patch_inv / n_keep (PatchDropout);  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

@@ -32,6 +32,7 @@ struct SgemmParams {
     const int64_t* labels;
     float scale;
     float* pmax; float* psum; float* lab;  // workspace views (EPI_LSE)
+    int* pidx;                             // EPI_LSE, optional: first column of each 64-column slice that attains its maximum
     int nparts;
     const float* lse; float coef; float* Gm; float* GmT; float* dscale;  // EPI_GRAD
 };
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
             const int mc = m < p.M ? m : p.M - 1;
             const long label = p.labels[mc];
             float mx = -INFINITY;
+            int amx = 0x7fffffff;   // this lane's first column with v == mx (n grows with a, then r: strict > keeps the first)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -149,9 +151,15 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
                     const float v = n < p.N ? acc[a][b][r] * sc2 : -INFINITY;
                     if (n == label && m < p.M) p.lab[m] = acc[a][b][r] * p.scale;  // exactly one lane owns it
                     acc[a][b][r] = v;
+                    if (v > mx) amx = n;
                     mx = fmaxf(mx, v);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            {
+                const float omx = __shfl_xor(mx, 32, 64);
+                const int oamx = __shfl_xor(amx, 32, 64);
+                if (omx > mx || (omx == mx && oamx < amx)) amx = oamx;   // torch.argmax: the first index among equal maxima
+                mx = fmaxf(mx, omx);
+            }
             float sm = 0.f;
             if (mx > -INFINITY) {
 #pragma unroll
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
                 const int part = tn * 2 + wn;
                 p.pmax[(size_t)m * p.nparts + part] = mx;   // log2 units
                 p.psum[(size_t)m * p.nparts + part] = sm;
+                if (p.pidx) p.pidx[(size_t)m * p.nparts + part] = amx;
             }
         }
     } else {
@@ -210,16 +219,28 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SgemmParams p) {
 }
 
 // one wave per row: fold the per-column-slice partials into lse (natural log) and the per-row loss
+// pidx / argmax (optional): the row's arg max over all G columns = the smallest recorded column among the slices whose maximum
+// is the row maximum (slices are disjoint column ranges, each recorded its FIRST maximal column) -- what
+// `similarity.argmax(dim=1)` of sc/loss.py:127-130 returns, without the similarity matrix.
 __global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restrict__ pmax,
                                                           const float* __restrict__ psum,
                                                           const float* __restrict__ lab, float* __restrict__ lse,
-                                                          float* __restrict__ loss_rows, int N, int nparts) {
+                                                          float* __restrict__ loss_rows, int N, int nparts,
+                                                          const int* __restrict__ pidx, int* __restrict__ argmax) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
     float mx = -INFINITY;
     for (int i = lane; i < nparts; i += 64) mx = fmaxf(mx, pmax[(size_t)row * nparts + i]);
     mx = wave_max(mx);
+    if (pidx && argmax) {
+        int am = 0x7fffffff;
+        for (int i = lane; i < nparts; i += 64)
+            if (pmax[(size_t)row * nparts + i] == mx) am = min(am, pidx[(size_t)row * nparts + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
+        if (lane == 0) argmax[row] = am;
+    }
     float s = 0.f;
     for (int i = lane; i < nparts; i += 64) {
         const float pm = pmax[(size_t)row * nparts + i];
@@ -266,9 +287,18 @@ long cx_infonce_ws_floats(int N, int G) {
     const long nparts = 2L * ((G + SBN - 1) / SBN);
     return (long)N * (2 * nparts + 1);
 }
+long cx_infonce_argmax_ws_floats(int N, int G) {
+    const long nparts = 2L * ((G + SBN - 1) / SBN);
+    return (long)N * (3 * nparts + 1);
+}
 
 int cx_infonce_fwd(const float* Q, const float* D, const int64_t* labels, float scale, float* ws, float* lse,
                    float* loss_rows, int N, int G, int dim, int ldq, int ldd, void* stream) {
+    return cx_infonce_fwd_argmax(Q, D, labels, scale, ws, lse, loss_rows, nullptr, N, G, dim, ldq, ldd, stream);
+}
+
+int cx_infonce_fwd_argmax(const float* Q, const float* D, const int64_t* labels, float scale, float* ws, float* lse,
+                          float* loss_rows, int32_t* argmax, int N, int G, int dim, int ldq, int ldd, void* stream) {
     if (N <= 0 || G <= 0) return CX_OK;
     if (!Q || !D || !labels || !ws || !lse || !loss_rows) return CX_ERR_ARG;
     int rc = check_common(N, G, dim, ldq, ldd);
@@ -281,10 +311,11 @@ int cx_infonce_fwd(const float* Q, const float* D, const int64_t* labels, float 
     p.pmax = ws;
     p.psum = ws + (size_t)N * p.nparts;
     p.lab = ws + (size_t)2 * N * p.nparts;
+    p.pidx = argmax ? reinterpret_cast<int*>(ws + (size_t)2 * N * p.nparts + N) : nullptr;   // (ws: cx_infonce_argmax_ws_floats)
     rc = launch<EPI_LSE>(p, (hipStream_t)stream);
     if (rc != CX_OK) return rc;
     hipLaunchKernelGGL(lse_combine_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, p.pmax, p.psum,
-                       p.lab, lse, loss_rows, N, p.nparts);
+                       p.lab, lse, loss_rows, N, p.nparts, p.pidx, argmax);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 

@@ -98,10 +98,13 @@ class _FusedInfoNCEFp8(torch.autograd.Function):
         return dq * gout, dd * gout, None, None, None, gparam
 
 
-def _infonce(q, d, labels, scale, coef, scale_param, use_fp8=False):
+def _infonce(q, d, labels, scale, coef, scale_param, use_fp8=False, argmax_out=None):
     """`use_fp8` (the recipe flag configs/train/contrastive_pretrain.yaml:24, TrainArgs.use_fp8) is an explicit argument
-    all the way down: there is no process-wide switch."""
-    return (_FusedInfoNCEFp8 if use_fp8 else _FusedInfoNCE).apply(q, d, labels, scale, coef, scale_param)
+    all the way down: there is no process-wide switch.  argmax_out: see _FusedInfoNCE.forward (the fp8 kernel has no such
+    output: its caller asks similarity_argmax)."""
+    if use_fp8:
+        return _FusedInfoNCEFp8.apply(q, d, labels, scale, coef, scale_param)
+    return _FusedInfoNCE.apply(q, d, labels, scale, coef, scale_param, argmax_out)
 
 
 def fp8_similarity_supported(n: int, g: int, dim: int) -> bool:
@@ -114,7 +117,9 @@ class _FusedInfoNCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q: torch.Tensor, d: torch.Tensor, labels: torch.Tensor, scale: float, coef: float,
-                scale_param: Optional[torch.Tensor]):
+                scale_param: Optional[torch.Tensor], argmax_out: Optional[torch.Tensor] = None):
+        """argmax_out ((N,) int32, optional): filled with every row's arg max over the G columns (cx_infonce_fwd_argmax) --
+        the in-batch accuracy of sc/loss.py:127-130 without a second, materialised similarity matrix."""
         if not q.is_cuda:
             raise RuntimeError("fused InfoNCE needs the HIP device path (no CPU fallback)")
         lib = _C.lib()
@@ -135,12 +140,20 @@ class _FusedInfoNCE(torch.autograd.Function):
         if ((N % 4) or (G % 4)) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             # the backward's two output GEMMs contract over N and G: fail here, not in the middle of loss.backward()
             raise ValueError(f"fused InfoNCE backward needs N and G to be multiples of 4 (got {N}, {G})")
-        ws = torch.empty(lib.cx_infonce_ws_floats(N, G), dtype=torch.float32, device=q.device)
         lse = torch.empty(N, dtype=torch.float32, device=q.device)
         rows = torch.empty(N, dtype=torch.float32, device=q.device)
-        _C.check(lib.cx_infonce_fwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), scale, ws.data_ptr(),
-                                    lse.data_ptr(), rows.data_ptr(), N, G, dim, q.stride(0), d.stride(0),
-                                    _C.cur_stream()), "cx_infonce_fwd")
+        if argmax_out is None:
+            ws = torch.empty(lib.cx_infonce_ws_floats(N, G), dtype=torch.float32, device=q.device)
+            _C.check(lib.cx_infonce_fwd(q.data_ptr(), d.data_ptr(), labels.data_ptr(), scale, ws.data_ptr(),
+                                        lse.data_ptr(), rows.data_ptr(), N, G, dim, q.stride(0), d.stride(0),
+                                        _C.cur_stream()), "cx_infonce_fwd")
+        else:
+            if argmax_out.dtype != torch.int32 or argmax_out.numel() != N or not argmax_out.is_contiguous():
+                raise ValueError("argmax_out must be a contiguous (N,) int32 tensor")
+            ws = torch.empty(lib.cx_infonce_argmax_ws_floats(N, G), dtype=torch.float32, device=q.device)
+            _C.check(lib.cx_infonce_fwd_argmax(q.data_ptr(), d.data_ptr(), labels.data_ptr(), scale, ws.data_ptr(),
+                                               lse.data_ptr(), rows.data_ptr(), argmax_out.data_ptr(), N, G, dim, q.stride(0),
+                                               d.stride(0), _C.cur_stream()), "cx_infonce_fwd_argmax")
         ctx.save_for_backward(q, d, labels, lse)
         ctx.scale, ctx.coef, ctx.has_scale_param = scale, coef, scale_param is not None
         ctx.loss_rows = rows
@@ -169,7 +182,16 @@ class _FusedInfoNCE(torch.autograd.Function):
         dd = dd * gout
         # d loss / d log_scale = (d loss / d scale) * scale   (scale = exp(param))
         gparam = (dscale[0] * ctx.scale * gout).reshape(()) if ctx.has_scale_param else None
-        return dq, dd, None, None, None, gparam
+        return dq, dd, None, None, None, gparam, None
+
+
+def similarity_argmax(query: torch.Tensor, document: torch.Tensor, labels: torch.Tensor, scale: float) -> torch.Tensor:
+    """`(scale * query @ document.T).argmax(dim=1)` as (N,) int32 through the fused kernel (no (N, G) matrix, no vendor BLAS):
+    for callers whose loss ran on another path (the fp8 similarity GEMM) and still want the reference's accuracy metric."""
+    out = torch.empty(query.shape[0], dtype=torch.int32, device=query.device)
+    with torch.no_grad():
+        _FusedInfoNCE.apply(query.detach(), document.detach(), labels, float(scale), 1.0, None, out)
+    return out
 
 
 def make_labels(n_query: int, n_docs_all: int, rank: int, world: int, device) -> torch.Tensor:
@@ -204,17 +226,21 @@ def clip_loss(query, document, logit_scale, step=None, gather_enabled=False, tra
     if bidirectional and G != n:
         raise ValueError("bidirectional clip_loss needs as many documents as queries (sc/loss.py:119-123 only "
                          "type-checks for one process without negatives)")
+    # sc/loss.py:127-130: with a tracker the in-batch accuracy (similarity.argmax(dim=1) == labels).mean() is logged.  The arg max
+    # comes out of the loss kernel's own pass over the logit tiles (cx_infonce_fwd_argmax): no second similarity GEMM, no
+    # materialised (n, G) matrix, no vendor BLAS (rounds 1-4 called torch.matmul here)
+    argmax = torch.empty(n, dtype=torch.int32, device=query.device) if tracker is not None and not use_fp8 else None
     if bidirectional:
         # sc/loss.py:119-123: CE(q->d) + CE(d->q) with the same labels, no world-size factor
-        l_qd = _infonce(query, document, labels, scale, 1.0 / n, scale_param, use_fp8)
+        l_qd = _infonce(query, document, labels, scale, 1.0 / n, scale_param, use_fp8, argmax)
         l_dq = _infonce(document, query, labels, scale, 1.0 / document.shape[0], scale_param, use_fp8)
         loss = l_qd + l_dq
     else:
-        loss = _infonce(query, document, labels, scale, float(world) / n, scale_param, use_fp8)
+        loss = _infonce(query, document, labels, scale, float(world) / n, scale_param, use_fp8, argmax)
     if tracker is not None:
-        with torch.no_grad():
-            sim = (query.float() @ document.float().T) * scale
-            acc = (sim.argmax(dim=1) == labels).float().mean()
+        if argmax is None:   # the fp8 similarity kernel keeps no arg max: one more pass of the exact kernel, logits still unwritten
+            argmax = similarity_argmax(query, document, labels, scale)
+        acc = (argmax == labels).float().mean()
         tracker.log({f"accuracy/accuracy_{dataset}": acc.detach().cpu().item()}, step=step)
     return loss
 
@@ -278,6 +304,7 @@ def get_chunked_embeddings(model, chunks, rand_states=None, keep_tail: int = 0, 
         if i >= first_kept:
             suspended = (trunk.selective_checkpointing_suspended() if hasattr(trunk, "selective_checkpointing_suspended")
                          else contextlib.nullcontext())
+            outstanding = getattr(trunk, "_outstanding", None)
             try:
                 with torch.enable_grad(), suspended:
                     out = model(**c)["embedding"]
@@ -285,7 +312,15 @@ def get_chunked_embeddings(model, chunks, rand_states=None, keep_tail: int = 0, 
                 embs.append(out.detach())
                 continue
             except torch.OutOfMemoryError:
+                if outstanding is not None:
+                    # an allocation above the engine call (projection, hamming LayerNorm) failed after the saving forward was
+                    # counted: its arena dies with the half-built graph, the count of saved forwards goes back too
+                    trunk._outstanding = outstanding
                 first_kept = n   # the estimate was too generous: what is kept so far stays, the rest is recomputed in pass 2
+                #  the failed forward may have drawn its dropout offsets already: the retry below starts from the
+                # snapshot pass 2 replays, not from wherever the failure left the generators
+                if rand_states is not None:
+                    rand_states[-1].restore()
                 _log_once(("gradcache-tail-oom",), "GradCache: a kept chunk ran out of memory; the rest of the step re-forwards")
         with torch.no_grad():
             embs.append(model(**c)["embedding"])

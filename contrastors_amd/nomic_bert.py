@@ -499,7 +499,9 @@ class NomicBertEngine(torch.nn.Module):
         _C.check(self.lib.cx_cast_f32_to_bf16(self.flat_param.data_ptr() + 4 * self._lin_begin, self.w16.data_ptr(),
                                                n, s), "cast")
         jobs = getattr(self, "_cast_jobs", None)
-        if jobs is None:   # one launch for every transposed shadow (CxCastJob table in device memory; the buffers never move)
+        if jobs is not None and (jobs[3] != self.flat_param.data_ptr() or jobs[4] != self.w16_t.data_ptr()):
+            jobs = None    #  the buffers were re-bound (.to(), a load that replaced them): the table holds raw pointers
+        if jobs is None:   # one launch for every transposed shadow (CxCastJob table in device memory)
             tab = np.zeros(len(self._linear_names), dtype=np.dtype([("in", "u8"), ("out", "u8"), ("rows", "i4"), ("cols", "i4")]))
             tiles = 0
             for i, name in enumerate(self._linear_names):
@@ -508,7 +510,6 @@ class NomicBertEngine(torch.nn.Module):
                 tiles = max(tiles, ((shape[0] + 63) // 64) * ((shape[1] + 63) // 64))
             dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device_)
             jobs = self._cast_jobs = (dev_tab, len(self._linear_names), tiles, self.flat_param.data_ptr(), self.w16_t.data_ptr())
-        assert jobs[3] == self.flat_param.data_ptr() and jobs[4] == self.w16_t.data_ptr(), "parameter buffers moved"
         _C.check(self.lib.cx_cast_transpose_f32_to_bf16_batched(jobs[0].data_ptr(), jobs[1], jobs[2], s), "cast_transpose")
 
     def zero_grad(self, set_to_none: bool = False):  # noqa: D401 - torch signature

@@ -36,6 +36,14 @@ class RandContext:
             for idx in _devices_of(items):
                 self._dev[idx] = torch.cuda.get_rng_state(idx)
 
+    def restore(self):
+        """Set the generators back to the snapshot for good (no outer state is kept): a forward that failed half-way may
+        have advanced them already, and its retry has to start where pass 2's replay will start."""
+        if self.needed:
+            torch.set_rng_state(self._cpu)
+            for i, s in self._dev.items():
+                torch.cuda.set_rng_state(s, i)
+
     def __enter__(self):
         if not self.needed:
             return self

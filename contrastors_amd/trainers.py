@@ -123,6 +123,12 @@ def encode_pair(model, q, d, normalize):
     qi, di = q["input_ids"], d["input_ids"]
     if qi.dim() != 2 or di.dim() != 2 or set(q) != set(d):
         return None
+    if not set(q) <= {"input_ids", "attention_mask", "seqlens"}:
+        return None   #  a key this function does not forward must not be dropped silently: two-call form
+    if qi.shape[1] != di.shape[1] and "attention_mask" not in q and "seqlens" not in q:
+        #  widths differ and nothing says where a row ends: the right-padding below would become real tokens of the
+        # narrower side (VarlenBatch.from_mask(None) takes every position) -- the two-call form applies
+        return None
     if max(qi.shape[0] * qi.shape[1], di.shape[0] * di.shape[1]) > PAIR_FUSE_MAX_TOKENS:
         return None
     S = max(qi.shape[1], di.shape[1])
@@ -138,6 +144,26 @@ def encode_pair(model, q, d, normalize):
     emb = model(**both, normalize=normalize)["embedding"]
     nq = qi.shape[0]
     return emb[:nq], emb[nq:]
+
+
+class JsonlTracker:
+    """The tracker the trainers hand to clip_loss when `train_args.wandb` is set and the `wandb` package is not importable (it is
+    not in this image): the call surface the reference uses -- `.log(dict, step=)` (sc/trainers/base.py:137-139, sc/loss.py:127-130)
+    -- appending one JSON object per call to <output_dir>/metrics.jsonl."""
+
+    def __init__(self, path: str):
+        import os
+
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        self.path = path
+        self.rows = 0
+
+    def log(self, metrics: dict, step=None):
+        import json
+
+        with open(self.path, "a") as f:
+            f.write(json.dumps({"step": step, **{k: (float(v) if hasattr(v, "__float__") else v) for k, v in metrics.items()}}) + "\n")
+        self.rows += 1
 
 
 class TextTextTrainer:
@@ -162,6 +188,8 @@ class TextTextTrainer:
         self.optimizer = self.get_optimizer(config)
         self.scheduler = self.get_scheduler(config, self.optimizer)
         self.step = 0
+        # sc/trainers/base.py:42-45,161-184: a tracker exists on rank 0 only, and only when the recipe asks for one
+        self.tracker = self.get_trackers(config) if getattr(config.train_args, "wandb", False) else None
         self._need_zero = True      # (gradient accumulation: the buffers are zeroed on the micro-step after an optimizer step)
         # sc/trainers/base.py:387-391: an EMA copy of the weights, updated after every training step
         if self._wants_ema(config):
@@ -169,6 +197,25 @@ class TextTextTrainer:
 
             self.model["ema"] = EmaWeights([p for g in self.optimizer.param_groups for p in g["params"]], self._ema_decay(config))
             self.model["ema_gettr"] = lambda m: m
+
+    def get_trackers(self, config):
+        """sc/trainers/base.py:161-184: wandb.init(...) on rank 0 when the package exists; otherwise a JSON-lines file with the
+        same `.log(metrics, step=)` surface.  Ranks > 0 get None, as in the reference (their clip_loss logs nothing)."""
+        if self.rank != 0:
+            return None
+        ta = config.train_args
+        run_name = ta.wandb_run_name or (ta.output_dir or "run").replace("ckpts/", "")
+        try:
+            import wandb  # noqa: F401  (absent from this image; a deployment that has it gets the reference's tracker)
+        except ImportError:
+            import os
+
+            return JsonlTracker(os.path.join(ta.output_dir or ".", "metrics.jsonl"))
+        return wandb.init(project=ta.wandb_project_name, entity=ta.wandb_entity or None, name=run_name)
+
+    def log(self, metrics, step=None):   # sc/trainers/base.py:137-139
+        if self.rank == 0 and self.tracker is not None:
+            self.tracker.log(metrics, step=step)
 
     def _wants_ema(self, config) -> bool:
         return bool(getattr(config.model_args, "ema", False)) if config.model_args is not None else False
@@ -258,8 +305,14 @@ class TextTextTrainer:
             queries = model(**q, normalize=normalize)["embedding"]
             documents = model(**d, normalize=normalize)["embedding"]
         all_documents = gather_with_grad(documents)
+        # sc/trainers/text_text.py:352-378: the tracker (rank 0, `wandb: true`) receives the in-batch accuracy from clip_loss
+        # under the dataset's name (per Matryoshka width: `<dataset>_matryoshka_<dim>`)
+        dataset_name = batch.get("dataset_name", "") if isinstance(batch, dict) else ""
+        if isinstance(dataset_name, (list, tuple)):
+            dataset_name = dataset_name[0] if dataset_name else ""
+        log = dict(tracker=self.tracker, step=self.step) if self.tracker is not None else {}
         if not dims:
-            return clip_loss(queries, all_documents, scale, use_fp8=bool(ta.use_fp8))
+            return clip_loss(queries, all_documents, scale, use_fp8=bool(ta.use_fp8), dataset=dataset_name, **log)
         # Matryoshka (text_text.py:352-369): one InfoNCE per prefix width on re-normalised prefixes, weighted sum.
         # The fused loss kernel reads the (N, dim) prefix views in place (leading dimension 768).
         weights = ta.matryoshka_loss_weights or [1.0] * len(dims)
@@ -267,7 +320,7 @@ class TextTextTrainer:
         for w, dim in zip(weights, dims):
             rq = torch.nn.functional.normalize(queries[:, :dim], dim=-1)
             rd = torch.nn.functional.normalize(all_documents[:, :dim], dim=-1)
-            loss = loss + w * clip_loss(rq, rd, scale, use_fp8=bool(ta.use_fp8))
+            loss = loss + w * clip_loss(rq, rd, scale, use_fp8=bool(ta.use_fp8), dataset=f"{dataset_name}_matryoshka_{dim}", **log)
         return loss
 
     def backward(self, loss: torch.Tensor):
@@ -403,6 +456,11 @@ class TextTextTrainer:
                 break
             loss = self.training_step(batch)
             losses.append(loss)
+            if self.tracker is not None:   # sc/trainers/base.py:485-502 (loss every step; lr every log_lr_every steps)
+                self.log({"loss": float(loss)}, step=self.step - 1)
+                every = int(getattr(self.config.train_args, "log_lr_every", 0) or 0)
+                if every and i > 0 and i % every == 0:
+                    self.log({"lr": self.scheduler.get_last_lr()[0]}, step=self.step - 1)
             if log_every and (i + 1) % log_every == 0 and self.rank == 0:
                 print(f"step {self.step} loss {float(loss):.4f} lr {self.scheduler.get_last_lr()[0]:.3e}", flush=True)
         return losses

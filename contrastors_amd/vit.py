@@ -214,6 +214,13 @@ class ViTEngine(NomicBertEngine):
         inv.scatter_(1, keep, torch.arange(K, dtype=torch.int32).expand(B, K))
         return keep.to(torch.int32).to(self.device_), inv.to(self.device_), K
 
+    @property
+    def uses_rng(self) -> bool:
+        """PatchDropout draws from torch's CPU generator (`_patch_subset`): GradCache's re-forward must replay the draw, so the
+        per-chunk RandContext of sc/loss.py:141-145 has to be taken although every dropout probability of the tower is 0
+        (without this, pass 2 re-forwarded a different patch subset than the one the cached gradient belongs to)."""
+        return self.training and (float(getattr(self.config, "patch_dropout", 0.0) or 0.0) > 0.0 or super().uses_rng)
+
     def _set_patch_subset(self, arena: _ChunkArena, subset):
         d = arena.desc
         if subset is None:

@@ -301,6 +301,13 @@ int cx_pool_normalize_bwd(const float* demb, const float* emb, const float* norm
 long cx_infonce_ws_floats(int N, int G);
 int cx_infonce_fwd(const float* Q, const float* D, const int64_t* labels, float scale, float* ws, float* lse,
                    float* loss_rows, int N, int G, int dim, int ldq, int ldd, void* stream);
+/* The same forward that also returns every row's arg max over the G columns (cx_abi_version >= 9): argmax:(N) int32 = the
+ * FIRST column attaining the row maximum, i.e. `similarity.argmax(dim=1)` of the in-batch accuracy the reference logs
+ * (sc/loss.py:127-130), read off the tiles the loss walks anyway -- the (N,G) similarity is not written for it either.
+ * ws: cx_infonce_argmax_ws_floats(N,G) floats.  argmax == NULL: exactly cx_infonce_fwd. */
+long cx_infonce_argmax_ws_floats(int N, int G);
+int cx_infonce_fwd_argmax(const float* Q, const float* D, const int64_t* labels, float scale, float* ws, float* lse,
+                          float* loss_rows, int32_t* argmax, int N, int G, int dim, int ldq, int ldd, void* stream);
 /* backward of  coef * sum_i loss_rows[i]:  Gm[i][j] = coef*scale*(softmax_ij - [j==label_i]) is written to
  * Gmat:(N,G) and GmatT:(G,N) fp32 scratch; dQ:(N,dim) = Gm D, dD:(G,dim) = Gm^T Q (overwritten);
  * dscale_accum (may be NULL): += coef * sum_ij (softmax_ij - y_ij) * (Q D^T)_ij   (d loss / d scale).

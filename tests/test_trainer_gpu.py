@@ -230,3 +230,55 @@ def test_ema_copy_of_the_weights_is_updated_every_step(tmp_path):
     for a, b in zip(tr2.model["ema"].shadow, ema.shadow):
         assert torch.equal(a, b)
     assert tr2.model["ema"].num_updates == 3
+
+
+def test_encode_pair_declines_what_it_cannot_express():
+    """the one-call form right-pads the narrower side with token id 0.  Without masks or lengths those positions would
+    become real tokens (VarlenBatch.from_mask(None) takes every position), so unequal widths with neither present take the
+    two-call form; so does a batch carrying a key encode_pair would not forward."""
+    from contrastors_amd import trainers as T
+
+    tr = _trainer(False)
+    m = tr.model["model"]
+    g = torch.Generator().manual_seed(2)
+    q = {"input_ids": torch.randint(3, 512, (4, 16), generator=g).cuda()}
+    d = {"input_ids": torch.randint(3, 512, (4, 24), generator=g).cuda()}
+    assert T.encode_pair(m, q, d, True) is None
+    d16 = {"input_ids": d["input_ids"][:, :16].contiguous()}
+    with torch.no_grad():
+        both = T.encode_pair(m, q, d16, True)          # equal widths need no mask: every position is a token on both routes
+        assert both is not None
+        assert torch.equal(both[0], m(**q)["embedding"]) and torch.equal(both[1], m(**d16)["embedding"])
+        extra = {"token_type_ids": torch.zeros(4, 16, dtype=torch.long, device="cuda")}
+        assert T.encode_pair(m, {**q, **extra}, {**d16, **extra}, True) is None
+        # unequal widths WITH lengths: the pad is beyond the lengths, one call is fine and equals the two calls
+        ql, dl = {**q, "seqlens": [16] * 4}, {**d, "seqlens": [24] * 4}
+        both = T.encode_pair(m, ql, dl, True)
+        assert both is not None
+        assert torch.allclose(both[0], m(**q)["embedding"], atol=1e-6) and torch.allclose(both[1], m(**d)["embedding"], atol=1e-6)
+
+
+def test_direct_step_hands_the_tracker_to_clip_loss(tmp_path):
+    """sc/trainers/text_text.py:352-378 + sc/loss.py:127-130: with `wandb: true` rank 0 owns a tracker and every direct step logs
+    the in-batch accuracy under the dataset's name (per Matryoshka width `<dataset>_matryoshka_<dim>`).  wandb is not in the
+    image: the stand-in writes <output_dir>/metrics.jsonl through the same `.log(dict, step=)` surface."""
+    import json
+
+    from contrastors_amd.trainers import JsonlTracker
+
+    cfg = Config(train_args=TrainArgs(learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, grad_cache=False, chunk_size=4,
+                                      schedule_type="linear", max_grad_norm=1.0, wandb=True, output_dir=str(tmp_path),
+                                      matryoshka_dims=[32, 64], matryoshka_loss_weights=[1.0, 1.0]),
+                 data_args=DataArgs(batch_size=16, seed=7),
+                 model_args=ModelArgs(logit_scale=20.0, pooling="mean", model_name="tiny"))
+    tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
+    tr = TextTextTrainer(cfg, torch.bfloat16, device="cuda", trunk_config=tc, total_steps=20)
+    assert isinstance(tr.tracker, JsonlTracker)
+    batch = dict(next(iter(synthetic_batches(1, 16, 24, 512, seed=3))))
+    batch["dataset_name"] = "toy"
+    tr.train([batch, batch], max_steps=2)
+    rows = [json.loads(l) for l in open(tmp_path / "metrics.jsonl")]
+    keys = [k for r in rows for k in r if k != "step"]
+    assert keys.count("accuracy/accuracy_toy_matryoshka_32") == 2 and keys.count("accuracy/accuracy_toy_matryoshka_64") == 2
+    assert keys.count("loss") == 2
+    assert all(0.0 <= r[k] <= 1.0 for r in rows for k in r if k.startswith("accuracy/"))

@@ -326,3 +326,48 @@ def test_vit_patch_dropout_matches_reference_golden(gold, pooling):
     full, _ = eng.forward_chunk(pix, False)
     ref_full = vit_ref.vit_embedding({k: v.to(DEV) for k, v in sd.items()}, ns, pix, pooling)
     assert max_err(full, ref_full) <= 5e-3
+
+
+def test_gradcache_replays_the_patch_dropout_draw():
+    """PatchDropout draws from torch's CPU generator.  GradCache's pass 2 re-forwards every chunk, and the cached
+    embedding gradients belong to the patch subsets pass 1 drew -- the per-chunk RandContext has to replay the draw although
+    every dropout PROBABILITY of the image tower is 0 (ViTEngine.uses_rng).  Two-pass grad_cache_loss (resident=False) on an
+    image tower (queries) and a text tower (documents) with patch_dropout = 0.5 against the direct loss on the same draws."""
+    from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
+    from contrastors_amd.loss import clip_loss, grad_cache_loss
+    from contrastors_amd.nomic_bert import NomicBertConfig
+    from contrastors_amd.policy import GradCachePolicy
+    from oracle.make_golden import TINY_NOMIC
+
+    vc = ViTConfig(n_embd=256, n_layer=2, n_head=4, n_inner=512, img_size=32, patch_size=8, patch_dropout=0.5)
+    tc = NomicBertConfig(**{k: v for k, v in TINY_NOMIC.items() if k in NomicBertConfig.__dataclass_fields__})
+    vis = BiEncoder(BiEncoderConfig(model_name="v", pooling="cls", trunk_config=vc), device=DEV, seed=1).train()
+    txt = BiEncoder(BiEncoderConfig(model_name="t", pooling="mean", trunk_config=tc), device=DEV, seed=2).train()
+    assert vis.trunk.uses_rng and not txt.trunk.uses_rng
+    scale = LogitScale(SimpleNamespace(logit_scale=20.0, trainable_logit_scale=False)).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    pix = {"input_ids": torch.randn(16, 3, 32, 32, generator=g).to(DEV)}
+    doc = {"input_ids": torch.randint(3, 512, (16, 24), generator=g).to(DEV), "attention_mask": torch.ones(16, 24, dtype=torch.long, device=DEV)}
+
+    def direct(chunk):
+        # the direct loss with the SAME draws GradCache's pass 1 makes: one CPU randn per chunk of `chunk` images, in chunk order
+        torch.manual_seed(77)
+        vis.trunk.zero_grad(); txt.trunk.zero_grad()
+        qs = [vis(input_ids=pix["input_ids"][a:a + chunk])["embedding"] for a in range(0, 16, chunk)]
+        loss = clip_loss(torch.cat(qs), txt(**doc)["embedding"], scale)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), vis.trunk.flat_grad.clone(), txt.trunk.flat_grad.clone()
+
+    l_ref, gv_ref, gt_ref = direct(4)
+    torch.manual_seed(77)
+    vis.trunk.zero_grad(); txt.trunk.zero_grad()
+    loss = grad_cache_loss(vis, pix, txt, doc, chunk_size=4, logit_scale=scale, policy=GradCachePolicy(chunk="exact", resident=False))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - l_ref) <= 1e-5 * abs(l_ref), (float(loss), l_ref)
+    ev = float((vis.trunk.flat_grad - gv_ref).norm() / gv_ref.norm())
+    et = float((txt.trunk.flat_grad - gt_ref).norm() / gt_ref.norm())
+    report("gradcache_patch_dropout", e_vision=ev, e_text=et)
+    # same kernels on the same chunks: only the accumulation order of the chunks' gradients differs.  A re-forward on ANOTHER
+    # patch subset (the bug) gives gradients of a different function: e_vision ~ 1
+    assert ev < 2e-3 and et < 2e-3, (ev, et)
