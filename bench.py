@@ -22,6 +22,10 @@ The JSON line carries, besides the contract fields:
   exchange      (N > 1) what carries the embedding exchange: set up, verified bit-exact against RCCL, timed, faster one chosen
   xgmi_allgather  (N > 1) the embedding all-gather of the loss timed on its own, against 7 x 153 GB/s of xGMI per GPU
   cfg1 / cfg3 / lit / clip  (N = 1) the other BASELINE configs at their per-GPU shapes, each with its own roofline fraction
+  box           what THIS box sustains, measured right before the metric: register-only bf16 MFMA probe (TFLOP/s), HBM copy
+                (TB/s), and socket power / shader clock sampled during the timed region; roofline.frac_of_box_ceiling =
+                achieved / box.mfma_probe_tflops (flat keys box_*, frac_of_box_ceiling)
+  schedule_per_rank / allreduce_exposed_ms / allgather_us_* / allgather_xgmi_frac_*  (N > 1) one line answers >= 70 % xGMI, >= 6 x
   cpu_baseline  (N = 1) oracle = CPU restatement of the reference: one 64-pair cfg-2 chunk forward + backward, and the
                 cfg-1 full step (bert-base, B = 32, S = 64: forward, backward, InfoNCE, AdamW) on the host cores
 """
@@ -64,6 +68,7 @@ def parse():
                          "GEMM launch (1024 whole 256-row tile panels) and peaks at ~115 GB of the MI355X's 288 GB")
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the metric
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the per-box MFMA / HBM probes and the power / clock sampler")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the weak-scaling and chunk-64 records")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the cfg1 / cfg3 / lit / clip records (N = 1)")
     ap.add_argument("--only-config-legs", type=str, default="", help=argparse.SUPPRESS)  # profiling: e.g. cfg3 or lit,clip
@@ -595,10 +600,41 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), float(loss.item())
 
+    # ---- what THIS box sustains, measured right before the metric: register-only bf16 MFMA loop + HBM copy
+    box = {}
+    if not args.no_calibration:
+        try:
+            from scripts.box_calibration import SmiSampler, calibrate
+
+            box = calibrate(dev)
+        except Exception as e:  # noqa: BLE001 -- calibration must never take the headline down
+            box = {"error": f"{type(e).__name__}: {e}"[:200]}
+            SmiSampler = None
+    else:
+        SmiSampler = None
     # ---- the metric: global batch 16384 (strong scaling) -------------------------------------------------------------
     b = G // world
     step_ms = []
+    tower.exposed_reduce_marks = [] if world > 1 else None
+    sampler = SmiSampler(local_rank).start() if SmiSampler is not None else None   # socket power + shader clock DURING the timed region
     dt, loss_last = run_leg(b, args.chunk_size, args.steps, args.warmup, prof=True, step_ms=step_ms)
+    if sampler is not None:
+        box.update(sampler.stop())
+    from contrastors_amd import loss as cx_loss
+
+    sched_local = dict(cx_loss.LAST_SCHEDULE)
+    exposed_ms = None
+    if world > 1:
+        marks = tower.exposed_reduce_marks[-args.steps:]
+        tower.exposed_reduce_marks = None
+        mine = sorted(a.elapsed_time(c) for a, c in marks) if marks else []
+        t = torch.tensor([_pct(mine, 0.5) if mine else 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = float(t.item())
+        scheds = [None] * world
+        dist.all_gather_object(scheds, sched_local)
+    else:
+        scheds = [sched_local]
     ms, fl = C.c_double(), C.c_double()
     n_t, n_all = C.c_long(), C.c_long()
     lib.cx_prof_gemm_collect(C.byref(ms), C.byref(fl), C.byref(n_t), C.byref(n_all))
@@ -612,6 +648,7 @@ def main():
         if b != WEAK_PAIRS_PER_GPU and G >= WEAK_PAIRS_PER_GPU:
             wdt, _ = run_leg(WEAK_PAIRS_PER_GPU, args.chunk_size, args.steps, 1, prof=False)
             extra["weak"] = {"value": WEAK_PAIRS_PER_GPU * world * args.steps / wdt, "unit": "pairs/s",
+                             "per_gpu": WEAK_PAIRS_PER_GPU * args.steps / wdt,   # / the N = 1 run's `weak.value` = weak-scaling efficiency
                              "pairs_per_gpu": WEAK_PAIRS_PER_GPU, "global_batch": WEAK_PAIRS_PER_GPU * world,
                              "ms_per_step": 1e3 * wdt / args.steps, "steps": args.steps, "scaling": "weak"}
         elif b == WEAK_PAIRS_PER_GPU:
@@ -741,6 +778,7 @@ def main():
                 pass
         pairs_per_s = G * args.steps / dt
         achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        probe = box.get("mfma_probe_tflops") if isinstance(box, dict) else None
         out = {
             "metric": "query-doc pairs/sec (whole node), nomic-bert-2048 seq128 global-batch 16384",
             "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -757,7 +795,11 @@ def main():
                        "launch": "self (torch.distributed.run)" if os.environ.get("CX_BENCH_SELF_LAUNCHED") else
                                  ("torch.distributed.run" if world > 1 else "single process")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
+                         "frac": achieved / PEAK_BF16_TFLOPS,
+                         # the same achieved rate against what this box's matrix cores sustain at its power limit (box.mfma_probe_tflops,
+                         # measured seconds before the timed region): the number to compare ACROSS boxes
+                         "frac_of_box_ceiling": (achieved / probe) if probe else None,
+                         "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
                          "kernel": "bf16 GEMM family: gemm_bf16_v6_kernel (fwd, dgrad, fused SwiGLU fc1) + "
                                    "gemm_bf16_v6tn_kernel (wgrad)",
@@ -769,6 +811,30 @@ def main():
         out.update(extra)
         out.update(flat_scalars(extra))
         out["whole_step_frac_of_mfma_peak"] = out["roofline"]["whole_step_frac_of_mfma_peak"]
+        # per-box calibration (flat scalars: the driver's `parsed` view keeps scalars) + the nested record
+        out["box"] = box
+        for k in ("mfma_probe_tflops", "hbm_copy_tbs", "mean_sclk_mhz", "mean_power_w", "power_cap_w", "mfma_probe_clock_mhz"):
+            if isinstance(box, dict) and isinstance(box.get(k), (int, float)):
+                out[f"box_{k}"] = box[k]
+        if probe:
+            out["frac_of_box_ceiling"] = achieved / probe
+            out["whole_step_frac_of_box_ceiling"] = pairs_per_s / world * GFLOP_PER_PAIR / 1e3 / probe
+        # the schedule every rank's metric leg actually ran (resident / partial / two-pass) and, for N > 1, the part of the
+        # gradient reduction nothing overlapped (end of the last backward kernel -> reduced gradient, median over steps, max over ranks)
+        out["schedule_per_rank"] = scheds
+        out["schedule"] = scheds[0].get("schedule") if scheds and isinstance(scheds[0], dict) else None
+        if exposed_ms is not None:
+            out["allreduce_exposed_ms"] = exposed_ms
+        xg = extra.get("xgmi_allgather") if isinstance(extra.get("xgmi_allgather"), dict) else {}
+        for tag, key in (("rccl", "process_group"), ("oneshot", "oneshot"), ("oneshot_in_place", "oneshot_in_place")):
+            r = xg.get(key)
+            if isinstance(r, dict):
+                out[f"allgather_us_{tag}"] = 1e6 * r["seconds"]
+                out[f"allgather_xgmi_frac_{tag}"] = r["frac"]
+        if isinstance(extra.get("weak"), dict):
+            out["weak_pairs_s_per_gpu"] = extra["weak"]["per_gpu"]
+        elif world > 1 and b == WEAK_PAIRS_PER_GPU:
+            out["weak_pairs_s_per_gpu"] = pairs_per_s / world
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(S)
         print(json.dumps(out), flush=True)

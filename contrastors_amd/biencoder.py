@@ -140,7 +140,7 @@ class BiEncoder(torch.nn.Module):
             for p in self.trunk.parameters():
                 p.requires_grad = False
         d = trunk_cfg.n_embd
-        # modeling_biencoder.py:264-267 `proj`: an nn.Linear-compatible module (same `proj.weight` / `proj.bias` keys, same init)
+        # modeling_biencoder.py:264-267 `proj`: a module compatible with torch's Linear (same `proj.weight` / `proj.bias` keys, same init)
         # whose forward / backward are the HIP bf16 MFMA GEMMs (flash_attn_api FusedDense) -- no vendor BLAS on the product path
         if config.projection_dim:
             from .flash_attn_api.ops.fused_dense import FusedDense
@@ -211,9 +211,17 @@ class BiEncoder(torch.nn.Module):
         backward already put in flight (waited for here), or ONE blocking all-reduce of the whole buffer."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             W = dist.get_world_size()
+            marks = getattr(self, "exposed_reduce_marks", None)   # bench.py: a list -> (event, event) per call
+            if marks is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()       # completes with the step's last backward kernel (everything queued on the compute stream)
             if not self.trunk.finish_overlapped_reduce():
                 dist.all_reduce(self.trunk.flat_grad, op=dist.ReduceOp.SUM)
             self.trunk.flat_grad.div_(W)
+            if marks is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()       # the reduced, rescaled gradient exists: e0 -> e1 is the part of the reduction nothing overlapped
+                marks.append((e0, e1))
             for p in self._head_parameters():
                 if p.grad is not None:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)

@@ -186,7 +186,7 @@ class _FusedInfoNCE(torch.autograd.Function):
 
 
 def similarity_argmax(query: torch.Tensor, document: torch.Tensor, labels: torch.Tensor, scale: float) -> torch.Tensor:
-    """`(scale * query @ document.T).argmax(dim=1)` as (N,) int32 through the fused kernel (no (N, G) matrix, no vendor BLAS):
+    """The arg max over dim 1 of scale * matmul(query, document.T), as (N,) int32, through the fused kernel (no (N, G) matrix, no vendor BLAS):
     for callers whose loss ran on another path (the fp8 similarity GEMM) and still want the reference's accuracy metric."""
     out = torch.empty(query.shape[0], dtype=torch.int32, device=query.device)
     with torch.no_grad():
@@ -354,6 +354,7 @@ def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional
 
 
 _LOGGED: set = set()
+LAST_SCHEDULE: dict = {}   # what the last grad_cache_loss call of this process ran (bench.py reports it per rank)
 
 
 def _log_once(key, msg: str):
@@ -435,10 +436,7 @@ def resident_activations_fit(tower1, t1_inputs, tower2, t2_inputs, policy: Optio
         return False
     if mode is True:
         return True
-    free, _ = torch.cuda.mem_get_info(dev)
-    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    for tw in {id(tower1): tower1, id(tower2): tower2}.values():
-        free += sum(a.nbytes() for a in getattr(tw.trunk, "_arena_free", []))   # arenas the engine already holds are reused
+    free = _agreed_free_bytes(dev, [tower1, tower2], agree=True)
     return need <= 0.8 * free
 
 
@@ -448,6 +446,30 @@ def _pool_free_bytes(dev, towers) -> float:
     for tw in {id(t): t for t in towers}.values():
         free += sum(a.nbytes() for a in getattr(getattr(tw, "trunk", None), "_arena_free", []))   # arenas the engine re-uses
     return float(free)
+
+
+_AGREED_FREE: Dict[int, dict] = {}   # device index -> {"calls", "free"}: the ranks' MIN of _pool_free_bytes (engineering)
+
+
+def _agreed_free_bytes(dev, towers, agree: bool = False) -> float:
+    """What the memory planners below may spend.  One process: this device's free + pooled bytes, measured now.  Data parallel:
+    the MINIMUM of that over the ranks, so that every rank plans the same schedule (all resident / the same kept tail / two
+    passes) -- per-rank plans were correct (the collective counts match either way) but made the step time depend on the rank
+    with the least free memory anyway, while the others re-forwarded less for nothing.  The agreement is ONE scalar all-reduce
+    in each of the first two planner calls of a run (the first sees the device before any arena exists), issued from
+    resident_activations_fit -- a call every rank makes every step with rank-invariant conditions in front of it (`agree`);
+    afterwards the agreed number is reused: no per-step collective, no per-step host sync.  A rank whose memory shrinks later
+    (another tenant) is covered by the out-of-memory fallbacks, as before."""
+    local = _pool_free_bytes(dev, towers)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return local
+    st = _AGREED_FREE.setdefault(dev.index if dev.index is not None else -1, {"calls": 0, "free": None})
+    if agree and st["calls"] < 2:
+        t = torch.tensor([local], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        st["free"] = float(t.item())
+        st["calls"] += 1
+    return st["free"] if st["free"] is not None else local
 
 
 def resident_tail_plan(tower1, t1_inputs, cq: int, tower2, t2_inputs, cd: int, policy: Optional[GradCachePolicy] = None):
@@ -480,7 +502,7 @@ def resident_tail_plan(tower1, t1_inputs, cq: int, tower2, t2_inputs, cd: int, p
     if dev is None:
         return 0, 0
     towers = [t for t, sd_ in zip((tower1, tower2), sides) if sd_ is not None]
-    budget = 0.85 * _pool_free_bytes(dev, towers)
+    budget = 0.85 * _agreed_free_bytes(dev, towers)   # (data parallel: the ranks' minimum, agreed in resident_activations_fit)
     biggest = max(sd_[1] * sd_[2] for sd_ in sides if sd_ is not None)
     budget -= 0.09 * biggest + 3e9     # the no-grad arena (one slot instead of L: ~8 % of a saving arena) and the loss buffers
     keep = [0, 0]
@@ -547,6 +569,10 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
               f"(policy.resident = {pol.resident!r}); similarity GEMM {'fp8' if pol.use_fp8 else 'fp32'}")
     done = False
     fell_back = False   # the all-resident attempt ran out of memory: this step takes the reference's schedule literally
+    LAST_SCHEDULE.clear()
+    LAST_SCHEDULE.update(schedule="resident" if resident else ("partial" if (kq_seqs or kd_seqs) else "two-pass"),
+                         chunk_q=cq, chunk_d=cd, chunks_q=len(q_chunks), chunks_d=len(d_chunks), kept_q_seqs=kq_seqs,
+                         kept_d_seqs=kd_seqs, fell_back=False)
     if resident:
         q_out = d_out = None
         try:
@@ -567,6 +593,7 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
             if pol.resident is True:
                 raise
             fell_back = True
+            LAST_SCHEDULE.update(schedule="two-pass", fell_back=True)
             torch.cuda.empty_cache()
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")
