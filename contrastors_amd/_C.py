@@ -197,6 +197,7 @@ _DEV_SIGS = {
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_attn_dropout_keep_mask": (i32, [vp, i32, i32, i32, f32, u64, u64, u32, vp]),
+    "cx_probe_rmw": (i32, [vp, i64, i32, i32, i32, vp]),
     "cx_probe_mfma_rate16": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_probe_dma_bw": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
 }

@@ -33,6 +33,17 @@ namespace {
 #ifndef CX_V6_DEFER_SPREAD
 #define CX_V6_DEFER_SPREAD 1  // K-tiles of the next tile the 32 deferred stores of a tile are spread over (8, 4, 2 or 1; 1 measured best)
 #endif
+// SwiGLU-backward epilogue (round 5).  HI_EARLY: all 16 (act, gate) row loads of pass b + 1 are issued right after pass b's rows
+// have been staged (1), instead of rows 16..31 only after the pass's arithmetic (0: they then have ~700 cycles -- the row reads and
+// store issue of pass b -- to land before pass b + 1 stages them).  That needs 32 more registers through the arithmetic, which
+// the kernel (256 VGPRs) did not have: OPAQUE passes the lane index the staging addresses derive from through an empty asm per
+// tile (1) / per pass (2), so that the compiler re-derives the ~50 LDS addresses (a few VALU each) instead of keeping them live.
+#ifndef CX_V6_HI_EARLY
+#define CX_V6_HI_EARLY 0
+#endif
+#ifndef CX_V6_OPAQUE
+#define CX_V6_OPAQUE 0
+#endif
 #ifndef CX_V6_NT
 #define CX_V6_NT 3   // measured on the whole step (scripts/gpu_variant_bench.sh): 0 -> 3861..3873, 1 -> 3895, 3 -> 3907 pairs/s
 #endif
@@ -681,7 +692,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 // pass b's stores; they land while the wave does the pass's sigmoid arithmetic.
                 const bool fast_bwd = m0 + 128 <= p.M && n0 + 128 <= p.N;
                 if (fast_bwd) {
-                    const int lrow = lane >> 5, lch = lane & 31;
+                    int lane_e = lane;
+#if CX_V6_OPAQUE >= 1
+                    asm volatile("" : "+v"(lane_e));
+#endif
+                    const int lrow = lane_e >> 5, lch = lane_e & 31;
                     // (AG: chunk lch of the 512-B row = columns [8 lch, 8 lch + 8) of [y0|g0|y1|g1|y2|g2|y3|g3]: 32-column group
                     // lch >> 3 of this wave's 128 activation columns, from Act (y slot) or G (gate slot))
                     const bf16_t* src = AG ? ((lch & 4) ? g_in : yg_in) + (size_t)(m0 + lrow) * p.ldo2 + n0 + (lch >> 3) * 32 + (lch & 3) * 8
@@ -695,9 +710,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #define CX_STAGE_ALL CX_S(0) CX_S(1) CX_S(2) CX_S(3) CX_S(4) CX_S(5) CX_S(6) CX_S(7) CX_S(8) CX_S(9) CX_S(10) CX_S(11) CX_S(12) CX_S(13) CX_S(14) CX_S(15)
                     auto one_pass = [&](auto bc) {
                         constexpr int b = decltype(bc)::value;
+                        int lane_p = lane_e;
+#if CX_V6_OPAQUE >= 2
+                        asm volatile("" : "+v"(lane_p));
+#endif
+                        const int lrow = lane_p >> 5, lch = lane_p & 31, l31 = lane_p & 31, hi = lane_p >> 5;   // (shadow the kernel's)
                         CX_STAGE_ALL
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (b < 3) { CX_LOAD_LO(b + 1) }  // rows 0..15 of the next pass fly under the arithmetic
+#if CX_V6_HI_EARLY
+                        if constexpr (b < 3) { CX_LOAD_HI(b + 1) }  // ... and rows 16..31 with them (round 5)
+#endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
@@ -721,7 +744,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             }
                             __builtin_amdgcn_sched_barrier(0);  // one accumulator block at a time (register pressure)
                         }
+#if !CX_V6_HI_EARLY
                         if constexpr (b < 3) { CX_LOAD_HI(b + 1) }  // rows 16..31: still ahead of this pass's stores
+#endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {  // (named registers: a small uint4 array lands in scratch memory here)

@@ -133,9 +133,35 @@ __global__ __launch_bounds__(512) void probe_mfma_rate16_kernel(const uint4* __r
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// ---- dQ read-modify-write probe (round 5): what the accumulation traffic of a single-owner fused long-sequence
+// attention backward costs BY ITSELF.  One workgroup owns a (sequence, head) problem; with dK / dV in registers and the query
+// blocks in the inner loop, every (key block, query block) pair adds a 128 x 64 fp32 partial to the problem's dQ scratch: per
+// problem `sweeps` (= key blocks) passes of load + add + store over `floats` (= S x 64) floats that only this workgroup touches.
+// No MFMA, no softmax: the floor the fused form pays on top of its five GEMMs.
+__global__ __launch_bounds__(256) void probe_rmw_kernel(float* __restrict__ buf, long floats, int sweeps, int n_problems) {
+    for (int pr = blockIdx.x; pr < n_problems; pr += gridDim.x) {
+        float4* base = reinterpret_cast<float4*>(buf + (size_t)pr * floats);
+        const long n4 = floats / 4;
+        for (int sw = 0; sw < sweeps; ++sw) {
+            const float add = 1.0f + sw;
+            for (long i = threadIdx.x; i < n4; i += 256) {
+                float4 v = base[i];
+                v.x += add; v.y += add; v.z += add; v.w += add;
+                base[i] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+int cx_probe_rmw(float* buf, long floats_per_problem, int sweeps, int n_problems, int nwg, void* stream) {
+    if (!buf || floats_per_problem <= 0 || (floats_per_problem & 3) || sweeps <= 0 || n_problems <= 0 || nwg <= 0) return CX_ERR_ARG;
+    hipLaunchKernelGGL(probe_rmw_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, buf, floats_per_problem, sweeps, n_problems);
+    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
+}
 int cx_probe_mfma_rate16(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
                          void* stream) {
     if (waves < 1 || waves > 8) return CX_ERR_SHAPE;

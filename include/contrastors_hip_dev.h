@@ -70,6 +70,9 @@ int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* str
 /* keep[b][h][q][key] in {0, 1}: the mask cx_attn_varlen_dropout_fwd/_bwd apply (tests) */
 int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
                               unsigned long long offset, unsigned int site, void* stream);
+/* what the dQ accumulation of a single-owner fused long-sequence attention backward costs by itself: every workgroup walks its
+ * problems (floats_per_problem fp32 each, contiguous), `sweeps` load + add + store passes over each (scripts/dq_rmw_probe.py) */
+int cx_probe_rmw(float* buf, long floats_per_problem, int sweeps, int n_problems, int nwg, void* stream);
 int cx_probe_mfma_rate16(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
                          void* stream);  /* the same loop from v_mfma_f32_16x16x32_bf16 */
 int cx_probe_mfma_rate(const void* seed_2048x16B, int waves, int iters, int nwg, long long* cycles_nwg_x8, float* sink,
