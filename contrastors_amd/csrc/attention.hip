@@ -15,6 +15,12 @@
 #ifndef CX_ATTN_ROT_AHEAD
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
+#ifndef CX_ATTN_ROWMAJOR
+#define CX_ATTN_ROWMAJOR 0  // fused S <= 128 backward: Q / dO tiles row-major (staged with 16-B writes) instead of transposed (round 5)
+#endif
+#ifndef CX_ATTN_ROT_PRE
+#define CX_ATTN_ROT_PRE 0   // fused S <= 128 backward: the inverse rotation's table rows fetched once per problem ahead of the store phases (round 5)
+#endif
 #ifndef CX_ATTN_PF
 #define CX_ATTN_PF 0   // L2 prefetch of the next problem in the fused S <= 128 backward: measured 595 us with, 567 us without at T = 131072
 #endif
@@ -847,6 +853,57 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
         pk.y = pack_bf16x2(hh[2], hh[3]);
         *reinterpret_cast<uint2*>(stage + tile64_off(l31, 4 + qd) + hi * 8) = pk;
         __builtin_amdgcn_sched_barrier(0);  // one qd at a time: hoisting all four cos/sin fetches costs 32 registers
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + tile64_off(r, c));
+        if (r < rows_valid) *reinterpret_cast<uint4*>(g0 + (size_t)r * row_stride + c * 8) = v;
+    }
+}
+
+// The inverse rotation's table rows of ONE position, all 32 column pairs of this lane's accumulator layout (d = 8 qd + 4 hi + e):
+// fetched once per problem by the fused S <= 128 backward (round 5) -- the lane's key row (dK) and its query row (dQ) are the same
+// index there, so the 8 float4 serve both store phases and no global round trip sits inside either of them.
+struct RotRow {
+    float4 c[4], s[4];
+};
+CX_DEVICE void load_rot_row(const float* cosv, const float* sinv, int pos, int hi, RotRow& o) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        o.c[qd] = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + 8 * qd + 4 * hi);
+        o.s[qd] = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + 8 * qd + 4 * hi);
+    }
+}
+// store_unrotated_rows with the table rows in registers (by reference + flag: a pointer would put the struct in scratch memory)
+CX_DEVICE void store_unrotated_rows_pre(char* stage, bf16_t* g0, size_t row_stride, int rows_valid, const f32x16_t (&acc)[2],
+                                        float scale, const RotRow& rot, bool use_rot, int hi, int lane) {
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        float lo[4], hh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = acc[0][4 * qd + e] * scale;
+            hh[e] = acc[1][4 * qd + e] * scale;
+        }
+        if (use_rot) {
+            const float4 c = rot.c[qd], s = rot.s[qd];
+            const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gl = lo[e], gh = hh[e];
+                lo[e] = gl * cc[e] + gh * ss[e];
+                hh[e] = gh * cc[e] - gl * ss[e];
+            }
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(lo[0], lo[1]);
+        pk.y = pack_bf16x2(lo[2], lo[3]);
+        *reinterpret_cast<uint2*>(stage + tile64_off(l31, qd) + hi * 8) = pk;
+        pk.x = pack_bf16x2(hh[0], hh[1]);
+        pk.y = pack_bf16x2(hh[2], hh[3]);
+        *reinterpret_cast<uint2*>(stage + tile64_off(l31, 4 + qd) + hi * 8) = pk;
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1818,8 +1875,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             dpart[i] = acc;
         }
         if (p.cosv) rotate_pair(q, cs);
+#if CX_ATTN_ROWMAJOR
+        // Q and dO stay ROW-major ([128 q][64 d], tile64 swizzle, 4 x 16-B writes per thread and tensor): S / dP take their A
+        // operands as plain 16-B row reads, dK / dV theirs through the transposing read -- the same two access forms as with the
+        // transposed tiles, roles swapped, without the element-wise transposition while staging (32 x 4-B writes + ~50 VALU per
+        // thread and tensor)
+        stage_rows(Qt, kp, cp, q);
+        stage_rows(dOt, kp, cp, dO);
+#else
         stage_transposed_sw(Qt, kp, cp, q);
         stage_transposed_sw(dOt, kp, cp, dO);
+#endif
         if (cp == 0) {
             dl_s[2 * kp] = dpart[0];
             dl_s[2 * kp + 1] = dpart[1];
@@ -1860,8 +1926,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+#if CX_ATTN_ROWMAJOR
+                a_s = mfma_bf16_32x32x16(lds_read_frag(Qt, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
+                a_dp = mfma_bf16_32x32x16(lds_read_frag(dOt, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
+#else
                 a_s = mfma_bf16_32x32x16(sw_tr_frag(Qt, qb * 32, ks * 16, lane), kf[ks], a_s);
                 a_dp = mfma_bf16_32x32x16(sw_tr_frag(dOt, qb * 32, ks * 16, lane), vf[ks], a_dp);
+#endif
             }
             float pr[16], ds[16];
 #pragma unroll
@@ -1894,22 +1965,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
+#if CX_ATTN_ROWMAJOR
+                    acc_dv[db] = mfma_bf16_32x32x16(tile64_tr_frag(dOt, db * 32, (qb * 2 + half) * 16, lane), pf, acc_dv[db]);
+                    acc_dk[db] = mfma_bf16_32x32x16(tile64_tr_frag(Qt, db * 32, (qb * 2 + half) * 16, lane), dsf, acc_dk[db]);
+#else
                     acc_dv[db] = mfma_bf16_32x32x16(sw_perm_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
                     acc_dk[db] = mfma_bf16_32x32x16(sw_perm_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
+#endif
                 }
             }
         }
         if (PIPE || p.prio) __builtin_amdgcn_s_setprio(0);
         CX_STAMP(5);  // main loop
+#if CX_ATTN_ROT_PRE
+        // the inverse rotation's table rows of this lane's position (its key for dK, its query for dQ: the same index), requested
+        // BEFORE the barrier into registers the main loop has just freed: their round trip hides behind the barrier wait instead
+        // of sitting inside the dK and dQ store phases (rounds 3-4 fetched them there, one column group ahead)
+        RotRow rot = {};
+        if (p.cosv) load_rot_row(p.cosv, p.sinv, row_ok ? row : len - 1, hi, rot);
+#endif
         __syncthreads();  // the dS tile is complete; lse / delta, Q^T and dO^T are dead: R2 becomes Kt
         CX_STAMP(6);  // barrier
         {   // dK, dV of this wave's 32 keys leave as full rows through the wave's slices of the dead Q^T / dO^T tiles
             bf16_t* k0 = p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)(p.H + h) * DH;
+#if CX_ATTN_ROT_PRE
+            // dV first: its stores are in flight while the table rows land
+            store_unrotated_rows_pre(dOt + wave * 4096, k0 + (size_t)p.H * DH, tok_stride, len - wave * 32, acc_dv, 1.f, rot, false, hi, lane);
+            store_unrotated_rows_pre(Qt + wave * 4096, k0, tok_stride, len - wave * 32, acc_dk, p.scale, rot, p.cosv != nullptr, hi, lane);
+#else
             const int pos = row_ok ? row : len - 1;
             store_unrotated_rows(Qt + wave * 4096, k0, tok_stride, len - wave * 32, acc_dk, p.scale, p.cosv, p.sinv, pos,
                                  hi, lane);
             store_unrotated_rows(dOt + wave * 4096, k0 + (size_t)p.H * DH, tok_stride, len - wave * 32, acc_dv, 1.f,
                                  nullptr, nullptr, 0, hi, lane);
+#endif
         }
         CX_STAMP(7);  // dK, dV stored
         stage_transposed_sw(R2, kp, cp, k);
@@ -1932,8 +2021,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         }
         CX_STAMP(10);  // dQ products
         if constexpr (PIPE) u_next = request(u + gridDim.x, qo, ko, vo, dOo, oo, cso, lseo);   // q, k, v, dO, o, cs are dead: the next problem's rows fly under the dQ store
+#if CX_ATTN_ROT_PRE
+        store_unrotated_rows_pre(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
+                                 len - wave * 32, acc_dq, p.scale, rot, p.cosv != nullptr, hi, lane);
+#else
         store_unrotated_rows(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
                              len - wave * 32, acc_dq, p.scale, p.cosv, p.sinv, row_ok ? row : len - 1, hi, lane);
+#endif
         CX_STAMP(11);  // dQ stored
         __syncthreads();  // LDS is restaged by the next problem
         CX_STAMP(12);  // barrier

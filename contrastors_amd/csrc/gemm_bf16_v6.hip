@@ -38,11 +38,14 @@ namespace {
 // store issue of pass b -- to land before pass b + 1 stages them).  That needs 32 more registers through the arithmetic, which
 // the kernel (256 VGPRs) did not have: OPAQUE passes the lane index the staging addresses derive from through an empty asm per
 // tile (1) / per pass (2), so that the compiler re-derives the ~50 LDS addresses (a few VALU each) instead of keeping them live.
+// Same-box A/B at the metric's fc2-dgrad launch (T = 262144; profiles/r5_gemm_swiglu_bwd_hi_early_ab.txt, interleaved rounds, outputs
+// bit-identical): HI_EARLY 0 / OPAQUE 0 1840 us | 1 / 1 1802 us (-2.1 %) | 1 / 2 1852 us | 0 / 2 1884 us (what re-deriving the
+// addresses per pass costs: +2.4 %; issuing the loads early buys 3 % of it back).  Shipped: 1 / 1.
 #ifndef CX_V6_HI_EARLY
-#define CX_V6_HI_EARLY 0
+#define CX_V6_HI_EARLY 1
 #endif
 #ifndef CX_V6_OPAQUE
-#define CX_V6_OPAQUE 0
+#define CX_V6_OPAQUE 1
 #endif
 #ifndef CX_V6_NT
 #define CX_V6_NT 3   // measured on the whole step (scripts/gpu_variant_bench.sh): 0 -> 3861..3873, 1 -> 3895, 3 -> 3907 pairs/s

@@ -310,7 +310,8 @@ class TextTextTrainer:
         dataset_name = batch.get("dataset_name", "") if isinstance(batch, dict) else ""
         if isinstance(dataset_name, (list, tuple)):
             dataset_name = dataset_name[0] if dataset_name else ""
-        log = dict(tracker=self.tracker, step=self.step) if self.tracker is not None else {}
+        tracker = getattr(self, "tracker", None)
+        log = dict(tracker=tracker, step=getattr(self, "step", None)) if tracker is not None else {}
         if not dims:
             return clip_loss(queries, all_documents, scale, use_fp8=bool(ta.use_fp8), dataset=dataset_name, **log)
         # Matryoshka (text_text.py:352-369): one InfoNCE per prefix width on re-normalised prefixes, weighted sum.
