@@ -15,11 +15,11 @@
 #ifndef CX_ATTN_ROT_AHEAD
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
-#ifndef CX_ATTN_ROWMAJOR
-#define CX_ATTN_ROWMAJOR 0  // fused S <= 128 backward: Q / dO tiles row-major (staged with 16-B writes) instead of transposed (round 5)
+#ifndef CX_ATTN_CS_FIRST
+#define CX_ATTN_CS_FIRST 0  // fused S <= 128 backward: the forward rotation's table rows requested before the Q / K / V / dO / O rows (round 5 A/B)
 #endif
 #ifndef CX_ATTN_ROT_PRE
-#define CX_ATTN_ROT_PRE 0   // fused S <= 128 backward: the inverse rotation's table rows fetched once per problem ahead of the store phases (round 5)
+#define CX_ATTN_ROT_PRE 1   // fused S <= 128 backward: the inverse rotation's table rows fetched once per problem ahead of the store phases (round 5: 924 -> 862 us at T = 262144, same box)
 #endif
 #ifndef CX_ATTN_PF
 #define CX_ATTN_PF 0   // L2 prefetch of the next problem in the fused S <= 128 backward: measured 595 us with, 567 us without at T = 131072
@@ -1157,14 +1157,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(AttnParams p) {
                 const float4 l4 = *reinterpret_cast<const float4*>(lse_s + row);
                 const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                // DROP: this lane holds ONE key and four consecutive queries.  Rounds 2-4 drew one Philox4x32-10 word quadruple per
+                // ELEMENT here (attn_keep1: the four lanes of a key group each computed the same quadruple and kept one word) --
+                // the streaming backward under dropout ran 2.4-3.2 x slower than without.  As in the fused S <= 128 backward: lane j
+                // of a quad draws the quadruple of query row + j and the 4 x 4 block is transposed across the quad with DPP
+                // (quad_keep4): one call per four mask values, the same masks bit for bit.
+                float kq[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (DROP) quad_keep4(p, (uint32_t)(b * p.H + h), q0 + row, key, lane, kq);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
                     // (keys_full: every key of this workgroup's 128 exists -- wave-uniform, no per-element select)
                     const float pe = fast_exp2(__builtin_fmaf(a_s[r], sc2, -ll[e]));
                     const float pv = (keys_full || key_ok) ? pe : 0.f;
-                    if constexpr (DROP) {  // this lane: ONE key, four consecutive queries -> one mask word per element
-                        const float kp = attn_keep1(p, (uint32_t)(b * p.H + h), q0 + row + e, key);
+                    if constexpr (DROP) {
+                        const float kp = kq[e];
                         pr[r] = pv * kp;                          // dV = (P * keep / (1 - p))^T dO
                         ds[r] = pv * (a_dp[r] * kp - dd[e]);
                     } else {
@@ -1840,12 +1847,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             ra = ra < len ? ra : len - 1;
             rb = rb < len ? rb : len - 1;
             const bf16_t* qbase = p.qkv + (size_t)h * DH;
+#if CX_ATTN_CS_FIRST
+            // the rotation table rows FIRST: the K rows are the first thing staged and they are rotated on the way -- with the table
+            // requested last (rounds 3-4) the first use waited for every row of the problem (loads return in order)
+            if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
+#endif
             load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, kl);
             load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, vl);
             load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, ql);
             load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dOl);
             load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, ol);
+#if !CX_ATTN_CS_FIRST
             if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
+#endif
             if (tid < 128) {
                 const bool ok = tid < len;
                 // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
@@ -1875,17 +1889,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             dpart[i] = acc;
         }
         if (p.cosv) rotate_pair(q, cs);
-#if CX_ATTN_ROWMAJOR
-        // Q and dO stay ROW-major ([128 q][64 d], tile64 swizzle, 4 x 16-B writes per thread and tensor): S / dP take their A
-        // operands as plain 16-B row reads, dK / dV theirs through the transposing read -- the same two access forms as with the
-        // transposed tiles, roles swapped, without the element-wise transposition while staging (32 x 4-B writes + ~50 VALU per
-        // thread and tensor)
-        stage_rows(Qt, kp, cp, q);
-        stage_rows(dOt, kp, cp, dO);
-#else
+        // (round 5 measured the row-major alternative -- Q / dO staged with 16-B writes, S / dP operands as plain row reads, dK / dV
+        // operands through the transposing read: bit-identical, -1.9 % alone, but +3.7 % on top of the table prefetch below;
+        // profiles/r5_attn_bwd_s128_ab.txt -- not kept)
         stage_transposed_sw(Qt, kp, cp, q);
         stage_transposed_sw(dOt, kp, cp, dO);
-#endif
         if (cp == 0) {
             dl_s[2 * kp] = dpart[0];
             dl_s[2 * kp + 1] = dpart[1];
@@ -1926,13 +1934,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-#if CX_ATTN_ROWMAJOR
-                a_s = mfma_bf16_32x32x16(lds_read_frag(Qt, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
-                a_dp = mfma_bf16_32x32x16(lds_read_frag(dOt, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
-#else
                 a_s = mfma_bf16_32x32x16(sw_tr_frag(Qt, qb * 32, ks * 16, lane), kf[ks], a_s);
                 a_dp = mfma_bf16_32x32x16(sw_tr_frag(dOt, qb * 32, ks * 16, lane), vf[ks], a_dp);
-#endif
             }
             float pr[16], ds[16];
 #pragma unroll
@@ -1965,13 +1968,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-#if CX_ATTN_ROWMAJOR
-                    acc_dv[db] = mfma_bf16_32x32x16(tile64_tr_frag(dOt, db * 32, (qb * 2 + half) * 16, lane), pf, acc_dv[db]);
-                    acc_dk[db] = mfma_bf16_32x32x16(tile64_tr_frag(Qt, db * 32, (qb * 2 + half) * 16, lane), dsf, acc_dk[db]);
-#else
                     acc_dv[db] = mfma_bf16_32x32x16(sw_perm_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
                     acc_dk[db] = mfma_bf16_32x32x16(sw_perm_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
-#endif
                 }
             }
         }
