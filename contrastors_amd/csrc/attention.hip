@@ -16,7 +16,7 @@
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
 #ifndef CX_ATTN_CS_FIRST
-#define CX_ATTN_CS_FIRST 0  // fused S <= 128 backward: the forward rotation's table rows requested before the Q / K / V / dO / O rows (round 5 A/B)
+#define CX_ATTN_CS_FIRST 1  // fused S <= 128 backward: the forward rotation's table rows requested before the Q / K / V / dO / O rows (round 5: 890 -> 861 us same-box, bit-identical)
 #endif
 #ifndef CX_ATTN_ROT_PRE
 #define CX_ATTN_ROT_PRE 1   // fused S <= 128 backward: the inverse rotation's table rows fetched once per problem ahead of the store phases (round 5: 924 -> 862 us at T = 262144, same box)

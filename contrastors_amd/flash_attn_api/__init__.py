@@ -2,8 +2,10 @@
 libcontrastors_hip.so.  `install()` registers this package under the name `flash_attn` so the reference's
 `sc/layers/*.py` and `sc/models/encoder/modeling_nomic_bert.py` import it unchanged.
 
-Supported on the device path: bf16 tensors, head_dim 64, non-causal, dropout 0 (everything the five BASELINE configs
-use).  Anything else raises — there is no silent fallback to a generic implementation.
+Supported on the device path: bf16 tensors, head_dim 64, non-causal; attention dropout (`dropout_p > 0`, the reference's
+bert-base-uncased recipes) on the self-attention functions -- Philox masks keyed by the torch generator's (seed, offset), regenerated in
+backward and under RandContext, never stored -- but not inside the kv-packed cross-attention.  That covers the five BASELINE configs;
+anything else raises: there is no silent fallback to a generic implementation.
 """
 from __future__ import annotations
 

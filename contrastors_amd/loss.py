@@ -340,8 +340,10 @@ def accumulate_gradients(model, chunks, cache, rand_states=None, final: bool = F
             model.arm_overlapped_reduce()
         with state:
             out = model(**c)["embedding"]
-        surrogate = torch.dot(out.flatten(), g.flatten().to(out.dtype))
-        surrogate.backward()
+        # sc/loss.py:158-161 builds `surrogate = dot(reps.flatten(), gradient.flatten())` and back-propagates that scalar; its
+        # gradient with respect to `reps` IS `gradient`, so the cached gradient is handed to autograd directly -- no vendor-BLAS
+        # dot kernel (and no BLAS handle, whose workspace allocation was the first thing to fail under memory pressure)
+        out.backward(g.to(out.dtype))
 
 
 def cache_loss(query_embeddings, document_embeddings, logit_scale, bidirectional=False, *, use_fp8=False):
