@@ -158,8 +158,11 @@ CX_DEVICE int xcd_remap(int bid, int nwg) {
 CX_DEVICE uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        // one 32 x 32 -> 64-bit product per multiplier (v_mad_u64_u32): written as __umulhi + a 32-bit multiply the compiler emitted
+        // v_mul_hi_u32 AND v_mul_lo_u32 -- four quarter-rate instructions per round instead of two (round 5)
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;
