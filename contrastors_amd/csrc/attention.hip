@@ -15,6 +15,9 @@
 #ifndef CX_ATTN_ROT_AHEAD
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
+#ifndef CX_ATTN_BWD_MODE
+#define CX_ATTN_BWD_MODE 3  // product: which fused S <= 128 backward cx_attn_varlen_bwd launches (3 serial = shipped; 5 = LDS-DMA prefetch, A/B builds)
+#endif
 #ifndef CX_ATTN_CS_FIRST
 #define CX_ATTN_CS_FIRST 1  // fused S <= 128 backward: the forward rotation's table rows requested before the Q / K / V / dO / O rows (round 5: 890 -> 861 us same-box, bit-identical)
 #endif
@@ -1759,7 +1762,11 @@ constexpr int FUSED2_LDS = 16384 * 3 + 32768;  // 80 KiB
 // and the loop overhead instead of starting behind the stores (one in-order vmcnt: a load issued after a store cannot be
 // waited for without waiting for the store).  s_setprio 1 around the S / dP / dV / dK loop: the SIMD's other wave belongs to
 // the CU's other workgroup and is usually in a load / store phase.
-template <bool DROP, bool PIPE = false>
+// PIPE 2 (round 5, A/B): the next problem's K / V / Q / dO rows by LDS-DMA (global_load_lds_dwordx4, no registers) into the three tiles
+// that are dead after the dQ products (dO^T, R2 = K^T, R3 = dS: 64 of the 80 KiB), requested ahead of the dQ stores; only O, the
+// forward rotation's table rows and lse travel in registers (33).  The next iteration starts by reading its raw rows back from LDS
+// (16 x 16 B per thread, its own DMA targets: conflict-free) instead of waiting for global memory: + 2 barriers per problem.
+template <bool DROP, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams p, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
@@ -1825,10 +1832,57 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         }
         return un;
     };
+    // ---- PIPE 2: raw-row landing zones (each thread's four 16-B pieces of a tensor at zone + j * 4096 + tid * 16; a wave's
+    // instruction j writes 1 KiB at M0 = zone + j * 4096 + wave * 1024, lane L at + L * 16)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr uint32_t ZK = 32768, ZV = 16384, ZQ = 49152, ZDO = 65536;   // raw K -> R2, raw V -> dO^T, raw Q / dO -> R3
+    auto dma16 = [&](uint32_t zone_off, const bf16_t* g) {
+        const uint32_t m0v = lds_base + zone_off + wave_u * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "memory");
+    };
+    auto dma_pair = [&](uint32_t zone, const bf16_t* base, size_t stride, int t0, int ra, int rb) {
+        const bf16_t* a = base + (size_t)(t0 + ra) * stride;
+        const bf16_t* b2 = base + (size_t)(t0 + rb) * stride;
+        dma16(zone + 0 * 4096, a + cp * 8);
+        dma16(zone + 1 * 4096, a + 32 + cp * 8);
+        dma16(zone + 2 * 4096, b2 + cp * 8);
+        dma16(zone + 3 * 4096, b2 + 32 + cp * 8);
+    };
+    auto read_raw = [&](uint32_t zone, RowPairLoads& x) {
+        const char* z = smem + zone + tid * 16;
+        x.lo[0] = *reinterpret_cast<const uint4*>(z);
+        x.hi[0] = *reinterpret_cast<const uint4*>(z + 4096);
+        x.lo[1] = *reinterpret_cast<const uint4*>(z + 8192);
+        x.hi[1] = *reinterpret_cast<const uint4*>(z + 12288);
+    };
+    auto request_dma = [&](int un, RowPairLoads& o, CosSin& cs, float& lse_v) {
+        for (; un < n_units; un += gridDim.x) {
+            const int b = un / p.H;
+            if (p.cu[b + 1] - p.cu[b] > 0) break;
+        }
+        if (un >= n_units) return n_units;
+        const int b = un / p.H, h = un - b * p.H;
+        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+        int ra = 2 * kp, rb = ra + 1;
+        ra = ra < len ? ra : len - 1;
+        rb = rb < len ? rb : len - 1;
+        const bf16_t* qbase = p.qkv + (size_t)h * DH;
+        (void)cs;   // (the forward rotation's table rows are fetched at the top of the problem's own iteration: 16 registers less to carry)
+        dma_pair(ZK, qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb);
+        dma_pair(ZV, qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb);
+        dma_pair(ZQ, qbase, tok_stride, t0, ra, rb);
+        dma_pair(ZDO, p.dout + (size_t)h * DH, o_stride, t0, ra, rb);
+        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
+        lse_v = 0.f;
+        if (tid < 128) lse_v = tid < len ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
+        return un;
+    };
     int u_next = n_units;
-    if constexpr (PIPE) u_next = request(blockIdx.x, qo, ko, vo, dOo, oo, cso, lseo);
+    if constexpr (PIPE == 1) u_next = request(blockIdx.x, qo, ko, vo, dOo, oo, cso, lseo);
+    if constexpr (PIPE == 2) u_next = request_dma(blockIdx.x, oo, cso, lseo);
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        if constexpr (PIPE) {
+        if constexpr (PIPE != 0) {
             u = u_next;              // (the problem whose rows are in flight; empty sequences were skipped by `request`)
             if (u >= n_units) break;
         }
@@ -1842,7 +1896,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         RowPairLoads ql, kl, vl, dOl, ol;
         CosSin csl;
         float lsel = 0.f;
-        if constexpr (!PIPE) {   // (the serial form, exactly as it shipped in round 3: its register allocation is a fragile optimum)
+        if constexpr (PIPE == 0) {   // (the serial form, exactly as it shipped in round 3: its register allocation is a fragile optimum)
             int ra = 2 * kp, rb = ra + 1;
             ra = ra < len ? ra : len - 1;
             rb = rb < len ? rb : len - 1;
@@ -1866,9 +1920,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 lsel = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
             }
         }
-        RowPairLoads &q = PIPE ? qo : ql, &k = PIPE ? ko : kl, &v = PIPE ? vo : vl, &dO = PIPE ? dOo : dOl, &o = PIPE ? oo : ol;
-        CosSin& cs = PIPE ? cso : csl;
-        const float lse_v = PIPE ? lseo : lsel;
+        if constexpr (PIPE == 2) {
+            // this problem's rows were requested by the previous iteration (or the prologue): every wave's DMA has landed, then each
+            // thread takes its own pieces into registers, and only when everybody has may the zones be restaged
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (p.cosv) {   // (an L2-resident table: lands under the raw reads and the second barrier)
+                int ra = 2 * kp, rb = ra + 1;
+                ra = ra < len ? ra : len - 1;
+                rb = rb < len ? rb : len - 1;
+                load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
+            }
+            read_raw(ZK, kl);
+            read_raw(ZV, vl);
+            read_raw(ZQ, ql);
+            read_raw(ZDO, dOl);
+            ol = oo;
+            lsel = lseo;
+            __syncthreads();
+        }
+        RowPairLoads &q = PIPE == 1 ? qo : ql, &k = PIPE == 1 ? ko : kl, &v = PIPE == 1 ? vo : vl, &dO = PIPE == 1 ? dOo : dOl, &o = PIPE == 1 ? oo : ol;
+        CosSin& cs = PIPE == 1 ? cso : csl;
+        const float lse_v = PIPE == 1 ? lseo : lsel;
         CX_STAMP(1);  // loads landed
         // ---- K, V row-major (for this wave's key fragments), then everything that depends on dO / O / Q ----
         if (p.cosv) rotate_pair(k, cs);
@@ -1900,7 +1973,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         }
         if (tid < 128) lse_s[tid] = lse_v;
 #if CX_ATTN_PF
-        if constexpr (PIPE) {
+        if constexpr (PIPE != 0) {
             if (u + 2 * (int)gridDim.x < n_units) l2_prefetch(u + 2 * gridDim.x);
         } else {
             if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
@@ -1926,7 +1999,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
-        if (PIPE || p.prio) __builtin_amdgcn_s_setprio(1);
+        if (PIPE == 1 || p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1  // (rolled: unrolling makes the compiler hoist ~100 loop-invariant LDS addresses and spill)
         for (int qb = 0; qb < 4; ++qb) {
             f32x16_t a_s, a_dp;
@@ -1973,7 +2046,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 }
             }
         }
-        if (PIPE || p.prio) __builtin_amdgcn_s_setprio(0);
+        if (PIPE == 1 || p.prio) __builtin_amdgcn_s_setprio(0);
         CX_STAMP(5);  // main loop
 #if CX_ATTN_ROT_PRE
         // the inverse rotation's table rows of this lane's position (its key for dK, its query for dQ: the same index), requested
@@ -2018,7 +2091,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 acc_dq[db] = mfma_bf16_32x32x16(sw_linear_frag(R2, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
         }
         CX_STAMP(10);  // dQ products
-        if constexpr (PIPE) u_next = request(u + gridDim.x, qo, ko, vo, dOo, oo, cso, lseo);   // q, k, v, dO, o, cs are dead: the next problem's rows fly under the dQ store
+        if constexpr (PIPE == 1) u_next = request(u + gridDim.x, qo, ko, vo, dOo, oo, cso, lseo);   // q, k, v, dO, o, cs are dead: the next problem's rows fly under the dQ store
+        if constexpr (PIPE == 2) {
+            __syncthreads();   // every wave is through its dQ products: K^T (R2), dS (R3) and the dV staging (dO^T) are dead
+            u_next = request_dma(u + gridDim.x, oo, cso, lseo);
+        }
 #if CX_ATTN_ROT_PRE
         store_unrotated_rows_pre(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
                                  len - wave * 32, acc_dq, p.scale, rot, p.cosv != nullptr, hi, lane);
@@ -2236,7 +2313,7 @@ extern "C" {
 #ifndef CX_PRODUCT
 int g_attn_prio = 0;
 void cx_attn_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
-void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 4) ? mode : 3; }
+void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 5) ? mode : 3; }
 void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
 #endif
 
@@ -2285,16 +2362,31 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     p.prio = g_attn_prio;
     const int bwd_mode = g_bwd_s128;
 #else
-    constexpr int bwd_mode = 3;
+    constexpr int bwd_mode = CX_ATTN_BWD_MODE;
 #endif
+#ifndef CX_PRODUCT
     if (max_seqlen <= 128 && bwd_mode == 4) {  // the same with the next problem's loads ahead of the dQ store (A/B; round 4)
         static CxLdsOptIn lds2p;
-        if (!lds2p.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false, true>), FUSED2_LDS)) return CX_ERR_LAUNCH;
+        if (!lds2p.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false, 1>), FUSED2_LDS)) return CX_ERR_LAUNCH;
         const int n_units = B * H;
-        hipLaunchKernelGGL((attn_bwd_fused2_s128_kernel<false, true>), dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
+        hipLaunchKernelGGL((attn_bwd_fused2_s128_kernel<false, 1>), dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
                            (hipStream_t)stream, p, B);
         return done();
     }
+#endif
+#if !defined(CX_PRODUCT) || CX_ATTN_BWD_MODE == 5
+    // the same with the next problem's rows by LDS-DMA into the dead tiles (round 5; dev library + A/B builds of the product):
+    // bit-identical, 1.39 x SLOWER at the metric's shape (profiles/r5_attn_bwd_s128_ab.txt) -- two more barriers, a raw-row round
+    // trip through LDS and 47 spilled registers cost more than the load wait they remove while the CU's other workgroup covers it
+    if (max_seqlen <= 128 && bwd_mode == 5) {
+        static CxLdsOptIn lds2q;
+        if (!lds2q.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false, 2>), FUSED2_LDS)) return CX_ERR_LAUNCH;
+        const int n_units = B * H;
+        hipLaunchKernelGGL((attn_bwd_fused2_s128_kernel<false, 2>), dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
+                           (hipStream_t)stream, p, B);
+        return done();
+    }
+#endif
     if (max_seqlen <= 128 && bwd_mode == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
         static CxLdsOptIn lds2;
         if (!lds2.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false>), FUSED2_LDS)) return CX_ERR_LAUNCH;
