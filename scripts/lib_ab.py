@@ -45,6 +45,8 @@ T, d, I, H, S = a.chunk * 128, 768, 3072, 12, a.seq
 x, res = rn(T, d), rn(T, d)
 w1, w2t, w2, wo, wqkv = rn(2 * I, d, std=0.05), rn(I, d, std=0.05), rn(d, I, std=0.05), rn(d, d, std=0.05), rn(3 * d, d, std=0.05)
 act, gate = rn(T, I), rn(T, I, std=2.0)
+x3, wqkv_t = rn(T, 3 * d), rn(d, 3 * d, std=0.05)
+x6, w1_t = rn(T, 2 * I), rn(d, 2 * I, std=0.05)
 dyg = torch.empty(T, 2 * I, device=dev, dtype=torch.bfloat16)
 out_d = torch.empty(T, d, device=dev, dtype=torch.bfloat16)
 out_3d = torch.empty(T, 3 * d, device=dev, dtype=torch.bfloat16)
@@ -76,6 +78,8 @@ cases = {
     "qkv_fwd": (2.0 * T * 3 * d * d, [out_3d], lambda L: L.cx_gemm_bf16_nt(P(x), P(wqkv), P(out_3d), None, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.0, s)),
     "out_fwd_res": (2.0 * T * d * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(x), P(wo), P(out_d), None, P(res), T, d, d, d, d, d, d, s)),
     "fc2_fwd_res": (2.0 * T * I * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(act), P(w2), P(out_d), None, P(res), T, d, I, I, I, d, d, s)),
+    "qkv_dgrad_res": (2.0 * T * 3 * d * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(x3), P(wqkv_t), P(out_d), None, P(res), T, d, 3 * d, 3 * d, 3 * d, d, d, s)),
+    "fc1_dgrad_res": (2.0 * T * 2 * I * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(x6), P(w1_t), P(out_d), None, P(res), T, d, 2 * I, 2 * I, 2 * I, d, d, s)),
     "attn_fwd": (4.0 * S * S * 64 * B * H, [att_out, lse], lambda L: L.cx_attn_varlen_fwd(P(qkv), P(cu), P(cos), P(sin), P(att_out), P(lse), B, H, T, S, 0.125, s)),
     "attn_bwd": (10.0 * S * S * 64 * B * H, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S, 0.125, s)),
     "attn_bwd_ragged": (0.0, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu_r), P(cos), P(sin), P(delta), P(dqkv), B, H, T_r, S, 0.125, s)),
