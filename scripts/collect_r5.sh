@@ -13,6 +13,8 @@ cp $O/pmc_sq_summary.txt profiles/r5_pmc_sq_step_summary.txt
 for leg in cfg1 lit clip; do cp $O/kernel_summary_$leg.txt profiles/r5_kernel_summary_$leg.txt; done
 cp $O/gemm_microbench.txt profiles/r5_microbench_gemm2048.txt
 cp $O/attn_microbench.txt profiles/r5_microbench_attention.txt
-cp $O/attn_microbench_dropout.txt profiles/r5_microbench_attention_dropout.txt
-tail -3 gpurun_out/final5/gpu_tests.txt > profiles/r5_gpu_tests.txt; tail -1 $O/smoke.log >> profiles/r5_gpu_tests.txt
+cp $O/attn_microbench_dropout.txt profiles/r5_microbench_attention_dropout_final.txt
+tail -3 $O/gpu_tests.txt > profiles/r5_gpu_tests.txt; tail -1 $O/two_tenants.txt >> profiles/r5_gpu_tests.txt; tail -1 $O/smoke.log >> profiles/r5_gpu_tests.txt
+cp $O/box_calibration.json profiles/r5_box_calibration.json
+cp $O/step_ab_r5_vs_r4_kernels.txt profiles/r5_step_ab_r5_vs_r4_kernels.txt
 ls profiles | grep r5_
