@@ -15,7 +15,7 @@ timeout 60 python scripts/box_calibration.py > $O/box_calibration.json 2>/dev/nu
 cp gpurun_out/kernel_report.jsonl $O/kernel_report.jsonl 2>/dev/null
 # --- HBM traffic of the GEMM family (separate passes, guide's corrections), at the bench's launch sizes
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$ctr -o b -- python $R/bench.py --steps 1 --warmup 0 --global-batch 2048 --no-cpu-baseline --no-extra-legs > $O/pmc_$ctr.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$ctr -o b -- python $R/bench.py --steps 1 --warmup 0 --global-batch 2048 --no-cpu-baseline --no-extra-legs --no-calibration > $O/pmc_$ctr.log 2>&1)
   python scripts/pmc_summary.py $(find $O/pmc_$ctr -name "*counter_collection.csv" | head -1) $ctr > $O/pmc_${ctr}_summary.txt 2>&1
   rm -rf $O/pmc_$ctr
 done
@@ -24,14 +24,14 @@ python -c "import json; json.load(open('$O/pmc_gemm_traffic.json'))" && cp $O/pm
 # --- the bench line (reads the traffic file just written)
 timeout 1500 python bench.py --steps 5 --warmup 2 > $O/bench.log 2>&1; grep "^{" $O/bench.log | cut -c1-300
 # --- kernel stats of the headline leg
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/prof.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs --no-calibration > $O/prof.log 2>&1)
 t=$(find $O/prof -name "*kernel_trace*.csv" | head -1); [[ -n "$t" ]] && python scripts/prof_summary.py "$t" > $O/kernel_summary.txt 2>&1
 f=$(find $O/prof -name "*kernel_stats*.csv" | head -1); [[ -n "$f" ]] && cp "$f" $O/kernel_stats.csv
 rm -rf $O/prof
 head -12 $O/kernel_summary.txt | cut -c1-150
 # --- SQ / MFMA counters over one step
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
-(cd /tmp && timeout 600 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $O/pmc_sq -o g -- python $R/bench.py --steps 1 --warmup 0 --global-batch 2048 --no-cpu-baseline --no-extra-legs > $O/pmc_sq.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $O/pmc_sq -o g -- python $R/bench.py --steps 1 --warmup 0 --global-batch 2048 --no-cpu-baseline --no-extra-legs --no-calibration > $O/pmc_sq.log 2>&1)
 python scripts/pmc_multi.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_summary.txt 2>&1
 rm -rf $O/pmc_sq
 # --- the legs this round changed: kernel stats per leg (dropout recipe of BERT-base in cfg1 / lit)
