@@ -177,12 +177,6 @@ CX_DEVICE void attn_keep4(const AttnParams& p, uint32_t unit, int q, int key, fl
     dropout_keep4(p.drop, p.drop_site, ((unsigned long long)unit << 40) | ((unsigned long long)(uint32_t)q << 20) | (uint32_t)(key >> 2),
                   keep);
 }
-CX_DEVICE float attn_keep1(const AttnParams& p, uint32_t unit, int q, int key) {
-    float k4[4];
-    attn_keep4(p, unit, q, key & ~3, k4);
-    const int e = key & 3;
-    return e == 0 ? k4[0] : e == 1 ? k4[1] : e == 2 ? k4[2] : k4[3];
-}
 
 // keep-scales of ONE key (`key`, this lane's) for the four consecutive queries q0 .. q0 + 3.  The lanes of a quad (lane & ~3)
 // hold the keys 4m .. 4m + 3 of one Philox key group: lane j = lane & 3 draws the four words of query q0 + j (keys 4m .. 4m + 3)
@@ -1161,7 +1155,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(AttnParams p) {
                 const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
                 // DROP: this lane holds ONE key and four consecutive queries.  Rounds 2-4 drew one Philox4x32-10 word quadruple per
-                // ELEMENT here (attn_keep1: the four lanes of a key group each computed the same quadruple and kept one word) --
+                // ELEMENT here (the four lanes of a key group each computed the same quadruple and kept one word) --
                 // the streaming backward under dropout ran 2.4-3.2 x slower than without.  As in the fused S <= 128 backward: lane j
                 // of a quad draws the quadruple of query row + j and the 4 x 4 block is transposed across the quad with DPP
                 // (quad_keep4): one call per four mask values, the same masks bit for bit.

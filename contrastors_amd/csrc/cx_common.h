@@ -35,13 +35,6 @@ CX_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
 }
 CX_DEVICE bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
-// a * b with the DX9 rule 0 * anything = 0 (v_mul_legacy_f32: also 0 * inf and 0 * NaN)
-CX_DEVICE float mul_legacy_f32(float a, float b) {
-    float r;
-    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // Backward of act = y * silu(g) from the saved (act, gate) pair (round 3's compact save: y = act / silu(g) is recovered
 // inside the derivative):  d y = d * g * s,  d gate = d * y * silu'(g) = d * act * (1 / g + 1 - s),  s = sigmoid(g).
 // An exactly-zero gate (or a silu that underflowed) means act = 0, y is not recoverable and d gate comes out 0.  1 / g is
