@@ -15,6 +15,9 @@
 #ifndef CX_ATTN_ROT_AHEAD
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
+#ifndef CX_ATTN_DELTA_IN
+#define CX_ATTN_DELTA_IN 0  // fused S <= 128 backward reads delta from p.delta instead of loading O (A/B only: nothing writes that delta in the product)
+#endif
 #ifndef CX_ATTN_BWD_MODE
 #define CX_ATTN_BWD_MODE 3  // product: which fused S <= 128 backward cx_attn_varlen_bwd launches (3 serial = shipped; 5 = LDS-DMA prefetch, A/B builds)
 #endif
@@ -1904,7 +1907,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, vl);
             load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, ql);
             load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dOl);
+#if !CX_ATTN_DELTA_IN
             load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, ol);
+#endif
 #if !CX_ATTN_CS_FIRST
             if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
 #endif
@@ -1941,7 +1946,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         if (p.cosv) rotate_pair(k, cs);
         stage_rows(R3, kp, cp, k);
         stage_rows(R3 + 16384, kp, cp, v);
-        float dpart[2];
+        float dpart[2] = {0.f, 0.f};
+#if CX_ATTN_DELTA_IN
+        // (A/B, round 5: delta = rowsum(dO * O) arrives precomputed in p.delta (H, T) -- what an out_proj-dgrad epilogue could
+        // write -- and O is not read at all: 16 of the problem's 128 KB and ~100 VALU instructions per thread less)
+        if (tid < 128) dpart[0] = tid < len ? p.delta[(size_t)h * p.T + t0 + tid] : 0.f;
+#else
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // delta = rowsum(dO * O): 16 of the 64 columns of rows (2kp, 2kp+1) per thread
             float a[8], c[8], acc = 0.f;
@@ -1955,16 +1965,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             acc += __shfl_xor(acc, 2, 64);
             dpart[i] = acc;
         }
+#endif
         if (p.cosv) rotate_pair(q, cs);
         // (round 5 measured the row-major alternative -- Q / dO staged with 16-B writes, S / dP operands as plain row reads, dK / dV
         // operands through the transposing read: bit-identical, -1.9 % alone, but +3.7 % on top of the table prefetch below;
         // profiles/r5_attn_bwd_s128_ab.txt -- not kept)
         stage_transposed_sw(Qt, kp, cp, q);
         stage_transposed_sw(dOt, kp, cp, dO);
+#if CX_ATTN_DELTA_IN
+        if (tid < 128) dl_s[tid] = dpart[0];
+#else
         if (cp == 0) {
             dl_s[2 * kp] = dpart[0];
             dl_s[2 * kp + 1] = dpart[1];
         }
+#endif
         if (tid < 128) lse_s[tid] = lse_v;
 #if CX_ATTN_PF
         if constexpr (PIPE != 0) {

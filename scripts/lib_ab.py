@@ -82,6 +82,8 @@ cases = {
     "fc1_dgrad_res": (2.0 * T * 2 * I * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(x6), P(w1_t), P(out_d), None, P(res), T, d, 2 * I, 2 * I, 2 * I, d, d, s)),
     "attn_fwd": (4.0 * S * S * 64 * B * H, [att_out, lse], lambda L: L.cx_attn_varlen_fwd(P(qkv), P(cu), P(cos), P(sin), P(att_out), P(lse), B, H, T, S, 0.125, s)),
     "attn_bwd": (10.0 * S * S * 64 * B * H, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S, 0.125, s)),
+    # (A/B of CX_ATTN_DELTA_IN builds: `delta` is filled beforehand by the base library's general kernels, see below)
+    "attn_bwd_dpre": (10.0 * S * S * 64 * B * H, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S, 0.125, s)),
     "attn_bwd_ragged": (0.0, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu_r), P(cos), P(sin), P(delta), P(dqkv), B, H, T_r, S, 0.125, s)),
 }
 want = [c for c in a.cases.split(",") if c] or list(cases)
@@ -93,6 +95,9 @@ for cname in want:
     if cname.startswith("attn_bwd"):   # its inputs: a forward of the base library on the same sequences
         libs[names[0]].cx_attn_varlen_fwd(P(qkv), P(cu_r if cname.endswith("ragged") else cu), P(cos), P(sin), P(att_out), P(lse), B, H,
                                            T_r if cname.endswith("ragged") else T, S, 0.125, s)
+    if cname == "attn_bwd_dpre":   # delta = rowsum(dO * O) into `delta` (H, T): the general (max_seqlen > 128) path computes it first
+        assert libs[names[0]].cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S + 1, 0.125, s) == 0
+        torch.cuda.synchronize()
     ref, diffs = None, {}
     for n in names:
         for o in outs:
