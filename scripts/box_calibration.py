@@ -5,9 +5,10 @@ package sustains under this load is set by its power budget, and that differs by
 reader tell box from code.  This module gives the line three things:
 
   calibrate(dev)    BEFORE the headline leg: ~2 s of a register-only bf16 MFMA loop on random fragments (cx_calib_mfma_bf16:
-                    one wave per SIMD on every CU -- the ceiling any GEMM main loop has on THIS package at its power limit) and
-                    a 2 GB 16-byte-per-lane copy (cx_calib_copy: the HBM stream rate), each timed with events after a warm-up
-                    half so that the package is at its sustained clock, not its boost clock.
+                    one wave per SIMD on every CU -- the ceiling any GEMM main loop has on THIS package at its power limit), ~1 s
+                    of the same loop with its fragments re-read from LDS at the GEMM's rate (cx_calib_mfma_lds_bf16) and a 2 GB
+                    16-byte-per-lane copy (cx_calib_copy: the HBM stream rate), each timed with events after a warm-up half so that
+                    the package is at its sustained clock, not its boost clock; socket power / shader clock of each probe sampled.
   SmiSampler        DURING the timed region: a background thread reading socket power and the shader clock from
                     librocm_smi64 through ctypes (no subprocess, ~10 Hz); every value is optional -- a box that does not
                     expose a sensor yields null, never an exception.
@@ -46,35 +47,47 @@ def calibrate(dev=None, mfma_seconds: float = 2.0, copy_gb: float = 2.0) -> dict
         iters = 20000
         flop = n_cu * 4 * iters * 8 * 2.0 * 32 * 32 * 16
 
-        def launch():
-            _C.check(lib.cx_calib_mfma_bf16(seed.data_ptr(), iters, n_cu, cyc.data_ptr(), sink.data_ptr(), s), "cx_calib_mfma_bf16")
+        def probe(fn, what, seconds, prefix):
+            """`seconds` of back-to-back launches: the first half untimed (the package reaches its sustained clock), the second half with
+            events around every launch; socket power / shader clock sampled over the timed half."""
+            def launch():
+                _C.check(fn(seed.data_ptr(), iters, n_cu, cyc.data_ptr(), sink.data_ptr(), s), what)
 
-        # warm-up half: the package reaches its sustained (power-limited) clock; timed half: events around every launch
-        launch()
-        torch.cuda.synchronize()
-        t_end = time.perf_counter() + mfma_seconds / 2
-        while time.perf_counter() < t_end:
-            for _ in range(16):
-                launch()
+            launch()
             torch.cuda.synchronize()
-        evs = []
-        t_end = time.perf_counter() + mfma_seconds / 2
-        while time.perf_counter() < t_end:
-            batch = [torch.cuda.Event(enable_timing=True) for _ in range(17)]
-            batch[0].record()
-            for i in range(16):
-                launch()
-                batch[i + 1].record()
-            torch.cuda.synchronize()
-            evs += [batch[i].elapsed_time(batch[i + 1]) for i in range(16)]
-        evs.sort()
-        med = evs[len(evs) // 2]
-        mean_cyc = float(cyc.double().mean())
-        out["mfma_probe_tflops"] = flop / (med * 1e-3) / 1e12
-        out["mfma_probe_ms"] = med
-        out["mfma_probe_launches"] = len(evs)
-        out["mfma_probe_clock_mhz"] = mean_cyc / (med * 1e-3) / 1e6 if med > 0 else None   # s_memtime ticks per wall second of the last launch
-        out["mfma_probe_cycles_per_mfma"] = mean_cyc / (iters * 8)
+            t_end = time.perf_counter() + seconds / 2
+            while time.perf_counter() < t_end:
+                for _ in range(16):
+                    launch()
+                torch.cuda.synchronize()
+            smp = SmiSampler(dev.index or 0, hz=20.0).start()
+            evs = []
+            t_end = time.perf_counter() + seconds / 2
+            while time.perf_counter() < t_end:
+                batch = [torch.cuda.Event(enable_timing=True) for _ in range(17)]
+                batch[0].record()
+                for i in range(16):
+                    launch()
+                    batch[i + 1].record()
+                torch.cuda.synchronize()
+                evs += [batch[i].elapsed_time(batch[i + 1]) for i in range(16)]
+            smi = smp.stop()
+            evs.sort()
+            med = evs[len(evs) // 2]
+            mean_cyc = float(cyc.double().mean())
+            out[prefix + "_tflops"] = flop / (med * 1e-3) / 1e12
+            out[prefix + "_ms"] = med
+            out[prefix + "_launches"] = len(evs)
+            out[prefix + "_clock_mhz"] = mean_cyc / (med * 1e-3) / 1e6 if med > 0 else None   # s_memtime ticks per wall second of the last launch
+            out[prefix + "_cycles_per_mfma"] = mean_cyc / (iters * 8)
+            out[prefix + "_power_w"] = smi["mean_power_w"]
+            out[prefix + "_sclk_mhz"] = smi["mean_sclk_mhz"]
+
+        # register-only loop: the matrix pipes' own limit on this package (does not reach the power cap on the boxes measured)
+        probe(lib.cx_calib_mfma_bf16, "cx_calib_mfma_bf16", mfma_seconds, "mfma_probe")
+        # the same loop fed from LDS at the GEMM main loop's rate: closer to what the GEMMs' clock is set by (the cap)
+        if hasattr(lib, "cx_calib_mfma_lds_bf16"):
+            probe(lib.cx_calib_mfma_lds_bf16, "cx_calib_mfma_lds_bf16", mfma_seconds / 2, "mfma_lds_probe")
         # HBM stream: copy_gb read + copy_gb written per launch
         nbytes = int(copy_gb * (1 << 30)) & ~15
         src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
