@@ -813,13 +813,9 @@ def main():
         out["whole_step_frac_of_mfma_peak"] = out["roofline"]["whole_step_frac_of_mfma_peak"]
         # per-box calibration (flat scalars: the driver's `parsed` view keeps scalars) + the nested record
         out["box"] = box
-        for k in ("mfma_probe_tflops", "mfma_lds_probe_tflops", "hbm_copy_tbs", "mean_sclk_mhz", "mean_power_w", "power_cap_w", "mfma_probe_clock_mhz",
-                  "mfma_probe_power_w", "mfma_lds_probe_power_w", "mfma_lds_probe_clock_mhz"):
+        for k in ("mfma_probe_tflops", "hbm_copy_tbs", "mean_sclk_mhz", "mean_power_w", "power_cap_w", "mfma_probe_clock_mhz", "mfma_probe_power_w"):
             if isinstance(box, dict) and isinstance(box.get(k), (int, float)):
                 out[f"box_{k}"] = box[k]
-        lds_probe = box.get("mfma_lds_probe_tflops") if isinstance(box, dict) else None
-        if lds_probe:   # against the LDS-fed probe (runs nearer the power cap the GEMMs run at): the steadier of the two across boxes
-            out["frac_of_box_lds_ceiling"] = achieved / lds_probe
         if probe:
             out["frac_of_box_ceiling"] = achieved / probe
             out["whole_step_frac_of_box_ceiling"] = pairs_per_s / world * GFLOP_PER_PAIR / 1e3 / probe

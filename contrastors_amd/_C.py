@@ -77,7 +77,6 @@ _SIGS = {
     "cx_prof_gemm_config": (i32, [i32, i32]),
     "cx_prof_gemm_collect": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "cx_calib_mfma_bf16": (i32, [vp, i32, i32, vp, vp, vp]),
-    "cx_calib_mfma_lds_bf16": (i32, [vp, i32, i32, vp, vp, vp]),
     "cx_calib_copy": (i32, [vp, vp, i64, vp]),
     "cx_transpose_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "cx_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),

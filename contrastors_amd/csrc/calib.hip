@@ -40,46 +40,6 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(const uint4* __restrict
     if (cyc && (threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-// The same loop with its operands re-read from LDS at the GEMM's rate (one ds_read_b128 per two MFMAs, fragments double-buffered one
-// iteration ahead): the register-only probe does not reach the package's power cap (~1200 W of 1400 on the boxes measured), the GEMMs
-// do -- their clock is the cap's, not the matrix pipes' own limit.  This probe sits between the two.
-__global__ __launch_bounds__(256) void calib_mfma_lds_kernel(const uint4* __restrict__ seed, int iters, long long* cyc, float* sink) {
-    __shared__ uint4 lds[2048];   // 32 KiB
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        uint4 v = seed[(threadIdx.x + 256 * j) & 1023];
-        v.x ^= (uint32_t)j * 0x01010101u;
-        lds[threadIdx.x + 256 * j] = v;
-    }
-    __syncthreads();
-    cb_f32x16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    uint4 c0 = lds[threadIdx.x], c1 = lds[threadIdx.x + 256], c2 = lds[threadIdx.x + 512], c3 = lds[threadIdx.x + 768];
-    const long long t0 = __builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-        const int o = (threadIdx.x + 64 * (it + 1)) & 1023;
-        const uint4 n0 = lds[o], n1 = lds[o + 1024], n2 = lds[(o + 512) & 2047], n3 = lds[(o + 1536) & 2047];   // next iteration's fragments
-        const cb_bf16x8 fa0 = __builtin_bit_cast(cb_bf16x8, c0), fa1 = __builtin_bit_cast(cb_bf16x8, c1);
-        const cb_bf16x8 fb0 = __builtin_bit_cast(cb_bf16x8, c2), fb1 = __builtin_bit_cast(cb_bf16x8, c3);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((i & 1) ? fa1 : fa0, (i & 2) ? fb1 : fb0, acc[i], 0, 0, 0);
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    }
-    const long long t1 = __builtin_amdgcn_s_memtime();
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[i][r];
-    if (s == 12345.678f) sink[0] = s;
-    if (cyc && (threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-}
-
 __global__ __launch_bounds__(256) void calib_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
@@ -94,14 +54,6 @@ extern "C" {
 int cx_calib_mfma_bf16(const void* seed_1024x16B, int iters, int nwg, long long* cycles_nwg_x4, float* sink, void* stream) {
     if (!seed_1024x16B || !sink || iters <= 0 || nwg <= 0) return CX_ERR_ARG;
     hipLaunchKernelGGL(calib_mfma_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const uint4*)seed_1024x16B, iters,
-                       cycles_nwg_x4, sink);
-    return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
-}
-
-// as cx_calib_mfma_bf16, operands re-read from LDS (one 16-B read per two MFMAs, like the GEMM main loop)
-int cx_calib_mfma_lds_bf16(const void* seed_1024x16B, int iters, int nwg, long long* cycles_nwg_x4, float* sink, void* stream) {
-    if (!seed_1024x16B || !sink || iters <= 0 || nwg <= 0) return CX_ERR_ARG;
-    hipLaunchKernelGGL(calib_mfma_lds_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const uint4*)seed_1024x16B, iters,
                        cycles_nwg_x4, sink);
     return hipGetLastError() == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }

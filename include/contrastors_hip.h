@@ -59,8 +59,6 @@ int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_ti
  * `iters` x 8 MFMAs on fragments from seed (1024 x 16 B, random bf16): FLOPs = nwg * 4 * iters * 8 * 32768; cycles (NULL ok):
  * nwg x 4 s_memtime deltas.  cx_calib_copy: 16 B per lane grid-stride copy, bytes % 16 == 0 (HBM stream rate). */
 int cx_calib_mfma_bf16(const void* seed_1024x16B, int iters, int nwg, long long* cycles_nwg_x4, float* sink, void* stream);
-/* the same loop with its fragments re-read from LDS at the GEMM main loop's rate (one ds_read_b128 per two MFMAs) */
-int cx_calib_mfma_lds_bf16(const void* seed_1024x16B, int iters, int nwg, long long* cycles_nwg_x4, float* sink, void* stream);
 int cx_calib_copy(const void* src, void* dst, long bytes, void* stream);
 
 /* Out[c][r] = In[r][c] for r < rows, zero for rows <= r < rows_pad (token padding for the wgrad reduction).

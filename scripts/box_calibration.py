@@ -5,10 +5,9 @@ package sustains under this load is set by its power budget, and that differs by
 reader tell box from code.  This module gives the line three things:
 
   calibrate(dev)    BEFORE the headline leg: ~2 s of a register-only bf16 MFMA loop on random fragments (cx_calib_mfma_bf16:
-                    one wave per SIMD on every CU -- the ceiling any GEMM main loop has on THIS package at its power limit), ~1 s
-                    of the same loop with its fragments re-read from LDS at the GEMM's rate (cx_calib_mfma_lds_bf16) and a 2 GB
+                    one wave per SIMD on every CU -- the ceiling any GEMM main loop has on THIS package at its power limit) and a 2 GB
                     16-byte-per-lane copy (cx_calib_copy: the HBM stream rate), each timed with events after a warm-up half so that
-                    the package is at its sustained clock, not its boost clock; socket power / shader clock of each probe sampled.
+                    the package is at its sustained clock, not its boost clock; socket power / shader clock of the probe sampled.
   SmiSampler        DURING the timed region: a background thread reading socket power and the shader clock from
                     librocm_smi64 through ctypes (no subprocess, ~10 Hz); every value is optional -- a box that does not
                     expose a sensor yields null, never an exception.
@@ -85,9 +84,9 @@ def calibrate(dev=None, mfma_seconds: float = 2.0, copy_gb: float = 2.0) -> dict
 
         # register-only loop: the matrix pipes' own limit on this package (does not reach the power cap on the boxes measured)
         probe(lib.cx_calib_mfma_bf16, "cx_calib_mfma_bf16", mfma_seconds, "mfma_probe")
-        # the same loop fed from LDS at the GEMM main loop's rate: closer to what the GEMMs' clock is set by (the cap)
-        if hasattr(lib, "cx_calib_mfma_lds_bf16"):
-            probe(lib.cx_calib_mfma_lds_bf16, "cx_calib_mfma_lds_bf16", mfma_seconds / 2, "mfma_lds_probe")
+        # (round 5 also tried the same loop with its fragments re-read from LDS at the GEMM's rate as a second ceiling: that naive
+        # loop issues an MFMA every 42 cycles where the shipped GEMM main loop manages 37 -- a "ceiling" the product beats per cycle
+        # is none; dropped.  gpurun_out/r5g: 1508 vs 1921 TFLOP/s on that box.)
         # HBM stream: copy_gb read + copy_gb written per launch
         nbytes = int(copy_gb * (1 << 30)) & ~15
         src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
