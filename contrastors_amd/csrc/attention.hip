@@ -15,6 +15,9 @@
 #ifndef CX_ATTN_ROT_AHEAD
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
+#ifndef CX_ATTN_BWD_PF
+#define CX_ATTN_BWD_PF 2   // streaming backward kernels (S > 128): bit 0 dQ kernel / bit 1 dK-dV kernel prefetch the next 64-row chunk into registers; bit 1 (and bit 2 for dQ) = 2 workgroups per CU.  Shipped: 2 (same-box A/B, bit-identical: S = 2048 -1.0 %, 512 -2.9 %, 197 -4.5 %; the dQ kernel gains nothing from it: profiles/r5_attn_bwd_streaming_prefetch_ab.txt)
+#endif
 #ifndef CX_ATTN_DELTA_IN
 #define CX_ATTN_DELTA_IN 0  // fused S <= 128 backward reads delta from p.delta instead of loading O (A/B only: nothing writes that delta in the product)
 #endif
@@ -914,8 +917,12 @@ CX_DEVICE void store_unrotated_rows_pre(char* stage, bf16_t* g0, size_t row_stri
 }
 
 // ---------------------------------------------------------------------------------------------------- dQ
+// CX_ATTN_BWD_PF (round 5): the two streaming backward kernels loaded each 64-row chunk straight into LDS -- global round trip, barrier,
+// compute, barrier, per chunk and workgroup, covered only by the CU's other workgroups (three of them at 168 registers).  With the
+// switch the NEXT chunk's rows are requested right after the barrier that publishes the current chunk and wait in 16 registers through
+// the compute (the forward kernel has done this since round 2); the register budget goes from 168 (3 workgroups per CU) to 256 (2).
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 4) ? 2 : 3) void attn_bwd_dq_kernel(AttnParams p) {
     // Qs/dOs are only needed to build the loop-invariant register fragments; the K / V tiles alias them.
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -972,7 +979,56 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
 
+#if CX_ATTN_BWD_PF & 1
+    // raw rows of a chunk: waves 0-1 a K row pair (chunks cp, cp + 4 of both rows), waves 2-3 four V row pieces
+    uint4 pf0, pf1, pf2, pf3;
+    auto issue_chunk = [&](int kv0) {
+        if (wave < 2) {
+            const int kp = tid >> 2, cp = tid & 3;
+            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
+            k0i = k0i < lenk ? k0i : lenk - 1;
+            k1i = k1i < lenk ? k1i : lenk - 1;
+            const bf16_t* ra = kbase + (size_t)(t0k + k0i) * kv_stride;
+            const bf16_t* rb = kbase + (size_t)(t0k + k1i) * kv_stride;
+            pf0 = *reinterpret_cast<const uint4*>(ra + cp * 8);
+            pf1 = *reinterpret_cast<const uint4*>(ra + 32 + cp * 8);
+            pf2 = *reinterpret_cast<const uint4*>(rb + cp * 8);
+            pf3 = *reinterpret_cast<const uint4*>(rb + 32 + cp * 8);
+        } else {
+            const int t2 = tid - 128, c = t2 & 7;
+            int r0 = kv0 + (t2 >> 3), r1 = r0 + 16, r2 = r0 + 32, r3 = r0 + 48;
+            r0 = r0 < lenk ? r0 : lenk - 1; r1 = r1 < lenk ? r1 : lenk - 1; r2 = r2 < lenk ? r2 : lenk - 1; r3 = r3 < lenk ? r3 : lenk - 1;
+            pf0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r0) * kv_stride + c * 8);
+            pf1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r1) * kv_stride + c * 8);
+            pf2 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r2) * kv_stride + c * 8);
+            pf3 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r3) * kv_stride + c * 8);
+        }
+    };
+    if (lenk > 0) issue_chunk(0);
+#endif
     for (int kv0 = 0; kv0 < lenk; kv0 += 64) {
+#if CX_ATTN_BWD_PF & 1
+        if (wave < 2) {
+            const int kp = tid >> 2, cp = tid & 3;
+            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
+            k0i = k0i < lenk ? k0i : lenk - 1;
+            k1i = k1i < lenk ? k1i : lenk - 1;
+            rotate_loaded(pf0, pf1, cp, p.lcos, p.lsin, k0i);
+            rotate_loaded(pf2, pf3, cp, p.lcos, p.lsin, k1i);
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp)) = pf0;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp + 4)) = pf1;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp)) = pf2;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp + 4)) = pf3;
+        } else {
+            const int t2 = tid - 128, r = t2 >> 3, c = t2 & 7;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r, c)) = pf0;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r + 16, c)) = pf1;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r + 32, c)) = pf2;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r + 48, c)) = pf3;
+        }
+        __syncthreads();
+        if (kv0 + 64 < lenk) issue_chunk(kv0 + 64);   // in flight through this chunk's compute
+#else
         if (wave < 2) {  // K: rotated, row-major (its transpose for dQ comes from tile64_tr_frag).  item = (key pair, chunk pair)
             const int kp = tid >> 2, cp = tid & 3;
             int k0i = kv0 + 2 * kp, k1i = k0i + 1;
@@ -997,6 +1053,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
             }
         }
         __syncthreads();
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t a_s, a_dp;
@@ -1046,7 +1103,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 2) ? 2 : 3) void attn_bwd_dkv_kernel(AttnParams p) {
     // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | lse[64] | delta[64]
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -1104,7 +1161,57 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
 
+#if CX_ATTN_BWD_PF & 2
+    // raw rows of a chunk: waves 0-1 a Q row pair, waves 2-3 a dO row pair (chunks cp, cp + 4 of both rows); threads 0-63 lse, delta
+    uint4 pf0, pf1, pf2, pf3;
+    float pf_lse = 0.f, pf_dl = 0.f;
+    auto issue_chunk = [&](int q0) {
+        const int t2 = wave < 2 ? tid : tid - 128;
+        const int rp = t2 >> 2, cp = t2 & 3;
+        int r0i = q0 + 2 * rp, r1i = r0i + 1;
+        r0i = r0i < len ? r0i : len - 1;
+        r1i = r1i < len ? r1i : len - 1;
+        const bf16_t* ra = wave < 2 ? qbase + (size_t)(t0 + r0i) * tok_stride : dobase + (size_t)(t0 + r0i) * o_stride;
+        const bf16_t* rb = wave < 2 ? qbase + (size_t)(t0 + r1i) * tok_stride : dobase + (size_t)(t0 + r1i) * o_stride;
+        pf0 = *reinterpret_cast<const uint4*>(ra + cp * 8);
+        pf1 = *reinterpret_cast<const uint4*>(ra + 32 + cp * 8);
+        pf2 = *reinterpret_cast<const uint4*>(rb + cp * 8);
+        pf3 = *reinterpret_cast<const uint4*>(rb + 32 + cp * 8);
+        if (tid < 64) {
+            int r = q0 + tid;
+            const bool ok = r < len;
+            r = ok ? r : len - 1;
+            pf_lse = ok ? p.lse[(size_t)h * p.T + t0 + r] * LOG2E : INFINITY;   // rows past the end: P = exp2(-inf) = 0
+            pf_dl = p.delta[(size_t)h * p.T + t0 + r];
+        }
+    };
+    if (len > 0) issue_chunk(0);
+#endif
     for (int q0 = 0; q0 < len; q0 += 64) {
+#if CX_ATTN_BWD_PF & 2
+        {
+            const int t2 = wave < 2 ? tid : tid - 128;
+            const int rp = t2 >> 2, cp = t2 & 3;
+            char* dst = wave < 2 ? Qs : dOs;
+            if (wave < 2) {
+                int r0i = q0 + 2 * rp, r1i = r0i + 1;
+                r0i = r0i < len ? r0i : len - 1;
+                r1i = r1i < len ? r1i : len - 1;
+                rotate_loaded(pf0, pf1, cp, p.lcos, p.lsin, r0i);
+                rotate_loaded(pf2, pf3, cp, p.lcos, p.lsin, r1i);
+            }
+            *reinterpret_cast<uint4*>(dst + tile64_off(2 * rp, cp)) = pf0;
+            *reinterpret_cast<uint4*>(dst + tile64_off(2 * rp, cp + 4)) = pf1;
+            *reinterpret_cast<uint4*>(dst + tile64_off(2 * rp + 1, cp)) = pf2;
+            *reinterpret_cast<uint4*>(dst + tile64_off(2 * rp + 1, cp + 4)) = pf3;
+            if (tid < 64) {
+                lse_s[tid] = pf_lse;
+                dl_s[tid] = pf_dl;
+            }
+        }
+        __syncthreads();
+        if (q0 + 64 < len) issue_chunk(q0 + 64);   // in flight through this chunk's compute
+#else
         if (wave < 2) {  // Q rotated, row-major; item = (row pair, chunk pair)
             const int rp = tid >> 2, cp = tid & 3;
             int r0i = q0 + 2 * rp, r1i = r0i + 1;
@@ -1140,6 +1247,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(AttnParams p) {
             dl_s[tid] = p.delta[(size_t)h * p.T + t0 + r];
         }
         __syncthreads();
+#endif
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16_t a_s, a_dp;
