@@ -596,6 +596,14 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
                 raise
             fell_back = True
             LAST_SCHEDULE.update(schedule="two-pass", fell_back=True)
+            # the arenas of the failed attempt went back to the engines' pools, not to the allocator: the device is still as
+            # full as when the allocation failed, and the two-pass schedule needs a no-grad arena it does not have yet (round 5:
+            # with a second tenant on the device the fallback itself ran out of memory).  Give everything idle back; the two
+            # passes re-allocate the one saving arena and the one no-grad arena they need.
+            for tw in {id(tower1): tower1, id(tower2): tower2}.values():
+                drop = getattr(getattr(tw, "trunk", None), "drop_idle_arenas", None)
+                if drop is not None:
+                    drop()
             torch.cuda.empty_cache()
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")
