@@ -16,7 +16,7 @@
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
 #ifndef CX_ATTN_BWD_PF
-#define CX_ATTN_BWD_PF 2   // streaming backward kernels (S > 128): bit 0 dQ kernel / bit 1 dK-dV kernel prefetch the next 64-row chunk into registers; bit 1 (and bit 2 for dQ) = 2 workgroups per CU.  Shipped: 2 (same-box A/B, bit-identical: S = 2048 -1.0 %, 512 -2.9 %, 197 -4.5 %; the dQ kernel gains nothing from it: profiles/r5_attn_bwd_streaming_prefetch_ab.txt)
+#define CX_ATTN_BWD_PF 2   // streaming backward kernels (S > 128): bit 0 dQ kernel / bit 1 the DROPOUT form of the dK-dV kernel prefetch the next 64-row chunk into registers at 2 workgroups per CU (bit 2: the dQ kernel at 2 per CU too).  Shipped: 2 -- the dropout dK-dV form spilled 72 registers at the 168 of three workgroups per CU.  The plain form keeps round 4's shape: with rotation at the loads the prefetch won 1-4.5 %, but the engine never rotates there (S > 128 pre-rotates qkv, BERT / ViT have no table) and WITHOUT rotation it loses 2-7 % (profiles/r5_attn_bwd_streaming_prefetch_ab.txt)
 #endif
 #ifndef CX_ATTN_DELTA_IN
 #define CX_ATTN_DELTA_IN 0  // fused S <= 128 backward reads delta from p.delta instead of loading O (A/B only: nothing writes that delta in the product)
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 4) ? 2 : 3) void attn_bwd_dq
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 2) ? 2 : 3) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (DROP && (CX_ATTN_BWD_PF & 2)) ? 2 : 3) void attn_bwd_dkv_kernel(AttnParams p) {
     // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | lse[64] | delta[64]
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -1161,9 +1161,10 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 2) ? 2 : 3) void attn_bwd_dk
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
 
-#if CX_ATTN_BWD_PF & 2
+    // DKV_PF: see CX_ATTN_BWD_PF at the top of the file -- the dropout instantiation only
+    constexpr bool DKV_PF = DROP && (CX_ATTN_BWD_PF & 2) != 0;
     // raw rows of a chunk: waves 0-1 a Q row pair, waves 2-3 a dO row pair (chunks cp, cp + 4 of both rows); threads 0-63 lse, delta
-    uint4 pf0, pf1, pf2, pf3;
+    uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};
     float pf_lse = 0.f, pf_dl = 0.f;
     auto issue_chunk = [&](int q0) {
         const int t2 = wave < 2 ? tid : tid - 128;
@@ -1185,11 +1186,11 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 2) ? 2 : 3) void attn_bwd_dk
             pf_dl = p.delta[(size_t)h * p.T + t0 + r];
         }
     };
-    if (len > 0) issue_chunk(0);
-#endif
+    if constexpr (DKV_PF) {
+        if (len > 0) issue_chunk(0);
+    }
     for (int q0 = 0; q0 < len; q0 += 64) {
-#if CX_ATTN_BWD_PF & 2
-        {
+        if constexpr (DKV_PF) {
             const int t2 = wave < 2 ? tid : tid - 128;
             const int rp = t2 >> 2, cp = t2 & 3;
             char* dst = wave < 2 ? Qs : dOs;
@@ -1208,10 +1209,9 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 2) ? 2 : 3) void attn_bwd_dk
                 lse_s[tid] = pf_lse;
                 dl_s[tid] = pf_dl;
             }
-        }
-        __syncthreads();
-        if (q0 + 64 < len) issue_chunk(q0 + 64);   // in flight through this chunk's compute
-#else
+            __syncthreads();
+            if (q0 + 64 < len) issue_chunk(q0 + 64);   // in flight through this chunk's compute
+        } else {
         if (wave < 2) {  // Q rotated, row-major; item = (row pair, chunk pair)
             const int rp = tid >> 2, cp = tid & 3;
             int r0i = q0 + 2 * rp, r1i = r0i + 1;
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 2) ? 2 : 3) void attn_bwd_dk
             dl_s[tid] = p.delta[(size_t)h * p.T + t0 + r];
         }
         __syncthreads();
-#endif
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16_t a_s, a_dp;

@@ -21,6 +21,7 @@ ap.add_argument("--chunk", type=int, default=2048)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--seq", type=int, default=128)
+ap.add_argument("--rotary", type=int, default=1, help="0: no rotation tables (pre-rotated long sequences, image towers)")
 a = ap.parse_args()
 
 
@@ -59,6 +60,8 @@ cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=dev)
 inv = 1.0 / (1000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
 fr = torch.outer(torch.arange(max(S, 128), dtype=torch.float32), inv)
 cos, sin = torch.cos(fr).to(dev).contiguous(), torch.sin(fr).to(dev).contiguous()
+if not a.rotary:
+    cos = sin = None
 att_out = torch.empty(T, H * 64, device=dev, dtype=torch.bfloat16)
 lse = torch.empty(H * T, device=dev)
 dout = rn(T, H * 64)
