@@ -12,7 +12,8 @@ reader tell box from code.  This module gives the line three things:
                     librocm_smi64 through ctypes (no subprocess, ~10 Hz); every value is optional -- a box that does not
                     expose a sensor yields null, never an exception.
   frac_of_box_ceiling = roofline.achieved / box.mfma_probe_tflops, next to roofline.frac (which stays priced against the
-                    2.5 PFLOP/s data-sheet peak).
+                    2.5 PFLOP/s data-sheet peak); vs_box_blas = roofline.achieved / box.blas_ref_tflops (the vendor BLAS behind
+                    torch.matmul on two of the step's GEMM shapes, measured on the same box seconds earlier: measurement only).
 
 Usage on its own:  python scripts/box_calibration.py   -> one JSON object.
 """
@@ -87,6 +88,41 @@ def calibrate(dev=None, mfma_seconds: float = 2.0, copy_gb: float = 2.0) -> dict
         # (round 5 also tried the same loop with its fragments re-read from LDS at the GEMM's rate as a second ceiling: that naive
         # loop issues an MFMA every 42 cycles where the shipped GEMM main loop manages 37 -- a "ceiling" the product beats per cycle
         # is none; dropped.  gpurun_out/r5g: 1508 vs 1921 TFLOP/s on that box.)
+        # Vendor-BLAS reference (measurement only -- nothing under contrastors_amd/ calls it): torch.matmul (hipBLASLt) on two of the step's
+        # own GEMM shapes, ~0.6 s each after a warm-up third.  Unlike the register-only probe it loads LDS and HBM like the shipped GEMMs
+        # and runs into the same power cap: a frozen library on a fixed shape is the steadier per-box yardstick (round 5 saw a box whose
+        # MFMA probe read 9 % low while its step -- and its in-step clock -- were 1-2 % low).
+        try:
+            tf = []
+            for (M, N, K) in ((131072, 3072, 768), (131072, 768, 3072)):
+                xa = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+                wb = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+                yo = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+                for _ in range(5):
+                    torch.matmul(xa, wb.t(), out=yo)
+                torch.cuda.synchronize()
+                t_end = time.perf_counter() + 0.25
+                while time.perf_counter() < t_end:
+                    for _ in range(8):
+                        torch.matmul(xa, wb.t(), out=yo)
+                    torch.cuda.synchronize()
+                ts = []
+                t_end = time.perf_counter() + 0.5
+                while time.perf_counter() < t_end:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(8):
+                        torch.matmul(xa, wb.t(), out=yo)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / 8)
+                ts.sort()
+                tf.append(2.0 * M * N * K / (ts[len(ts) // 2] * 1e-3) / 1e12)
+                del xa, wb, yo
+            out["blas_ref_tflops"] = sum(tf) / len(tf)
+            out["blas_ref_tflops_short_k"], out["blas_ref_tflops_long_k"] = tf
+        except Exception as e:  # noqa: BLE001
+            out["blas_ref_error"] = f"{type(e).__name__}: {e}"[:160]
         # HBM stream: copy_gb read + copy_gb written per launch
         nbytes = int(copy_gb * (1 << 30)) & ~15
         src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)

@@ -17,4 +17,4 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print({k:d[k] for k in d if k.startswith('box_') or 'frac' in k or k in ('value','ms_per_step','schedule')})
 print(d['box'])"
-timeout 400 CX_TEST_TWO_TENANTS=1 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -x -q -s > $O/two_tenants.txt 2>&1; tail -6 $O/two_tenants.txt | cut -c1-1500
+CX_TEST_TWO_TENANTS=1 timeout 400 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -x -q -s > $O/two_tenants.txt 2>&1; tail -6 $O/two_tenants.txt | cut -c1-1500

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/r5b
 export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/r5b
 timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape > $O/gpu_tests.txt 2>&1; tail -15 $O/gpu_tests.txt | cut -c1-300
-timeout 400 CX_TEST_TWO_TENANTS=1 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -x -q -s > $O/two_tenants.txt 2>&1; grep -E "two tenants|passed|failed|Error" $O/two_tenants.txt | cut -c1-2500
+CX_TEST_TWO_TENANTS=1 timeout 400 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -x -q -s > $O/two_tenants.txt 2>&1; grep -E "two tenants|passed|failed|Error" $O/two_tenants.txt | cut -c1-2500
 timeout 400 python scripts/lib_ab.py --libs base,rot,rm,rmrot --cases attn_bwd,attn_bwd_ragged --rounds 9 > $O/ab_attn_bwd.txt 2>&1; cat $O/ab_attn_bwd.txt
 timeout 300 python scripts/gemm_grid_power_sweep.py > $O/grid_power.txt 2>&1; cat $O/grid_power.txt
 for gn in 1 2 4 8; do

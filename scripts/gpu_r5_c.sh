@@ -9,4 +9,4 @@ timeout 300 python scripts/lib_ab.py --libs base,csf --cases attn_bwd,attn_bwd_r
 timeout 600 python -m pytest tests/test_dropout_gpu.py tests/test_shim_gpu.py tests/test_kernels_gpu.py -q -k "drop or attn or attention" > $O/tests_dropout.txt 2>&1; tail -3 $O/tests_dropout.txt
 timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 128,197,512,2048 > $O/attn_p0.txt 2>&1; cat $O/attn_p0.txt | tail -5
 timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 128,197,512,2048 --pdrop 0.1 > $O/attn_p01.txt 2>&1; cat $O/attn_p01.txt | tail -5
-timeout 400 CX_TEST_TWO_TENANTS=1 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -x -q -s > $O/two_tenants.txt 2>&1; grep -E "two tenants|passed|failed|Error" $O/two_tenants.txt | cut -c1-3000
+CX_TEST_TWO_TENANTS=1 timeout 400 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -x -q -s > $O/two_tenants.txt 2>&1; grep -E "two tenants|passed|failed|Error" $O/two_tenants.txt | cut -c1-3000

@@ -10,7 +10,7 @@ R=$PWD; O=$R/gpurun_out/final5
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # --- the whole GPU suite (the two-tenant planner test on its own: it fills the device)
 timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape > $O/gpu_tests.txt 2>&1; tail -3 $O/gpu_tests.txt
-timeout 400 CX_TEST_TWO_TENANTS=1 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -q -s > $O/two_tenants.txt 2>&1; tail -1 $O/two_tenants.txt
+CX_TEST_TWO_TENANTS=1 timeout 400 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -q -s > $O/two_tenants.txt 2>&1; tail -1 $O/two_tenants.txt
 timeout 60 python scripts/box_calibration.py > $O/box_calibration.json 2>/dev/null; cut -c1-400 $O/box_calibration.json
 cp gpurun_out/kernel_report.jsonl $O/kernel_report.jsonl 2>/dev/null
 # --- HBM traffic of the GEMM family (separate passes, guide's corrections), at the bench's launch sizes

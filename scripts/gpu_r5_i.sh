@@ -6,7 +6,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 O=gpurun_out/r5i
 timeout 600 python -m pytest tests/test_loss_gpu.py -q > $O/loss_tests.txt 2>&1; tail -2 $O/loss_tests.txt
 for i in 1 2 3; do
-  timeout 300 CX_TEST_TWO_TENANTS=1 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -q -s > $O/two_tenants_$i.txt 2>&1
+  CX_TEST_TWO_TENANTS=1 timeout 300 python -m pytest tests/test_distributed_gpu.py::test_two_tenants_at_the_metric_per_rank_shape -q -s > $O/two_tenants_$i.txt 2>&1
   grep -E "passed|failed" $O/two_tenants_$i.txt | tail -1
   grep -E "^two tenants" $O/two_tenants_$i.txt | python -c "
 import sys, json
