@@ -15,6 +15,9 @@
 #ifndef CX_ATTN_ROT_AHEAD
 #define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
 #endif
+#ifndef CX_ATTN_DROP_EARLY
+#define CX_ATTN_DROP_EARLY 1   // fused S <= 128 backward, dropout form: keep decisions drawn ahead of the S / dP products and carried as 16 bits (round 5: 57 -> 40 spilled registers; -7.4 % with rotation tables, -11 % without, -8.7 % at S = 64, bit-identical: profiles/r5_attn_bwd_s128_ab.txt)
+#endif
 #ifndef CX_ATTN_BWD_PF
 #define CX_ATTN_BWD_PF 2   // streaming backward kernels (S > 128): bit 0 dQ kernel / bit 1 the DROPOUT form of the dK-dV kernel prefetch the next 64-row chunk into registers at 2 workgroups per CU (bit 2: the dQ kernel at 2 per CU too).  Shipped: 2 -- the dropout dK-dV form spilled 72 registers at the 168 of three workgroups per CU.  The plain form keeps round 4's shape: with rotation at the loads the prefetch won 1-4.5 %, but the engine never rotates there (S > 128 pre-rotates qkv, BERT / ViT have no table) and WITHOUT rotation it loses 2-7 % (profiles/r5_attn_bwd_streaming_prefetch_ab.txt)
 #endif
@@ -2119,6 +2122,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         if (PIPE == 1 || p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1  // (rolled: unrolling makes the compiler hoist ~100 loop-invariant LDS addresses and spill)
         for (int qb = 0; qb < 4; ++qb) {
+#if CX_ATTN_DROP_EARLY
+            // DROP: the 16 keep decisions of this (key, query block) are drawn BEFORE the S / dP products and carried as one 16-bit word:
+            // the generator's temporaries are live while the two accumulator blocks (32 registers) are not
+            uint32_t kbits = 0;
+            if constexpr (DROP) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float kq0[4] = {0.f, 1.f, 1.f, 1.f};
+                    quad_keep4(p, (uint32_t)u, qb * 32 + 8 * qd + 4 * hi, row, lane, kq0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kbits |= (kq0[e] != 0.f ? 1u : 0u) << (4 * qd + e);
+                }
+            }
+            const float keep_inv = DROP ? 1.f / (1.f - p.drop.p) : 1.f;
+#endif
             f32x16_t a_s, a_dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
@@ -2135,7 +2153,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 const float4 d4 = *reinterpret_cast<const float4*>(dl_s + qrow);
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
                 float kq[4] = {1.f, 1.f, 1.f, 1.f};
+#if CX_ATTN_DROP_EARLY
+                if constexpr (DROP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kq[e] = ((kbits >> (4 * qd + e)) & 1u) ? keep_inv : 0.f;
+                }
+#else
                 if constexpr (DROP) kq[0] = 0.f, quad_keep4(p, (uint32_t)u, qrow, row, lane, kq);
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;

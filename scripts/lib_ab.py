@@ -87,6 +87,8 @@ cases = {
     "attn_bwd": (10.0 * S * S * 64 * B * H, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S, 0.125, s)),
     # (A/B of CX_ATTN_DELTA_IN builds: `delta` is filled beforehand by the base library's general kernels, see below)
     "attn_bwd_dpre": (10.0 * S * S * 64 * B * H, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S, 0.125, s)),
+    "attn_bwd_drop": (10.0 * S * S * 64 * B * H, [dqkv], lambda L: L.cx_attn_varlen_dropout_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu), P(cos), P(sin), P(delta), P(dqkv), B, H, T, S, 0.125, 0.1, 1234, 0, 0, s)),
+    "attn_fwd_drop": (4.0 * S * S * 64 * B * H, [att_out, lse], lambda L: L.cx_attn_varlen_dropout_fwd(P(qkv), P(cu), P(cos), P(sin), P(att_out), P(lse), B, H, T, S, 0.125, 0.1, 1234, 0, 0, s)),
     "attn_bwd_ragged": (0.0, [dqkv], lambda L: L.cx_attn_varlen_bwd(P(dout), P(qkv), P(att_out), P(lse), P(cu_r), P(cos), P(sin), P(delta), P(dqkv), B, H, T_r, S, 0.125, s)),
 }
 want = [c for c in a.cases.split(",") if c] or list(cases)
