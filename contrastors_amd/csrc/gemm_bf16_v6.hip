@@ -30,6 +30,11 @@ namespace {
 #ifndef CX_V6_DEFER_NT
 #define CX_V6_DEFER_NT 0      // the deferred register stores (DEFER) non-temporal?  measured: nt 1.55-1.70 x the staged kernel, plain 1.08-1.15 x
 #endif
+#ifndef CX_V6_DEFER_MODE
+#define CX_V6_DEFER_MODE 1    // how the tile gets into the 128 registers it leaves from: 0 = lane exchanges (a store writes 32 rows x 32 bytes:
+                              // measured slower, round 4), 1 = through the wave's LDS staging rows like the plain epilogue (a store writes
+                              // 4 rows x 256 bytes: whole lines) -- the stores still leave during the next tile's K loop
+#endif
 #ifndef CX_V6_DEFER_SPREAD
 #define CX_V6_DEFER_SPREAD 1  // K-tiles of the next tile the 32 deferred stores of a tile are spread over (8, 4, 2 or 1; 1 measured best)
 #endif
@@ -279,6 +284,23 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         for (int j = 0; j < 32; ++j) Pd[j] = cx_u32x4{0u, 0u, 0u, 0u};
         dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)((cp_tile >> 8) * BM6 + wm * 128) * p.ldo + (cp_tile & 255) * BN6 + wn * 128) * 2;
     }
+#if CX_V6_DEFER_MODE == 1
+    // Pd[8b + j] = rows b*32 + 4j + (lane >> 4), 16-byte piece (lane & 15) of the wave's 128 x 128 sub-tile: what the plain epilogue's
+    // row reads return.  One store: 4 rows x 256 contiguous bytes.
+    long long drowblk = (long long)p.ldo * 8;    // bytes per 4 output rows
+    uint32_t dvoff = (uint32_t)(lane >> 4) * (uint32_t)p.ldo * 2u + (uint32_t)(lane & 15) * 16u;
+    auto dstore = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const char* bb = dbase + J * drowblk;
+        const uint32_t vo = dvoff;                      // (locals: asm operands alone do not capture in a generic lambda)
+        const cx_u32x4 v = Pd[DEFER ? J : 0];
+#if CX_V6_DEFER_NT
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(vo), "v"(v), "s"(bb) : "memory");
+#else
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(v), "s"(bb) : "memory");
+#endif
+    };
+#else
     long long drowblk = (long long)p.ldo * 64;   // bytes per 32 output rows
     uint32_t dvoff = (uint32_t)l31 * (uint32_t)p.ldo * 2u + (uint32_t)hi * 16u;
     auto dstore = [&](auto jc) {   // one store: 32 rows x 32 contiguous bytes
@@ -292,6 +314,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(vo), "v"(v), "s"(bb), "n"((A * 32 + 16 * H) * 2) : "memory");
 #endif
     };
+#endif
     int cp_kt = 0;
     auto drain_all = [&]() {
 #define CX_D4(k_) dstore(std::integral_constant<int, 4 * (k_)>{}); dstore(std::integral_constant<int, 4 * (k_) + 1>{}); \
@@ -450,6 +473,41 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
             if constexpr ((DBG & 16) != 0) {
                 // ablation: no epilogue
+            } else if constexpr (DEFER && CX_V6_DEFER_MODE == 1) {
+                // (the previous tile's 32 stores were issued during this tile's first K-tiles: Pd is free)
+                // Four passes of 32 rows through the wave's staging rows, software-pipelined like the plain fast path: the 8 row reads
+                // of pass b are in flight while pass b + 1 is rounded; the LDS executes a wave's operations in order, so the staging
+                // writes of pass b + 1 follow the reads of pass b.  What the reads return stays in Pd.
+                const char* rd = my + (lane >> 4) * ROWB + (lane & 15) * 16;
+                char* wr = my + l31 * ROWB + hi * 8;
+                auto stage_pass = [&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        uint32_t p8[8];
+                        v6_pack_block(4 * b + a, p8);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wr + (a * 32 + 8 * q) * 2) = uint2{p8[2 * q], p8[2 * q + 1]};
+                    }
+                };
+#define CX_RD(j_) (*reinterpret_cast<const cx_u32x4*>(rd + 4 * (j_) * ROWB))
+#define CX_DEFER_PASS(b_)                                                                                  \
+    Pd[8 * (b_) + 0] = CX_RD(0); Pd[8 * (b_) + 1] = CX_RD(1); Pd[8 * (b_) + 2] = CX_RD(2); Pd[8 * (b_) + 3] = CX_RD(3);  \
+    Pd[8 * (b_) + 4] = CX_RD(4); Pd[8 * (b_) + 5] = CX_RD(5); Pd[8 * (b_) + 6] = CX_RD(6); Pd[8 * (b_) + 7] = CX_RD(7);  \
+    __builtin_amdgcn_sched_barrier(0);
+                stage_pass(std::integral_constant<int, 0>{});
+                CX_DEFER_PASS(0)
+                stage_pass(std::integral_constant<int, 1>{});
+                CX_DEFER_PASS(1)
+                stage_pass(std::integral_constant<int, 2>{});
+                CX_DEFER_PASS(2)
+                stage_pass(std::integral_constant<int, 3>{});
+                CX_DEFER_PASS(3)
+#undef CX_DEFER_PASS
+#undef CX_RD
+                // the rows must be in the registers before the staging area becomes a DMA target again (the barrier below)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)m0 * p.ldo + n0) * 2;
             } else if constexpr (DEFER) {
                 // (the previous tile's 32 stores were issued during this tile's K-tiles 0 .. 7: Pd is free)
                 pack_block(std::integral_constant<int, 0>{}); pack_block(std::integral_constant<int, 1>{});
@@ -1090,7 +1148,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             // above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead across the epilogue
             // (~150 cycles of exposed LDS latency per tile against 32 registers); the SwiGLU backward additionally rebuilds
             // its 16 DMA cursor offsets from (round, K-tile).
-            if constexpr ((EPI == GEMM_EPI_NONE || IS_SWIGLU_BWD) && !DEFER) {
+            if constexpr ((EPI == GEMM_EPI_NONE || IS_SWIGLU_BWD) && (!DEFER || CX_V6_DEFER_MODE == 1)) {
                 asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
                 if constexpr (IS_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
@@ -1108,7 +1166,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
             // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
             // (DEFER stages nothing: a tile boundary is an ordinary K-tile boundary)
-            if constexpr (!DEFER) __builtin_amdgcn_s_barrier();
+            if constexpr (!DEFER || CX_V6_DEFER_MODE == 1) __builtin_amdgcn_s_barrier();
         }
     }
 #undef CX_KSTEP

@@ -79,6 +79,7 @@ cases = {
     "swiglu_fwd_save": (2.0 * T * 2 * I * d, [gs, out_I], lambda L: L.cx_gemm_bf16_swiglu_gate(P(x), P(w1), P(gs), P(out_I), T, I, d, d, d, I, I, s)),
     "swiglu_fwd": (2.0 * T * 2 * I * d, [out_I], lambda L: L.cx_gemm_bf16_swiglu_gate(P(x), P(w1), None, P(out_I), T, I, d, d, d, I, I, s)),
     "qkv_fwd": (2.0 * T * 3 * d * d, [out_3d], lambda L: L.cx_gemm_bf16_nt(P(x), P(wqkv), P(out_3d), None, T, 3 * d, d, d, d, 3 * d, 0, 1, 1.0, s)),
+    "out_dgrad": (2.0 * T * d * d, [out_d], lambda L: L.cx_gemm_bf16_nt(P(x), P(wo), P(out_d), None, T, d, d, d, d, d, 0, 1, 1.0, s)),
     "out_fwd_res": (2.0 * T * d * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(x), P(wo), P(out_d), None, P(res), T, d, d, d, d, d, d, s)),
     "fc2_fwd_res": (2.0 * T * I * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(act), P(w2), P(out_d), None, P(res), T, d, I, I, I, d, d, s)),
     "qkv_dgrad_res": (2.0 * T * 3 * d * d, [out_d], lambda L: L.cx_gemm_bf16_nt_residual(P(x3), P(wqkv_t), P(out_d), None, P(res), T, d, 3 * d, 3 * d, 3 * d, d, d, s)),
