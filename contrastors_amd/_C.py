@@ -198,6 +198,8 @@ _DEV_SIGS = {
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_attn_dropout_keep_mask": (i32, [vp, i32, i32, i32, f32, u64, u64, u32, vp]),
     "cx_probe_rmw": (i32, [vp, i64, i32, i32, i32, vp]),
+    "cx_attn_bwd_fused_long_ws_floats": (i64, [i32, i32, i32]),
+    "cx_attn_varlen_bwd_fused_long": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
     "cx_probe_mfma_rate16": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_probe_dma_bw": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
 }

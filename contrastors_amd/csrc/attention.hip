@@ -1313,6 +1313,239 @@ __global__ __launch_bounds__(256, (DROP && (CX_ATTN_BWD_PF & 2)) ? 2 : 3) void a
     }
 }
 
+// ------------------------------------------------------------------------------- fused long-sequence backward (round 5)
+// ONE workgroup owns a whole (sequence, head) problem.  Outer loop over 128-key blocks with dK / dV in registers
+// (the dK / dV kernel above, same arithmetic in the same order: dK and dV come out bit-identical), inner loop over 64-query chunks;
+// S, dP and the softmax are recomputed ONCE per (key block, chunk) instead of once in each of two kernels, and the chunk's dQ
+// contribution  dQ^T[d][q] = sum_key K^T[d][key] dS[q][key]  (5 products instead of 7) is added into an fp32 scratch that only this
+// workgroup touches: single owner, fixed order, bit-reproducible.  dS goes through LDS once, as a [128 key][64 q] bf16 tile each wave
+// writes its 32 key rows of; both operands of the dQ product are transposing reads (K tile, dS tile).  The scratch is in the layout the
+// accumulators have (a wave's store is 1 KiB contiguous): chunk block [4 waves][4 qd][64 lanes] float4, element (q, d) of a chunk at
+// wave (q >> 5) * 2 + (d >> 5), lane ((d >> 2) & 1) * 32 + (q & 31), qd (d >> 3) & 3, e = d & 3; sequence b's rows start at
+// t0 + 64 b (a last partial chunk then never reaches the next sequence).  attn_dq_finish_kernel scales, un-rotates and writes bf16.
+// LDS: K 16 K (whole key block) | V, then dS 16 K | Q 8 K | dO 8 K | lse, delta 512 B = 49664 B.
+#ifndef CX_ATTN_FL_WGS
+#define CX_ATTN_FL_WGS 3
+#endif
+#ifndef CX_ATTN_FL_DBG
+#define CX_ATTN_FL_DBG 0   // ablation builds (wrong results): 1 no scratch traffic (the dQ product stays), 2 no dQ product / dS tile either, 4 scratch written, never read (no add)
+#endif
+#ifndef CX_PRODUCT  // A/B-only kernels: dev library (include/contrastors_hip_dev.h)
+template <bool DROP>
+__global__ __launch_bounds__(256, CX_ATTN_FL_WGS) void attn_bwd_fused_long_kernel(AttnParams p, float* ws, int B) {
+    __shared__ __attribute__((aligned(16))) char smem[49664];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const AttnView w = attn_view<false>(p, h, b);
+    const int t0 = w.t0q, len = w.lenq;
+    if (len <= 0) return;
+    const size_t tok_stride = w.qs;
+    const size_t o_stride = (size_t)p.H * DH;
+    const bf16_t* dobase = p.dout + (size_t)h * DH;
+    char* Ks = smem;
+    char* Vs = smem + 16384;
+    char* dSs = smem + 16384;
+    char* Qs = smem + 32768;
+    char* dOs = smem + 40960;
+    float* lse_s = reinterpret_cast<float*>(smem + 49152);
+    float* dl_s = lse_s + 64;
+    const float sc2 = p.scale * LOG2E;
+    // this problem's scratch rows: (h, t0 + 64 b + q), 64 floats each
+    float* ws_p = ws + ((size_t)h * ((size_t)p.T + 64 * (size_t)B) + (size_t)t0 + 64 * (size_t)b) * 64;
+
+    for (int k0 = 0; k0 < len; k0 += 128) {
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int r = pss * 64 + (tid >> 2), cp = tid & 3;
+            int tk = k0 + r;
+            tk = tk < len ? tk : len - 1;
+            uint4 lo, hi4;
+            load_row_pair(w.k + (size_t)(t0 + tk) * tok_stride, cp, p.lcos, p.lsin, tk, lo, hi4);
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
+            load_row_pair(w.v + (size_t)(t0 + tk) * tok_stride, cp, nullptr, nullptr, 0, lo, hi4);
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp)) = lo;
+            *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp + 4)) = hi4;
+        }
+        __syncthreads();
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = lds_read_frag(Ks, tile64_off(wave * 32 + l31, ks * 2 + hi));
+            vf[ks] = lds_read_frag(Vs, tile64_off(wave * 32 + l31, ks * 2 + hi));
+        }
+        // (the V tile becomes the dS tile: its first write comes after the first chunk's staging barrier)
+        const int key = k0 + wave * 32 + l31;
+        const bool key_ok = key < len;
+        const bool keys_full = k0 + 128 <= len;
+        f32x16_t acc_dk[2], acc_dv[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
+
+        for (int q0 = 0; q0 < len; q0 += 64) {
+            if (wave < 2) {  // Q (rotated at the load when tables are given), row-major; item = (row pair, chunk pair)
+                const int rp = tid >> 2, cp = tid & 3;
+                int r0i = q0 + 2 * rp, r1i = r0i + 1;
+                r0i = r0i < len ? r0i : len - 1;
+                r1i = r1i < len ? r1i : len - 1;
+                uint4 a_lo, a_hi, b_lo, b_hi;
+                load_row_pair(w.q + (size_t)(t0 + r0i) * tok_stride, cp, p.lcos, p.lsin, r0i, a_lo, a_hi);
+                load_row_pair(w.q + (size_t)(t0 + r1i) * tok_stride, cp, p.lcos, p.lsin, r1i, b_lo, b_hi);
+                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp)) = a_lo;
+                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp + 4)) = a_hi;
+                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp)) = b_lo;
+                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
+            } else {  // dO
+                const int t2 = tid - 128;
+                const int rp = t2 >> 2, cp = t2 & 3;
+                int r0i = q0 + 2 * rp, r1i = r0i + 1;
+                r0i = r0i < len ? r0i : len - 1;
+                r1i = r1i < len ? r1i : len - 1;
+                uint4 a_lo, a_hi, b_lo, b_hi;
+                load_row_pair(dobase + (size_t)(t0 + r0i) * o_stride, cp, nullptr, nullptr, 0, a_lo, a_hi);
+                load_row_pair(dobase + (size_t)(t0 + r1i) * o_stride, cp, nullptr, nullptr, 0, b_lo, b_hi);
+                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp)) = a_lo;
+                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp + 4)) = a_hi;
+                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp)) = b_lo;
+                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
+            }
+            if (tid < 64) {
+                int r = q0 + tid;
+                const bool ok = r < len;
+                r = ok ? r : len - 1;
+                lse_s[tid] = ok ? p.lse[(size_t)h * p.T + t0 + r] * LOG2E : INFINITY;   // rows past the end: P = exp2(-inf) = 0
+                dl_s[tid] = p.delta[(size_t)h * p.T + t0 + r];
+            }
+            // staging visible; every wave is past the previous chunk's dQ product (reads of the dS tile) and, in the first chunk, past
+            // its V fragment reads
+            __syncthreads();
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16_t a_s, a_dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    a_s = mfma_bf16_32x32x16(lds_read_frag(Qs, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
+                    a_dp = mfma_bf16_32x32x16(lds_read_frag(dOs, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
+                }
+                float pr[16], ds[16];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int row = qb * 32 + 8 * qd + 4 * hi;
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + row);
+                    const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
+                    const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float kq[4] = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (DROP) quad_keep4(p, (uint32_t)(b * p.H + h), q0 + row, key, lane, kq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * qd + e;
+                        const float pe = fast_exp2(__builtin_fmaf(a_s[r], sc2, -ll[e]));
+                        const float pv = (keys_full || key_ok) ? pe : 0.f;
+                        if constexpr (DROP) {
+                            const float kp = kq[e];
+                            pr[r] = pv * kp;
+                            ds[r] = pv * (a_dp[r] * kp - dd[e]);
+                        } else {
+                            pr[r] = pv;
+                            ds[r] = pv * (a_dp[r] - dd[e]);
+                        }
+                    }
+                    // this lane's key row of the dS tile, queries qb*32 + 8 qd + 4 hi + {0..3}: 8 bytes of 16-byte chunk qb*4 + qd
+                    uint2 dpk;
+                    dpk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
+                    dpk.y = pack_bf16x2(ds[4 * qd + 2], ds[4 * qd + 3]);
+                    if constexpr ((CX_ATTN_FL_DBG & 2) == 0) *reinterpret_cast<uint2*>(dSs + tile64_off(wave * 32 + l31, qb * 4 + qd) + hi * 8) = dpk;
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        acc_dv[db] = mfma_bf16_32x32x16(tile64_tr_frag(dOs, db * 32, qb * 32 + half * 16, lane), pf, acc_dv[db]);
+                        acc_dk[db] = mfma_bf16_32x32x16(tile64_tr_frag(Qs, db * 32, qb * 32 + half * 16, lane), dsf, acc_dk[db]);
+                    }
+                }
+            }
+            __syncthreads();   // the dS tile is complete; nobody reads Qs / dOs any more (the next chunk's staging may overwrite them)
+            if constexpr ((CX_ATTN_FL_DBG & 2) == 0) {
+                // dQ^T block (d block = wave & 1, query block = wave >> 1) of this chunk from the 128 keys of the block
+                f32x16_t aq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) aq[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    aq = mfma_bf16_32x32x16(tile64_tr_frag(Ks, (wave & 1) * 32, ks * 16, lane), tile64_tr_frag(dSs, (wave >> 1) * 32, ks * 16, lane), aq);
+                float4* wp = reinterpret_cast<float4*>(ws_p + (size_t)q0 * 64) + wave * 256 + lane;
+                if constexpr ((CX_ATTN_FL_DBG & 1) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(aq[r]));
+                } else if ((CX_ATTN_FL_DBG & 4) != 0 || k0 == 0) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) wp[qd * 64] = make_float4(aq[4 * qd], aq[4 * qd + 1], aq[4 * qd + 2], aq[4 * qd + 3]);
+                } else {
+                    float4 old[4];
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) old[qd] = wp[qd * 64];
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        wp[qd * 64] = make_float4(old[qd].x + aq[4 * qd], old[qd].y + aq[4 * qd + 1], old[qd].z + aq[4 * qd + 2], old[qd].w + aq[4 * qd + 3]);
+                }
+            }
+        }
+        __syncthreads();   // every wave is past its last dQ product: the K and dS tiles become the stores' staging rows
+        {
+            bf16_t* kr0 = p.dqkv + (size_t)(p.H + h) * DH + (size_t)(t0 + k0 + wave * 32) * tok_stride;
+            const int valid = len - (k0 + wave * 32);
+            store_unrotated_rows(smem + wave * 4096, kr0, tok_stride, valid, acc_dk, p.scale, p.cosv, p.sinv, key_ok ? key : len - 1, hi, lane);
+            store_unrotated_rows(smem + 16384 + wave * 4096, kr0 + (size_t)p.H * DH, tok_stride, valid, acc_dv, 1.f, nullptr, nullptr, 0, hi, lane);
+        }
+        __syncthreads();   // the staging rows are free again before the next key block's K / V are staged
+    }
+}
+
+// dQ of the fused long-sequence backward: scratch (fp32, the accumulators' layout) -> scaled, un-rotated bf16 rows of dqkv.
+// One workgroup per (64-query chunk, head, sequence); thread (row = tid >> 2, cp = tid & 3) owns d = 8 cp .. 8 cp + 7 and 32 + the same.
+__global__ __launch_bounds__(256) void attn_dq_finish_kernel(AttnParams p, const float* ws, int B) {
+    const int tid = threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
+    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
+    if (q0 >= len) return;
+    const int ql = tid >> 2, cp = tid & 3, q = q0 + ql;
+    if (q >= len) return;
+    const float4* blk = reinterpret_cast<const float4*>(ws + ((size_t)h * ((size_t)p.T + 64 * (size_t)B) + (size_t)t0 + 64 * (size_t)b + q0) * 64);
+    const int w0 = (ql >> 5) * 2;
+    float lo[8], hh[8];
+    {
+        const float4 a = blk[((w0 * 4 + cp) * 64) + (ql & 31)], c = blk[((w0 * 4 + cp) * 64) + 32 + (ql & 31)];
+        const float4 e = blk[(((w0 + 1) * 4 + cp) * 64) + (ql & 31)], g = blk[(((w0 + 1) * 4 + cp) * 64) + 32 + (ql & 31)];
+        lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w; lo[4] = c.x; lo[5] = c.y; lo[6] = c.z; lo[7] = c.w;
+        hh[0] = e.x; hh[1] = e.y; hh[2] = e.z; hh[3] = e.w; hh[4] = g.x; hh[5] = g.y; hh[6] = g.z; hh[7] = g.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] *= p.scale; hh[j] *= p.scale; }
+    if (p.cosv) {
+        float cc[8], ss[8];
+        *reinterpret_cast<float4*>(cc) = *reinterpret_cast<const float4*>(p.cosv + (size_t)q * 32 + cp * 8);
+        *reinterpret_cast<float4*>(cc + 4) = *reinterpret_cast<const float4*>(p.cosv + (size_t)q * 32 + cp * 8 + 4);
+        *reinterpret_cast<float4*>(ss) = *reinterpret_cast<const float4*>(p.sinv + (size_t)q * 32 + cp * 8);
+        *reinterpret_cast<float4*>(ss + 4) = *reinterpret_cast<const float4*>(p.sinv + (size_t)q * 32 + cp * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gl = lo[j], gh = hh[j];
+            lo[j] = gl * cc[j] + gh * ss[j];
+            hh[j] = gh * cc[j] - gl * ss[j];
+        }
+    }
+    bf16_t* row = p.dqkv + (size_t)(t0 + q) * (3 * (size_t)p.H * DH) + (size_t)h * DH;
+    *reinterpret_cast<uint4*>(row + cp * 8) = pack8(lo);
+    *reinterpret_cast<uint4*>(row + 32 + cp * 8) = pack8(hh);
+}
+#endif  // !CX_PRODUCT
+
 // ------------------------------------------------------------------------------- backward, sequences <= 128
 // Same idea as attn_fwd_s128_kernel: one workgroup owns a whole (sequence, head) problem, EVERY global load is issued
 // before anything is staged (one HBM latency per workgroup instead of three serial load -> LDS -> compute phases), and
@@ -2655,6 +2888,37 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
 }
 
 #ifndef CX_PRODUCT
+// fused long-sequence backward (dev library; round 5): delta kernel, the single-owner fused kernel, the dQ
+// finish kernel.  `ws`: cx_attn_bwd_fused_long_ws_floats(B, H, T) floats of scratch (contents irrelevant).  prerotated != 0:
+// qkv holds rotated q / k (the engine's long-sequence path), the tables only un-rotate the gradients.  p_drop = 0: no dropout.
+long long cx_attn_bwd_fused_long_ws_floats(int B, int H, int T) { return (long long)H * ((long long)T + 64LL * B) * 64LL; }
+int cx_attn_varlen_bwd_fused_long(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
+                                  const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, int prerotated, float* delta,
+                                  uint16_t* dqkv, float* ws, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
+                                  unsigned long long seed, unsigned long long offset, unsigned int site, void* stream) {
+    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
+    if (!dout || !qkv || !out || !lse || !cu_seqlens || !delta || !dqkv || !ws) return CX_ERR_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
+    AttnParams p = {};
+    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin;
+    p.lcos = prerotated ? nullptr : rot_cos; p.lsin = prerotated ? nullptr : rot_sin;
+    p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
+    p.dout = dout; p.delta = delta; p.dqkv = dqkv;
+    p.H = H; p.T = T; p.scale = softmax_scale;
+    long nthreads = (long)T * H * 8;
+    int g = (int)((nthreads + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    if (p_drop > 0.f) {
+        p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
+        hipLaunchKernelGGL(attn_bwd_fused_long_kernel<true>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p, ws, B);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_fused_long_kernel<false>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p, ws, B);
+    }
+    hipLaunchKernelGGL(attn_dq_finish_kernel, dim3((max_seqlen + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, p, ws, B);
+    return done();
+}
+
 // test helper (dev library): keep[b][h][q][key] in {0, 1} of the mask the kernels above apply
 int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
                               unsigned long long offset, unsigned int site, void* stream) {

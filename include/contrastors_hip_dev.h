@@ -70,6 +70,15 @@ int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* str
 /* keep[b][h][q][key] in {0, 1}: the mask cx_attn_varlen_dropout_fwd/_bwd apply (tests) */
 int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
                               unsigned long long offset, unsigned int site, void* stream);
+/* fused long-sequence attention backward (round 5): one workgroup per (sequence, head), dK / dV in registers over the query chunks,
+ * dQ added into `ws` (cx_attn_bwd_fused_long_ws_floats(B, H, T) floats, contents irrelevant), then scaled / un-rotated into dqkv.
+ * Same arguments as cx_attn_varlen_bwd (+ prerotated: qkv holds rotated q / k as in cx_attn_varlen_bwd_prerotated; p_drop = 0: no
+ * dropout, otherwise the mask of cx_attn_varlen_dropout_bwd).  scripts/attn_bwd_long_ab.py, tests/test_kernels_gpu.py */
+long long cx_attn_bwd_fused_long_ws_floats(int B, int H, int T);
+int cx_attn_varlen_bwd_fused_long(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
+                                  const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, int prerotated, float* delta,
+                                  uint16_t* dqkv, float* ws, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
+                                  unsigned long long seed, unsigned long long offset, unsigned int site, void* stream);
 /* what the dQ accumulation of a single-owner fused long-sequence attention backward costs by itself: every workgroup walks its
  * problems (floats_per_problem fp32 each, contiguous), `sweeps` load + add + store passes over each (scripts/dq_rmw_probe.py) */
 int cx_probe_rmw(float* buf, long floats_per_problem, int sweeps, int n_problems, int nwg, void* stream);
