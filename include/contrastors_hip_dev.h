@@ -72,7 +72,7 @@ int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_
                               unsigned long long offset, unsigned int site, void* stream);
 /* fused long-sequence attention backward (round 5): one workgroup per (sequence, head), dK / dV in registers over the query chunks,
  * dQ added into `ws` (cx_attn_bwd_fused_long_ws_floats(B, H, T) floats, contents irrelevant), then scaled / un-rotated into dqkv.
- * Same arguments as cx_attn_varlen_bwd (+ prerotated: qkv holds rotated q / k as in cx_attn_varlen_bwd_prerotated; p_drop = 0: no
+ * Arguments of the product backward entry point, plus prerotated: qkv holds rotated q / k as in cx_attn_varlen_bwd_prerotated; p_drop = 0: no
  * dropout, otherwise the mask of cx_attn_varlen_dropout_bwd).  scripts/attn_bwd_long_ab.py, tests/test_kernels_gpu.py */
 long long cx_attn_bwd_fused_long_ws_floats(int B, int H, int T);
 int cx_attn_varlen_bwd_fused_long(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
