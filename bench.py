@@ -506,7 +506,7 @@ def main():
 
     from contrastors_amd import _C
     from contrastors_amd.biencoder import BiEncoder, BiEncoderConfig, LogitScale
-    from contrastors_amd.distributed import exchange_report, gather_with_grad, set_exchange_timeout
+    from contrastors_amd.distributed import exchange_report, set_exchange_timeout
     from contrastors_amd.loss import grad_cache_loss
     from contrastors_amd.nomic_bert import NomicBertConfig
     from contrastors_amd.optimizer import FusedAdamW

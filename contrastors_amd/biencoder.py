@@ -7,7 +7,6 @@ result contract as the reference; trunk + pooling + L2-normalise are one native 
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Optional, Union
 

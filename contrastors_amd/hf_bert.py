@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import re
 from collections import OrderedDict
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn.functional as F

@@ -11,7 +11,6 @@ the decoder weight is the embedding matrix and is not stored twice).
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 from typing import Dict, Iterable, Optional
 
