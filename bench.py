@@ -813,9 +813,12 @@ def main():
         out["whole_step_frac_of_mfma_peak"] = out["roofline"]["whole_step_frac_of_mfma_peak"]
         # per-box calibration (flat scalars: the driver's `parsed` view keeps scalars) + the nested record
         out["box"] = box
-        for k in ("mfma_probe_tflops", "blas_ref_tflops", "hbm_copy_tbs", "mean_sclk_mhz", "mean_power_w", "power_cap_w", "mfma_probe_clock_mhz", "mfma_probe_power_w"):
+        for k in ("mfma_probe_tflops", "blas_ref_tflops", "v6_same_shapes_tflops", "hbm_copy_tbs", "mean_sclk_mhz", "mean_power_w", "power_cap_w", "mfma_probe_clock_mhz", "mfma_probe_power_w"):
             if isinstance(box, dict) and isinstance(box.get(k), (int, float)):
                 out[f"box_{k}"] = box[k]
+        for k in ("like_for_like", "like_for_like_short_k", "like_for_like_long_k"):   # plain v6 / vendor BLAS on the calibration's two shapes, interleaved windows (round 6)
+            if isinstance(box, dict) and isinstance(box.get(k), (int, float)):
+                out[k] = box[k]
         blas_ref = box.get("blas_ref_tflops") if isinstance(box, dict) else None
         if blas_ref:   # the shipped GEMM family against the vendor BLAS on the same box (two of the step's shapes): steadier across boxes than the probe
             out["vs_box_blas"] = achieved / blas_ref

@@ -92,35 +92,52 @@ def calibrate(dev=None, mfma_seconds: float = 2.0, copy_gb: float = 2.0) -> dict
         # own GEMM shapes, ~0.6 s each after a warm-up third.  Unlike the register-only probe it loads LDS and HBM like the shipped GEMMs
         # and runs into the same power cap: a frozen library on a fixed shape is the steadier per-box yardstick (round 5 saw a box whose
         # MFMA probe read 9 % low while its step -- and its in-step clock -- were 1-2 % low).
+        # Round 6: the PRODUCT kernel (cx_gemm_bf16_nt -> gemm_bf16_v6) on the same two shapes, in the same windows:
+        # per shape a warm-up, then alternating ~0.3 s windows vendor / v6 / vendor / v6 -> `v6_same_shapes_tflops` and
+        # `like_for_like` = v6 / vendor, a ratio of two plain GEMMs on one shape, one box and one power state.
         try:
-            tf = []
+            tf, tf6 = [], []
             for (M, N, K) in ((131072, 3072, 768), (131072, 768, 3072)):
                 xa = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
                 wb = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
                 yo = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-                for _ in range(5):
-                    torch.matmul(xa, wb.t(), out=yo)
-                torch.cuda.synchronize()
-                t_end = time.perf_counter() + 0.25
-                while time.perf_counter() < t_end:
-                    for _ in range(8):
-                        torch.matmul(xa, wb.t(), out=yo)
+                wbt = wb.t()
+                f_vendor = lambda: torch.matmul(xa, wbt, out=yo)   # noqa: E731
+                f_v6 = lambda: _C.check(lib.cx_gemm_bf16_nt(xa.data_ptr(), wb.data_ptr(), yo.data_ptr(), None, M, N, K, K, K, N, 0, 1, 1.0, s),   # noqa: E731
+                                        "cx_gemm_bf16_nt")
+
+                def window(fn, seconds):
+                    ts = []
+                    t_end = time.perf_counter() + seconds
+                    while time.perf_counter() < t_end:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(8):
+                            fn()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1) / 8)
+                    ts.sort()
+                    return ts[len(ts) // 2]
+
+                for fn in (f_vendor, f_v6):
+                    for _ in range(3):
+                        fn()
                     torch.cuda.synchronize()
-                ts = []
-                t_end = time.perf_counter() + 0.5
-                while time.perf_counter() < t_end:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(8):
-                        torch.matmul(xa, wb.t(), out=yo)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ts.append(e0.elapsed_time(e1) / 8)
-                ts.sort()
-                tf.append(2.0 * M * N * K / (ts[len(ts) // 2] * 1e-3) / 1e12)
-                del xa, wb, yo
+                window(f_vendor, 0.25)
+                tv, t6 = [], []
+                for _ in range(2):
+                    tv.append(window(f_vendor, 0.3))
+                    t6.append(window(f_v6, 0.3))
+                tf.append(2.0 * M * N * K / (sum(tv) / len(tv) * 1e-3) / 1e12)
+                tf6.append(2.0 * M * N * K / (sum(t6) / len(t6) * 1e-3) / 1e12)
+                del xa, wb, yo, wbt
             out["blas_ref_tflops"] = sum(tf) / len(tf)
             out["blas_ref_tflops_short_k"], out["blas_ref_tflops_long_k"] = tf
+            out["v6_same_shapes_tflops"] = sum(tf6) / len(tf6)
+            out["v6_same_shapes_tflops_short_k"], out["v6_same_shapes_tflops_long_k"] = tf6
+            out["like_for_like"] = out["v6_same_shapes_tflops"] / out["blas_ref_tflops"]
+            out["like_for_like_short_k"], out["like_for_like_long_k"] = tf6[0] / tf[0], tf6[1] / tf[1]
         except Exception as e:  # noqa: BLE001
             out["blas_ref_error"] = f"{type(e).__name__}: {e}"[:160]
         # HBM stream: copy_gb read + copy_gb written per launch
