@@ -128,7 +128,7 @@ def cmd_parse(a):
     per = defaultdict(dict)   # dispatch id -> {counter: value, "_k": kernel name}
     for path in a.csv:
         for r in csv.DictReader(open(path)):
-            did = (path, int(r["Dispatch_Id"]))
+            did = (path, int(r.get("Dispatch_Id") or r.get("Correlation_Id") or 0))
             per[did]["_k"] = r["Kernel_Name"]
             per[did][r["Counter_Name"]] = per[did].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     # the workload's order inside each file: per shape `reps` vendor launches, then `reps` v6 launches
