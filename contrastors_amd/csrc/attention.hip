@@ -2676,6 +2676,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
     }
 }
 
+#include "attn_s256.inc"
+
 #ifndef CX_PRODUCT
 int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
@@ -2715,6 +2717,10 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 #endif
     if (max_seqlen <= 128) {  // one workgroup per (sequence, head) problem, single pass
         hipLaunchKernelGGL(attn_fwd_s128v_kernel<false>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (max_seqlen <= 256) {  // the same with K / V of up to 256 rows resident (round 6: the ViT's 197 tokens)
+        static CxLdsOptIn lds_f256;
+        if (!lds_f256.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<false>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
+        hipLaunchKernelGGL(attn_fwd_s256_kernel<false>, dim3(H, B), dim3(256), S256_LDS_FWD, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
         hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -2843,6 +2849,12 @@ int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, c
 #endif
     if (max_seqlen <= 128 && single_pass) {   // the single-pass kernel with the mask (round 4)
         hipLaunchKernelGGL(attn_fwd_s128v_kernel<true>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+        return done();
+    }
+    if (max_seqlen <= 256 && single_pass) {
+        static CxLdsOptIn lds_f256d;
+        if (!lds_f256d.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<true>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
+        hipLaunchKernelGGL(attn_fwd_s256_kernel<true>, dim3(H, B), dim3(256), S256_LDS_FWD, (hipStream_t)stream, p);
         return done();
     }
     dim3 grid((max_seqlen + 127) / 128, H, B);

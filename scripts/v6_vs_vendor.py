@@ -126,10 +126,13 @@ def _is_gemm(name: str) -> str | None:
 
 def cmd_parse(a):
     per = defaultdict(dict)   # dispatch id -> {counter: value, "_k": kernel name}
+    import gzip
     for path in a.csv:
-        for r in csv.DictReader(open(path)):
+        for r in csv.DictReader(gzip.open(path, "rt") if path.endswith(".gz") else open(path)):
             did = (path, int(r.get("Dispatch_Id") or r.get("Correlation_Id") or 0))
             per[did]["_k"] = r["Kernel_Name"]
+            if r.get("End_Timestamp") and r.get("Start_Timestamp"):
+                per[did]["duration_us (this pass)"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             per[did][r["Counter_Name"]] = per[did].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     # the workload's order inside each file: per shape `reps` vendor launches, then `reps` v6 launches
     table = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))   # shape -> kernel -> counter -> values
@@ -153,11 +156,15 @@ def cmd_parse(a):
                     for c, val in v.items():
                         if c != "_k":
                             table[name][kern][c].append(val)
+                    # effective shader clock of THIS dispatch: GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_BUSY_CYCLES over 32 SEs
+                    if "GRBM_GUI_ACTIVE" in v and v.get("duration_us (this pass)"):
+                        table[name][kern]["effective_clock_MHz (GRBM/8/duration)"].append(v["GRBM_GUI_ACTIVE"] / 8 / v["duration_us (this pass)"])
+                    if "SQ_BUSY_CYCLES" in v and v.get("duration_us (this pass)"):
+                        table[name][kern]["effective_clock_MHz (SQ_BUSY/32/duration)"].append(v["SQ_BUSY_CYCLES"] / 32 / v["duration_us (this pass)"])
     for name, N, K in SHAPES:
         if name not in table:
             continue
         fl = 2.0 * T * N * K
-        mfma32 = fl / (2.0 * 32 * 32 * 16) / 64 * 64 / 64   # 32x32x16 wave-instruction equivalents (one per 32768 FLOP)
         print(f"== {name}  N={N} K={K}   ({fl / 1e12:.3f} TFLOP = {fl / 32768 / 1e6:.2f} M 32x32x16-MFMA equivalents)")
         print(f"   vendor kernel: {names[name].get('vendor', '?')}")
         print(f"   v6 kernel:     {names[name].get('v6', '?')}")
