@@ -114,6 +114,7 @@ _SIGS = {
     "cx_bias_gelu_bwd_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     "cx_bias_act_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cx_bias_act_bwd_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cx_gemm_bf16_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cx_attn_varlen_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),
     "cx_attn_varlen_bwd_prerotated": (i32, [vp] * 9 + [i32, i32, i32, i32, f32, vp]),

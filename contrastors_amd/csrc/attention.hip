@@ -2786,6 +2786,13 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
         return done();
     }
 #endif
+    if (max_seqlen > 128 && max_seqlen <= 256 && bwd_mode) {  // one persistent 8-wave workgroup per CU, K / V resident (round 6: the ViT's 197 tokens)
+        static CxLdsOptIn lds_b256;
+        if (!lds_b256.ensure(reinterpret_cast<const void*>(&attn_bwd_s256_kernel<false>), S256_LDS_BWD)) return CX_ERR_LAUNCH;
+        const int n_units = B * H;
+        hipLaunchKernelGGL(attn_bwd_s256_kernel<false>, dim3(n_units < 256 ? n_units : 256), dim3(512), S256_LDS_BWD, (hipStream_t)stream, p, B);
+        return done();
+    }
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;
@@ -2887,6 +2894,13 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
         const int n_units = B * H;
         hipLaunchKernelGGL(attn_bwd_fused2_s128_kernel<true>, dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
                            (hipStream_t)stream, p, B);
+        return done();
+    }
+    if (max_seqlen <= 256 && fused) {
+        static CxLdsOptIn lds_b256d;
+        if (!lds_b256d.ensure(reinterpret_cast<const void*>(&attn_bwd_s256_kernel<true>), S256_LDS_BWD)) return CX_ERR_LAUNCH;
+        const int n_units = B * H;
+        hipLaunchKernelGGL(attn_bwd_s256_kernel<true>, dim3(n_units < 256 ? n_units : 256), dim3(512), S256_LDS_BWD, (hipStream_t)stream, p, B);
         return done();
     }
     long nthreads = (long)T * H * 8;

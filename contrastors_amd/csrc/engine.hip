@@ -328,6 +328,11 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         int fused = CX_ERR_SHAPE;
         if (enc->gated)  // fc2 dgrad + SwiGLU backward in one kernel: d(act) never touches HBM
             fused = cx_gemm_bf16_swiglu_bwd_gate(dm, w.Wfc2T, s.act(l), s.yg(l), buf->g_wide, T, I, d, d, d, I, s.wfc1, stream);
+        // plain MLP whose forward took the fused bias + activation kernel (yg = the biased pre-activation): fc2 dgrad, the activation
+        // backward and the fc1 bias gradient's partials in ONE kernel (round 6) -- d(act) never touches HBM either
+        if (!enc->gated && gelu_fused_shape(T, s.wfc1, d))
+            fused = cx_gemm_bf16_act_bwd(dm, w.Wfc2T, s.yg(l), buf->g_wide, w.gbfc1, buf->ws_f32, buf->ws_floats, T, I, d, d, d, I, I,
+                                         enc->mlp_act, stream);
         if (fused != CX_ERR_SHAPE) {
             CX_TRY(fused);
         } else {
@@ -336,7 +341,7 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
         if (enc->gated) {
             if (fused == CX_ERR_SHAPE)
                 CX_TRY(cx_swiglu_bwd_gate(buf->g_act, s.act(l), s.yg(l), buf->g_wide, T, I, stream));
-        } else {
+        } else if (fused == CX_ERR_SHAPE) {
             // (yg holds the biased pre-activation when the forward took the fused kernel: same predicate as there)
             // GELU backward and the fc1 bias gradient in one pass over (dact, pre)
             CX_TRY(cx_bias_act_bwd_colsum(buf->g_act, s.yg(l), gelu_fused_shape(T, s.wfc1, d) ? nullptr : w.bfc1, buf->g_wide,
@@ -725,7 +730,7 @@ int cx_vit_backward_hidden(const CxEncoderDesc* enc, const CxChunkBuffers* buf, 
     return vit_backward_impl(enc, buf, cu_seqlens, Bc, n_patch, nullptr, nullptr, dhidden, stream);
 }
 
-int cx_abi_version(void) { return 9; }  // 9: cx_infonce_fwd_argmax; 8: cx_cast_transpose_f32_to_bf16_batched / CxCastJob; 7: CxChunkBuffers.patch_keep / patch_inv / n_keep (PatchDropout);  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
+int cx_abi_version(void) { return 10; }  // 10: cx_gemm_bf16_act_bwd; 9: cx_infonce_fwd_argmax; 8: cx_cast_transpose_f32_to_bf16_batched / CxCastJob; 7: CxChunkBuffers.patch_keep / patch_inv / n_keep (PatchDropout);  // 2: CxChunkBuffers.checkpoint; 3: dropout state, sorted embedding backward; 4: CxEncoderDesc.attn_pdrop; 5: CxChunkBuffers.layer_events, cx_layernorm_bwd_pooled; 6: CxChunkBuffers.ckpt_keep
 const char* cx_build_info(void) { return "contrastors_hip gfx950 " __DATE__ " " __VERSION__; }
 const char* cx_error_string(int code) {
     switch (code) {

@@ -268,6 +268,32 @@ int cx_gemm_bf16_swiglu_bwd_gate(const uint16_t* dY, const uint16_t* W, const ui
     return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD_AG, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
+// fc2 dgrad of the plain (GELU / quick_gelu) MLP with the activation backward fused into the epilogue (round 6; the reference gets the
+// pair from flash_attn.ops.fused_dense.FusedMLP, sc/layers/mlp.py:30-34): dPre (M, N) bf16 = bf16(bf16(dY W^T) * act'(Pre)), Pre: the
+// biased pre-activation the forward saved (cx_gemm_bf16_bias_act), W: (N, K) the transposed fc2 shadow.  Bit-identical to
+// cx_gemm_bf16_nt + cx_bias_act_bwd_colsum(bias = NULL) without the (M, N) d(act) round trip.  dbias (optional): fp32 [N] += column sums
+// of the bf16 dPre (the fc1 bias gradient), through `ws` (>= ceil(M / 128) * N floats) and a fixed-order reduction: deterministic.
+// CX_ERR_SHAPE = not covered (K % 64, N % 8, leading dimensions % 8, workspace too small): run the two kernels instead.
+int cx_gemm_bf16_act_bwd(const uint16_t* dY, const uint16_t* W, const uint16_t* Pre, uint16_t* dPre, float* dbias, float* ws,
+                         long ws_floats, int M, int N, int K, int ldx, int ldw, int ld_pre, int ld_dpre, int act, void* stream) {
+    if (M <= 0 || N <= 0) return CX_OK;
+    if (!dY || !W || !Pre || !dPre || (act != 0 && act != 1)) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (N % 8) != 0 || (ld_pre % 8) != 0 || (ld_dpre % 8) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    const int nblocks = (M + 127) / 128;
+    if (dbias && (!ws || ws_floats < (long)nblocks * N)) return CX_ERR_SHAPE;
+    GemmParams p = base_params(dY, W, dPre, nullptr, M, N, K, ldx, ldw, ld_dpre);
+    p.Out2 = const_cast<uint16_t*>(Pre); p.ldo2 = ld_pre;
+    p.act = act;
+    p.colsum_part = dbias ? ws : nullptr;
+    {
+        ProfScope prof(2.0 * (double)M * (double)N * (double)K, (hipStream_t)stream);
+        if (cx_launch_gemm_v6(p, GEMM_EPI_ACT_BWD, (hipStream_t)stream) != hipSuccess) return CX_ERR_LAUNCH;
+    }
+    if (dbias && cx_launch_colsum_part_reduce(ws, dbias, nblocks, N, (hipStream_t)stream) != hipSuccess) return CX_ERR_LAUNCH;
+    return CX_OK;
+}
+
 int cx_prof_gemm_config(int enable, int stride) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.enabled = enable != 0;

@@ -1030,4 +1030,25 @@ int cx_gemm_bf16_swiglu_bwd_gate(const uint16_t* dY, const uint16_t* W, const ui
     return cx_launch_gemm_v6(p, GEMM_EPI_SWIGLU_BWD_AG, (hipStream_t)stream) == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }
 
+// dev-library twin of gemm_api.hip's cx_gemm_bf16_act_bwd (fc2 dgrad + GELU / quick_gelu backward + bias-gradient partials; v6 only)
+int cx_gemm_bf16_act_bwd(const uint16_t* dY, const uint16_t* W, const uint16_t* Pre, uint16_t* dPre, float* dbias, float* ws,
+                         long ws_floats, int M, int N, int K, int ldx, int ldw, int ld_pre, int ld_dpre, int act, void* stream) {
+    if (M <= 0 || N <= 0) return CX_OK;
+    if (!dY || !W || !Pre || !dPre || (act != 0 && act != 1)) return CX_ERR_ARG;
+    if (K <= 0 || (K % 64) != 0 || (N % 8) != 0 || (ld_pre % 8) != 0 || (ld_dpre % 8) != 0) return CX_ERR_SHAPE;
+    if ((ldx % 8) != 0 || (ldw % 8) != 0) return CX_ERR_ALIGN;
+    if (cx_gemm_get_variant() != 6) return CX_ERR_SHAPE;
+    const int nblocks = (M + 127) / 128;
+    if (dbias && (!ws || ws_floats < (long)nblocks * N)) return CX_ERR_SHAPE;
+    GemmParams p = {};
+    p.X = dY; p.W = W; p.Out = dPre; p.bias = nullptr;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ld_dpre;
+    p.split_k = 1; p.alpha = 1.f; p.act = act;
+    p.Out2 = const_cast<uint16_t*>(Pre); p.ldo2 = ld_pre;
+    p.colsum_part = dbias ? ws : nullptr;
+    if (cx_launch_gemm_v6(p, GEMM_EPI_ACT_BWD, (hipStream_t)stream) != hipSuccess) return CX_ERR_LAUNCH;
+    if (dbias && cx_launch_colsum_part_reduce(ws, dbias, nblocks, N, (hipStream_t)stream) != hipSuccess) return CX_ERR_LAUNCH;
+    return CX_OK;
+}
+
 #include "gemm_splitk_small.inc"

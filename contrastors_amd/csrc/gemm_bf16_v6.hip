@@ -519,7 +519,43 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 pack_block(std::integral_constant<int, 12>{}); pack_block(std::integral_constant<int, 13>{});
                 pack_block(std::integral_constant<int, 14>{}); pack_block(std::integral_constant<int, 15>{});
                 dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)m0 * p.ldo + n0) * 2;
-            } else if constexpr (EPI == GEMM_EPI_NONE) {
+            } else if constexpr (EPI == GEMM_EPI_NONE || EPI == GEMM_EPI_ACT_BWD || EPI == GEMM_EPI_QACT_BWD) {
+                // ACT_BWD (round 6): the same epilogue with the residual slot holding the saved pre-activation of the plain MLP and
+                // the combine step Out = bf16(bf16(acc) * act'(pre)) instead of an add -- the arithmetic of the standalone
+                // cx_bias_act_bwd_colsum pass on the bf16 d(act) this GEMM used to write (bit-identical), without the (M, N) round
+                // trip; the column sums of the bf16 result (the fc1 bias gradient) leave as one fp32 partial row per 128-row block.
+                constexpr bool ACTB = EPI == GEMM_EPI_ACT_BWD || EPI == GEMM_EPI_QACT_BWD;
+                float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cs4 = 0.f, cs5 = 0.f, cs6 = 0.f, cs7 = 0.f;
+                constexpr int act_kind = EPI == GEMM_EPI_QACT_BWD ? CX_ACT_QUICK_GELU : CX_ACT_GELU;
+                auto mul_grad = [&](uint4& v, const uint4& r) {
+#define CX_MG(w_, ca, cb)                                                                              \
+    {                                                                                                 \
+        const float o0 = bf16lo_to_f32(v.w_) * act_grad(bf16lo_to_f32(r.w_), act_kind);               \
+        const float o1 = bf16hi_to_f32(v.w_) * act_grad(bf16hi_to_f32(r.w_), act_kind);               \
+        v.w_ = pack_bf16x2(o0, o1);                                                                   \
+        ca += bf16lo_to_f32(v.w_);                                                                    \
+        cb += bf16hi_to_f32(v.w_);                                                                    \
+    }
+                    CX_MG(x, cs0, cs1) CX_MG(y, cs2, cs3) CX_MG(z, cs4, cs5) CX_MG(w, cs6, cs7)
+#undef CX_MG
+                };
+                // column sums of this wave's 128 rows: fold the four row groups (lane >> 4), lanes 0..15 own 8 columns each
+                auto flush_colsum = [&]() {
+                    if constexpr (ACTB) {
+                        float c[8] = {cs0, cs1, cs2, cs3, cs4, cs5, cs6, cs7};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            c[e] += __shfl_xor(c[e], 16, 64);
+                            c[e] += __shfl_xor(c[e], 32, 64);
+                        }
+                        const int n = n0 + (lane & 15) * 8;
+                        if (p.colsum_part && lane < 16 && m0 < p.M && n + 8 <= p.N) {
+                            float* dst = p.colsum_part + (size_t)(m0 >> 7) * p.N + n;
+                            *reinterpret_cast<float4*>(dst) = make_float4(c[0], c[1], c[2], c[3]);
+                            *reinterpret_cast<float4*>(dst + 4) = make_float4(c[4], c[5], c[6], c[7]);
+                        }
+                    }
+                };
                 const bool add_bias = p.bias != nullptr;
                 // `plain` (compile time): alpha == 1 and no bias -- the forward / dgrad launches of bias-free models;
                 // saves 256 multiplies per lane per tile in an epilogue that is VALU-issue-bound (one wave per SIMD)
@@ -624,6 +660,66 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     one_pass(std::integral_constant<int, 3>{});
 #undef CX_RES_ROWS
                 };
+                // ---- ACT_BWD, interior tiles: the plain fast path keeps 8 staged rows + 8 residual rows + the next pass's 16 packed pairs in
+                // registers (it sits at 256 VGPRs); with the activation derivative's temporaries on top the compiler parked values in the
+                // AGPRs -- inside the accumulators it cannot see (build.py's audit).  Here a pass is staged block by block (4 registers at a
+                // time) and leaves in two halves of 4 rows per lane: 4 staged + 4 pre-activation rows live, the next half's pre-activation
+                // rows requested BEFORE this half's stores (one in-order vmcnt).  The epilogue is VALU-bound either way (~20 instructions
+                // per element for the erf form): what it hides is the (M, N) d(act) write + read and the pre-activation's second read.
+                auto fast_tile_actb = [&]() {
+                    const int rrow = lane >> 4, rch = lane & 15;
+                    bf16_t* outp = reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8;
+                    const bf16_t* resp = resid + (size_t)(m0 + rrow) * p.ldo2 + n0 + rch * 8;
+                    const char* rd = my + rrow * ROWB + rch * 16;
+                    char* wr = my + l31 * ROWB + hi * 8;
+                    auto stage_pass = [&](int b) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            float blk[16];
+                            v6_read_block(4 * b + a, blk);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint2 pk2;
+                                pk2.x = pack_bf16x2(blk[4 * q], blk[4 * q + 1]);
+                                pk2.y = pack_bf16x2(blk[4 * q + 2], blk[4 * q + 3]);
+                                *reinterpret_cast<uint2*>(wr + (a * 32 + 8 * q) * 2) = pk2;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    };
+                    uint4 r0, r1, r2, r3;
+#define CX_PRE_ROWS(hh_)                                                        \
+    r0 = gld(resp + (size_t)((hh_) * 16 + 0) * p.ldo2);                         \
+    r1 = gld(resp + (size_t)((hh_) * 16 + 4) * p.ldo2);                         \
+    r2 = gld(resp + (size_t)((hh_) * 16 + 8) * p.ldo2);                         \
+    r3 = gld(resp + (size_t)((hh_) * 16 + 12) * p.ldo2);
+                    auto half_pass = [&](auto hc) {
+                        constexpr int hh = decltype(hc)::value;   // half-pass index 0..7: rows hh * 16 + {0, 4, 8, 12} + rrow of the wave's 128
+                        constexpr int h = hh & 1;
+                        uint4 v0 = *reinterpret_cast<const uint4*>(rd + (h * 16 + 0) * ROWB), v1 = *reinterpret_cast<const uint4*>(rd + (h * 16 + 4) * ROWB),
+                              v2 = *reinterpret_cast<const uint4*>(rd + (h * 16 + 8) * ROWB), v3 = *reinterpret_cast<const uint4*>(rd + (h * 16 + 12) * ROWB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mul_grad(v0, r0); __builtin_amdgcn_sched_barrier(0);
+                        mul_grad(v1, r1); __builtin_amdgcn_sched_barrier(0);
+                        mul_grad(v2, r2); __builtin_amdgcn_sched_barrier(0);
+                        mul_grad(v3, r3); __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (hh < 7) { CX_PRE_ROWS(hh + 1) }
+                        __builtin_amdgcn_sched_barrier(0);
+                        bf16_t* o = outp + (size_t)(hh * 16) * p.ldo;
+                        gst(o, v0);
+                        gst(o + (size_t)4 * p.ldo, v1);
+                        gst(o + (size_t)8 * p.ldo, v2);
+                        gst(o + (size_t)12 * p.ldo, v3);
+                        if constexpr (h == 1 && hh < 7) stage_pass((hh >> 1) + 1);   // (the LDS executes a wave's operations in order: after this pass's row reads)
+                    };
+                    CX_PRE_ROWS(0)
+                    stage_pass(0);
+                    half_pass(std::integral_constant<int, 0>{}); half_pass(std::integral_constant<int, 1>{});
+                    half_pass(std::integral_constant<int, 2>{}); half_pass(std::integral_constant<int, 3>{});
+                    half_pass(std::integral_constant<int, 4>{}); half_pass(std::integral_constant<int, 5>{});
+                    half_pass(std::integral_constant<int, 6>{}); half_pass(std::integral_constant<int, 7>{});
+#undef CX_PRE_ROWS
+                };
                 const bool fast = p.alpha == 1.f && !add_bias && m0 + 128 <= p.M && n0 + 128 <= p.N;
                 auto store_tile = [&](auto plain) {
 #pragma unroll
@@ -674,7 +770,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             const int row = ps * 4 + (lane >> 4), ch = lane & 15;
                             const int m = m0 + b * 32 + row, n = n0 + ch * 8;
                             uint4 vv = *reinterpret_cast<const uint4*>(my + row * ROWB + ch * 16);
-                            if (resid) {
+                            if (resid && ACTB) {
+                                const uint4 rr = ps == 0 ? r0 : ps == 1 ? r1 : ps == 2 ? r2 : ps == 3 ? r3 : ps == 4 ? r4 : ps == 5 ? r5
+                                                 : ps == 6 ? r6 : r7;
+                                if (m < p.M && n + 8 <= p.N) mul_grad(vv, rr);   // (only rows / columns that exist enter the column sums)
+                            } else if (resid) {
                                 const uint4 rr = ps == 0 ? r0 : ps == 1 ? r1 : ps == 2 ? r2 : ps == 3 ? r3 : ps == 4 ? r4 : ps == 5 ? r5
                                                  : ps == 6 ? r6 : r7;
                                 vv.x = pack_bf16x2(bf16lo_to_f32(vv.x) + bf16lo_to_f32(rr.x), bf16hi_to_f32(vv.x) + bf16hi_to_f32(rr.x));
@@ -687,7 +787,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         }
                     }
                 };
-                if (fast) {
+                if constexpr (ACTB) {   // (the launcher guarantees Pre, alpha == 1 and no bias)
+                    if (fast) {
+                        fast_tile_actb();
+                    } else {
+                        store_tile(std::true_type{});
+                    }
+                    flush_colsum();
+                } else if (fast) {
                     if (resid) {
                         fast_tile(std::true_type{});
                     } else {
@@ -1148,7 +1255,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             // above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead across the epilogue
             // (~150 cycles of exposed LDS latency per tile against 32 registers); the SwiGLU backward additionally rebuilds
             // its 16 DMA cursor offsets from (round, K-tile).
-            if constexpr ((EPI == GEMM_EPI_NONE || IS_SWIGLU_BWD) && (!DEFER || CX_V6_DEFER_MODE == 1)) {
+            if constexpr ((EPI == GEMM_EPI_NONE || EPI == GEMM_EPI_ACT_BWD || EPI == GEMM_EPI_QACT_BWD || IS_SWIGLU_BWD) && (!DEFER || CX_V6_DEFER_MODE == 1)) {
                 asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
                 if constexpr (IS_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
@@ -1510,6 +1617,26 @@ hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+namespace {
+// 64 columns x 4 block groups per workgroup; each thread sums every 4th block's partial of its column, the groups fold through LDS
+__global__ __launch_bounds__(256) void colsum_part_reduce_kernel(const float* __restrict__ part, float* dst, int nblocks, int N) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float sacc = 0.f;
+    if (col < N) {
+#pragma unroll 4
+        for (int b = grp; b < nblocks; b += 4) sacc += part[(size_t)b * N + col];
+    }
+    red[grp][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (grp == 0 && col < N) dst[col] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+}  // namespace
+hipError_t cx_launch_colsum_part_reduce(const float* part, float* dst, int nblocks, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(colsum_part_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, part, dst, nblocks, N);
+    return hipGetLastError();
+}
+
 // NT forms with bf16 output (plain / bias / alpha, or fused SwiGLU), K % 64 == 0, N % 8 == 0, split_k == 1.
 hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
     if (v7_takes(p, epi)) return cx_launch_gemm_v7(p, epi, g_v6_force_gn, stream);
@@ -1544,5 +1671,6 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
            : epi == GEMM_EPI_GELU ? launch6<GEMM_EPI_GELU>(p, stream)
            : epi == GEMM_EPI_QGELU ? launch6<GEMM_EPI_QGELU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD ? launch6<GEMM_EPI_SWIGLU_BWD>(p, stream)
+           : epi == GEMM_EPI_ACT_BWD ? (p.act == CX_ACT_QUICK_GELU ? launch6<GEMM_EPI_QACT_BWD>(p, stream) : launch6<GEMM_EPI_ACT_BWD>(p, stream))
                                   : launch6<GEMM_EPI_NONE>(p, stream);
 }

@@ -7,7 +7,10 @@ enum { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_F32_ATOMIC = 2, GEMM_OUT_F3
 enum { GEMM_EPI_NONE = 0, GEMM_EPI_SWIGLU = 1, GEMM_EPI_GELU = 2, GEMM_EPI_SWIGLU_BWD = 3,
        GEMM_EPI_QGELU = 4,   // GELU / QGELU: Out2 = act(acc + bias), Out (optional) = acc + bias; act = erf GELU / quick_gelu
        GEMM_EPI_SWIGLU_G = 5,        // SWIGLU whose optional save is the GATE alone: Out = G (M, N/2), Out2 = Act (M, N/2)
-       GEMM_EPI_SWIGLU_BWD_AG = 6 }; // SWIGLU_BWD from (Act, G): Out2 = Act, In3 = G (INPUTS, (M, N) each, ld = ldo2), Out = dYG
+       GEMM_EPI_SWIGLU_BWD_AG = 6,   // SWIGLU_BWD from (Act, G): Out2 = Act, In3 = G (INPUTS, (M, N) each, ld = ldo2), Out = dYG
+       GEMM_EPI_QACT_BWD = 8,        // ACT_BWD with quick_gelu (a compile-time twin: a run-time branch inside the derivative cost a register too many)
+       GEMM_EPI_ACT_BWD = 7 };       // fc2 dgrad of the plain MLP + GELU / quick_gelu backward: Out = bf16(bf16(acc) * act'(Pre)), Pre = Out2 (INPUT,
+                                     // (M, N) bf16, ld = ldo2); colsum_part (optional): fp32 [ceil(M / 128)][N] column sums of the bf16 Out per 128-row block
 // SWIGLU_BWD: acc = d(act); Out2 = YG (INPUT, (M, 2N) interleaved by 32), Out = dYG (same layout)
 
 struct GemmParams {
@@ -24,6 +27,7 @@ struct GemmParams {
     void* Out2; // SwiGLU epilogue: activation output (M, N/2) bf16
     int ldo2;
     const uint16_t* In3;  // SWIGLU_BWD_AG: the saved gate (M, N) bf16, leading dimension ldo2
+    float* colsum_part;   // ACT_BWD: per-128-row-block column sums of Out (the fc1 bias gradient's partials), or nullptr
     int sup_m, sup_n;  // v2: L2 super-tile (sup_m x sup_n tiles walked together); 0 = plain row-major order
     long long* trace;  // v5p only (set by its launcher): per-workgroup phase cycle counters, or nullptr
 };
@@ -37,6 +41,8 @@ void cx_gemm_v6_set_trace(long long* buf);
 void cx_gemm_v6_set_ablate(int mask);
 void cx_gemm_v6_set_defer(int mode);   // dev library only: -1 = CX_V6_DEFER, 0 = never, 1 = every launch the deferred-store form covers
 hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream);
+// dst[c] += sum_b part[b][c] (fixed order: deterministic), part: fp32 [nblocks][N] -- the ACT_BWD epilogue's bias-gradient partials
+hipError_t cx_launch_colsum_part_reduce(const float* part, float* dst, int nblocks, int N, hipStream_t stream);
 // gemm_bf16_v7.hip: two resident workgroups per CU, 256x128x64 tiles (plain / residual, SwiGLU with gate save, SwiGLU backward
 // from (act, gate)); cx_launch_gemm_v6 routes to it (policy there).  force_gn: 0 = heuristic XCD grid.
 bool cx_gemm_v7_covers(const GemmParams& p, int epi);

@@ -203,6 +203,14 @@ int cx_gemm_bf16_bias_gelu(const uint16_t* X, const uint16_t* W, const float* bi
  * sc/models/vit/clip.py:14-58). */
 int cx_gemm_bf16_bias_act(const uint16_t* X, const uint16_t* W, const float* bias, uint16_t* Pre, uint16_t* Act, int M,
                           int N, int K, int ldx, int ldw, int ld_pre, int ld_act, int act, void* stream);
+/* fc2 dgrad of the plain MLP with the GELU / quick_gelu backward fused into the epilogue (cx_abi_version >= 10; the reference gets the
+ * pair from flash_attn.ops.fused_dense / FusedMLP, sc/layers/mlp.py:30-34): dPre (M, N) = bf16(bf16(dY W^T) * act'(Pre)), Pre = the
+ * biased pre-activation saved by cx_gemm_bf16_bias_act, W: (N, K) row-major (the transposed fc2 weight), act as there.  Bit-identical to
+ * cx_gemm_bf16_nt + cx_bias_act_bwd_colsum(bias = NULL).  dbias (may be NULL): fp32 [N] += column sums of the bf16 dPre = the fc1 bias
+ * gradient, summed in a fixed order through `ws` (>= ceil(M / 128) * N floats): deterministic, no atomics.
+ * CX_ERR_SHAPE = not covered (K % 64, N % 8, ld % 8, workspace too small): run the two calls above instead. */
+int cx_gemm_bf16_act_bwd(const uint16_t* dY, const uint16_t* W, const uint16_t* Pre, uint16_t* dPre, float* dbias, float* ws,
+                         long ws_floats, int M, int N, int K, int ldx, int ldw, int ld_pre, int ld_dpre, int act, void* stream);
 /* fc2 dgrad of the gated MLP with the backward of `swiglu` (flash_attn.ops.activations, sc/layers/mlp.py:75) fused into
  * the epilogue: dYG (M, 2I) = d swiglu(YG) applied to dAct = dY W^T, YG / dYG in the interleaved-by-32 layout of
  * cx_gemm_bf16_swiglu; W: (I, K) row-major (the transposed fc2 weight).  dAct is never written to memory.

@@ -29,7 +29,7 @@ def test_header_symbols_exported(built):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_C.EXPORTED_SYMBOLS), declared ^ set(_C.EXPORTED_SYMBOLS)
-    assert lib.cx_abi_version() == 9  # 9: cx_infonce_fwd_argmax; 8: batched cast-transpose; 7: PatchDropout fields; 2: CxChunkBuffers.checkpoint; 3: dropout state + sorted embedding backward; 4: attn_pdrop; 5: layer_events; 6: ckpt_keep
+    assert lib.cx_abi_version() == 10  # 10: cx_gemm_bf16_act_bwd; 9: cx_infonce_fwd_argmax; 8: batched cast-transpose; 7: PatchDropout fields; 2: CxChunkBuffers.checkpoint; 3: dropout state + sorted embedding backward; 4: attn_pdrop; 5: layer_events; 6: ckpt_keep
     assert b"gfx950" in lib.cx_build_info()
     assert lib.cx_error_string(-1) == b"unsupported shape"
     assert lib.cx_infonce_ws_floats(2048, 16384) == 2048 * (2 * 2 * 128 + 1)

@@ -165,7 +165,8 @@ def test_grad_cache_with_dropout_uses_randcontext():
     assert predicted > 0 and abs((l1 - l0) - predicted) < 0.35 * predicted + 2e-3
 
 
-@pytest.mark.parametrize("S,lens", [(128, [128, 77, 128]), (320, [320, 200]), (128, [128, 128, 5, 64, 1, 127]), (64, [64, 33])])
+@pytest.mark.parametrize("S,lens", [(128, [128, 77, 128]), (320, [320, 200]), (128, [128, 128, 5, 64, 1, 127]), (64, [64, 33]),
+                                    (200, [197, 200, 130, 3]), (256, [256, 129, 225])])   # 128 < S <= 256: the single-pass K / V-resident kernels
 def test_attention_dropout_matches_torch_with_the_extracted_mask(S, lens):
     """attn_pdrop > 0 (flash_attn_varlen_qkvpacked_func(dropout_p > 0), sc/layers/attention.py:158-182): O = (P * keep /
     (1 - p)) V, dqkv through the same mask; keep(b, h, q, key) read back with the dev library's mask kernel."""

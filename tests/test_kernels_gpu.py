@@ -472,7 +472,8 @@ def test_attention_fused_long_backward_equals_the_two_kernel_backward(mode, lens
 
 @pytest.mark.parametrize("rotary", [True, False])
 @pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8, [2048, 1531],
-                                  [256, 129, 225, 224, 96, 1]])   # max 256 without rotary: the all-keys-in-LDS forward
+                                  [256, 129, 225, 224, 96, 1],    # 128 < max <= 256: the single-pass K / V-resident kernels (round 6)
+                                  [197, 197, 197, 197, 197], [255, 130, 2, 160, 33, 193]])
 def test_attention_fwd_bwd(rotary, lens):
     H, D = 3, 64
     T, B, mx = sum(lens), len(lens), max(lens)
@@ -693,6 +694,43 @@ def test_gemm_bias_gelu_fused(M, N, K):
     _C.check(L().cx_gemm_bf16_bias_gelu(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, act2.data_ptr(), M, N, K, K, K, N,
                                         N, S()))
     assert torch.equal(act, act2), "no-grad variant (no pre-activation store) must give identical activations"
+
+
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (1000, 512, 256), (257, 96, 64), (300, 3072, 768)])
+def test_gemm_act_bwd_fused_equals_the_two_kernel_backward(M, N, K, act):
+    """fc2 dgrad + GELU / quick_gelu backward + fc1 bias gradient in ONE kernel (round 6, sc/layers/mlp.py:30-34 through FusedMLP):
+    dPre bit-identical to cx_gemm_bf16_nt followed by cx_bias_act_bwd_colsum(bias = NULL); the bias gradient (column sums of the bf16
+    dPre, accumulated INTO dbias) equal to the fp32 sum of that tensor up to summation order; both against an fp32 torch reference."""
+    dy, w = bf(_randn(M, K, seed=170)), bf(_randn(N, K, seed=171, std=0.05))
+    pre = bf(_randn(M, N, seed=172, std=1.5))
+    dact = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    dpre2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    db2 = torch.full((N,), 0.25, device=DEV)
+    _C.check(L().cx_gemm_bf16_nt(dy.data_ptr(), w.data_ptr(), dact.data_ptr(), None, M, N, K, K, K, N, 0, 1, 1.0, S()))
+    _C.check(L().cx_bias_act_bwd_colsum(dact.data_ptr(), pre.data_ptr(), None, dpre2.data_ptr(), db2.data_ptr(), M, N, act, S()))
+    dpre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    db = torch.full((N,), 0.25, device=DEV)
+    nblk = (M + 127) // 128
+    ws = torch.full((nblk * N + 5,), float("nan"), device=DEV)
+    rc = L().cx_gemm_bf16_act_bwd(dy.data_ptr(), w.data_ptr(), pre.data_ptr(), dpre.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  M, N, K, K, K, N, N, act, S())
+    _C.check(rc)
+    assert torch.equal(dpre, dpre2), "fused dPre must be bit-identical to GEMM + standalone activation backward"
+    want_db = 0.25 + dpre2.float().sum(0)
+    assert rel_err(db, want_db) < 1e-5 and rel_err(db2, want_db) < 1e-5
+    # fp32 reference of the op itself
+    x = pre.float().requires_grad_()
+    y = torch.nn.functional.gelu(x) if act == 0 else x * torch.sigmoid(1.702 * x)
+    y.backward(dy.float() @ w.float().T)
+    assert rel_err(dpre.float(), x.grad) < 6e-3
+    # no bias gradient wanted: no workspace needed, same dPre; a workspace that is too small is declined
+    dpre3 = torch.empty_like(dpre)
+    _C.check(L().cx_gemm_bf16_act_bwd(dy.data_ptr(), w.data_ptr(), pre.data_ptr(), dpre3.data_ptr(), None, None, 0, M, N, K, K, K, N, N,
+                                      act, S()))
+    assert torch.equal(dpre3, dpre)
+    assert L().cx_gemm_bf16_act_bwd(dy.data_ptr(), w.data_ptr(), pre.data_ptr(), dpre3.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                    nblk * N - 1, M, N, K, K, K, N, N, act, S()) == _C.CX_ERR_SHAPE
 
 
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (1000, 512, 256), (257, 256, 64)])
