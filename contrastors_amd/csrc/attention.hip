@@ -2677,9 +2677,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
 }
 
 #include "attn_s256.inc"
+#include "attn_long.inc"
 
 #ifndef CX_PRODUCT
 int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
+int g_fwd_long = 1;  // cx_attn_set_fwd_long: 1 = attn_fwd_long_kernel for max_seqlen > 256 without rotate-on-load (default), 0 = attn_fwd_kernel
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
 #endif
 
@@ -2692,6 +2694,7 @@ int g_attn_prio = 0;
 void cx_attn_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
 void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 5) ? mode : 3; }
 void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
+void cx_attn_set_fwd_long(int on) { g_fwd_long = on ? 1 : 0; }
 #endif
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
@@ -2703,6 +2706,11 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     AttnParams p = {};
     p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin; p.lcos = rot_cos; p.lsin = rot_sin; p.out = out; p.lse = lse;
     p.H = H; p.T = T; p.scale = softmax_scale;
+#ifndef CX_PRODUCT
+    const bool fwd_long = g_fwd_long != 0;   // (dev library: cx_attn_set_fwd_long(0) keeps round 1's streaming kernel for A/B)
+#else
+    constexpr bool fwd_long = true;
+#endif
 #ifndef CX_PRODUCT
     if (max_seqlen <= 128 && g_fwd_s128 == 1) {
         const int n_units = B * H;
@@ -2721,6 +2729,8 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
         static CxLdsOptIn lds_f256;
         if (!lds_f256.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<false>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
         hipLaunchKernelGGL(attn_fwd_s256_kernel<false>, dim3(H, B), dim3(256), S256_LDS_FWD, (hipStream_t)stream, p);
+    } else if (!rot_cos && fwd_long) {  // long sequences, q / k already rotated (or no rotary at all): 64 rows per wave, K / V by LDS-DMA (round 6)
+        hipLaunchKernelGGL(attn_fwd_long_kernel<false>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
         hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -2862,6 +2872,10 @@ int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, c
         static CxLdsOptIn lds_f256d;
         if (!lds_f256d.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<true>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
         hipLaunchKernelGGL(attn_fwd_s256_kernel<true>, dim3(H, B), dim3(256), S256_LDS_FWD, (hipStream_t)stream, p);
+        return done();
+    }
+    if (max_seqlen > 256 && !rot_cos && single_pass) {
+        hipLaunchKernelGGL(attn_fwd_long_kernel<true>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
         return done();
     }
     dim3 grid((max_seqlen + 127) / 128, H, B);

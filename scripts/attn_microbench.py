@@ -20,8 +20,11 @@ ap.add_argument("--warm-seconds", type=float, default=0.6, help="back-to-back la
 ap.add_argument("--pdrop", type=float, default=0.0, help="> 0: the attention-dropout entry points (cx_attn_varlen_dropout_fwd / _bwd)")
 ap.add_argument("--fwd-mode", type=int, default=None, help="cx_attn_set_fwd_s128 (dev library); with --pdrop: 0 = general kernel")
 ap.add_argument("--rotary", type=int, default=1, help="0: no rotation tables (image towers; what the engine passes for pre-rotated long sequences)")
+ap.add_argument("--fwd-long", type=int, default=None, help="cx_attn_set_fwd_long (dev library): 0 = round 1's streaming forward for S > 256")
 a = ap.parse_args()
 lib = _C.dev_lib()
+if a.fwd_long is not None:
+    lib.cx_attn_set_fwd_long(a.fwd_long)
 if a.bwd_mode is not None:
     lib.cx_attn_set_bwd_s128(a.bwd_mode)
 if a.fwd_mode is not None:

@@ -730,7 +730,7 @@ def test_gemm_act_bwd_fused_equals_the_two_kernel_backward(M, N, K, act):
                                       act, S()))
     assert torch.equal(dpre3, dpre)
     assert L().cx_gemm_bf16_act_bwd(dy.data_ptr(), w.data_ptr(), pre.data_ptr(), dpre3.data_ptr(), db.data_ptr(), ws.data_ptr(),
-                                    nblk * N - 1, M, N, K, K, K, N, N, act, S()) == _C.CX_ERR_SHAPE
+                                    nblk * N - 1, M, N, K, K, K, N, N, act, S()) == -1   # CX_ERR_SHAPE
 
 
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (1000, 512, 256), (257, 256, 64)])
