@@ -195,6 +195,8 @@ _DEV_SIGS = {
     "cx_attn_set_prio": (None, [i32]),
     "cx_attn_set_fwd_s128": (None, [i32]),
     "cx_attn_set_fwd_long": (None, [i32]),
+    "cx_attn_set_bwd_long": (None, [i32]),
+    "cx_attn_set_bwd_s256": (None, [i32]),
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),

@@ -2681,6 +2681,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
 
 #ifndef CX_PRODUCT
 int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
+int g_bwd_long = 1;  // cx_attn_set_bwd_long: 1 = attn_bwd_dq_long / attn_bwd_dkv_long for max_seqlen > 128 without rotate-on-load (default), 0 = round 1's pair
+int g_bwd_s256 = 0;  // cx_attn_set_bwd_s256: 1 = the fused persistent backward for 128 < max_seqlen <= 256 (A/B: slower than the streaming pair)
 int g_fwd_long = 1;  // cx_attn_set_fwd_long: 1 = attn_fwd_long_kernel for max_seqlen > 256 without rotate-on-load (default), 0 = attn_fwd_kernel
 int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
 #endif
@@ -2695,6 +2697,8 @@ void cx_attn_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
 void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 5) ? mode : 3; }
 void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
 void cx_attn_set_fwd_long(int on) { g_fwd_long = on ? 1 : 0; }
+void cx_attn_set_bwd_long(int on) { g_bwd_long = on ? 1 : 0; }
+void cx_attn_set_bwd_s256(int on) { g_bwd_s256 = on ? 1 : 0; }
 #endif
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
@@ -2752,8 +2756,10 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
 #ifndef CX_PRODUCT
     p.prio = g_attn_prio;
     const int bwd_mode = g_bwd_s128;
+    const bool bwd_long = g_bwd_long != 0, bwd_s256 = g_bwd_s256 != 0;
 #else
     constexpr int bwd_mode = CX_ATTN_BWD_MODE;
+    constexpr bool bwd_long = true, bwd_s256 = false;
 #endif
 #ifndef CX_PRODUCT
     if (max_seqlen <= 128 && bwd_mode == 4) {  // the same with the next problem's loads ahead of the dQ store (A/B; round 4)
@@ -2796,7 +2802,12 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
         return done();
     }
 #endif
-    if (max_seqlen > 128 && max_seqlen <= 256 && bwd_mode) {  // one persistent 8-wave workgroup per CU, K / V resident (round 6: the ViT's 197 tokens)
+    if (max_seqlen > 128 && !p.lcos && bwd_long) {   // second-generation streaming kernels (round 6): no delta pass
+        hipLaunchKernelGGL(attn_bwd_dq_long_kernel<false>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<false>, dim3((max_seqlen + 127) / 128, H, B), dim3(256), LONG_LDS_DKV, (hipStream_t)stream, p);
+        return done();
+    }
+    if (max_seqlen > 128 && max_seqlen <= 256 && bwd_mode && bwd_s256) {  // one persistent 8-wave workgroup per CU, K / V resident (dev A/B: slower, see attn_s256.inc)
         static CxLdsOptIn lds_b256;
         if (!lds_b256.ensure(reinterpret_cast<const void*>(&attn_bwd_s256_kernel<false>), S256_LDS_BWD)) return CX_ERR_LAUNCH;
         const int n_units = B * H;
@@ -2834,6 +2845,16 @@ int cx_attn_varlen_bwd_prerotated(const uint16_t* dout, const uint16_t* qkv_rota
     p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
     p.dout = dout; p.delta = delta; p.dqkv = dqkv;
     p.H = H; p.T = T; p.scale = softmax_scale;
+#ifndef CX_PRODUCT
+    const bool bwd_long = g_bwd_long != 0;
+#else
+    constexpr bool bwd_long = true;
+#endif
+    if (bwd_long) {   // second-generation streaming kernels (round 6): delta inside the dQ kernel
+        hipLaunchKernelGGL(attn_bwd_dq_long_kernel<false>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<false>, dim3((max_seqlen + 127) / 128, H, B), dim3(256), LONG_LDS_DKV, (hipStream_t)stream, p);
+        return done();
+    }
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;
@@ -2899,8 +2920,10 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
     p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
 #ifndef CX_PRODUCT
     const bool fused = g_bwd_s128 != 0;         // (dev library: cx_attn_set_bwd_s128(0) keeps the general kernels for A/B)
+    const bool s256_drop_bwd = g_bwd_s256 != 0;
 #else
     constexpr bool fused = true;
+    constexpr bool s256_drop_bwd = false;
 #endif
     if (max_seqlen <= 128 && fused) {   // fused persistent kernel with the mask (delta inline: `delta` is not written)
         static CxLdsOptIn lds2d;
@@ -2910,7 +2933,12 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
                            (hipStream_t)stream, p, B);
         return done();
     }
-    if (max_seqlen <= 256 && fused) {
+    if (max_seqlen > 128 && !p.lcos && fused) {   // second-generation streaming kernels with the mask (round 6)
+        hipLaunchKernelGGL(attn_bwd_dq_long_kernel<true>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<true>, dim3((max_seqlen + 127) / 128, H, B), dim3(256), LONG_LDS_DKV, (hipStream_t)stream, p);
+        return done();
+    }
+    if (max_seqlen <= 256 && fused && s256_drop_bwd) {
         static CxLdsOptIn lds_b256d;
         if (!lds_b256d.ensure(reinterpret_cast<const void*>(&attn_bwd_s256_kernel<true>), S256_LDS_BWD)) return CX_ERR_LAUNCH;
         const int n_units = B * H;

@@ -450,27 +450,61 @@ def _pool_free_bytes(dev, towers) -> float:
     return float(free)
 
 
-_AGREED_FREE: Dict[int, dict] = {}   # device index -> {"calls", "free"}: the ranks' MIN of _pool_free_bytes (engineering)
+# (device index, world size, id of the default process group) -> {"calls", "since", "free"}: the ranks' MIN of _pool_free_bytes.
+# Keyed by the process group: a number agreed by one group must not survive into another trainer's group, a re-initialised
+# group or a different world size.  reset_agreed_free() drops everything (trainer construction calls it).
+_AGREED_FREE: Dict[tuple, dict] = {}
+AGREED_REFRESH_EVERY = 64   # planner calls between two re-agreements (one scalar all-reduce each)
+
+
+def _agreed_key(dev) -> tuple:
+    grp = getattr(getattr(dist, "group", None), "WORLD", None)
+    return (dev.index if dev.index is not None else -1, dist.get_world_size(), id(grp))
+
+
+def reset_agreed_free() -> None:
+    """Forget every agreed budget: the next planner call of each process group agrees again.  Must be called by ALL ranks at the same
+    point of the program (trainer construction does); never from a rank-local event such as an out-of-memory fallback."""
+    _AGREED_FREE.clear()
+
+
+def note_local_memory_shortfall(dev, towers) -> None:
+    """A planner-approved schedule ran out of memory on THIS rank (another tenant, fragmentation): until the group's next periodic
+    re-agreement this rank plans with what it measures now if that is less -- no collective (the event is rank-local), and no repeat
+    of the failed attempt on every following step (a stale-high agreed number made every step pay the attempt, the
+    fallback's drop_idle_arenas + empty_cache and the two-pass step)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    st = _AGREED_FREE.get(_agreed_key(dev))
+    if st is not None and st["free"] is not None:
+        st["free"] = min(st["free"], _pool_free_bytes(dev, towers))
 
 
 def _agreed_free_bytes(dev, towers, agree: bool = False) -> float:
     """What the memory planners below may spend.  One process: this device's free + pooled bytes, measured now.  Data parallel:
     the MINIMUM of that over the ranks, so that every rank plans the same schedule (all resident / the same kept tail / two
     passes) -- per-rank plans were correct (the collective counts match either way) but made the step time depend on the rank
-    with the least free memory anyway, while the others re-forwarded less for nothing.  The agreement is ONE scalar all-reduce
-    in each of the first two planner calls of a run (the first sees the device before any arena exists), issued from
-    resident_activations_fit -- a call every rank makes every step with rank-invariant conditions in front of it (`agree`);
-    afterwards the agreed number is reused: no per-step collective, no per-step host sync.  A rank whose memory shrinks later
-    (another tenant) is covered by the out-of-memory fallbacks, as before."""
+    with the least free memory anyway, while the others re-forwarded less for nothing.  The agreement is ONE scalar all-reduce,
+    issued only from call sites every rank reaches every step with rank-invariant conditions in front of it (`agree`:
+    resident_activations_fit under policy "auto", resident_tail_plan when nothing has been agreed yet): in the first two such calls
+    of a process group (the first sees the device before any arena exists) and then every AGREED_REFRESH_EVERY-th call -- the
+    schedule is a deterministic function of the call count, so the ranks' collectives always pair up; memory that appears or
+    disappears later (eval buffers, a second tenant, a different model) is seen within that many steps, not never.
+    Between agreements the agreed number is reused: no per-step collective, no per-step host sync.  A rank whose memory shrinks
+    in between is covered by the out-of-memory fallbacks, which also clamp ITS number (note_local_memory_shortfall)."""
     local = _pool_free_bytes(dev, towers)
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return local
-    st = _AGREED_FREE.setdefault(dev.index if dev.index is not None else -1, {"calls": 0, "free": None})
-    if agree and st["calls"] < 2:
-        t = torch.tensor([local], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        st["free"] = float(t.item())
+    st = _AGREED_FREE.setdefault(_agreed_key(dev), {"calls": 0, "since": 0, "free": None})
+    if agree:
+        due = st["calls"] < 2 or st["since"] >= AGREED_REFRESH_EVERY
         st["calls"] += 1
+        st["since"] += 1
+        if due:
+            t = torch.tensor([local], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            st["free"] = float(t.item())
+            st["since"] = 0
     return st["free"] if st["free"] is not None else local
 
 
@@ -504,7 +538,11 @@ def resident_tail_plan(tower1, t1_inputs, cq: int, tower2, t2_inputs, cd: int, p
     if dev is None:
         return 0, 0
     towers = [t for t, sd_ in zip((tower1, tower2), sides) if sd_ is not None]
-    budget = 0.85 * _agreed_free_bytes(dev, towers)   # (data parallel: the ranks' minimum, agreed in resident_activations_fit)
+    # (data parallel: the ranks' minimum, normally agreed in resident_activations_fit one call earlier; a caller that comes here first
+    # -- this function is reached under rank-invariant conditions too -- triggers the first agreement itself)
+    nothing_agreed = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                      and _AGREED_FREE.get(_agreed_key(dev), {}).get("free") is None)
+    budget = 0.85 * _agreed_free_bytes(dev, towers, agree=nothing_agreed)
     biggest = max(sd_[1] * sd_[2] for sd_ in sides if sd_ is not None)
     budget -= 0.09 * biggest + 3e9     # the no-grad arena (one slot instead of L: ~8 % of a saving arena) and the loss buffers
     keep = [0, 0]
@@ -605,6 +643,9 @@ def grad_cache_loss(tower1, t1_inputs, tower2, t2_inputs, chunk_size, logit_scal
                 if drop is not None:
                     drop()
             torch.cuda.empty_cache()
+            ids_ = t1_inputs.get("input_ids") if isinstance(t1_inputs, dict) else None
+            if ids_ is not None and ids_.is_cuda:
+                note_local_memory_shortfall(ids_.device, [tower1, tower2])   # this rank stops re-trying until the next agreement
             _log_once(("gradcache-oom",), "GradCache: resident activations ran out of memory; falling back to the two-pass "
                                           "schedule (set train_args.gradcache_resident: false to skip the attempt)")
         else:

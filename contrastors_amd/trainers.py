@@ -173,6 +173,8 @@ class TextTextTrainer:
             raise NotImplementedError("the native path computes in bf16 with fp32 master weights (--dtype=bf16)")
         self.accum = _accumulation_steps(config.train_args)
         self.config = config
+        from .loss import reset_agreed_free
+        reset_agreed_free()   # every rank builds its trainer at the same point: the memory planner's agreed budget starts over
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1

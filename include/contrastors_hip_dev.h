@@ -62,7 +62,9 @@ void cx_attn_set_prio(int on);         /* experiments: the MFMA loop of the fuse
  * 0 the first one-problem-per-workgroup form (<= 1 bf16 ulp apart), 1 persistent workgroups that prefetch the next
  * problem (bit-identical to 0).  A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
 void cx_attn_set_fwd_s128(int mode);
-void cx_attn_set_fwd_long(int on);   /* 1 (default): attn_fwd_long_kernel for max_seqlen > 256 without rotate-on-load; 0: round 1's attn_fwd_kernel */
+void cx_attn_set_fwd_long(int on);
+void cx_attn_set_bwd_long(int on);   /* 1 (default): attn_bwd_dq_long / _dkv_long for max_seqlen > 128 without rotate-on-load; 0: round 1's three kernels */
+void cx_attn_set_bwd_s256(int on);   /* 1: the fused persistent backward for 128 < max_seqlen <= 256 (A/B only: slower) */   /* 1 (default): attn_fwd_long_kernel for max_seqlen > 256 without rotate-on-load; 0: round 1's attn_fwd_kernel */
 
 /* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */

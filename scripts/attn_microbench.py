@@ -21,8 +21,14 @@ ap.add_argument("--pdrop", type=float, default=0.0, help="> 0: the attention-dro
 ap.add_argument("--fwd-mode", type=int, default=None, help="cx_attn_set_fwd_s128 (dev library); with --pdrop: 0 = general kernel")
 ap.add_argument("--rotary", type=int, default=1, help="0: no rotation tables (image towers; what the engine passes for pre-rotated long sequences)")
 ap.add_argument("--fwd-long", type=int, default=None, help="cx_attn_set_fwd_long (dev library): 0 = round 1's streaming forward for S > 256")
+ap.add_argument("--bwd-long", type=int, default=None, help="cx_attn_set_bwd_long (dev library): 0 = round 1's delta + dQ + dK/dV kernels for S > 128")
+ap.add_argument("--bwd-s256", type=int, default=None, help="cx_attn_set_bwd_s256 (dev library): 1 = the fused persistent backward for 128 < S <= 256 (with --bwd-long 0)")
 a = ap.parse_args()
 lib = _C.dev_lib()
+if a.bwd_long is not None:
+    lib.cx_attn_set_bwd_long(a.bwd_long)
+if a.bwd_s256 is not None:
+    lib.cx_attn_set_bwd_s256(a.bwd_s256)
 if a.fwd_long is not None:
     lib.cx_attn_set_fwd_long(a.fwd_long)
 if a.bwd_mode is not None:
