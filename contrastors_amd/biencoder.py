@@ -189,7 +189,12 @@ class BiEncoder(torch.nn.Module):
                 emb, _ = self.trunk.forward_chunk(vb, False, eng_norm)
         if not plain:
             if self.hamming:  # LayerNorm without affine on the pooled vector (modeling_biencoder.py:282-285,307)
-                emb = F.layer_norm(emb, (emb.shape[-1],))
+                if emb.is_cuda:   # the library's LayerNorm kernel (fp32 in / out, fp32 statistics), not an eager torch op
+                    from .flash_attn_api.ops.layer_norm import layer_norm as _cx_layer_norm
+                    d_ = emb.shape[-1]
+                    emb = _cx_layer_norm(emb, torch.ones(d_, device=emb.device), torch.zeros(d_, device=emb.device), 1e-5)
+                else:
+                    emb = F.layer_norm(emb, (emb.shape[-1],))
             emb = self.proj(emb)
             if binarize:
                 emb = (emb > 0).float()
