@@ -196,14 +196,11 @@ _DEV_SIGS = {
     "cx_attn_set_fwd_s128": (None, [i32]),
     "cx_attn_set_fwd_long": (None, [i32]),
     "cx_attn_set_bwd_long": (None, [i32]),
-    "cx_attn_set_bwd_s256": (None, [i32]),
     "cx_probe_mfma_layout": (i32, [vp, vp]),
     "cx_probe_ds_read_tr16": (i32, [vp, vp, vp]),
     "cx_probe_mfma_rate": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_attn_dropout_keep_mask": (i32, [vp, i32, i32, i32, f32, u64, u64, u32, vp]),
     "cx_probe_rmw": (i32, [vp, i64, i32, i32, i32, vp]),
-    "cx_attn_bwd_fused_long_ws_floats": (i64, [i32, i32, i32]),
-    "cx_attn_varlen_bwd_fused_long": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, u64, u32, vp]),
     "cx_probe_mfma_rate16": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "cx_probe_dma_bw": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
 }

@@ -12,36 +12,11 @@
 // read with the same permutation: rows {4hi..4hi+3, 8+4hi..8+4hi+3} (+16h) of a TRANSPOSED LDS tile
 // (two ds_read_b64).  Transposed tiles are built while staging (pairs of rows packed into 32-bit LDS writes).
 #include "cx_common.h"
-#ifndef CX_ATTN_ROT_AHEAD
-#define CX_ATTN_ROT_AHEAD 1   // store_unrotated_rows: fetch the inverse rotation's cos / sin one column group ahead
-#endif
-#ifndef CX_ATTN_DROP_EARLY
-#define CX_ATTN_DROP_EARLY 1   // fused S <= 128 backward, dropout form: keep decisions drawn ahead of the S / dP products and carried as 16 bits (round 5: 57 -> 40 spilled registers; -7.4 % with rotation tables, -11 % without, -8.7 % at S = 64, bit-identical: profiles/r5_attn_bwd_s128_ab.txt)
-#endif
-#ifndef CX_ATTN_BWD_PF
-#define CX_ATTN_BWD_PF 2   // streaming backward kernels (S > 128): bit 0 dQ kernel / bit 1 the DROPOUT form of the dK-dV kernel prefetch the next 64-row chunk into registers at 2 workgroups per CU (bit 2: the dQ kernel at 2 per CU too).  Shipped: 2 -- the dropout dK-dV form spilled 72 registers at the 168 of three workgroups per CU.  The plain form keeps round 4's shape: with rotation at the loads the prefetch won 1-4.5 %, but the engine never rotates there (S > 128 pre-rotates qkv, BERT / ViT have no table) and WITHOUT rotation it loses 2-7 % (profiles/r5_attn_bwd_streaming_prefetch_ab.txt)
-#endif
-#ifndef CX_ATTN_DELTA_IN
-#define CX_ATTN_DELTA_IN 0  // fused S <= 128 backward reads delta from p.delta instead of loading O (A/B only: nothing writes that delta in the product)
-#endif
-#ifndef CX_ATTN_BWD_MODE
-#define CX_ATTN_BWD_MODE 3  // product: which fused S <= 128 backward cx_attn_varlen_bwd launches (3 serial = shipped; 5 = LDS-DMA prefetch, A/B builds)
-#endif
-#ifndef CX_ATTN_CS_FIRST
-#define CX_ATTN_CS_FIRST 1  // fused S <= 128 backward: the forward rotation's table rows requested before the Q / K / V / dO / O rows (round 5: 890 -> 861 us same-box, bit-identical)
-#endif
-#ifndef CX_ATTN_ROT_PRE
-#define CX_ATTN_ROT_PRE 1   // fused S <= 128 backward: the inverse rotation's table rows fetched once per problem ahead of the store phases (round 5: 924 -> 862 us at T = 262144, same box)
-#endif
-#ifndef CX_ATTN_PF
-#define CX_ATTN_PF 0   // L2 prefetch of the next problem in the fused S <= 128 backward: measured 595 us with, 567 us without at T = 131072
-#endif
 #include "../../include/contrastors_hip.h"
 
 namespace {
 
 constexpr int DH = 64;
-constexpr int TSTRIDE = 136;  // bytes per row of a transposed [64 d][64 idx] tile (+8 B pad: conflict-free b64 reads)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -103,28 +78,6 @@ CX_DEVICE void rotate_loaded(uint4& lo, uint4& hi, int cp, const float* cosv, co
     }
     lo = pack8(o1);
     hi = pack8(o2);
-}
-
-// Write the 8 columns [c8, c8+8) of rows (2*kp, 2*kp+1) into a transposed tile: T[d][idx] at byte d*TSTRIDE+idx*2.
-CX_DEVICE void write_transposed_pair(char* tile, int kp, int c8, const uint4& r0, const uint4& r1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const uint32_t w = (uint32_t)elem16(r0, e) | ((uint32_t)elem16(r1, e) << 16);
-        *reinterpret_cast<uint32_t*>(tile + (c8 + e) * TSTRIDE + kp * 4) = w;
-    }
-}
-
-// A-fragment of a transposed tile for reduction block `blk16` (16 indices): lane (d, hi) gets indices
-// base+{0..3} and base+8+{0..3}, base = blk16*16 + 4*hi  (matches accumulator registers 8h..8h+7, see header).
-CX_DEVICE bf16x8_t read_transposed_frag(const char* tile, int d, int blk16, int hi) {
-    const char* p = tile + d * TSTRIDE + (blk16 * 16 + 4 * hi) * 2;
-    union {
-        uint2 u[2];
-        bf16x8_t v;
-    } x;
-    x.u[0] = *reinterpret_cast<const uint2*>(p);
-    x.u[1] = *reinterpret_cast<const uint2*>(p + 16);
-    return x.v;
 }
 
 // accumulator registers 8*half .. 8*half+7 -> bf16 B fragment
@@ -423,7 +376,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 // BERT-style contrastive batches (seq_len 128, the BASELINE metric) fit a whole (sequence, head) problem in one
 // workgroup: Q, K and V^T (128 keys) live in LDS at once.  All global loads are issued up front (one memory latency
 // instead of three), there is one barrier, and softmax is single-pass (no online rescale).
-constexpr int VT128_STRIDE = 264;  // bytes per d-row of the [64 d][128 keys] transposed V tile (+8 B pad)
 
 CX_DEVICE void rot8(const uint4& lo_in, const uint4& hi_in, const float4 (&c)[2], const float4 (&s)[2], uint4& lo,
                     uint4& hi) {
@@ -441,313 +393,8 @@ CX_DEVICE void rot8(const uint4& lo_in, const uint4& hi_in, const float4 (&c)[2]
     hi = pack8(o2);
 }
 
-CX_DEVICE bf16x8_t read_vt128_frag(const char* tile, int d, int blk16, int hi) {
-    const char* p = tile + d * VT128_STRIDE + (blk16 * 16 + 4 * hi) * 2;
-    union { uint2 u[2]; bf16x8_t v; } x;
-    x.u[0] = *reinterpret_cast<const uint2*>(p);
-    x.u[1] = *reinterpret_cast<const uint2*>(p + 16);
-    return x.v;
-}
 
-#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
-__global__ __launch_bounds__(256, 2) void attn_fwd_s128_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[16384 + 16384 + 64 * VT128_STRIDE];
-    char* Qs = smem;
-    char* Ks = smem + 16384;
-    char* Vt = smem + 32768;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-    if (len <= 0) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
 
-    // ---- every global load first ----------------------------------------------------------------------------
-    uint4 qlo[2], qhi[2], klo[2], khi[2], v0[2], v1[2];
-    float4 cs[2][2], sn[2][2];
-    const int cp = tid & 3;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        int r = it * 64 + (tid >> 2);
-        r = r < len ? r : len - 1;
-        const bf16_t* qrow = qbase + (size_t)(t0 + r) * tok_stride;
-        const bf16_t* krow = kbase + (size_t)(t0 + r) * tok_stride;
-        qlo[it] = *reinterpret_cast<const uint4*>(qrow + cp * 8);
-        qhi[it] = *reinterpret_cast<const uint4*>(qrow + 32 + cp * 8);
-        klo[it] = *reinterpret_cast<const uint4*>(krow + cp * 8);
-        khi[it] = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
-        if (p.cosv) {
-            const float* c = p.cosv + (size_t)r * 32 + cp * 8;
-            const float* s = p.sinv + (size_t)r * 32 + cp * 8;
-            cs[it][0] = *reinterpret_cast<const float4*>(c);
-            cs[it][1] = *reinterpret_cast<const float4*>(c + 4);
-            sn[it][0] = *reinterpret_cast<const float4*>(s);
-            sn[it][1] = *reinterpret_cast<const float4*>(s + 4);
-        }
-        int ka = it * 64 + 2 * (tid >> 3), kb2 = ka + 1;
-        ka = ka < len ? ka : len - 1;
-        kb2 = kb2 < len ? kb2 : len - 1;
-        v0[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + ka) * tok_stride + (tid & 7) * 8);
-        v1[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + kb2) * tok_stride + (tid & 7) * 8);
-    }
-    // ---- rotate, stage ---------------------------------------------------------------------------------------
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int r = it * 64 + (tid >> 2);
-        uint4 a_lo = qlo[it], a_hi = qhi[it], b_lo = klo[it], b_hi = khi[it];
-        if (p.cosv) {
-            rot8(qlo[it], qhi[it], cs[it], sn[it], a_lo, a_hi);
-            rot8(klo[it], khi[it], cs[it], sn[it], b_lo, b_hi);
-        }
-        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = a_lo;
-        *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = a_hi;
-        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = b_lo;
-        *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = b_hi;
-        const int kp = it * 32 + (tid >> 3), c8 = (tid & 7) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t w = (uint32_t)elem16(v0[it], e) | ((uint32_t)elem16(v1[it], e) << 16);
-            *reinterpret_cast<uint32_t*>(Vt + (c8 + e) * VT128_STRIDE + kp * 4) = w;
-        }
-    }
-    __syncthreads();
-
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
-    const float sc2 = p.scale * LOG2E;
-    float s[4][16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        f32x16_t a;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + acc_row(r, hi);
-            s[kb][r] = key < len ? a[r] * sc2 : -INFINITY;
-            mx = fmaxf(mx, s[kb][r]);
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[kb][r] = fast_exp2(s[kb][r] - mx);
-            psum += s[kb][r];
-        }
-    f32x16_t acc_o[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bf16x8_t pf = pack_frag(s[kb], half);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-                acc_o[db] = mfma_bf16_32x32x16(read_vt128_frag(Vt, db * 32 + l31, kb * 2 + half, hi), pf, acc_o[db]);
-        }
-    const float l_tot = psum + __shfl_xor(psum, 32, 64);
-    const float inv = 1.f / l_tot;
-    const int q = wave * 32 + l31;
-    if (q < len) {
-        bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 pk;
-                pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
-                pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
-            }
-        if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mx + log2f(l_tot)) * LN2;
-    }
-}
-#endif  // !CX_PRODUCT
-
-// Persistent form of attn_fwd_s128_kernel (A/B switch cx_attn_set_fwd_s128(1), not the default): a workgroup walks
-// (sequence, head) problems with stride gridDim.x and issues the NEXT problem's global loads right after staging the
-// current one, so they fly under its MFMA / softmax / stores; the rotary tables depend only on the row a thread
-// stages, so they are loaded once.  Measured 188-215 us vs 194-204 us for the one-shot form at T = 131072: hiding the
-// load latency buys nothing, the kernel is bound by its VALU work (rotary, exp2, masking, V transpose: ~5 k VALU
-// cycles per problem and SIMD against ~1 k MFMA cycles), not by bytes in flight.
-struct Fwd128Raw {
-    uint4 qlo[2], qhi[2], klo[2], khi[2], v0[2], v1[2];
-};
-
-CX_DEVICE void fwd128_issue(const AttnParams& p, int h, int t0, int len, int tid, Fwd128Raw& w) {
-    const size_t tok_stride = (size_t)3 * p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
-    const int cp = tid & 3;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        int r = it * 64 + (tid >> 2);
-        r = r < len ? r : len - 1;
-        const bf16_t* qrow = qbase + (size_t)(t0 + r) * tok_stride;
-        const bf16_t* krow = kbase + (size_t)(t0 + r) * tok_stride;
-        w.qlo[it] = *reinterpret_cast<const uint4*>(qrow + cp * 8);
-        w.qhi[it] = *reinterpret_cast<const uint4*>(qrow + 32 + cp * 8);
-        w.klo[it] = *reinterpret_cast<const uint4*>(krow + cp * 8);
-        w.khi[it] = *reinterpret_cast<const uint4*>(krow + 32 + cp * 8);
-        int ka = it * 64 + 2 * (tid >> 3), kb2 = ka + 1;
-        ka = ka < len ? ka : len - 1;
-        kb2 = kb2 < len ? kb2 : len - 1;
-        w.v0[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + ka) * tok_stride + (tid & 7) * 8);
-        w.v1[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0 + kb2) * tok_stride + (tid & 7) * 8);
-    }
-}
-
-#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
-__global__ __launch_bounds__(256, 2) void attn_fwd_s128p_kernel(AttnParams p, int B, int max_seqlen) {
-    __shared__ __attribute__((aligned(16))) char smem[16384 + 16384 + 64 * VT128_STRIDE];
-    char* Qs = smem;
-    char* Ks = smem + 16384;
-    char* Vt = smem + 32768;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int cp = tid & 3;
-    const int n_units = B * p.H;
-    // rotary rows of the two token rows this thread stages; rows >= len are staged but never used, so clamping the
-    // table row to max_seqlen - 1 (the table is at least that long) changes nothing that is read
-    float4 cs[2][2], sn[2][2];
-    if (p.cosv) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            int r = it * 64 + (tid >> 2);
-            r = r < max_seqlen ? r : max_seqlen - 1;
-            const float* c = p.cosv + (size_t)r * 32 + cp * 8;
-            const float* sp = p.sinv + (size_t)r * 32 + cp * 8;
-            cs[it][0] = *reinterpret_cast<const float4*>(c);
-            cs[it][1] = *reinterpret_cast<const float4*>(c + 4);
-            sn[it][0] = *reinterpret_cast<const float4*>(sp);
-            sn[it][1] = *reinterpret_cast<const float4*>(sp + 4);
-        }
-    }
-    int unit = blockIdx.x;
-    int t0 = 0, len = 0;
-    Fwd128Raw w;
-    while (unit < n_units) {  // first problem with tokens
-        const int b = unit / p.H;
-        t0 = p.cu[b];
-        len = p.cu[b + 1] - t0;
-        if (len > 0) break;
-        unit += gridDim.x;
-    }
-    if (unit >= n_units) return;
-    fwd128_issue(p, unit % p.H, t0, len, tid, w);
-    const float sc2 = p.scale * LOG2E;
-    while (true) {
-        const int h = unit % p.H;
-        // ---- rotate, stage -----------------------------------------------------------------------------------
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int r = it * 64 + (tid >> 2);
-            uint4 a_lo = w.qlo[it], a_hi = w.qhi[it], b_lo = w.klo[it], b_hi = w.khi[it];
-            if (p.cosv) {
-                rot8(w.qlo[it], w.qhi[it], cs[it], sn[it], a_lo, a_hi);
-                rot8(w.klo[it], w.khi[it], cs[it], sn[it], b_lo, b_hi);
-            }
-            *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp)) = a_lo;
-            *reinterpret_cast<uint4*>(Qs + tile64_off(r, cp + 4)) = a_hi;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = b_lo;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = b_hi;
-            const int kp = it * 32 + (tid >> 3), c8 = (tid & 7) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t ww = (uint32_t)elem16(w.v0[it], e) | ((uint32_t)elem16(w.v1[it], e) << 16);
-                *reinterpret_cast<uint32_t*>(Vt + (c8 + e) * VT128_STRIDE + kp * 4) = ww;
-            }
-        }
-        __syncthreads();
-        // ---- next problem's loads, under this problem's compute ----------------------------------------------------
-        int nunit = unit + gridDim.x, nt0 = 0, nlen = 0;
-        while (nunit < n_units) {
-            const int nb = nunit / p.H;
-            nt0 = p.cu[nb];
-            nlen = p.cu[nb + 1] - nt0;
-            if (nlen > 0) break;
-            nunit += gridDim.x;
-        }
-        if (nunit < n_units) fwd128_issue(p, nunit % p.H, nt0, nlen, tid, w);
-        // ---- S^T = K Q^T, softmax over the lane-resident row, O = P V -----------------------------------------------
-        bf16x8_t qf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_frag(Qs, tile64_off(wave * 32 + l31, ks * 2 + hi));
-        float s[4][16];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f32x16_t a;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                a = mfma_bf16_32x32x16(lds_read_frag(Ks, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * 32 + acc_row(r, hi);
-                s[kb][r] = key < len ? a[r] * sc2 : -INFINITY;
-                mx = fmaxf(mx, s[kb][r]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[kb][r] = fast_exp2(s[kb][r] - mx);
-                psum += s[kb][r];
-            }
-        f32x16_t acc_o[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const bf16x8_t pf = pack_frag(s[kb], half);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    acc_o[db] = mfma_bf16_32x32x16(read_vt128_frag(Vt, db * 32 + l31, kb * 2 + half, hi), pf, acc_o[db]);
-            }
-        const float l_tot = psum + __shfl_xor(psum, 32, 64);
-        const float inv = 1.f / l_tot;
-        const int q = wave * 32 + l31;
-        if (q < len) {
-            bf16_t* orow = p.out + ((size_t)(t0 + q) * p.H + h) * DH;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(acc_o[db][4 * qd] * inv, acc_o[db][4 * qd + 1] * inv);
-                    pk.y = pack_bf16x2(acc_o[db][4 * qd + 2] * inv, acc_o[db][4 * qd + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + db * 32 + 8 * qd + 4 * hi) = pk;
-                }
-            if (hi == 0) p.lse[(size_t)h * p.T + t0 + q] = (mx + log2f(l_tot)) * LN2;
-        }
-        if (nunit >= n_units) break;
-        unit = nunit; t0 = nt0; len = nlen;
-        __syncthreads();  // every wave is done with this problem's LDS tiles before they are restaged
-    }
-}
-#endif  // !CX_PRODUCT
 
 // ------------------------------------------------------------------------------------- delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
@@ -813,7 +460,6 @@ CX_DEVICE void store_unrotated(bf16_t* row, const f32x16_t (&acc)[2], float scal
 CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, int rows_valid, const f32x16_t (&acc)[2],
                                     float scale, const float* cosv, const float* sinv, int pos, int hi, int lane) {
     const int l31 = lane & 31;
-#if CX_ATTN_ROT_AHEAD
     // the table rows are fetched ONE column group ahead of their use (8 more registers): the four global round trips of
     // the first version were serialised, each behind whatever stores the wave had just issued (one in-order vmcnt) --
     // phase timers put the dK / dV store phase of the fused S <= 128 backward at 10.9 k of its 44.5 k cycles per problem
@@ -822,7 +468,6 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
         cn = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + 4 * hi);
         sn = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + 4 * hi);
     }
-#endif
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
         const int d = 8 * qd + 4 * hi;
@@ -833,16 +478,11 @@ CX_DEVICE void store_unrotated_rows(char* stage, bf16_t* g0, size_t row_stride, 
             hh[e] = acc[1][4 * qd + e] * scale;
         }
         if (cosv) {
-#if CX_ATTN_ROT_AHEAD
             const float4 c = cn, s = sn;
             if (qd < 3) {
                 cn = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + d + 8);
                 sn = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + d + 8);
             }
-#else
-            const float4 c = *reinterpret_cast<const float4*>(cosv + (size_t)pos * 32 + d);
-            const float4 s = *reinterpret_cast<const float4*>(sinv + (size_t)pos * 32 + d);
-#endif
             const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -925,7 +565,7 @@ CX_DEVICE void store_unrotated_rows_pre(char* stage, bf16_t* g0, size_t row_stri
 // switch the NEXT chunk's rows are requested right after the barrier that publishes the current chunk and wait in 16 registers through
 // the compute (the forward kernel has done this since round 2); the register budget goes from 168 (3 workgroups per CU) to 256 (2).
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 4) ? 2 : 3) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     // Qs/dOs are only needed to build the loop-invariant register fragments; the K / V tiles alias them.
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -982,56 +622,7 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 4) ? 2 : 3) void attn_bwd_dq
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
 
-#if CX_ATTN_BWD_PF & 1
-    // raw rows of a chunk: waves 0-1 a K row pair (chunks cp, cp + 4 of both rows), waves 2-3 four V row pieces
-    uint4 pf0, pf1, pf2, pf3;
-    auto issue_chunk = [&](int kv0) {
-        if (wave < 2) {
-            const int kp = tid >> 2, cp = tid & 3;
-            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
-            k0i = k0i < lenk ? k0i : lenk - 1;
-            k1i = k1i < lenk ? k1i : lenk - 1;
-            const bf16_t* ra = kbase + (size_t)(t0k + k0i) * kv_stride;
-            const bf16_t* rb = kbase + (size_t)(t0k + k1i) * kv_stride;
-            pf0 = *reinterpret_cast<const uint4*>(ra + cp * 8);
-            pf1 = *reinterpret_cast<const uint4*>(ra + 32 + cp * 8);
-            pf2 = *reinterpret_cast<const uint4*>(rb + cp * 8);
-            pf3 = *reinterpret_cast<const uint4*>(rb + 32 + cp * 8);
-        } else {
-            const int t2 = tid - 128, c = t2 & 7;
-            int r0 = kv0 + (t2 >> 3), r1 = r0 + 16, r2 = r0 + 32, r3 = r0 + 48;
-            r0 = r0 < lenk ? r0 : lenk - 1; r1 = r1 < lenk ? r1 : lenk - 1; r2 = r2 < lenk ? r2 : lenk - 1; r3 = r3 < lenk ? r3 : lenk - 1;
-            pf0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r0) * kv_stride + c * 8);
-            pf1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r1) * kv_stride + c * 8);
-            pf2 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r2) * kv_stride + c * 8);
-            pf3 = *reinterpret_cast<const uint4*>(vbase + (size_t)(t0k + r3) * kv_stride + c * 8);
-        }
-    };
-    if (lenk > 0) issue_chunk(0);
-#endif
     for (int kv0 = 0; kv0 < lenk; kv0 += 64) {
-#if CX_ATTN_BWD_PF & 1
-        if (wave < 2) {
-            const int kp = tid >> 2, cp = tid & 3;
-            int k0i = kv0 + 2 * kp, k1i = k0i + 1;
-            k0i = k0i < lenk ? k0i : lenk - 1;
-            k1i = k1i < lenk ? k1i : lenk - 1;
-            rotate_loaded(pf0, pf1, cp, p.lcos, p.lsin, k0i);
-            rotate_loaded(pf2, pf3, cp, p.lcos, p.lsin, k1i);
-            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp)) = pf0;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp, cp + 4)) = pf1;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp)) = pf2;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(2 * kp + 1, cp + 4)) = pf3;
-        } else {
-            const int t2 = tid - 128, r = t2 >> 3, c = t2 & 7;
-            *reinterpret_cast<uint4*>(Vs + tile64_off(r, c)) = pf0;
-            *reinterpret_cast<uint4*>(Vs + tile64_off(r + 16, c)) = pf1;
-            *reinterpret_cast<uint4*>(Vs + tile64_off(r + 32, c)) = pf2;
-            *reinterpret_cast<uint4*>(Vs + tile64_off(r + 48, c)) = pf3;
-        }
-        __syncthreads();
-        if (kv0 + 64 < lenk) issue_chunk(kv0 + 64);   // in flight through this chunk's compute
-#else
         if (wave < 2) {  // K: rotated, row-major (its transpose for dQ comes from tile64_tr_frag).  item = (key pair, chunk pair)
             const int kp = tid >> 2, cp = tid & 3;
             int k0i = kv0 + 2 * kp, k1i = k0i + 1;
@@ -1056,7 +647,6 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 4) ? 2 : 3) void attn_bwd_dq
             }
         }
         __syncthreads();
-#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t a_s, a_dp;
@@ -1106,7 +696,7 @@ __global__ __launch_bounds__(256, (CX_ATTN_BWD_PF & 4) ? 2 : 3) void attn_bwd_dq
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
 template <bool X, bool DROP = false>
-__global__ __launch_bounds__(256, (DROP && (CX_ATTN_BWD_PF & 2)) ? 2 : 3) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, DROP ? 2 : 3) void attn_bwd_dkv_kernel(AttnParams p) {
     // prologue: K,V tiles [128][64] (2 x 16 KiB); loop: Qs 8K | dOs 8K | lse[64] | delta[64]
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -1165,7 +755,7 @@ __global__ __launch_bounds__(256, (DROP && (CX_ATTN_BWD_PF & 2)) ? 2 : 3) void a
         for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
 
     // DKV_PF: see CX_ATTN_BWD_PF at the top of the file -- the dropout instantiation only
-    constexpr bool DKV_PF = DROP && (CX_ATTN_BWD_PF & 2) != 0;
+    constexpr bool DKV_PF = DROP;
     // raw rows of a chunk: waves 0-1 a Q row pair, waves 2-3 a dO row pair (chunks cp, cp + 4 of both rows); threads 0-63 lse, delta
     uint4 pf0 = {}, pf1 = {}, pf2 = {}, pf3 = {};
     float pf_lse = 0.f, pf_dl = 0.f;
@@ -1313,238 +903,6 @@ __global__ __launch_bounds__(256, (DROP && (CX_ATTN_BWD_PF & 2)) ? 2 : 3) void a
     }
 }
 
-// ------------------------------------------------------------------------------- fused long-sequence backward (round 5)
-// ONE workgroup owns a whole (sequence, head) problem.  Outer loop over 128-key blocks with dK / dV in registers
-// (the dK / dV kernel above, same arithmetic in the same order: dK and dV come out bit-identical), inner loop over 64-query chunks;
-// S, dP and the softmax are recomputed ONCE per (key block, chunk) instead of once in each of two kernels, and the chunk's dQ
-// contribution  dQ^T[d][q] = sum_key K^T[d][key] dS[q][key]  (5 products instead of 7) is added into an fp32 scratch that only this
-// workgroup touches: single owner, fixed order, bit-reproducible.  dS goes through LDS once, as a [128 key][64 q] bf16 tile each wave
-// writes its 32 key rows of; both operands of the dQ product are transposing reads (K tile, dS tile).  The scratch is in the layout the
-// accumulators have (a wave's store is 1 KiB contiguous): chunk block [4 waves][4 qd][64 lanes] float4, element (q, d) of a chunk at
-// wave (q >> 5) * 2 + (d >> 5), lane ((d >> 2) & 1) * 32 + (q & 31), qd (d >> 3) & 3, e = d & 3; sequence b's rows start at
-// t0 + 64 b (a last partial chunk then never reaches the next sequence).  attn_dq_finish_kernel scales, un-rotates and writes bf16.
-// LDS: K 16 K (whole key block) | V, then dS 16 K | Q 8 K | dO 8 K | lse, delta 512 B = 49664 B.
-#ifndef CX_ATTN_FL_WGS
-#define CX_ATTN_FL_WGS 3
-#endif
-#ifndef CX_ATTN_FL_DBG
-#define CX_ATTN_FL_DBG 0   // ablation builds (wrong results): 1 no scratch traffic (the dQ product stays), 2 no dQ product / dS tile either, 4 scratch written, never read (no add)
-#endif
-#ifndef CX_PRODUCT  // A/B-only kernels: dev library (include/contrastors_hip_dev.h)
-template <bool DROP>
-__global__ __launch_bounds__(256, CX_ATTN_FL_WGS) void attn_bwd_fused_long_kernel(AttnParams p, float* ws, int B) {
-    __shared__ __attribute__((aligned(16))) char smem[49664];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const AttnView w = attn_view<false>(p, h, b);
-    const int t0 = w.t0q, len = w.lenq;
-    if (len <= 0) return;
-    const size_t tok_stride = w.qs;
-    const size_t o_stride = (size_t)p.H * DH;
-    const bf16_t* dobase = p.dout + (size_t)h * DH;
-    char* Ks = smem;
-    char* Vs = smem + 16384;
-    char* dSs = smem + 16384;
-    char* Qs = smem + 32768;
-    char* dOs = smem + 40960;
-    float* lse_s = reinterpret_cast<float*>(smem + 49152);
-    float* dl_s = lse_s + 64;
-    const float sc2 = p.scale * LOG2E;
-    // this problem's scratch rows: (h, t0 + 64 b + q), 64 floats each
-    float* ws_p = ws + ((size_t)h * ((size_t)p.T + 64 * (size_t)B) + (size_t)t0 + 64 * (size_t)b) * 64;
-
-    for (int k0 = 0; k0 < len; k0 += 128) {
-#pragma unroll
-        for (int pss = 0; pss < 2; ++pss) {
-            const int r = pss * 64 + (tid >> 2), cp = tid & 3;
-            int tk = k0 + r;
-            tk = tk < len ? tk : len - 1;
-            uint4 lo, hi4;
-            load_row_pair(w.k + (size_t)(t0 + tk) * tok_stride, cp, p.lcos, p.lsin, tk, lo, hi4);
-            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp)) = lo;
-            *reinterpret_cast<uint4*>(Ks + tile64_off(r, cp + 4)) = hi4;
-            load_row_pair(w.v + (size_t)(t0 + tk) * tok_stride, cp, nullptr, nullptr, 0, lo, hi4);
-            *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp)) = lo;
-            *reinterpret_cast<uint4*>(Vs + tile64_off(r, cp + 4)) = hi4;
-        }
-        __syncthreads();
-        bf16x8_t kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = lds_read_frag(Ks, tile64_off(wave * 32 + l31, ks * 2 + hi));
-            vf[ks] = lds_read_frag(Vs, tile64_off(wave * 32 + l31, ks * 2 + hi));
-        }
-        // (the V tile becomes the dS tile: its first write comes after the first chunk's staging barrier)
-        const int key = k0 + wave * 32 + l31;
-        const bool key_ok = key < len;
-        const bool keys_full = k0 + 128 <= len;
-        f32x16_t acc_dk[2], acc_dv[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
-
-        for (int q0 = 0; q0 < len; q0 += 64) {
-            if (wave < 2) {  // Q (rotated at the load when tables are given), row-major; item = (row pair, chunk pair)
-                const int rp = tid >> 2, cp = tid & 3;
-                int r0i = q0 + 2 * rp, r1i = r0i + 1;
-                r0i = r0i < len ? r0i : len - 1;
-                r1i = r1i < len ? r1i : len - 1;
-                uint4 a_lo, a_hi, b_lo, b_hi;
-                load_row_pair(w.q + (size_t)(t0 + r0i) * tok_stride, cp, p.lcos, p.lsin, r0i, a_lo, a_hi);
-                load_row_pair(w.q + (size_t)(t0 + r1i) * tok_stride, cp, p.lcos, p.lsin, r1i, b_lo, b_hi);
-                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp)) = a_lo;
-                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp, cp + 4)) = a_hi;
-                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp)) = b_lo;
-                *reinterpret_cast<uint4*>(Qs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
-            } else {  // dO
-                const int t2 = tid - 128;
-                const int rp = t2 >> 2, cp = t2 & 3;
-                int r0i = q0 + 2 * rp, r1i = r0i + 1;
-                r0i = r0i < len ? r0i : len - 1;
-                r1i = r1i < len ? r1i : len - 1;
-                uint4 a_lo, a_hi, b_lo, b_hi;
-                load_row_pair(dobase + (size_t)(t0 + r0i) * o_stride, cp, nullptr, nullptr, 0, a_lo, a_hi);
-                load_row_pair(dobase + (size_t)(t0 + r1i) * o_stride, cp, nullptr, nullptr, 0, b_lo, b_hi);
-                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp)) = a_lo;
-                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp, cp + 4)) = a_hi;
-                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp)) = b_lo;
-                *reinterpret_cast<uint4*>(dOs + tile64_off(2 * rp + 1, cp + 4)) = b_hi;
-            }
-            if (tid < 64) {
-                int r = q0 + tid;
-                const bool ok = r < len;
-                r = ok ? r : len - 1;
-                lse_s[tid] = ok ? p.lse[(size_t)h * p.T + t0 + r] * LOG2E : INFINITY;   // rows past the end: P = exp2(-inf) = 0
-                dl_s[tid] = p.delta[(size_t)h * p.T + t0 + r];
-            }
-            // staging visible; every wave is past the previous chunk's dQ product (reads of the dS tile) and, in the first chunk, past
-            // its V fragment reads
-            __syncthreads();
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16_t a_s, a_dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    a_s = mfma_bf16_32x32x16(lds_read_frag(Qs, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
-                    a_dp = mfma_bf16_32x32x16(lds_read_frag(dOs, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
-                }
-                float pr[16], ds[16];
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int row = qb * 32 + 8 * qd + 4 * hi;
-                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + row);
-                    const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
-                    const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-                    float kq[4] = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (DROP) quad_keep4(p, (uint32_t)(b * p.H + h), q0 + row, key, lane, kq);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * qd + e;
-                        const float pe = fast_exp2(__builtin_fmaf(a_s[r], sc2, -ll[e]));
-                        const float pv = (keys_full || key_ok) ? pe : 0.f;
-                        if constexpr (DROP) {
-                            const float kp = kq[e];
-                            pr[r] = pv * kp;
-                            ds[r] = pv * (a_dp[r] * kp - dd[e]);
-                        } else {
-                            pr[r] = pv;
-                            ds[r] = pv * (a_dp[r] - dd[e]);
-                        }
-                    }
-                    // this lane's key row of the dS tile, queries qb*32 + 8 qd + 4 hi + {0..3}: 8 bytes of 16-byte chunk qb*4 + qd
-                    uint2 dpk;
-                    dpk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
-                    dpk.y = pack_bf16x2(ds[4 * qd + 2], ds[4 * qd + 3]);
-                    if constexpr ((CX_ATTN_FL_DBG & 2) == 0) *reinterpret_cast<uint2*>(dSs + tile64_off(wave * 32 + l31, qb * 4 + qd) + hi * 8) = dpk;
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        acc_dv[db] = mfma_bf16_32x32x16(tile64_tr_frag(dOs, db * 32, qb * 32 + half * 16, lane), pf, acc_dv[db]);
-                        acc_dk[db] = mfma_bf16_32x32x16(tile64_tr_frag(Qs, db * 32, qb * 32 + half * 16, lane), dsf, acc_dk[db]);
-                    }
-                }
-            }
-            __syncthreads();   // the dS tile is complete; nobody reads Qs / dOs any more (the next chunk's staging may overwrite them)
-            if constexpr ((CX_ATTN_FL_DBG & 2) == 0) {
-                // dQ^T block (d block = wave & 1, query block = wave >> 1) of this chunk from the 128 keys of the block
-                f32x16_t aq;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) aq[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    aq = mfma_bf16_32x32x16(tile64_tr_frag(Ks, (wave & 1) * 32, ks * 16, lane), tile64_tr_frag(dSs, (wave >> 1) * 32, ks * 16, lane), aq);
-                float4* wp = reinterpret_cast<float4*>(ws_p + (size_t)q0 * 64) + wave * 256 + lane;
-                if constexpr ((CX_ATTN_FL_DBG & 1) != 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(aq[r]));
-                } else if ((CX_ATTN_FL_DBG & 4) != 0 || k0 == 0) {
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) wp[qd * 64] = make_float4(aq[4 * qd], aq[4 * qd + 1], aq[4 * qd + 2], aq[4 * qd + 3]);
-                } else {
-                    float4 old[4];
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) old[qd] = wp[qd * 64];
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd)
-                        wp[qd * 64] = make_float4(old[qd].x + aq[4 * qd], old[qd].y + aq[4 * qd + 1], old[qd].z + aq[4 * qd + 2], old[qd].w + aq[4 * qd + 3]);
-                }
-            }
-        }
-        __syncthreads();   // every wave is past its last dQ product: the K and dS tiles become the stores' staging rows
-        {
-            bf16_t* kr0 = p.dqkv + (size_t)(p.H + h) * DH + (size_t)(t0 + k0 + wave * 32) * tok_stride;
-            const int valid = len - (k0 + wave * 32);
-            store_unrotated_rows(smem + wave * 4096, kr0, tok_stride, valid, acc_dk, p.scale, p.cosv, p.sinv, key_ok ? key : len - 1, hi, lane);
-            store_unrotated_rows(smem + 16384 + wave * 4096, kr0 + (size_t)p.H * DH, tok_stride, valid, acc_dv, 1.f, nullptr, nullptr, 0, hi, lane);
-        }
-        __syncthreads();   // the staging rows are free again before the next key block's K / V are staged
-    }
-}
-
-// dQ of the fused long-sequence backward: scratch (fp32, the accumulators' layout) -> scaled, un-rotated bf16 rows of dqkv.
-// One workgroup per (64-query chunk, head, sequence); thread (row = tid >> 2, cp = tid & 3) owns d = 8 cp .. 8 cp + 7 and 32 + the same.
-__global__ __launch_bounds__(256) void attn_dq_finish_kernel(AttnParams p, const float* ws, int B) {
-    const int tid = threadIdx.x;
-    const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-    if (q0 >= len) return;
-    const int ql = tid >> 2, cp = tid & 3, q = q0 + ql;
-    if (q >= len) return;
-    const float4* blk = reinterpret_cast<const float4*>(ws + ((size_t)h * ((size_t)p.T + 64 * (size_t)B) + (size_t)t0 + 64 * (size_t)b + q0) * 64);
-    const int w0 = (ql >> 5) * 2;
-    float lo[8], hh[8];
-    {
-        const float4 a = blk[((w0 * 4 + cp) * 64) + (ql & 31)], c = blk[((w0 * 4 + cp) * 64) + 32 + (ql & 31)];
-        const float4 e = blk[(((w0 + 1) * 4 + cp) * 64) + (ql & 31)], g = blk[(((w0 + 1) * 4 + cp) * 64) + 32 + (ql & 31)];
-        lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w; lo[4] = c.x; lo[5] = c.y; lo[6] = c.z; lo[7] = c.w;
-        hh[0] = e.x; hh[1] = e.y; hh[2] = e.z; hh[3] = e.w; hh[4] = g.x; hh[5] = g.y; hh[6] = g.z; hh[7] = g.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { lo[j] *= p.scale; hh[j] *= p.scale; }
-    if (p.cosv) {
-        float cc[8], ss[8];
-        *reinterpret_cast<float4*>(cc) = *reinterpret_cast<const float4*>(p.cosv + (size_t)q * 32 + cp * 8);
-        *reinterpret_cast<float4*>(cc + 4) = *reinterpret_cast<const float4*>(p.cosv + (size_t)q * 32 + cp * 8 + 4);
-        *reinterpret_cast<float4*>(ss) = *reinterpret_cast<const float4*>(p.sinv + (size_t)q * 32 + cp * 8);
-        *reinterpret_cast<float4*>(ss + 4) = *reinterpret_cast<const float4*>(p.sinv + (size_t)q * 32 + cp * 8 + 4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float gl = lo[j], gh = hh[j];
-            lo[j] = gl * cc[j] + gh * ss[j];
-            hh[j] = gh * cc[j] - gl * ss[j];
-        }
-    }
-    bf16_t* row = p.dqkv + (size_t)(t0 + q) * (3 * (size_t)p.H * DH) + (size_t)h * DH;
-    *reinterpret_cast<uint4*>(row + cp * 8) = pack8(lo);
-    *reinterpret_cast<uint4*>(row + 32 + cp * 8) = pack8(hh);
-}
-#endif  // !CX_PRODUCT
 
 // ------------------------------------------------------------------------------- backward, sequences <= 128
 // Same idea as attn_fwd_s128_kernel: one workgroup owns a whole (sequence, head) problem, EVERY global load is issued
@@ -1592,218 +950,8 @@ CX_DEVICE void stage_rows(char* tile, int kp, int cp, const RowPairLoads& x) {  
     *reinterpret_cast<uint4*>(tile + tile64_off(2 * kp + 1, cp)) = x.lo[1];
     *reinterpret_cast<uint4*>(tile + tile64_off(2 * kp + 1, cp + 4)) = x.hi[1];
 }
-CX_DEVICE void stage_transposed128(char* tile, int kp, int cp, const RowPairLoads& x) {  // [64 d][128 idx], stride 264
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const uint32_t wl = (uint32_t)elem16(x.lo[0], e) | ((uint32_t)elem16(x.lo[1], e) << 16);
-        const uint32_t wh = (uint32_t)elem16(x.hi[0], e) | ((uint32_t)elem16(x.hi[1], e) << 16);
-        *reinterpret_cast<uint32_t*>(tile + (cp * 8 + e) * VT128_STRIDE + kp * 4) = wl;
-        *reinterpret_cast<uint32_t*>(tile + (32 + cp * 8 + e) * VT128_STRIDE + kp * 4) = wh;
-    }
-}
 
-#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_s128_kernel(AttnParams p) {
-    // phase 1: Qs | dOs (only to build the register fragments);  phase 2: Ks | Vs alias them, Kt is separate
-    __shared__ __attribute__((aligned(16))) char smem[32768 + 64 * VT128_STRIDE];
-    char* A0 = smem;
-    char* A1 = smem + 16384;
-    char* Kt = smem + 32768;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-    if (len <= 0) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
-    const bf16_t* dobase = p.dout + (size_t)h * DH;
-    const int kp = tid >> 2, cp = tid & 3;
-    int ra = 2 * kp, rb = ra + 1;
-    ra = ra < len ? ra : len - 1;
-    rb = rb < len ? rb : len - 1;
 
-    // ---- every global load first ----
-    RowPairLoads q, k, v, dO;
-    CosSin cs;
-    load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
-    load_pair_raw(dobase, o_stride, t0, ra, rb, cp, dO);
-    load_pair_raw(kbase, tok_stride, t0, ra, rb, cp, k);
-    load_pair_raw(vbase, tok_stride, t0, ra, rb, cp, v);
-    if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
-    const int qrow = wave * 32 + l31;
-    const int qc = qrow < len ? qrow : len - 1;
-    const float lse2 = p.lse[(size_t)h * p.T + t0 + qc] * LOG2E;
-    const float dl = p.delta[(size_t)h * p.T + t0 + qc];
-
-    if (p.cosv) rotate_pair(q, cs);
-    stage_rows(A0, kp, cp, q);
-    stage_rows(A1, kp, cp, dO);
-    __syncthreads();
-    bf16x8_t qf[4], dof[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = lds_read_frag(A0, tile64_off(qrow, ks * 2 + hi));
-        dof[ks] = lds_read_frag(A1, tile64_off(qrow, ks * 2 + hi));
-    }
-    __syncthreads();
-    if (p.cosv) rotate_pair(k, cs);
-    stage_rows(A0, kp, cp, k);
-    stage_rows(A1, kp, cp, v);
-    stage_transposed128(Kt, kp, cp, k);
-    __syncthreads();
-
-    const float sc2 = p.scale * LOG2E;
-    f32x16_t acc_dq[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        f32x16_t a_s, a_dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            a_s = mfma_bf16_32x32x16(lds_read_frag(A0, tile64_off(kb * 32 + l31, ks * 2 + hi)), qf[ks], a_s);
-            a_dp = mfma_bf16_32x32x16(lds_read_frag(A1, tile64_off(kb * 32 + l31, ks * 2 + hi)), dof[ks], a_dp);
-        }
-        float ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + acc_row(r, hi);
-            const float pr = key < len ? fast_exp2(a_s[r] * sc2 - lse2) : 0.f;
-            ds[r] = pr * (a_dp[r] - dl);
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bf16x8_t dsf = pack_frag(ds, half);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-                acc_dq[db] = mfma_bf16_32x32x16(read_vt128_frag(Kt, db * 32 + l31, kb * 2 + half, hi), dsf, acc_dq[db]);
-        }
-    }
-    if (qrow < len)
-        store_unrotated(p.dqkv + (size_t)(t0 + qrow) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, qrow,
-                        hi);
-}
-#endif  // !CX_PRODUCT
-
-#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p) {
-    // phase 1: Ks | Vs (register fragments);  phase 2: Qs | dOs alias them, Qt | dOt | lse | delta are separate
-    __shared__ __attribute__((aligned(16))) char smem[32768 + 2 * 64 * VT128_STRIDE + 1024];
-    char* A0 = smem;
-    char* A1 = smem + 16384;
-    char* Qt = smem + 32768;
-    char* dOt = Qt + 64 * VT128_STRIDE;
-    float* lse_s = reinterpret_cast<float*>(dOt + 64 * VT128_STRIDE);
-    float* dl_s = lse_s + 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-    if (len <= 0) return;
-    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
-    const bf16_t* qbase = p.qkv + (size_t)h * DH;
-    const bf16_t* kbase = qbase + (size_t)p.H * DH;
-    const bf16_t* vbase = kbase + (size_t)p.H * DH;
-    const bf16_t* dobase = p.dout + (size_t)h * DH;
-    const int kp = tid >> 2, cp = tid & 3;
-    int ra = 2 * kp, rb = ra + 1;
-    ra = ra < len ? ra : len - 1;
-    rb = rb < len ? rb : len - 1;
-
-    // ---- every global load first ----
-    RowPairLoads q, k, v, dO;
-    CosSin cs;
-    load_pair_raw(kbase, tok_stride, t0, ra, rb, cp, k);
-    load_pair_raw(vbase, tok_stride, t0, ra, rb, cp, v);
-    load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
-    load_pair_raw(dobase, o_stride, t0, ra, rb, cp, dO);
-    if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
-    float lse_v = 0.f, dl_v = 0.f;
-    if (tid < 128) {
-        const bool ok = tid < len;
-        const int r = ok ? tid : len - 1;
-        // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
-        lse_v = ok ? p.lse[(size_t)h * p.T + t0 + r] * LOG2E : INFINITY;
-        dl_v = p.delta[(size_t)h * p.T + t0 + r];
-    }
-
-    if (p.cosv) rotate_pair(k, cs);
-    stage_rows(A0, kp, cp, k);
-    stage_rows(A1, kp, cp, v);
-    __syncthreads();
-    const int key = wave * 32 + l31;
-    const bool key_ok = key < len;
-    bf16x8_t kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = lds_read_frag(A0, tile64_off(key, ks * 2 + hi));
-        vf[ks] = lds_read_frag(A1, tile64_off(key, ks * 2 + hi));
-    }
-    __syncthreads();
-    if (p.cosv) rotate_pair(q, cs);
-    stage_rows(A0, kp, cp, q);
-    stage_rows(A1, kp, cp, dO);
-    stage_transposed128(Qt, kp, cp, q);
-    stage_transposed128(dOt, kp, cp, dO);
-    if (tid < 128) {
-        lse_s[tid] = lse_v;
-        dl_s[tid] = dl_v;
-    }
-    __syncthreads();
-
-    const float sc2 = p.scale * LOG2E;
-    f32x16_t acc_dk[2], acc_dv[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-        f32x16_t a_s, a_dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            a_s = mfma_bf16_32x32x16(lds_read_frag(A0, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s);
-            a_dp = mfma_bf16_32x32x16(lds_read_frag(A1, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp);
-        }
-        float pr[16], ds[16];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int row = qb * 32 + 8 * qd + 4 * hi;
-            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + row);
-            const float4 d4 = *reinterpret_cast<const float4*>(dl_s + row);
-            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * qd + e;
-                const float pv = key_ok ? fast_exp2(a_s[r] * sc2 - ll[e]) : 0.f;
-                pr[r] = pv;
-                ds[r] = pv * (a_dp[r] - dd[e]);
-            }
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                acc_dv[db] = mfma_bf16_32x32x16(read_vt128_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
-                acc_dk[db] = mfma_bf16_32x32x16(read_vt128_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
-            }
-        }
-    }
-    if (key_ok) {
-        bf16_t* krow = p.dqkv + (size_t)(t0 + key) * tok_stride + (size_t)(p.H + h) * DH;
-        bf16_t* vrow = krow + (size_t)p.H * DH;
-        store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, key, hi);
-        store_unrotated(vrow, acc_dv, 1.f, nullptr, nullptr, 0, hi);
-    }
-}
-#endif  // !CX_PRODUCT
 
 // ----------------------------------------------------------------- backward, sequences <= 128, ONE fused kernel
 // dQ, dK, dV (and delta) of a whole (sequence, head) problem in one workgroup, reading Q, K, V, dO, O from HBM once
@@ -1814,230 +962,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_s128_kernel(AttnParams p)
 // 116 KiB of LDS -> one workgroup (4 waves, one per SIMD, 512 registers each) per CU: the workgroup is persistent and
 // L2-prefetches the NEXT problem while the current one is computed.
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_attn;
-constexpr int DSROW = 256;  // bytes per key row of the [128 key][128 query] dS tile
 // 16-B chunk swizzle of the dS tile: 4 row bits permute the 16 chunks of a row, so that the writers (32 keys x 8 B per
 // instruction) and the transposing readers (4 rows x 32 B per 16-lane group) are both spread over the banks
 CX_DEVICE int ds_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-CX_DEVICE bf16x8_t ds_tr_frag(const char* tile, int q0, int k0, int lane) {  // B[k = k0 + 8*(lane>>5) + e][j = q0 + (lane&31)]
-    const int g = lane >> 4, pp = lane & 15;
-    const int t = k0 + 8 * (g >> 1) + (pp >> 2);
-    const int f = q0 + 16 * (g & 1) + 4 * (pp & 3);
-    union { bf16x4_t h[2]; bf16x8_t v; } u;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int tt = t + 4 * half;
-        const int chunk = (f >> 3) ^ ds_swz(tt);
-        u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_attn)(tile + tt * DSROW + chunk * 16 + (f & 4) * 2));
-    }
-    return u.v;
-}
-// A[i = d][k = k0 + 8*hi + e] of a transposed [64 d][128 k] tile (k contiguous): the plain reduction-index order, to
-// pair with ds_tr_frag (read_vt128_frag uses the accumulator-register order instead)
-CX_DEVICE bf16x8_t read_vt128_linear(const char* tile, int d, int k0, int hi) {
-    const char* p = tile + d * VT128_STRIDE + (k0 + 8 * hi) * 2;
-    union { uint2 u[2]; bf16x8_t v; } x;
-    x.u[0] = *reinterpret_cast<const uint2*>(p);
-    x.u[1] = *reinterpret_cast<const uint2*>(p + 8);
-    return x.v;
-}
-
-constexpr int FUSED_LDS = 32768 + 3 * 64 * VT128_STRIDE + 32768 + 1024;
-
-#ifndef CX_PRODUCT  // A/B-only kernel: dev library (include/contrastors_hip_dev.h)
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_fused_s128_kernel(AttnParams p,
-                                                                                                               int B) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qs = smem;                         // [128][64] row-major (tile64 swizzle)
-    char* dOs = smem + 16384;
-    char* Qt = smem + 32768;                 // [64 d][128 q]
-    char* dOt = Qt + 64 * VT128_STRIDE;
-    char* Kt = dOt + 64 * VT128_STRIDE;      // [64 d][128 k]
-    char* dSs = Kt + 64 * VT128_STRIDE;      // [128 k][128 q]; K / V row-major staging aliases it (phase 1 only)
-    float* lse_s = reinterpret_cast<float*>(dSs + 32768);
-    float* dl_s = lse_s + 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int kp = tid >> 2, cp = tid & 3;
-    const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
-    const int n_units = B * p.H;
-
-    RowPairLoads q, k, v, dO, o;
-    CosSin cs;
-    float lse_v = 0.f;
-    auto issue_loads = [&](int u) {  // unit u = (b, h)
-        const int b = u / p.H, h = u - b * p.H;
-        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-        if (len <= 0) return;
-        int ra = 2 * kp, rb = ra + 1;
-        ra = ra < len ? ra : len - 1;
-        rb = rb < len ? rb : len - 1;
-        const bf16_t* qbase = p.qkv + (size_t)h * DH;
-        load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, k);
-        load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, v);
-        load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
-        load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dO);
-        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
-        if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
-        if (tid < 128) {
-            const bool ok = tid < len;
-            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
-            lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
-        }
-    };
-
-    // L2 prefetch of the NEXT problem: one dword load per 128-B line (each (row, tensor, head) is exactly one line), issued
-    // once the current problem sits in LDS; its real loads at the top of the next iteration then pay L2, not HBM,
-    // latency.  (Prefetching into registers instead makes the allocator park the values in AGPRs, which needs the data
-    // at once.)  The loaded values are never used; pf_sink keeps the destination register reserved.
-    uint32_t pf_sink = 0;
-    auto l2_prefetch = [&](int un) {
-        const int b = un / p.H, h = un - b * p.H;
-        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-        if (tid < len && tid < 128) {
-            const bf16_t* qrow = p.qkv + (size_t)(t0 + tid) * tok_stride + (size_t)h * DH;
-            const bf16_t* krow = qrow + (size_t)p.H * DH;
-            const bf16_t* vrow = krow + (size_t)p.H * DH;
-            const bf16_t* drow = p.dout + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
-            const bf16_t* orow = p.out + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(qrow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(krow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(vrow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(drow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(orow) : "memory");
-        }
-    };
-
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const int b = u / p.H, h = u - b * p.H;
-        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-        if (len <= 0) continue;  // (uniform per workgroup)
-        issue_loads(u);
-        // ---- delta = rowsum(dO * O): this thread holds 16 of the 64 columns of rows (2kp, 2kp+1) ----
-        float dpart[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float a[8], c[8], acc = 0.f;
-            unpack8(dO.lo[i], a); unpack8(o.lo[i], c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
-            unpack8(dO.hi[i], a); unpack8(o.hi[i], c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += a[e] * c[e];
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            dpart[i] = acc;
-        }
-        // ---- phase 1: K, V row-major -> the key-owner fragments of this wave ----
-        if (p.cosv) { rotate_pair(k, cs); rotate_pair(q, cs); }
-        stage_rows(dSs, kp, cp, k);
-        stage_rows(dSs + 16384, kp, cp, v);
-        stage_transposed128(Kt, kp, cp, k);
-        stage_rows(Qs, kp, cp, q);
-        stage_rows(dOs, kp, cp, dO);
-        stage_transposed128(Qt, kp, cp, q);
-        stage_transposed128(dOt, kp, cp, dO);
-        if (cp == 0) {
-            dl_s[2 * kp] = dpart[0];
-            dl_s[2 * kp + 1] = dpart[1];
-        }
-        if (tid < 128) lse_s[tid] = lse_v;
-        if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
-        __syncthreads();
-        const int row = wave * 32 + l31;  // this lane's key (dK, dV) and later its query (dQ)
-        const bool row_ok = row < len;
-        bf16x8_t kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = lds_read_frag(dSs, tile64_off(row, ks * 2 + hi));
-            vf[ks] = lds_read_frag(dSs + 16384, tile64_off(row, ks * 2 + hi));
-        }
-        __syncthreads();  // the K / V staging area becomes the dS tile
-
-        const float sc2 = p.scale * LOG2E;
-        f32x16_t acc_dk[2], acc_dv[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
-        // two query blocks at a time: four independent MFMA accumulation chains (one wave per SIMD has nobody else to
-        // cover the latency of a dependent chain)
-#pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-            f32x16_t a_s[2], a_dp[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a_s[j][r] = a_dp[j][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int qb = 2 * qp + j;
-                    a_s[j] = mfma_bf16_32x32x16(lds_read_frag(Qs, tile64_off(qb * 32 + l31, ks * 2 + hi)), kf[ks], a_s[j]);
-                    a_dp[j] = mfma_bf16_32x32x16(lds_read_frag(dOs, tile64_off(qb * 32 + l31, ks * 2 + hi)), vf[ks], a_dp[j]);
-                }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int qb = 2 * qp + j;
-                float pr[16], ds[16];
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int qrow = qb * 32 + 8 * qd + 4 * hi;
-                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qrow);
-                    const float4 d4 = *reinterpret_cast<const float4*>(dl_s + qrow);
-                    const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * qd + e;
-                        const float pv = row_ok ? fast_exp2(a_s[j][r] * sc2 - ll[e]) : 0.f;
-                        pr[r] = pv;
-                        ds[r] = pv * (a_dp[j][r] - dd[e]);
-                    }
-                    // dS[key = row][queries qrow .. qrow+3] -> the [key][query] tile (swizzled like the GEMM's TN tiles)
-                    uint2 pk;
-                    pk.x = pack_bf16x2(ds[4 * qd], ds[4 * qd + 1]);
-                    pk.y = pack_bf16x2(ds[4 * qd + 2], ds[4 * qd + 3]);
-                    *reinterpret_cast<uint2*>(dSs + row * DSROW + (((qrow >> 3) ^ ds_swz(row)) << 4) + (qrow & 4) * 2) = pk;
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const bf16x8_t pf = pack_frag(pr, half), dsf = pack_frag(ds, half);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        acc_dv[db] = mfma_bf16_32x32x16(read_vt128_frag(dOt, db * 32 + l31, qb * 2 + half, hi), pf, acc_dv[db]);
-                        acc_dk[db] = mfma_bf16_32x32x16(read_vt128_frag(Qt, db * 32 + l31, qb * 2 + half, hi), dsf, acc_dk[db]);
-                    }
-                }
-            }
-        }
-        if (row_ok) {
-            bf16_t* krow = p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)(p.H + h) * DH;
-            store_unrotated(krow, acc_dk, p.scale, p.cosv, p.sinv, row, hi);
-            store_unrotated(krow + (size_t)p.H * DH, acc_dv, 1.f, nullptr, nullptr, 0, hi);
-        }
-        __syncthreads();  // the dS tile is complete
-
-        // ---- dQ^T[d][q] = sum_k K^T[d][k] dS[k][q] for this wave's 32 queries ----
-        f32x16_t acc_dq[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const bf16x8_t dsf = ds_tr_frag(dSs, wave * 32, kc * 16, lane);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-                acc_dq[db] = mfma_bf16_32x32x16(read_vt128_linear(Kt, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
-        }
-        if (row_ok)
-            store_unrotated(p.dqkv + (size_t)(t0 + row) * tok_stride + (size_t)h * DH, acc_dq, p.scale, p.cosv, p.sinv, row,
-                            hi);
-        __syncthreads();  // LDS is restaged by the next problem
-    }
-    if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
-}
-#endif  // !CX_PRODUCT
 
 // ------------------------------------------------ backward, sequences <= 128, fused, TWO workgroups per CU (80 KiB)
 // Same algorithm as attn_bwd_fused_s128_kernel with an LDS diet so that two workgroups share a CU (two waves per SIMD:
@@ -2098,16 +1026,9 @@ constexpr int FUSED2_LDS = 16384 * 3 + 32768;  // 80 KiB
 // a lane holds ONE key and four consecutive queries per accumulator quad.  The four lanes of a key group (keys 4m .. 4m + 3)
 // would each draw the same four Philox words per query; instead lane j draws the word quadruple of query q0 + j and the 4 x 4
 // block is transposed across the quad with DPP (one Philox call per four mask values, as in the forward).
-// PIPE (round 4): the NEXT problem's rows (Q, K, V, dO, O, rotation table, lse) are requested after the dQ products, ahead of the
-// dQ store phase, into the registers the current problem no longer needs: their flight overlaps the store phase, the barrier
-// and the loop overhead instead of starting behind the stores (one in-order vmcnt: a load issued after a store cannot be
-// waited for without waiting for the store).  s_setprio 1 around the S / dP / dV / dK loop: the SIMD's other wave belongs to
-// the CU's other workgroup and is usually in a load / store phase.
-// PIPE 2 (round 5, A/B): the next problem's K / V / Q / dO rows by LDS-DMA (global_load_lds_dwordx4, no registers) into the three tiles
-// that are dead after the dQ products (dO^T, R2 = K^T, R3 = dS: 64 of the 80 KiB), requested ahead of the dQ stores; only O, the
-// forward rotation's table rows and lse travel in registers (33).  The next iteration starts by reading its raw rows back from LDS
-// (16 x 16 B per thread, its own DMA targets: conflict-free) instead of waiting for global memory: + 2 barriers per problem.
-template <bool DROP, int PIPE = 0>
+// (Rounds 4-5 also built two pipelined forms -- the next problem's rows requested ahead of the dQ store into registers, or by LDS-DMA into
+// the dead tiles: bit-identical, 1.0-1.39 x slower, profiles/r4_attn_s128_experiments.txt, r5_attn_bwd_s128_ab.txt; removed in round 6.)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams p, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
@@ -2120,113 +1041,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
     const int kp = tid >> 2, cp = tid & 3;
     const size_t tok_stride = (size_t)3 * p.H * DH, o_stride = (size_t)p.H * DH;
     const int n_units = B * p.H;
-    uint32_t pf_sink = 0;
-    auto l2_prefetch = [&](int un) {
-        const int b = un / p.H, h = un - b * p.H;
-        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-        if (tid < len && tid < 128) {
-            const bf16_t* qrow = p.qkv + (size_t)(t0 + tid) * tok_stride + (size_t)h * DH;
-            const bf16_t* krow = qrow + (size_t)p.H * DH;
-            const bf16_t* vrow = krow + (size_t)p.H * DH;
-            const bf16_t* drow = p.dout + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
-            const bf16_t* orow = p.out + (size_t)(t0 + tid) * o_stride + (size_t)h * DH;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(qrow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(krow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(vrow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(drow) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(orow) : "memory");
-        }
-    };
-
 #ifdef CX_ATTN_TRACE
     long long* tr = reinterpret_cast<long long*>(p.delta);
     int it = -1;
 #endif
-    RowPairLoads qo, ko, vo, dOo, oo;   // (PIPE only: loop-carried; the serial form keeps its loads inside the loop body)
-    CosSin cso;
-    float lseo = 0.f;
-    // every global load of problem `un` (skipping empty sequences); returns the unit it loaded, or n_units when there is none
-    auto request = [&](int un, RowPairLoads& q, RowPairLoads& k, RowPairLoads& v, RowPairLoads& dO, RowPairLoads& o, CosSin& cs,
-                       float& lse_v) {
-        for (; un < n_units; un += gridDim.x) {
-            const int b = un / p.H;
-            if (p.cu[b + 1] - p.cu[b] > 0) break;
-        }
-        if (un >= n_units) return n_units;
-        const int b = un / p.H, h = un - b * p.H;
-        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-        int ra = 2 * kp, rb = ra + 1;
-        ra = ra < len ? ra : len - 1;
-        rb = rb < len ? rb : len - 1;
-        const bf16_t* qbase = p.qkv + (size_t)h * DH;
-        load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, k);
-        load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, v);
-        load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, q);
-        load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dO);
-        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
-        if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, cs);
-        lse_v = 0.f;
-        if (tid < 128) {
-            const bool ok = tid < len;
-            // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
-            lse_v = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
-        }
-        return un;
-    };
-    // ---- PIPE 2: raw-row landing zones (each thread's four 16-B pieces of a tensor at zone + j * 4096 + tid * 16; a wave's
-    // instruction j writes 1 KiB at M0 = zone + j * 4096 + wave * 1024, lane L at + L * 16)
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr uint32_t ZK = 32768, ZV = 16384, ZQ = 49152, ZDO = 65536;   // raw K -> R2, raw V -> dO^T, raw Q / dO -> R3
-    auto dma16 = [&](uint32_t zone_off, const bf16_t* g) {
-        const uint32_t m0v = lds_base + zone_off + wave_u * 1024;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "memory");
-    };
-    auto dma_pair = [&](uint32_t zone, const bf16_t* base, size_t stride, int t0, int ra, int rb) {
-        const bf16_t* a = base + (size_t)(t0 + ra) * stride;
-        const bf16_t* b2 = base + (size_t)(t0 + rb) * stride;
-        dma16(zone + 0 * 4096, a + cp * 8);
-        dma16(zone + 1 * 4096, a + 32 + cp * 8);
-        dma16(zone + 2 * 4096, b2 + cp * 8);
-        dma16(zone + 3 * 4096, b2 + 32 + cp * 8);
-    };
-    auto read_raw = [&](uint32_t zone, RowPairLoads& x) {
-        const char* z = smem + zone + tid * 16;
-        x.lo[0] = *reinterpret_cast<const uint4*>(z);
-        x.hi[0] = *reinterpret_cast<const uint4*>(z + 4096);
-        x.lo[1] = *reinterpret_cast<const uint4*>(z + 8192);
-        x.hi[1] = *reinterpret_cast<const uint4*>(z + 12288);
-    };
-    auto request_dma = [&](int un, RowPairLoads& o, CosSin& cs, float& lse_v) {
-        for (; un < n_units; un += gridDim.x) {
-            const int b = un / p.H;
-            if (p.cu[b + 1] - p.cu[b] > 0) break;
-        }
-        if (un >= n_units) return n_units;
-        const int b = un / p.H, h = un - b * p.H;
-        const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
-        int ra = 2 * kp, rb = ra + 1;
-        ra = ra < len ? ra : len - 1;
-        rb = rb < len ? rb : len - 1;
-        const bf16_t* qbase = p.qkv + (size_t)h * DH;
-        (void)cs;   // (the forward rotation's table rows are fetched at the top of the problem's own iteration: 16 registers less to carry)
-        dma_pair(ZK, qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb);
-        dma_pair(ZV, qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb);
-        dma_pair(ZQ, qbase, tok_stride, t0, ra, rb);
-        dma_pair(ZDO, p.dout + (size_t)h * DH, o_stride, t0, ra, rb);
-        load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, o);
-        lse_v = 0.f;
-        if (tid < 128) lse_v = tid < len ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
-        return un;
-    };
-    int u_next = n_units;
-    if constexpr (PIPE == 1) u_next = request(blockIdx.x, qo, ko, vo, dOo, oo, cso, lseo);
-    if constexpr (PIPE == 2) u_next = request_dma(blockIdx.x, oo, cso, lseo);
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        if constexpr (PIPE != 0) {
-            u = u_next;              // (the problem whose rows are in flight; empty sequences were skipped by `request`)
-            if (u >= n_units) break;
-        }
         const int b = u / p.H, h = u - b * p.H;
         const int t0 = p.cu[b], len = p.cu[b + 1] - t0;
         if (len <= 0) continue;  // (uniform per workgroup)
@@ -2237,65 +1056,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         RowPairLoads ql, kl, vl, dOl, ol;
         CosSin csl;
         float lsel = 0.f;
-        if constexpr (PIPE == 0) {   // (the serial form, exactly as it shipped in round 3: its register allocation is a fragile optimum)
+        {   // (the serial form, exactly as it shipped in round 3: its register allocation is a fragile optimum)
             int ra = 2 * kp, rb = ra + 1;
             ra = ra < len ? ra : len - 1;
             rb = rb < len ? rb : len - 1;
             const bf16_t* qbase = p.qkv + (size_t)h * DH;
-#if CX_ATTN_CS_FIRST
             // the rotation table rows FIRST: the K rows are the first thing staged and they are rotated on the way -- with the table
             // requested last (rounds 3-4) the first use waited for every row of the problem (loads return in order)
             if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
-#endif
             load_pair_raw(qbase + (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, kl);
             load_pair_raw(qbase + 2 * (size_t)p.H * DH, tok_stride, t0, ra, rb, cp, vl);
             load_pair_raw(qbase, tok_stride, t0, ra, rb, cp, ql);
             load_pair_raw(p.dout + (size_t)h * DH, o_stride, t0, ra, rb, cp, dOl);
-#if !CX_ATTN_DELTA_IN
             load_pair_raw(p.out + (size_t)h * DH, o_stride, t0, ra, rb, cp, ol);
-#endif
-#if !CX_ATTN_CS_FIRST
-            if (p.cosv) load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
-#endif
             if (tid < 128) {
                 const bool ok = tid < len;
                 // rows past the end of the sequence get lse = +inf -> P = exp2(-inf) = 0: they contribute nothing
                 lsel = ok ? p.lse[(size_t)h * p.T + t0 + tid] * LOG2E : INFINITY;
             }
         }
-        if constexpr (PIPE == 2) {
-            // this problem's rows were requested by the previous iteration (or the prologue): every wave's DMA has landed, then each
-            // thread takes its own pieces into registers, and only when everybody has may the zones be restaged
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (p.cosv) {   // (an L2-resident table: lands under the raw reads and the second barrier)
-                int ra = 2 * kp, rb = ra + 1;
-                ra = ra < len ? ra : len - 1;
-                rb = rb < len ? rb : len - 1;
-                load_cossin(p.cosv, p.sinv, ra, rb, cp, csl);
-            }
-            read_raw(ZK, kl);
-            read_raw(ZV, vl);
-            read_raw(ZQ, ql);
-            read_raw(ZDO, dOl);
-            ol = oo;
-            lsel = lseo;
-            __syncthreads();
-        }
-        RowPairLoads &q = PIPE == 1 ? qo : ql, &k = PIPE == 1 ? ko : kl, &v = PIPE == 1 ? vo : vl, &dO = PIPE == 1 ? dOo : dOl, &o = PIPE == 1 ? oo : ol;
-        CosSin& cs = PIPE == 1 ? cso : csl;
-        const float lse_v = PIPE == 1 ? lseo : lsel;
+        RowPairLoads &q = ql, &k = kl, &v = vl, &dO = dOl, &o = ol;
+        CosSin& cs = csl;
+        const float lse_v = lsel;
         CX_STAMP(1);  // loads landed
         // ---- K, V row-major (for this wave's key fragments), then everything that depends on dO / O / Q ----
         if (p.cosv) rotate_pair(k, cs);
         stage_rows(R3, kp, cp, k);
         stage_rows(R3 + 16384, kp, cp, v);
         float dpart[2] = {0.f, 0.f};
-#if CX_ATTN_DELTA_IN
-        // (A/B, round 5: delta = rowsum(dO * O) arrives precomputed in p.delta (H, T) -- what an out_proj-dgrad epilogue could
-        // write -- and O is not read at all: 16 of the problem's 128 KB and ~100 VALU instructions per thread less)
-        if (tid < 128) dpart[0] = tid < len ? p.delta[(size_t)h * p.T + t0 + tid] : 0.f;
-#else
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // delta = rowsum(dO * O): 16 of the 64 columns of rows (2kp, 2kp+1) per thread
             float a[8], c[8], acc = 0.f;
@@ -2309,29 +1097,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
             acc += __shfl_xor(acc, 2, 64);
             dpart[i] = acc;
         }
-#endif
         if (p.cosv) rotate_pair(q, cs);
         // (round 5 measured the row-major alternative -- Q / dO staged with 16-B writes, S / dP operands as plain row reads, dK / dV
         // operands through the transposing read: bit-identical, -1.9 % alone, but +3.7 % on top of the table prefetch below;
         // profiles/r5_attn_bwd_s128_ab.txt -- not kept)
         stage_transposed_sw(Qt, kp, cp, q);
         stage_transposed_sw(dOt, kp, cp, dO);
-#if CX_ATTN_DELTA_IN
-        if (tid < 128) dl_s[tid] = dpart[0];
-#else
         if (cp == 0) {
             dl_s[2 * kp] = dpart[0];
             dl_s[2 * kp + 1] = dpart[1];
         }
-#endif
         if (tid < 128) lse_s[tid] = lse_v;
-#if CX_ATTN_PF
-        if constexpr (PIPE != 0) {
-            if (u + 2 * (int)gridDim.x < n_units) l2_prefetch(u + 2 * gridDim.x);
-        } else {
-            if (u + (int)gridDim.x < n_units) l2_prefetch(u + gridDim.x);
-        }
-#endif
         CX_STAMP(2);  // staged
         __syncthreads();
         CX_STAMP(3);  // barrier
@@ -2352,10 +1128,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_dk[db][r] = acc_dv[db][r] = 0.f;
-        if (PIPE == 1 || p.prio) __builtin_amdgcn_s_setprio(1);
+        if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1  // (rolled: unrolling makes the compiler hoist ~100 loop-invariant LDS addresses and spill)
         for (int qb = 0; qb < 4; ++qb) {
-#if CX_ATTN_DROP_EARLY
             // DROP: the 16 keep decisions of this (key, query block) are drawn BEFORE the S / dP products and carried as one 16-bit word:
             // the generator's temporaries are live while the two accumulator blocks (32 registers) are not
             uint32_t kbits = 0;
@@ -2369,7 +1144,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 }
             }
             const float keep_inv = DROP ? 1.f / (1.f - p.drop.p) : 1.f;
-#endif
             f32x16_t a_s, a_dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a_s[r] = a_dp[r] = 0.f;
@@ -2386,14 +1160,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 const float4 d4 = *reinterpret_cast<const float4*>(dl_s + qrow);
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
                 float kq[4] = {1.f, 1.f, 1.f, 1.f};
-#if CX_ATTN_DROP_EARLY
                 if constexpr (DROP) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) kq[e] = ((kbits >> (4 * qd + e)) & 1u) ? keep_inv : 0.f;
                 }
-#else
-                if constexpr (DROP) kq[0] = 0.f, quad_keep4(p, (uint32_t)u, qrow, row, lane, kq);
-#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
@@ -2421,30 +1191,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 }
             }
         }
-        if (PIPE == 1 || p.prio) __builtin_amdgcn_s_setprio(0);
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
         CX_STAMP(5);  // main loop
-#if CX_ATTN_ROT_PRE
         // the inverse rotation's table rows of this lane's position (its key for dK, its query for dQ: the same index), requested
         // BEFORE the barrier into registers the main loop has just freed: their round trip hides behind the barrier wait instead
         // of sitting inside the dK and dQ store phases (rounds 3-4 fetched them there, one column group ahead)
         RotRow rot = {};
         if (p.cosv) load_rot_row(p.cosv, p.sinv, row_ok ? row : len - 1, hi, rot);
-#endif
         __syncthreads();  // the dS tile is complete; lse / delta, Q^T and dO^T are dead: R2 becomes Kt
         CX_STAMP(6);  // barrier
         {   // dK, dV of this wave's 32 keys leave as full rows through the wave's slices of the dead Q^T / dO^T tiles
             bf16_t* k0 = p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)(p.H + h) * DH;
-#if CX_ATTN_ROT_PRE
             // dV first: its stores are in flight while the table rows land
             store_unrotated_rows_pre(dOt + wave * 4096, k0 + (size_t)p.H * DH, tok_stride, len - wave * 32, acc_dv, 1.f, rot, false, hi, lane);
             store_unrotated_rows_pre(Qt + wave * 4096, k0, tok_stride, len - wave * 32, acc_dk, p.scale, rot, p.cosv != nullptr, hi, lane);
-#else
-            const int pos = row_ok ? row : len - 1;
-            store_unrotated_rows(Qt + wave * 4096, k0, tok_stride, len - wave * 32, acc_dk, p.scale, p.cosv, p.sinv, pos,
-                                 hi, lane);
-            store_unrotated_rows(dOt + wave * 4096, k0 + (size_t)p.H * DH, tok_stride, len - wave * 32, acc_dv, 1.f,
-                                 nullptr, nullptr, 0, hi, lane);
-#endif
         }
         CX_STAMP(7);  // dK, dV stored
         stage_transposed_sw(R2, kp, cp, k);
@@ -2466,23 +1226,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused2_s128_kernel(AttnParams
                 acc_dq[db] = mfma_bf16_32x32x16(sw_linear_frag(R2, db * 32 + l31, kc * 16, hi), dsf, acc_dq[db]);
         }
         CX_STAMP(10);  // dQ products
-        if constexpr (PIPE == 1) u_next = request(u + gridDim.x, qo, ko, vo, dOo, oo, cso, lseo);   // q, k, v, dO, o, cs are dead: the next problem's rows fly under the dQ store
-        if constexpr (PIPE == 2) {
-            __syncthreads();   // every wave is through its dQ products: K^T (R2), dS (R3) and the dV staging (dO^T) are dead
-            u_next = request_dma(u + gridDim.x, oo, cso, lseo);
-        }
-#if CX_ATTN_ROT_PRE
         store_unrotated_rows_pre(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
                                  len - wave * 32, acc_dq, p.scale, rot, p.cosv != nullptr, hi, lane);
-#else
-        store_unrotated_rows(Qt + wave * 4096, p.dqkv + (size_t)(t0 + wave * 32) * tok_stride + (size_t)h * DH, tok_stride,
-                             len - wave * 32, acc_dq, p.scale, p.cosv, p.sinv, row_ok ? row : len - 1, hi, lane);
-#endif
         CX_STAMP(11);  // dQ stored
         __syncthreads();  // LDS is restaged by the next problem
         CX_STAMP(12);  // barrier
     }
-    if (pf_sink == 0x7fc12345u && p.T < 0) p.delta[0] = (float)pf_sink;  // keeps pf_sink live
 }
 
 #ifndef CX_PRODUCT
@@ -2680,11 +1429,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_s128v_kernel(AttnParams p) {
 #include "attn_long.inc"
 
 #ifndef CX_PRODUCT
-int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: 2 lean-VALU + full-row stores (default), 0 first one-shot form, 1 persistent + prefetch
+int g_fwd_s128 = 2;  // cx_attn_set_fwd_s128: non-zero = the single-pass kernels for max_seqlen <= 128 / <= 256 (default), 0 = the general streaming kernel (A/B, tests)
 int g_bwd_long = 1;  // cx_attn_set_bwd_long: 1 = attn_bwd_dq_long / attn_bwd_dkv_long for max_seqlen > 128 without rotate-on-load (default), 0 = round 1's pair
-int g_bwd_s256 = 0;  // cx_attn_set_bwd_s256: 1 = the fused persistent backward for 128 < max_seqlen <= 256 (A/B: slower than the streaming pair)
 int g_fwd_long = 1;  // cx_attn_set_fwd_long: 1 = attn_fwd_long_kernel for max_seqlen > 256 without rotate-on-load (default), 0 = attn_fwd_kernel
-int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 fused, 2 workgroups/CU; 2 fused, 1 workgroup/CU; 1 one-pass dq + dkv; 0 general
+int g_bwd_s128 = 3;  // cx_attn_set_bwd_s128: max_seqlen <= 128 -> 3 = the fused persistent kernel (default), 0 = the general streaming kernels (A/B, tests)
 #endif
 
 }  // namespace
@@ -2694,11 +1442,10 @@ extern "C" {
 #ifndef CX_PRODUCT
 int g_attn_prio = 0;
 void cx_attn_set_prio(int on) { g_attn_prio = on ? 1 : 0; }
-void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = (mode >= 0 && mode <= 5) ? mode : 3; }
-void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = (mode >= 0 && mode <= 2) ? mode : 2; }
+void cx_attn_set_bwd_s128(int mode) { g_bwd_s128 = mode == 0 ? 0 : 3; }
+void cx_attn_set_fwd_s128(int mode) { g_fwd_s128 = mode == 0 ? 0 : 2; }
 void cx_attn_set_fwd_long(int on) { g_fwd_long = on ? 1 : 0; }
 void cx_attn_set_bwd_long(int on) { g_bwd_long = on ? 1 : 0; }
-void cx_attn_set_bwd_s256(int on) { g_bwd_s256 = on ? 1 : 0; }
 #endif
 
 int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin,
@@ -2712,28 +1459,17 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
     p.H = H; p.T = T; p.scale = softmax_scale;
 #ifndef CX_PRODUCT
     const bool fwd_long = g_fwd_long != 0;   // (dev library: cx_attn_set_fwd_long(0) keeps round 1's streaming kernel for A/B)
+    const bool single_pass = g_fwd_s128 != 0;
 #else
-    constexpr bool fwd_long = true;
+    constexpr bool fwd_long = true, single_pass = true;
 #endif
-#ifndef CX_PRODUCT
-    if (max_seqlen <= 128 && g_fwd_s128 == 1) {
-        const int n_units = B * H;
-        hipLaunchKernelGGL(attn_fwd_s128p_kernel, dim3(n_units < 512 ? n_units : 512), dim3(256), 0,
-                           (hipStream_t)stream, p, B, max_seqlen);
-        return done();
-    }
-    if (max_seqlen <= 128 && g_fwd_s128 == 0) {
-        hipLaunchKernelGGL(attn_fwd_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
-        return done();
-    }
-#endif
-    if (max_seqlen <= 128) {  // one workgroup per (sequence, head) problem, single pass
+    if (max_seqlen <= 128 && single_pass) {  // one workgroup per (sequence, head) problem, single pass
         hipLaunchKernelGGL(attn_fwd_s128v_kernel<false>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (max_seqlen <= 256) {  // the same with K / V of up to 256 rows resident (round 6: the ViT's 197 tokens)
+    } else if (max_seqlen <= 256 && single_pass) {  // the same with K / V of up to 256 rows resident (round 6: the ViT's 197 tokens)
         static CxLdsOptIn lds_f256;
         if (!lds_f256.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<false>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
         hipLaunchKernelGGL(attn_fwd_s256_kernel<false>, dim3(H, B), dim3(256), S256_LDS_FWD, (hipStream_t)stream, p);
-    } else if (!rot_cos && fwd_long) {  // long sequences, q / k already rotated (or no rotary at all): 64 rows per wave, K / V by LDS-DMA (round 6)
+    } else if (max_seqlen > 128 && !rot_cos && fwd_long) {  // long sequences, q / k already rotated (or no rotary at all): 64 rows per wave, K / V by LDS-DMA (round 6)
         hipLaunchKernelGGL(attn_fwd_long_kernel<false>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
     } else {
         dim3 grid((max_seqlen + 127) / 128, H, B);
@@ -2756,33 +1492,10 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
 #ifndef CX_PRODUCT
     p.prio = g_attn_prio;
     const int bwd_mode = g_bwd_s128;
-    const bool bwd_long = g_bwd_long != 0, bwd_s256 = g_bwd_s256 != 0;
+    const bool bwd_long = g_bwd_long != 0;
 #else
-    constexpr int bwd_mode = CX_ATTN_BWD_MODE;
-    constexpr bool bwd_long = true, bwd_s256 = false;
-#endif
-#ifndef CX_PRODUCT
-    if (max_seqlen <= 128 && bwd_mode == 4) {  // the same with the next problem's loads ahead of the dQ store (A/B; round 4)
-        static CxLdsOptIn lds2p;
-        if (!lds2p.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false, 1>), FUSED2_LDS)) return CX_ERR_LAUNCH;
-        const int n_units = B * H;
-        hipLaunchKernelGGL((attn_bwd_fused2_s128_kernel<false, 1>), dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
-                           (hipStream_t)stream, p, B);
-        return done();
-    }
-#endif
-#if !defined(CX_PRODUCT) || CX_ATTN_BWD_MODE == 5
-    // the same with the next problem's rows by LDS-DMA into the dead tiles (round 5; dev library + A/B builds of the product):
-    // bit-identical, 1.39 x SLOWER at the metric's shape (profiles/r5_attn_bwd_s128_ab.txt) -- two more barriers, a raw-row round
-    // trip through LDS and 47 spilled registers cost more than the load wait they remove while the CU's other workgroup covers it
-    if (max_seqlen <= 128 && bwd_mode == 5) {
-        static CxLdsOptIn lds2q;
-        if (!lds2q.ensure(reinterpret_cast<const void*>(&attn_bwd_fused2_s128_kernel<false, 2>), FUSED2_LDS)) return CX_ERR_LAUNCH;
-        const int n_units = B * H;
-        hipLaunchKernelGGL((attn_bwd_fused2_s128_kernel<false, 2>), dim3(n_units < 512 ? n_units : 512), dim3(256), FUSED2_LDS,
-                           (hipStream_t)stream, p, B);
-        return done();
-    }
+    constexpr int bwd_mode = 3;
+    constexpr bool bwd_long = true;
 #endif
     if (max_seqlen <= 128 && bwd_mode == 3) {  // fused persistent kernel, 80 KiB LDS: two workgroups per CU
         static CxLdsOptIn lds2;
@@ -2792,39 +1505,15 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
                            (hipStream_t)stream, p, B);
         return done();
     }
-#ifndef CX_PRODUCT
-    if (max_seqlen <= 128 && bwd_mode == 2) {  // one fused persistent kernel (computes delta itself)
-        static CxLdsOptIn lds1;
-        if (!lds1.ensure(reinterpret_cast<const void*>(&attn_bwd_fused_s128_kernel), FUSED_LDS)) return CX_ERR_LAUNCH;
-        const int n_units = B * H;
-        hipLaunchKernelGGL(attn_bwd_fused_s128_kernel, dim3(n_units < 256 ? n_units : 256), dim3(256), FUSED_LDS,
-                           (hipStream_t)stream, p, B);
-        return done();
-    }
-#endif
     if (max_seqlen > 128 && !p.lcos && bwd_long) {   // second-generation streaming kernels (round 6): no delta pass
         hipLaunchKernelGGL(attn_bwd_dq_long_kernel<false>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
         hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<false>, dim3((max_seqlen + 127) / 128, H, B), dim3(256), LONG_LDS_DKV, (hipStream_t)stream, p);
-        return done();
-    }
-    if (max_seqlen > 128 && max_seqlen <= 256 && bwd_mode && bwd_s256) {  // one persistent 8-wave workgroup per CU, K / V resident (dev A/B: slower, see attn_s256.inc)
-        static CxLdsOptIn lds_b256;
-        if (!lds_b256.ensure(reinterpret_cast<const void*>(&attn_bwd_s256_kernel<false>), S256_LDS_BWD)) return CX_ERR_LAUNCH;
-        const int n_units = B * H;
-        hipLaunchKernelGGL(attn_bwd_s256_kernel<false>, dim3(n_units < 256 ? n_units : 256), dim3(512), S256_LDS_BWD, (hipStream_t)stream, p, B);
         return done();
     }
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
-#ifndef CX_PRODUCT
-    if (max_seqlen <= 128 && bwd_mode) {
-        hipLaunchKernelGGL(attn_bwd_dq_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_s128_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
-        return done();
-    }
-#endif
     dim3 grid((max_seqlen + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -2920,10 +1609,8 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
     p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
 #ifndef CX_PRODUCT
     const bool fused = g_bwd_s128 != 0;         // (dev library: cx_attn_set_bwd_s128(0) keeps the general kernels for A/B)
-    const bool s256_drop_bwd = g_bwd_s256 != 0;
 #else
     constexpr bool fused = true;
-    constexpr bool s256_drop_bwd = false;
 #endif
     if (max_seqlen <= 128 && fused) {   // fused persistent kernel with the mask (delta inline: `delta` is not written)
         static CxLdsOptIn lds2d;
@@ -2938,13 +1625,6 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
         hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<true>, dim3((max_seqlen + 127) / 128, H, B), dim3(256), LONG_LDS_DKV, (hipStream_t)stream, p);
         return done();
     }
-    if (max_seqlen <= 256 && fused && s256_drop_bwd) {
-        static CxLdsOptIn lds_b256d;
-        if (!lds_b256d.ensure(reinterpret_cast<const void*>(&attn_bwd_s256_kernel<true>), S256_LDS_BWD)) return CX_ERR_LAUNCH;
-        const int n_units = B * H;
-        hipLaunchKernelGGL(attn_bwd_s256_kernel<true>, dim3(n_units < 256 ? n_units : 256), dim3(512), S256_LDS_BWD, (hipStream_t)stream, p, B);
-        return done();
-    }
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;
@@ -2956,37 +1636,6 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
 }
 
 #ifndef CX_PRODUCT
-// fused long-sequence backward (dev library; round 5): delta kernel, the single-owner fused kernel, the dQ
-// finish kernel.  `ws`: cx_attn_bwd_fused_long_ws_floats(B, H, T) floats of scratch (contents irrelevant).  prerotated != 0:
-// qkv holds rotated q / k (the engine's long-sequence path), the tables only un-rotate the gradients.  p_drop = 0: no dropout.
-long long cx_attn_bwd_fused_long_ws_floats(int B, int H, int T) { return (long long)H * ((long long)T + 64LL * B) * 64LL; }
-int cx_attn_varlen_bwd_fused_long(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
-                                  const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, int prerotated, float* delta,
-                                  uint16_t* dqkv, float* ws, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
-                                  unsigned long long seed, unsigned long long offset, unsigned int site, void* stream) {
-    if (B <= 0 || T <= 0 || max_seqlen <= 0) return CX_OK;
-    if (!dout || !qkv || !out || !lse || !cu_seqlens || !delta || !dqkv || !ws) return CX_ERR_ARG;
-    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return CX_ERR_ARG;
-    AttnParams p = {};
-    p.qkv = qkv; p.cu = cu_seqlens; p.cosv = rot_cos; p.sinv = rot_sin;
-    p.lcos = prerotated ? nullptr : rot_cos; p.lsin = prerotated ? nullptr : rot_sin;
-    p.out = const_cast<uint16_t*>(out); p.lse = const_cast<float*>(lse);
-    p.dout = dout; p.delta = delta; p.dqkv = dqkv;
-    p.H = H; p.T = T; p.scale = softmax_scale;
-    long nthreads = (long)T * H * 8;
-    int g = (int)((nthreads + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
-    if (p_drop > 0.f) {
-        p.drop = CxDropout{p_drop, seed, offset}; p.drop_site = site;
-        hipLaunchKernelGGL(attn_bwd_fused_long_kernel<true>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p, ws, B);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_fused_long_kernel<false>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p, ws, B);
-    }
-    hipLaunchKernelGGL(attn_dq_finish_kernel, dim3((max_seqlen + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, p, ws, B);
-    return done();
-}
-
 // test helper (dev library): keep[b][h][q][key] in {0, 1} of the mask the kernels above apply
 int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
                               unsigned long long offset, unsigned int site, void* stream) {

@@ -51,20 +51,16 @@ void cx_gemm_v7_period(int cycles);
 void cx_gemm_set_glds(int enable); /* 1 (default): operand tiles via global_load_lds DMA; 0: register staging */
 int cx_gemm_get_glds(void);
 
-/* backward kernel choice for max_seqlen <= 128: 3 = fused persistent kernel with an 80 KiB LDS layout, two workgroups
- * per CU (default; `delta` is not written), 2 = fused, 116 KiB, one workgroup per CU, 1 = one-pass dq + dkv kernels,
- * 0 = the general kernels */
-void cx_attn_set_bwd_s128(int mode);   /* 4 (round 4, A/B): mode 3 with the next problem's rows requested ahead of the dQ store */
+/* A/B switches of the attention dispatch (benchmarks, tests; process-global, dev library only).  The product library has none:
+ * max_seqlen <= 128 -> attn_fwd_s128v / attn_bwd_fused2_s128 (single pass, one workgroup per problem); 128 < max_seqlen <= 256 ->
+ * attn_fwd_s256 (K / V resident); longer, or any length beyond 128 in the backward -> the second-generation streaming kernels
+ * (attn_fwd_long / attn_bwd_dq_long / attn_bwd_dkv_long) unless tables ask for rotate-on-load or the call is kv-packed, which keep round
+ * 1's streaming kernels. */
+void cx_attn_set_fwd_s128(int mode);   /* 0: the general streaming forward also for max_seqlen <= 256; non-zero (default): single pass */
+void cx_attn_set_bwd_s128(int mode);   /* 0: the general streaming backward also for max_seqlen <= 128; non-zero (default): fused persistent kernel */
+void cx_attn_set_fwd_long(int on);     /* 0: round 1's attn_fwd_kernel for max_seqlen > 256; 1 (default): attn_fwd_long_kernel */
+void cx_attn_set_bwd_long(int on);     /* 0: round 1's delta + dQ + dK/dV kernels for max_seqlen > 128; 1 (default): attn_bwd_dq_long / _dkv_long */
 void cx_attn_set_prio(int on);         /* experiments: the MFMA loop of the fused S <= 128 backward at s_setprio 1 */
-
-/* forward kernel for max_seqlen <= 128: 2 (default) lean-VALU form with full-row output stores (V fragments through
- * the transposing LDS read, mask skipped for full sequences, scale folded into the exponent, output staged in LDS),
- * 0 the first one-problem-per-workgroup form (<= 1 bf16 ulp apart), 1 persistent workgroups that prefetch the next
- * problem (bit-identical to 0).  A/B switch for benchmarks (scripts/attn_fwd_ab.py). */
-void cx_attn_set_fwd_s128(int mode);
-void cx_attn_set_fwd_long(int on);
-void cx_attn_set_bwd_long(int on);   /* 1 (default): attn_bwd_dq_long / _dkv_long for max_seqlen > 128 without rotate-on-load; 0: round 1's three kernels */
-void cx_attn_set_bwd_s256(int on);   /* 1: the fused persistent backward for 128 < max_seqlen <= 256 (A/B only: slower) */   /* 1 (default): attn_fwd_long_kernel for max_seqlen > 256 without rotate-on-load; 0: round 1's attn_fwd_kernel */
 
 /* ---- hardware self-checks used by tests (MFMA fragment layout, transpose-read semantics) ------------------- */
 int cx_probe_mfma_layout(float* out_32x32, void* stream);           /* D = A*B with A[i][k]=i+1 (k==0), asymmetric B */
@@ -73,15 +69,6 @@ int cx_probe_ds_read_tr16(const uint16_t* in_64x4, uint16_t* out_64x4, void* str
 /* keep[b][h][q][key] in {0, 1}: the mask cx_attn_varlen_dropout_fwd/_bwd apply (tests) */
 int cx_attn_dropout_keep_mask(unsigned char* keep, int B, int H, int S, float p_drop, unsigned long long seed,
                               unsigned long long offset, unsigned int site, void* stream);
-/* fused long-sequence attention backward (round 5): one workgroup per (sequence, head), dK / dV in registers over the query chunks,
- * dQ added into `ws` (cx_attn_bwd_fused_long_ws_floats(B, H, T) floats, contents irrelevant), then scaled / un-rotated into dqkv.
- * Arguments of the product backward entry point, plus prerotated: qkv holds rotated q / k as in cx_attn_varlen_bwd_prerotated; p_drop = 0: no
- * dropout, otherwise the mask of cx_attn_varlen_dropout_bwd).  scripts/attn_bwd_long_ab.py, tests/test_kernels_gpu.py */
-long long cx_attn_bwd_fused_long_ws_floats(int B, int H, int T);
-int cx_attn_varlen_bwd_fused_long(const uint16_t* dout, const uint16_t* qkv, const uint16_t* out, const float* lse,
-                                  const int32_t* cu_seqlens, const float* rot_cos, const float* rot_sin, int prerotated, float* delta,
-                                  uint16_t* dqkv, float* ws, int B, int H, int T, int max_seqlen, float softmax_scale, float p_drop,
-                                  unsigned long long seed, unsigned long long offset, unsigned int site, void* stream);
 /* what the dQ accumulation of a single-owner fused long-sequence attention backward costs by itself: every workgroup walks its
  * problems (floats_per_problem fp32 each, contiguous), `sweeps` load + add + store passes over each (scripts/dq_rmw_probe.py) */
 int cx_probe_rmw(float* buf, long floats_per_problem, int sweeps, int n_problems, int nwg, void* stream);

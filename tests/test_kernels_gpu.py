@@ -419,57 +419,6 @@ def test_attention_prerotated_path_equals_rotate_on_load(lens):
     assert rel_err(o1.float(), o0.float()) < 4e-3 and rel_err(g1.float(), g0.float()) < 8e-3
 
 
-@pytest.mark.parametrize("mode", ["plain", "rotate_on_load", "prerotated", "dropout"])
-@pytest.mark.parametrize("lens", [[300, 129, 64], [1000, 257, 1], [2048, 1531]])
-def test_attention_fused_long_backward_equals_the_two_kernel_backward(mode, lens):
-    """Round 5: the single-owner fused long-sequence backward of the dev library (one workgroup per (sequence, head),
-    dK / dV in registers over the query chunks, dQ summed in an fp32 scratch only that workgroup touches).  Its dK / dV loop is the dK / dV
-    kernel's arithmetic in the same order: bit-identical; dQ is the same sum in another fp32 order.  Measured 1.4 x slower than the two
-    kernels it would replace (profiles/r5_attn_bwd_fused_long_ab.txt): not routed, kept with this test."""
-    H, D = 3, 64
-    T, B, mx = sum(lens), len(lens), max(lens)
-    dl = _C.dev_lib()
-    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
-    inv = 1.0 / (1000.0 ** (torch.arange(0, D, 2).float() / D))
-    fr = torch.outer(torch.arange(max(512, mx)).float(), inv)
-    cos, sin = torch.cos(fr).to(DEV).contiguous(), torch.sin(fr).to(DEV).contiguous()
-    scale = 1 / math.sqrt(D)
-    x = bf(_randn(T, 3, H, D, seed=52))
-    do = bf(_randn(T, H, D, seed=53))
-    out = torch.empty(T, H, D, dtype=torch.bfloat16, device=DEV)
-    lse = torch.empty(H, T, device=DEV)
-    delta = torch.empty(H, T, device=DEV)
-    ref = torch.full_like(x, float("nan"))
-    got = torch.full_like(x, float("nan"))
-    ws = torch.full((int(dl.cx_attn_bwd_fused_long_ws_floats(B, H, T)),), float("nan"), device=DEV)
-    p_drop, seed, off, site = (0.1, 77, 8, 2) if mode == "dropout" else (0.0, 0, 0, 0)
-    c, sn = (None, None) if mode in ("plain", "dropout") else (cos, sin)
-    if mode == "prerotated":
-        _C.check(dl.cx_rotary_qkv_inplace(x.data_ptr(), cu.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, H, T, mx, 1, S()))
-        _C.check(dl.cx_attn_varlen_fwd(x.data_ptr(), cu.data_ptr(), None, None, out.data_ptr(), lse.data_ptr(), B, H, T, mx, scale, S()))
-        _C.check(dl.cx_attn_varlen_bwd_prerotated(do.data_ptr(), x.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(), cos.data_ptr(),
-                                                  sin.data_ptr(), delta.data_ptr(), ref.data_ptr(), B, H, T, mx, scale, S()))
-    elif mode == "dropout":
-        _C.check(dl.cx_attn_varlen_dropout_fwd(x.data_ptr(), cu.data_ptr(), None, None, out.data_ptr(), lse.data_ptr(), B, H, T, mx, scale,
-                                               p_drop, seed, off, site, S()))
-        _C.check(dl.cx_attn_varlen_dropout_bwd(do.data_ptr(), x.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(), None, None,
-                                               delta.data_ptr(), ref.data_ptr(), B, H, T, mx, scale, p_drop, seed, off, site, S()))
-    else:
-        _C.check(dl.cx_attn_varlen_fwd(x.data_ptr(), cu.data_ptr(), _C.ptr(c), _C.ptr(sn), out.data_ptr(), lse.data_ptr(), B, H, T, mx, scale, S()))
-        _C.check(dl.cx_attn_varlen_bwd(do.data_ptr(), x.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(), _C.ptr(c), _C.ptr(sn),
-                                       delta.data_ptr(), ref.data_ptr(), B, H, T, max(mx, 129), scale, S()))   # (129: the general kernels)
-    delta.fill_(float("nan"))
-    _C.check(dl.cx_attn_varlen_bwd_fused_long(do.data_ptr(), x.data_ptr(), out.data_ptr(), lse.data_ptr(), cu.data_ptr(), _C.ptr(c), _C.ptr(sn),
-                                              1 if mode == "prerotated" else 0, delta.data_ptr(), got.data_ptr(), ws.data_ptr(), B, H, T, mx,
-                                              scale, p_drop, seed, off, site, S()))
-    torch.cuda.synchronize()
-    assert torch.isfinite(got.float()).all()
-    assert torch.equal(got[:, 1], ref[:, 1]) and torch.equal(got[:, 2], ref[:, 2])          # dK, dV: bit for bit
-    e_q = rel_err(got[:, 0].float(), ref[:, 0].float())
-    report("attention_fused_long_bwd", mode=mode, lens=str(lens), dq_vs_two_kernel=e_q)
-    assert e_q < 2e-3                                                                         # dQ: fp32 summation order, then one bf16 rounding
-
-
 @pytest.mark.parametrize("rotary", [True, False])
 @pytest.mark.parametrize("lens", [[128, 64, 100, 1], [197], [300, 129, 64], [128] * 8, [2048, 1531],
                                   [256, 129, 225, 224, 96, 1],    # 128 < max <= 256: the single-pass K / V-resident kernels (round 6)
