@@ -1460,15 +1460,19 @@ int cx_attn_varlen_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, const flo
 #ifndef CX_PRODUCT
     const bool fwd_long = g_fwd_long != 0;   // (dev library: cx_attn_set_fwd_long(0) keeps round 1's streaming kernel for A/B)
     const bool single_pass = g_fwd_s128 != 0;
+#elif defined(CX_AB_R5_ROUTES)   // evidence builds only (scripts/build_variant.py r5routes ...): round 5's kernel routing for a same-box A/B of the legs
+    constexpr bool fwd_long = false, single_pass = true;
 #else
     constexpr bool fwd_long = true, single_pass = true;
 #endif
     if (max_seqlen <= 128 && single_pass) {  // one workgroup per (sequence, head) problem, single pass
         hipLaunchKernelGGL(attn_fwd_s128v_kernel<false>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
+#ifndef CX_AB_R5_ROUTES
     } else if (max_seqlen <= 256 && single_pass) {  // the same with K / V of up to 256 rows resident (round 6: the ViT's 197 tokens)
         static CxLdsOptIn lds_f256;
         if (!lds_f256.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<false>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
         hipLaunchKernelGGL(attn_fwd_s256_kernel<false>, dim3(H, B), dim3(256), S256_LDS_FWD, (hipStream_t)stream, p);
+#endif
     } else if (max_seqlen > 128 && !rot_cos && fwd_long) {  // long sequences, q / k already rotated (or no rotary at all): 64 rows per wave, K / V by LDS-DMA (round 6)
         hipLaunchKernelGGL(attn_fwd_long_kernel<false>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
     } else {
@@ -1493,6 +1497,9 @@ int cx_attn_varlen_bwd(const uint16_t* dout, const uint16_t* qkv, const uint16_t
     p.prio = g_attn_prio;
     const int bwd_mode = g_bwd_s128;
     const bool bwd_long = g_bwd_long != 0;
+#elif defined(CX_AB_R5_ROUTES)
+    constexpr int bwd_mode = 3;
+    constexpr bool bwd_long = false;
 #else
     constexpr int bwd_mode = 3;
     constexpr bool bwd_long = true;
@@ -1536,6 +1543,8 @@ int cx_attn_varlen_bwd_prerotated(const uint16_t* dout, const uint16_t* qkv_rota
     p.H = H; p.T = T; p.scale = softmax_scale;
 #ifndef CX_PRODUCT
     const bool bwd_long = g_bwd_long != 0;
+#elif defined(CX_AB_R5_ROUTES)
+    constexpr bool bwd_long = false;
 #else
     constexpr bool bwd_long = true;
 #endif
@@ -1578,6 +1587,7 @@ int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, c
         hipLaunchKernelGGL(attn_fwd_s128v_kernel<true>, dim3(H, B), dim3(256), 0, (hipStream_t)stream, p);
         return done();
     }
+#ifndef CX_AB_R5_ROUTES
     if (max_seqlen <= 256 && single_pass) {
         static CxLdsOptIn lds_f256d;
         if (!lds_f256d.ensure(reinterpret_cast<const void*>(&attn_fwd_s256_kernel<true>), S256_LDS_FWD)) return CX_ERR_LAUNCH;
@@ -1588,6 +1598,7 @@ int cx_attn_varlen_dropout_fwd(const uint16_t* qkv, const int32_t* cu_seqlens, c
         hipLaunchKernelGGL(attn_fwd_long_kernel<true>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
         return done();
     }
+#endif
     dim3 grid((max_seqlen + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return done();
@@ -1620,11 +1631,13 @@ int cx_attn_varlen_dropout_bwd(const uint16_t* dout, const uint16_t* qkv, const 
                            (hipStream_t)stream, p, B);
         return done();
     }
+#ifndef CX_AB_R5_ROUTES
     if (max_seqlen > 128 && !p.lcos && fused) {   // second-generation streaming kernels with the mask (round 6)
         hipLaunchKernelGGL(attn_bwd_dq_long_kernel<true>, dim3((max_seqlen + 255) / 256, H, B), dim3(256), LONG_LDS, (hipStream_t)stream, p);
         hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<true>, dim3((max_seqlen + 127) / 128, H, B), dim3(256), LONG_LDS_DKV, (hipStream_t)stream, p);
         return done();
     }
+#endif
     long nthreads = (long)T * H * 8;
     int g = (int)((nthreads + 255) / 256);
     if (g > 2048) g = 2048;

@@ -330,9 +330,11 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
             fused = cx_gemm_bf16_swiglu_bwd_gate(dm, w.Wfc2T, s.act(l), s.yg(l), buf->g_wide, T, I, d, d, d, I, s.wfc1, stream);
         // plain MLP whose forward took the fused bias + activation kernel (yg = the biased pre-activation): fc2 dgrad, the activation
         // backward and the fc1 bias gradient's partials in ONE kernel (round 6) -- d(act) never touches HBM either
+#ifndef CX_AB_R5_ROUTES   // (evidence builds: scripts/build_variant.py r5routes attention.hip -DCX_AB_R5_ROUTES --- engine.hip -DCX_AB_R5_ROUTES)
         if (!enc->gated && gelu_fused_shape(T, s.wfc1, d))
             fused = cx_gemm_bf16_act_bwd(dm, w.Wfc2T, s.yg(l), buf->g_wide, w.gbfc1, buf->ws_f32, buf->ws_floats, T, I, d, d, d, I, I,
                                          enc->mlp_act, stream);
+#endif
         if (fused != CX_ERR_SHAPE) {
             CX_TRY(fused);
         } else {
