@@ -768,7 +768,7 @@ def main():
         # passes of this same command line (scripts/gpu_round.sh PMC=1 -> scripts/pmc_traffic.py) when they were
         # collected at the same launch sizes (same GradCache chunk), else null.
         traffic, traffic_src = None, None
-        for name in ("r5_pmc_gemm_traffic.json", "r4_pmc_gemm_traffic.json", "r3_pmc_gemm_traffic.json", "r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
+        for name in ("r6_pmc_gemm_traffic.json", "r5_pmc_gemm_traffic.json", "r4_pmc_gemm_traffic.json", "r3_pmc_gemm_traffic.json", "r2_pmc_gemm_traffic.json", "r1_pmc_gemm_traffic.json"):
             try:
                 tj = json.load(open(ROOT / "profiles" / name))
                 if tj.get("grad_cache_chunk") == min(args.chunk_size, b):

@@ -183,7 +183,13 @@ class _ChunkArena:
         # split-K workspace (fp32 partial slabs): 8 slabs of the largest weight, 16 of the smallest, for the wgrad GEMMs; every
         # arena has it, because the few-tile long-K projections of SMALL chunks take a split-K route too
         # (cx_gemm_bf16_nt_splitk) and a no-grad forward must round exactly like the saving forward of the same chunk
-        t["ws_f32"] = torch.empty(max(8 * max(3 * d, wfc1, patch_dim) * d, 16 * d * d), **f32)
+        # ... and, for a plain (GELU) MLP with a backward, the fc1 bias gradient's per-128-row partials of the fused fc2-dgrad + activation
+        # backward (cx_gemm_bf16_act_bwd, round 6): ceil(T / 128) x I floats -- at the CLIP leg's image tower (807 k token rows) 3 % more than
+        # the split-K slabs; without it that launch fell back to the two-kernel route
+        ws_floats = max(8 * max(3 * d, wfc1, patch_dim) * d, 16 * d * d)
+        if with_backward and wfc1 == I:
+            ws_floats = max(ws_floats, ((T_cap + 127) // 128) * I)
+        t["ws_f32"] = torch.empty(ws_floats, **f32)
         if with_backward:
             wide = max(3 * d, wfc1, patch_dim)
             for n in ("g_a", "g_b", "g_c"):

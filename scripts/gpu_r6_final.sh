@@ -55,13 +55,11 @@ timeout 300 python scripts/gemm_trace.py --chunk 2048 > $O/gemm_trace.txt 2>&1
 L=contrastors_amd/lib
 if [[ -f $L/variants/libcontrastors_hip_r5routes.so ]]; then
   cp $L/libcontrastors_hip.so /tmp/base.so
+  i=0
   for v in base r5routes base r5routes; do
+    i=$((i+1))
     if [[ $v == base ]]; then cp /tmp/base.so $L/libcontrastors_hip.so; else cp $L/variants/libcontrastors_hip_$v.so $L/libcontrastors_hip.so; fi
-    timeout 900 python bench.py --steps 3 --warmup 1 --only-config-legs cfg1,lit,clip,cfg3 > $O/legs_ab_$v.log 2>&1
-    echo "$v: $(grep '^{' $O/legs_ab_$v.log | tail -1 | python -c '
-import json,sys
-d=json.loads(sys.stdin.read())
-print("  ".join(f"{k} {d[k][\"value\"]:.1f} ({d[k][\"ms_per_step\"]:.1f} ms)" for k in ("cfg1","cfg3","lit","clip") if k in d))')" | tee -a $O/legs_ab_r6_vs_r5_routes.txt
+    timeout 900 python bench.py --steps 3 --warmup 1 --only-config-legs cfg1,lit,clip,cfg3 > $O/legs_ab_${v}_$i.log 2>&1
   done
   cp /tmp/base.so $L/libcontrastors_hip.so
 fi
