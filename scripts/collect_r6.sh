@@ -15,7 +15,6 @@ grep -v amdgpu.ids $O/gemm_microbench.txt > profiles/r6_microbench_gemm2048.txt
 grep -v amdgpu.ids $O/attn_microbench.txt > profiles/r6_microbench_attention.txt
 grep -v amdgpu.ids $O/attn_microbench_dropout.txt > profiles/r6_microbench_attention_dropout.txt
 grep -v amdgpu.ids $O/attn_bwd_s128_phase_trace.txt > profiles/r6_attn_bwd_s128_phase_trace.txt
-grep -v amdgpu.ids $O/gemm_trace.txt > profiles/r6_gemm_phase_trace.txt
 tail -3 $O/gpu_tests.txt > profiles/r6_gpu_tests.txt; tail -1 $O/smoke.log >> profiles/r6_gpu_tests.txt
 cp $O/box_calibration.json profiles/r6_box_calibration.json
 { echo "# Same-box A/B of the config legs: the product library against variant r5routes (round 5's kernel routing: round 1's streaming attention"

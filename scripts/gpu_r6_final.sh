@@ -50,7 +50,6 @@ timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 128,197,204
 if [[ -f contrastors_amd/lib/variants/libcontrastors_hip_dev_attntrace.so ]]; then
   CONTRASTORS_HIP_DEV_LIB=contrastors_amd/lib/variants/libcontrastors_hip_dev_attntrace.so timeout 200 python scripts/attn_trace.py > $O/attn_bwd_s128_phase_trace.txt 2>&1
 fi
-timeout 300 python scripts/gemm_trace.py --chunk 2048 > $O/gemm_trace.txt 2>&1
 # --- the config legs against round 5's kernel routing, same box, alternating libraries (host code identical)
 L=contrastors_amd/lib
 if [[ -f $L/variants/libcontrastors_hip_r5routes.so ]]; then
