@@ -91,6 +91,8 @@ _SIGS = {
                                            C.c_uint, vp]),
     "cx_dropout_add_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, C.c_ulonglong,
                                            C.c_ulonglong, C.c_uint, vp]),
+    "cx_dropout_add_layernorm_bwd_colsum": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, C.c_ulonglong,
+                                                  C.c_ulonglong, C.c_uint, vp]),
     "cx_dropout_scale": (i32, [vp, i64, f32, C.c_ulonglong, C.c_ulonglong, C.c_uint, vp]),
     "cx_layernorm_fwd_mixed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "cx_layernorm_bwd_mixed": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -406,14 +406,22 @@ int blocks_backward(const CxEncoderDesc* enc, const CxChunkBuffers* buf, const S
                 if (!buf->g_d) return CX_ERR_ARG;
                 const float p = enc->resid_pdrop;
                 bool f1 = false, f2 = false;
-                CX_TRY(cx_dropout_add_layernorm_bwd(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, buf->g_d, w.gln2_g,
-                                                    w.gln2_b, buf->ws_f32, buf->ws_floats, T, d, p, buf->drop_seed,
-                                                    buf->drop_offset, 2 * l + 1, stream));
-                CX_TRY(mlp_bwd(w, l, buf->g_d, s.h1(l), buf->g_c, &f1, false));   // -> g_b = d h1 (+ dz2 when folded)
-                CX_TRY(cx_dropout_add_layernorm_bwd(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l),
-                                                    s.rstd1(l), buf->g_a, buf->g_d, w.gln1_g, w.gln1_b, buf->ws_f32, buf->ws_floats,
-                                                    T, d, p, buf->drop_seed, buf->drop_offset, 2 * l, stream));
-                CX_TRY(attn_bwd(w, l, buf->g_d, h_in, buf->g_a, &f2, false));
+                // (round 6) the masked gradient g_d IS the gradient of the sub-layer's Linear output: its column sums = that Linear's bias
+                // gradient ride along in the LayerNorm backward when the arena's workspace holds the third partial vector
+#ifdef CX_AB_R5_ROUTES
+                const bool cs = false;
+#else
+                const bool cs = buf->ws_f32 && buf->ws_floats >= 3L * d * 256;
+#endif
+                CX_TRY(cx_dropout_add_layernorm_bwd_colsum(da, db, s.z2(l), w.ln2_g, s.mean2(l), s.rstd2(l), buf->g_c, buf->g_d, w.gln2_g,
+                                                           w.gln2_b, cs ? w.gbfc2 : nullptr, buf->ws_f32, buf->ws_floats, T, d, p,
+                                                           buf->drop_seed, buf->drop_offset, 2 * l + 1, stream));
+                CX_TRY(mlp_bwd(w, l, buf->g_d, s.h1(l), buf->g_c, &f1, cs));   // -> g_b = d h1 (+ dz2 when folded)
+                CX_TRY(cx_dropout_add_layernorm_bwd_colsum(f1 ? buf->g_b : buf->g_c, f1 ? nullptr : buf->g_b, s.z1(l), w.ln1_g, s.mean1(l),
+                                                           s.rstd1(l), buf->g_a, buf->g_d, w.gln1_g, w.gln1_b, cs ? w.gbout : nullptr,
+                                                           buf->ws_f32, buf->ws_floats, T, d, p, buf->drop_seed, buf->drop_offset, 2 * l,
+                                                           stream));
+                CX_TRY(attn_bwd(w, l, buf->g_d, h_in, buf->g_a, &f2, cs));
                 da = f2 ? buf->g_b : buf->g_a;
                 db = f2 ? nullptr : buf->g_b;
                 CX_TRY(mark_grads_done(buf, l, stream));

@@ -788,21 +788,27 @@ __global__ __launch_bounds__(256) void ln_fwd_drop_kernel(const bf16_t* __restri
     }
 }
 
-template <int NCH>
+// CS (round 6): the column sums of the bf16 dx0 written -- dx0 is the gradient of the sub-layer's OUTPUT (out_proj / fc2 of the block), so
+// they are that Linear's bias gradient, as in ln_bwd_kernel<., CS>: the dropout recipes (bert-base-uncased: cfg 1, the LiT / CLIP text towers)
+// ran a standalone colsum_kernel launch per bias (36 per step at cfg 1: 4.9 % of it, profiles/r6_kernel_summary_cfg1.txt).
+template <int NCH, bool CS = false>
 __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ dbb,
                                                           const bf16_t* __restrict__ z, const float* __restrict__ gamma,
                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                           bf16_t* __restrict__ dz, bf16_t* __restrict__ dx0, float* dgamma,
-                                                          float* dbeta, float* part, int rows, CxDropout dr, uint32_t site) {
+                                                          float* dbeta, float* part, float* part3, int rows, CxDropout dr, uint32_t site) {
     constexpr int D = NCH * 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float g[NCH][4], dg[NCH][4], db[NCH][4];
+    float g[NCH][4], dg[NCH][4], db[NCH][4], dc[CS ? NCH : 1][4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         load4_f32(gamma + (i * 64 + lane) * 4, g[i]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            dg[i][e] = db[i][e] = 0.f;
+            if (CS) dc[i][e] = 0.f;
+        }
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mean = mean_i[row], rstd = rstd_i[row];
@@ -842,7 +848,18 @@ __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const bf16_t* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) m[e] = o[e] * keep[e];
             store4_bf16(dz + off, o);
-            store4_bf16(dx0 + off, m);
+            if constexpr (CS) {
+                uint2 u;
+                u.x = pack_bf16x2(m[0], m[1]);
+                u.y = pack_bf16x2(m[2], m[3]);
+                *reinterpret_cast<uint2*>(dx0 + off) = u;
+                float r[4];
+                unpack4_bf16(u, r);   // (the bias gradient sums what the next kernels read: the bf16 dx0)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dc[i][e] += r[e];
+            } else {
+                store4_bf16(dx0 + off, m);
+            }
         }
     }
     if (part) {
@@ -850,6 +867,7 @@ __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const bf16_t* __restri
     } else {
         flush_param_grads<NCH>(dg, db, dgamma, dbeta, smem);
     }
+    if constexpr (CS) store_colsum_partials<NCH>(dc, part3, smem);
 }
 
 // x <- x * mask / (1 - p) in place (the embedding dropout on the embedding-LayerNorm output, and on its incoming gradient)
@@ -1008,6 +1026,16 @@ int cx_dropout_add_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b,
                                  const float* mean, const float* rstd, uint16_t* dz, uint16_t* dx0, float* dgamma, float* dbeta,
                                  float* ws, long ws_floats, int rows, int d, float p, unsigned long long seed,
                                  unsigned long long offset, unsigned int site, void* stream) {
+    return cx_dropout_add_layernorm_bwd_colsum(dout_a, dout_b, z, gamma, mean, rstd, dz, dx0, dgamma, dbeta, nullptr, ws, ws_floats, rows, d,
+                                               p, seed, offset, site, stream);
+}
+
+// The same with dx0_colsum (may be NULL): fp32[d] += column sums of the bf16 dx0 written = the bias gradient of the Linear whose (dropped)
+// output the LayerNorm consumed; needs the workspace (>= 3 * d * 256 floats), CX_ERR_ARG without it.
+int cx_dropout_add_layernorm_bwd_colsum(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                                        const float* mean, const float* rstd, uint16_t* dz, uint16_t* dx0, float* dgamma, float* dbeta,
+                                        float* dx0_colsum, float* ws, long ws_floats, int rows, int d, float p, unsigned long long seed,
+                                        unsigned long long offset, unsigned int site, void* stream) {
     if (rows <= 0) return CX_OK;
     if (!dout_a || !z || !gamma || !mean || !rstd || !dz || !dx0) return CX_ERR_ARG;
     if (!(p > 0.f) || p >= 1.f) return CX_ERR_ARG;
@@ -1015,18 +1043,28 @@ int cx_dropout_add_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b,
     const size_t smem = (size_t)8 * d * sizeof(float);
     int grid = ln_grid_bwd(rows);
     float* part = nullptr;
-    if (ws && ws_floats >= (long)2 * d * 256) {
-        long cap = ws_floats / (2L * d);
+    const long per_block = (dx0_colsum ? 3L : 2L) * d;
+    if (ws && ws_floats >= per_block * 256) {
+        long cap = ws_floats / per_block;
         grid = (rows + 31) / 32;   // (as in ln_bwd_launch)
         if (grid > 768) grid = 768;
         if (grid > cap) grid = (int)cap;
         part = ws;
     }
-    CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_drop_kernel<NCH>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
-                                         dout_b, z, gamma, mean, rstd, dz, dx0, dgamma, dbeta, part, rows, dr, site));
+    if (dx0_colsum && !part) return CX_ERR_ARG;
+    float* part3 = dx0_colsum ? part + (size_t)grid * 2 * d : nullptr;
+    if (dx0_colsum) {
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_drop_kernel<NCH, true>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                             dout_b, z, gamma, mean, rstd, dz, dx0, dgamma, dbeta, part, part3, rows, dr, site));
+    } else {
+        CX_LN_DISPATCH(d, hipLaunchKernelGGL((ln_bwd_drop_kernel<NCH, false>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dout_a,
+                                             dout_b, z, gamma, mean, rstd, dz, dx0, dgamma, dbeta, part, part3, rows, dr, site));
+    }
     if (part && (dgamma || dbeta))
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, dgamma, dbeta,
                            grid, d);
+    if (dx0_colsum)
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, part3, dx0_colsum, grid, d);
     return done();
 }
 

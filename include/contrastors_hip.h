@@ -126,6 +126,13 @@ int cx_dropout_add_layernorm_bwd(const uint16_t* dout_a, const uint16_t* dout_b,
                                  const float* mean, const float* rstd, uint16_t* dz, uint16_t* dx0, float* dgamma,
                                  float* dbeta, float* ws, long ws_floats, int rows, int d, float p,
                                  unsigned long long seed, unsigned long long offset, unsigned int site, void* stream);
+/* The same that also accumulates dx0_colsum[n] += sum_t dx0[t][n] (fp32[d], may be NULL: then identical to the call above) -- dx0 is the
+ * gradient of the (dropped) sub-layer output, so these are the bias gradient of the Linear that produced it (cx_abi_version >= 10; needs
+ * ws >= 3 * d * 256 floats, CX_ERR_ARG otherwise).  Deterministic two-stage reduction, no atomics. */
+int cx_dropout_add_layernorm_bwd_colsum(const uint16_t* dout_a, const uint16_t* dout_b, const uint16_t* z, const float* gamma,
+                                        const float* mean, const float* rstd, uint16_t* dz, uint16_t* dx0, float* dgamma, float* dbeta,
+                                        float* dx0_colsum, float* ws, long ws_floats, int rows, int d, float p, unsigned long long seed,
+                                        unsigned long long offset, unsigned int site, void* stream);
 /* x <- x * mask / (1 - p) in place, n % 4 == 0 (embedding dropout, sc/models/encoder/modeling_nomic_bert.py:534-535, and
  * its gradient). */
 int cx_dropout_scale(uint16_t* x, long n, float p, unsigned long long seed, unsigned long long offset, unsigned int site,

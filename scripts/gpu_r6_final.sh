@@ -14,11 +14,11 @@ timeout 1200 python -m pytest tests -m gpu -q --deselect tests/test_distributed_
 timeout 120 python scripts/box_calibration.py > $O/box_calibration.json 2>/dev/null; cut -c1-300 $O/box_calibration.json
 # --- HBM traffic of the GEMM family (separate passes, guide's corrections), at the bench's launch sizes
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$ctr -o b -- python $R/bench.py --steps 1 --warmup 0 --global-batch 2048 --no-cpu-baseline --no-extra-legs --no-config-legs --no-calibration > $O/pmc_$ctr.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$ctr -o b -- python $R/bench.py --steps 1 --warmup 0 --global-batch 4096 --no-cpu-baseline --no-extra-legs --no-config-legs --no-calibration > $O/pmc_$ctr.log 2>&1)
   python scripts/pmc_summary.py $(find $O/pmc_$ctr -name "*counter_collection.csv" | head -1) $ctr > $O/pmc_${ctr}_summary.txt 2>&1
   rm -rf $O/pmc_$ctr
 done
-python scripts/pmc_traffic.py $O/pmc_FETCH_SIZE_summary.txt $O/pmc_WRITE_SIZE_summary.txt 2048 > $O/pmc_gemm_traffic.json 2>&1
+python scripts/pmc_traffic.py $O/pmc_FETCH_SIZE_summary.txt $O/pmc_WRITE_SIZE_summary.txt 4096 > $O/pmc_gemm_traffic.json 2>&1
 python -c "import json; json.load(open('$O/pmc_gemm_traffic.json'))" && cp $O/pmc_gemm_traffic.json profiles/r6_pmc_gemm_traffic.json
 # --- the bench line (reads the traffic file just written)
 timeout 1800 python bench.py --steps 5 --warmup 2 > $O/bench.log 2>&1; grep "^{" $O/bench.log | cut -c1-300
@@ -30,7 +30,7 @@ rm -rf $O/prof
 head -12 $O/kernel_summary.txt | cut -c1-150
 # --- SQ / MFMA counters over one step
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
-(cd /tmp && timeout 600 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $O/pmc_sq -o g -- python $R/bench.py --steps 1 --warmup 0 --global-batch 2048 --no-cpu-baseline --no-extra-legs --no-config-legs --no-calibration > $O/pmc_sq.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $O/pmc_sq -o g -- python $R/bench.py --steps 1 --warmup 0 --global-batch 4096 --no-cpu-baseline --no-extra-legs --no-config-legs --no-calibration > $O/pmc_sq.log 2>&1)
 python scripts/pmc_multi.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_summary.txt 2>&1
 rm -rf $O/pmc_sq
 # --- kernel stats per config leg

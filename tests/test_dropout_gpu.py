@@ -61,6 +61,26 @@ def test_dropout_add_layernorm_kernel_vs_torch_with_the_same_mask(p):
     ref.backward(do.float())
     assert rel_err(dz.float(), rr.grad) < 1e-2 and rel_err(dx0.float(), xr.grad) < 1e-2
     assert rel_err(dg, gr.grad) < 1e-2 and rel_err(db, br.grad) < 1e-3
+    # the same backward with the column sums of dx0 riding along (round 6: the bias gradient of the Linear whose dropped output this
+    # LayerNorm consumed): identical dz / dx0, colsum = the fp32 sum of the bf16 dx0, accumulated INTO the buffer, deterministic
+    dz2, dx02 = torch.empty_like(z), torch.empty_like(z)
+    dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    cs = torch.full((d,), 0.5, device=DEV)
+    ws = torch.empty(3 * d * 256 + 7, device=DEV)
+    _C.check(L().cx_dropout_add_layernorm_bwd_colsum(do.data_ptr(), None, z.data_ptr(), gam.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                     dz2.data_ptr(), dx02.data_ptr(), dg2.data_ptr(), db2.data_ptr(), cs.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), rows, d, p, seed, off, site, S()))
+    assert torch.equal(dz2, dz) and torch.equal(dx02, dx0)
+    assert rel_err(cs, 0.5 + dx0.float().sum(0)) < 1e-5
+    assert rel_err(dg2, gr.grad) < 1e-2 and rel_err(db2, br.grad) < 1e-3
+    cs_b = torch.full((d,), 0.5, device=DEV)
+    _C.check(L().cx_dropout_add_layernorm_bwd_colsum(do.data_ptr(), None, z.data_ptr(), gam.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                     dz2.data_ptr(), dx02.data_ptr(), dg2.data_ptr(), db2.data_ptr(), cs_b.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), rows, d, p, seed, off, site, S()))
+    assert torch.equal(cs, cs_b)
+    assert L().cx_dropout_add_layernorm_bwd_colsum(do.data_ptr(), None, z.data_ptr(), gam.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   dz2.data_ptr(), dx02.data_ptr(), dg2.data_ptr(), db2.data_ptr(), cs_b.data_ptr(), None, 0,
+                                                   rows, d, p, seed, off, site, S()) == -3   # CX_ERR_ARG: the column sums need the workspace
     report("dropout_ln", p=p, keep_rate=rate)
 
 
