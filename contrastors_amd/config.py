@@ -28,6 +28,7 @@ class TrainArgs(BaseModel):
     wandb_project_name: str = ""
     wandb_entity: str = ""
     wandb_run_name: Optional[str] = None
+    wandb_group: Optional[str] = None
     log_grads_every: int = 100
     log_lr_every: int = 10
     save_every: Optional[int] = None

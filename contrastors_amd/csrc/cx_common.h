@@ -42,6 +42,9 @@ CX_DEVICE bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0x
 // next to a non-zero (denormal) act gives a finite d gate instead of inf * x -- round 4's legacy multiply covered act == 0 only.
 // No compare / select per element (the fc2-dgrad + SwiGLU-backward epilogue spends ~3200 VALU instructions per tile and wave in
 // the one wave that also issues the MFMAs).  Every |g| >= 1e-30 is untouched by the clamp: same bits as round 4 there.
+// NaN: v_med3_f32 returns a finite bound for a NaN 1/g, so a NaN GATE yields a finite (garbage) d gate here -- but d y = g * s * d is NaN for the
+// same element, and both leave in the same (T, 2I) gradient tensor that feeds the fc1 wgrad / dgrad: the non-finite value still reaches the
+// gradient norm the trainer checks.
 CX_DEVICE float rcp_clamped(float g) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(g), -1e30f, 1e30f); }
 CX_DEVICE void swiglu_bwd_from_act(float d, float act, float g, float& dy, float& dg) {
     const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));

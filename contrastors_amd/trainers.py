@@ -212,8 +212,13 @@ class TextTextTrainer:
         except ImportError:
             import os
 
-            return JsonlTracker(os.path.join(ta.output_dir or ".", "metrics.jsonl"))
-        return wandb.init(project=ta.wandb_project_name, entity=ta.wandb_entity or None, name=run_name)
+            if not ta.output_dir:   # (the fallback used to write ./metrics.jsonl into whatever the working directory was)
+                raise ValueError("train_args.wandb without the wandb package writes <output_dir>/metrics.jsonl: set train_args.output_dir")
+            return JsonlTracker(os.path.join(ta.output_dir, "metrics.jsonl"))
+        # sc/trainers/base.py:161-184: project, entity, run name, the run's group and the whole config as the run's payload
+        payload = config.model_dump() if hasattr(config, "model_dump") else (config.dict() if hasattr(config, "dict") else None)
+        return wandb.init(project=ta.wandb_project_name, entity=ta.wandb_entity or None, name=run_name,
+                          group=getattr(ta, "wandb_group", None) or None, config=payload)
 
     def log(self, metrics, step=None):   # sc/trainers/base.py:137-139
         if self.rank == 0 and self.tracker is not None:
@@ -459,8 +464,17 @@ class TextTextTrainer:
                 break
             loss = self.training_step(batch)
             losses.append(loss)
-            if self.tracker is not None:   # sc/trainers/base.py:485-502 (loss every step; lr every log_lr_every steps)
-                self.log({"loss": float(loss)}, step=self.step - 1)
+            if bool(getattr(self.config.train_args, "wandb", False)):   # sc/trainers/base.py:485-502 (loss every step; lr every log_lr_every steps)
+                # the reference gathers the loss from every rank and logs the mean (rank 0's own value made multi-GPU curves
+                # incomparable with reference runs); every rank takes part in the reduction, rank 0 alone has a tracker
+                lv = loss.detach().float()
+                if self.world > 1:
+                    import torch.distributed as dist
+
+                    lv = lv.clone()
+                    dist.all_reduce(lv)
+                    lv /= self.world
+                self.log({"loss": float(lv)}, step=self.step - 1)
                 every = int(getattr(self.config.train_args, "log_lr_every", 0) or 0)
                 if every and i > 0 and i % every == 0:
                     self.log({"lr": self.scheduler.get_last_lr()[0]}, step=self.step - 1)

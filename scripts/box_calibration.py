@@ -167,7 +167,10 @@ class _Freqs(C.Structure):   # rsmi_frequencies_t (rocm_smi.h: has_deep_sleep, n
 
 
 class SmiSampler:
-    """Background sampler of socket power (W) and shader clock (MHz) of device `index` through librocm_smi64.  start() / stop();
+    """Background sampler of socket power (W) and shader clock (MHz) of device `index` through librocm_smi64.  `index` is taken as the SMI
+    device index = torch's ordinal: true on the one-GPU boxes this runs on and for an un-remapped node; under HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES remapping the box_* power / clock fields may describe another GPU of the node (the timing fields are
+    unaffected).  start() / stop();
     stop() returns {mean_power_w, max_power_w, mean_sclk_mhz, min_sclk_mhz, power_cap_w, samples, source}; values a box does not
     expose are None.  Never raises: calibration data must not be able to take the benchmark down."""
 
