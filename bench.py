@@ -658,6 +658,10 @@ def main():
         # pass 2, identical loss and gradients (tests/test_loss_gpu.py), 3 forward-equivalents of FLOPs instead of 4
         if G >= WEAK_PAIRS_PER_GPU:
             try:
+                # (the headline's chunk-4096 arena -- 167 GB -- is twice what a 2048-pair side needs: pooled, it would sit beside the two
+                # resident arenas of this leg at ~270 of 288 GB; a training run with this schedule only ever holds ITS arenas)
+                tower.trunk.drop_idle_arenas()
+                torch.cuda.empty_cache()
                 rdt, _ = run_leg(WEAK_PAIRS_PER_GPU, args.chunk_size, args.steps, 1, prof=False, policy=POL["resident"])
                 extra["resident"] = {"value": WEAK_PAIRS_PER_GPU * world * args.steps / rdt, "unit": "pairs/s",
                                      "pairs_per_gpu": WEAK_PAIRS_PER_GPU, "global_batch": WEAK_PAIRS_PER_GPU * world,
