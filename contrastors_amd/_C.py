@@ -185,7 +185,6 @@ _DEV_SIGS = {
     "cx_gemm_v6_ablate": (None, [i32]),
     "cx_gemm_v6_trace": (None, [vp]),
     "cx_gemm_v7_mode": (None, [i32]),
-    "cx_gemm_v6_defer": (None, [i32]),
     "cx_gemm_v7_trace": (None, [vp]),
     "cx_gemm_v7_occupancy": (i32, []),
     "cx_gemm_v7_ablate": (None, [i32]),

@@ -646,7 +646,6 @@ void cx_gemm_set_trace(void* buf) { cx_gemm_v5_set_trace(static_cast<long long*>
 void cx_gemm_v6_trace(void* buf) { cx_gemm_v6_set_trace(static_cast<long long*>(buf)); }
 void cx_gemm_v6_ablate(int mask) { cx_gemm_v6_set_ablate(mask); }
 void cx_gemm_v7_mode(int mode) { cx_gemm_v7_set_mode(mode); }
-void cx_gemm_v6_defer(int mode) { cx_gemm_v6_set_defer(mode); }
 void cx_gemm_v7_trace(void* buf) { cx_gemm_v7_set_trace(static_cast<long long*>(buf)); }
 int cx_gemm_v7_occupancy(void) { return cx_gemm_v7_occupancy_query(); }
 void cx_gemm_v7_ablate(int mask) { cx_gemm_v7_set_ablate(mask); }

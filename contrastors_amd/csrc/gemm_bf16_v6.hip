@@ -5,12 +5,19 @@
 // fall out of phase (one waits ~600 cycles at every barrier) and the 64x128 wave tile needs 192 ds_read_b128 per
 // K-tile, which together with the 64 KiB of LDS-DMA writes keeps the LDS array busy for most of the iteration.
 //
-// Here a workgroup is 4 waves as 2(M) x 2(N), each owning a 128x128 sub-tile: 4x4 MFMA 32x32x16 accumulators = 256
-// fp32 registers, which live in the AGPR half of the unified 512-entry register file (one wave per SIMD).  Per K-tile a
-// wave issues 64 MFMAs against 32 ds_read_b128 (0.5 reads per MFMA instead of 0.75) and there is no second wave to
-// fall out of phase with.  Everything is software-pipelined in the instruction stream of that one wave: fragments are
-// read one k-step ahead, the 16 DMA instructions of the next K-tiles are spread between MFMAs, and the only
-// synchronisation per K-tile is one raw s_barrier across the 4 waves.
+// Here a workgroup is 4 waves as 2(M) x 2(N), each owning a 128x128 sub-tile = 256 fp32 accumulator registers, which live
+// in the AGPR half of the unified 512-entry register file (one wave per SIMD).  Per K-tile a wave reads 32 ds_read_b128
+// (every fragment row once) and there is no second wave to fall out of phase with.  Everything is software-pipelined in
+// the instruction stream of that one wave: fragments are read one k-step ahead, the 16 DMA instructions of the next
+// K-tiles are spread between MFMAs, and the only synchronisation per K-tile is one raw s_barrier across the 4 waves.
+//
+// Round 6: the matrix instruction is v_mfma_f32_16x16x32_bf16 (8 x 8 blocks of 16 x 16 per wave, 128 per K-tile), not
+// 32x32x16 (4 x 4 blocks, 64 per K-tile).  Same FLOPs, same LDS reads, one more issue cycle per 16 K FLOP -- and ~5 %
+// more work per joule: every launch of this kernel runs at the 1400 W cap, where throughput is set by energy per FLOP,
+// and the 16 x 16 form moves half the accumulator bytes per FLOP through the register file (4 registers read + written
+// per 16 K FLOP against 16 per 32 K).  Measured in situ before the rewrite (results discarded, 1-s windows at the cap,
+// profiles/r6_gemm_mfma16_in_situ.txt): 1546 -> 1768 MHz and +4.5 ... +6.4 % on the seven shapes of a block.  The
+// epilogues keep thinking in 32 x 32 regions of four blocks (gemm_v6_acc.inc); only the lane -> element map changed.
 //
 // LDS map (160 KiB): three 32 KiB X slots (X runs two K-tiles ahead), two 32 KiB W slots (one ahead), issue order per
 // K-tile [W of t+1 in k-steps 0,1][X of t+2 in k-steps 2,3]; "operands of t+1 landed" == s_waitcnt vmcnt(4) in front of the
@@ -27,17 +34,6 @@ namespace {
 // Epilogue traffic is touched once: outputs are not re-read by this launch and the streamed epilogue inputs (residual,
 // saved (y, gate)) are read once.  CX_V6_NT (bit 0 stores, bit 1 loads) marks them non-temporal so that they do not evict
 // the operand panels the XCD's other workgroups are about to re-use from L2.
-#ifndef CX_V6_DEFER_NT
-#define CX_V6_DEFER_NT 0      // the deferred register stores (DEFER) non-temporal?  measured: nt 1.55-1.70 x the staged kernel, plain 1.08-1.15 x
-#endif
-#ifndef CX_V6_DEFER_MODE
-#define CX_V6_DEFER_MODE 1    // how the tile gets into the 128 registers it leaves from: 0 = lane exchanges (a store writes 32 rows x 32 bytes:
-                              // measured slower, round 4), 1 = through the wave's LDS staging rows like the plain epilogue (a store writes
-                              // 4 rows x 256 bytes: whole lines) -- the stores still leave during the next tile's K loop
-#endif
-#ifndef CX_V6_DEFER_SPREAD
-#define CX_V6_DEFER_SPREAD 1  // K-tiles of the next tile the 32 deferred stores of a tile are spread over (8, 4, 2 or 1; 1 measured best)
-#endif
 // SwiGLU-backward epilogue (round 5).  HI_EARLY: all 16 (act, gate) row loads of pass b + 1 are issued right after pass b's rows
 // have been staged (1), instead of rows 16..31 only after the pass's arithmetic (0: they then have ~700 cycles -- the row reads and
 // store issue of pass b -- to land before pass b + 1 stages them).  That needs 32 more registers through the arithmetic, which
@@ -96,24 +92,27 @@ constexpr int BM6 = 256, BN6 = 256, BK6 = 64;
 constexpr int XS6 = 32768;          // one operand K-tile: 256 rows x 128 B
 constexpr int LDS6 = 5 * XS6;       // 3 X slots + 2 W slots
 
-struct Frags6 {
-    bf16x8_t w[4], x[4];
+struct Frags6 {   // one k-step (32 of K): 8 W fragments (16 output columns each) and 8 X fragments (16 output rows each)
+    bf16x8_t w[8], x[8];
 };
 
 #include "gemm_v6_acc.inc"
 
+// f(integral_constant<I0>) ... f(integral_constant<I1 - 1>): the accumulator accessors are switches over a literal block index -- a
+// `#pragma unroll` loop the compiler decides not to unroll (39 MFMAs in a row) turns them into jump tables over fragments in scratch
+template <int I0, int I1, class F>
+CX_DEVICE void v6_static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        v6_static_for<I0 + 1, I1>(f);
+    }
+}
+
 // DBG (ablation builds only, scripts/gemm_ablate.py; results are garbage, timing is the point): bit0 no DMA in the main
 // loop, bit1 no barrier, bit2 no fragment reads, bit3 no MFMA, bit4 no epilogue, bit5 no vmcnt wait.  With p.trace set,
 // wave 0 of every workgroup stores its s_memtime span and K-tile count.
-// DEFER (round 4, plain bf16 output only: alpha 1, no bias, no residual, every tile whole, K >= 512): the tile's results do
-// not leave through the LDS at the tile end.  They are rounded to bf16 into 128 VGPRs (v6_pack_block), put into 16-byte row
-// pieces with v_permlane32_swap (lanes l and l + 32 hold the two 8-byte halves of the same row piece), and stored straight
-// from the registers in the MFMA shadow of the NEXT tile's first K-tiles (CX_V6_DEFER_SPREAD of them): the idea was that the
-// 7.8 k cycles of a K = 768 tile's epilogue (22 % of the tile, profiles/r2_gemm_v6_ablation.txt) shrink to the register copy.
-// Bit-identical to the staged epilogue (tests/test_kernels_gpu.py), measured slower (see CX_V6_DEFER below): not routed.
-template <int EPI, int DBG = 0, bool DEFER = false>
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6_kernel(GemmParams p) {
-    static_assert(!DEFER || EPI == GEMM_EPI_NONE, "deferred stores: plain epilogue only");
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr bool IS_SWIGLU_BWD = EPI == GEMM_EPI_SWIGLU_BWD || EPI == GEMM_EPI_SWIGLU_BWD_AG;
     constexpr bool AG = EPI == GEMM_EPI_SWIGLU_BWD_AG;      // the saved pair is (act, gate) instead of (y, gate)
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
+    const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int nk = p.K / BK6;
     // Tile order.  Workgroup b runs on XCD b%8 (own 4 MiB L2).  The 8 XCDs form a gm x gn grid over the tile matrix
@@ -255,135 +254,61 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     int xs_slot = 0, ws_slot = 0;
 
     Frags6 F0, F1;
-    // fragment i of k-step ks: i = 0..3 -> W n-blocks, 4..7 -> X m-blocks
-    auto read_one = [&](Frags6& f, const char* xs, const char* ws, int ks, int i) {
+    // fragment i of k-step kk (32 of the K-tile's 64): i = 0..7 -> W blocks (16 output columns), 8..15 -> X blocks (16 output rows).
+    // Lane (l15, g4) reads row l15 of the block, 16-byte chunk 4 kk + g4 of the 128-byte K-tile row: 16 lanes x 16 rows cover every
+    // (row parity, swizzled chunk) pair once = all 64 banks (tile64_off XORs the chunk with (row >> 1) & 7).
+    auto read_one = [&](Frags6& f, const char* xs, const char* ws, int kk, int i) {
         if constexpr ((DBG & 4) != 0) return;
-        if (i < 4)
-            f.w[i] = lds_read_frag(ws, tile64_off(wn * 128 + i * 32 + l31, ks * 2 + hi));
+        if (i < 8)
+            f.w[i] = lds_read_frag(ws, tile64_off(wn * 128 + i * 16 + l15, kk * 4 + g4));
         else
-            f.x[i - 4] = lds_read_frag(xs, tile64_off(wm * 128 + (i - 4) * 32 + l31, ks * 2 + hi));
+            f.x[i - 8] = lds_read_frag(xs, tile64_off(wm * 128 + (i - 8) * 16 + l15, kk * 4 + g4));
     };
-    // i-th MFMA of a k-step: a = i & 3, b = i >> 2 (block index == i)
+    // i-th MFMA of a k-step: nb = i & 7, mb = i >> 3 (gemm_v6_acc.inc)
     auto mma1 = [&](const Frags6& f, int i) {
         if constexpr ((DBG & 8) != 0) return;
-        v6_mfma(i, f.w[i & 3], f.x[i >> 2]);
+        v6_mfma(i, f.w[i & 7], f.x[i >> 3]);
     };
     auto mma1z = [&](const Frags6& f, int i) {
         if constexpr ((DBG & 8) != 0) return;
-        v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]);
-    };
-    // ---- DEFER state: the previous tile as 32 x 16 bytes per lane.  Pd[2i + h] = block i (a = i & 3 n-block, b = i >> 2
-    // m-block), column half h: after the swaps lane (l31, hi) holds columns a*32 + 16h + 8hi .. +7 of row b*32 + l31 of the
-    // wave's 128 x 128 sub-tile.  All indices are literals (switch cases): the array must stay in registers.
-    // There is no "is there a previous tile" test in the K loop: until its first tile is complete a workgroup's stores write
-    // zeros over that same tile (dbase starts there), and the tile's real stores follow them in the wave's in-order stream.
-    cx_u32x4 Pd[DEFER ? 32 : 1];
-    const char* dbase = nullptr;                   // wave-uniform: row m0, column n0 of the tile held in Pd
-    if constexpr (DEFER) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) Pd[j] = cx_u32x4{0u, 0u, 0u, 0u};
-        dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)((cp_tile >> 8) * BM6 + wm * 128) * p.ldo + (cp_tile & 255) * BN6 + wn * 128) * 2;
-    }
-#if CX_V6_DEFER_MODE == 1
-    // Pd[8b + j] = rows b*32 + 4j + (lane >> 4), 16-byte piece (lane & 15) of the wave's 128 x 128 sub-tile: what the plain epilogue's
-    // row reads return.  One store: 4 rows x 256 contiguous bytes.
-    long long drowblk = (long long)p.ldo * 8;    // bytes per 4 output rows
-    uint32_t dvoff = (uint32_t)(lane >> 4) * (uint32_t)p.ldo * 2u + (uint32_t)(lane & 15) * 16u;
-    auto dstore = [&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        const char* bb = dbase + J * drowblk;
-        const uint32_t vo = dvoff;                      // (locals: asm operands alone do not capture in a generic lambda)
-        const cx_u32x4 v = Pd[DEFER ? J : 0];
-#if CX_V6_DEFER_NT
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(vo), "v"(v), "s"(bb) : "memory");
-#else
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(v), "s"(bb) : "memory");
-#endif
-    };
-#else
-    long long drowblk = (long long)p.ldo * 64;   // bytes per 32 output rows
-    uint32_t dvoff = (uint32_t)l31 * (uint32_t)p.ldo * 2u + (uint32_t)hi * 16u;
-    auto dstore = [&](auto jc) {   // one store: 32 rows x 32 contiguous bytes
-        constexpr int J = decltype(jc)::value, I = J >> 1, H = J & 1, A = I & 3, B = I >> 2;
-        const char* bb = dbase + B * drowblk;
-        const uint32_t vo = dvoff;                      // (locals: asm operands alone do not capture in a generic lambda)
-        const cx_u32x4 v = Pd[DEFER ? J : 0];
-#if CX_V6_DEFER_NT
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" ::"v"(vo), "v"(v), "s"(bb), "n"((A * 32 + 16 * H) * 2) : "memory");
-#else
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(vo), "v"(v), "s"(bb), "n"((A * 32 + 16 * H) * 2) : "memory");
-#endif
-    };
-#endif
-    int cp_kt = 0;
-    auto drain_all = [&]() {
-#define CX_D4(k_) dstore(std::integral_constant<int, 4 * (k_)>{}); dstore(std::integral_constant<int, 4 * (k_) + 1>{}); \
-                  dstore(std::integral_constant<int, 4 * (k_) + 2>{}); dstore(std::integral_constant<int, 4 * (k_) + 3>{});
-        CX_D4(0) CX_D4(1) CX_D4(2) CX_D4(3) CX_D4(4) CX_D4(5) CX_D4(6) CX_D4(7)
-#undef CX_D4
-    };
-    // accumulator block I -> Pd[2I], Pd[2I + 1]
-    auto pack_block = [&](auto ic) {
-        constexpr int I = decltype(ic)::value;
-        uint32_t pk[8];
-        v6_pack_block(I, pk);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {   // column groups (2h, 2h + 1): vdst = group 2h, src = group 2h + 1 (T21 of the guide)
-            const auto rx = __builtin_amdgcn_permlane32_swap(pk[4 * h], pk[4 * h + 2], false, false);
-            const auto ry = __builtin_amdgcn_permlane32_swap(pk[4 * h + 1], pk[4 * h + 3], false, false);
-            Pd[DEFER ? 2 * I + h : 0] = cx_u32x4{rx[0], ry[0], rx[1], ry[1]};
-        }
+        v6_mfma_z(i, f.w[i & 7], f.x[i >> 3]);
     };
 
-    // One k-step: 16 MFMAs on `cur`; after the first one, the 8 reads of the next k-step (into `nxt`) and up to 4 DMA
-    // instructions are interleaved one per MFMA, the rest of the MFMAs follow back to back.
-    // dma_kind: 0 none, 1 W instructions j0..j0+3, 2 X instructions j0..j0+3 (M0 write | MFMA | load, see the cursors)
-#define CX_KSTEP(MMA, cur, nxt, rxs, rws, rks, dma_kind, j0, HK)                                       \
+    // Pieces of a K-tile's instruction stream (64 MFMAs of 16 cycles per k-step, 128 per K-tile).  A fragment read or an LDS-DMA
+    // (M0 write | MFMA | load, see the cursors) rides behind an MFMA; nothing else sits between two MFMAs.
+    //   CX_MMAS(MMA, f, i0, i1)           MFMAs i0 .. i1 - 1 of the k-step on fragments f, back to back
+    //   CX_READS(MMA, f, i0, nxt, ...)    MFMA i0, then 16 x (one fragment read of k-step `rkk` into nxt | MFMA): i0 .. i0 + 16
+    //   CX_DMA4(MMA, f, i0, kind, j0)     4 x (M0 | MFMA | load): MFMAs i0 .. i0 + 3, DMA instructions j0 .. j0 + 3 of W (1) / X (2)
+#define CX_MMAS(MMA, f, i0, i1)                                                                        \
     do {                                                                                              \
-        MMA(cur, 0);                                                                                  \
-        HK(0);                                                                                        \
+        v6_static_for<(i0), (i1)>([&](auto ic_) __attribute__((always_inline)) { MMA(f, decltype(ic_)::value); }); \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                            \
-            read_one(nxt, rxs, rws, rks, i_);                                                         \
-            MMA(cur, 1 + i_);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                             \
-        CX_DMA_M0(dma_kind, (j0) + 0);                                                                \
-        MMA(cur, 9);                                                                                  \
-        CX_DMA_LD(dma_kind, (j0) + 0);                                                                \
-        CX_DMA_M0(dma_kind, (j0) + 1);                                                                \
-        MMA(cur, 10);                                                                                 \
-        CX_DMA_LD(dma_kind, (j0) + 1);                                                                \
-        CX_DMA_M0(dma_kind, (j0) + 2);                                                                \
-        MMA(cur, 11);                                                                                 \
-        CX_DMA_LD(dma_kind, (j0) + 2);                                                                \
-        CX_DMA_M0(dma_kind, (j0) + 3);                                                                \
-        MMA(cur, 12);                                                                                 \
-        CX_DMA_LD(dma_kind, (j0) + 3);                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        MMA(cur, 13);                                                                                 \
-        HK(1);                                                                                        \
-        MMA(cur, 14);                                                                                 \
-        HK(2);                                                                                        \
-        MMA(cur, 15);                                                                                 \
-        HK(3);                                                                                        \
     } while (0)
-#define CX_NOHOOK(s_) do {} while (0)
-    // DEFER: one deferred store of the previous tile behind an MFMA (its issue hides in the MFMA's pipe time); all four sit in
-    // the K-tile's LAST k-step, behind the vmcnt wait + barrier, so that a store has a whole K-tile to retire before the next
-    // K-tile's counted wait (which, on gfx9's one in-order vmcnt, waits for it along with the operands)
-#define CX_DRAINHOOK(s_)                                                      \
-    do {                                                                      \
-        if constexpr (DEFER && DRK >= 0 && DRK < CX_V6_DEFER_SPREAD) {        \
-            constexpr int PER_ = 8 / CX_V6_DEFER_SPREAD;   /* stores per hook */ \
-            constexpr int J0_ = ((DRK < 0 ? 0 : DRK) * 4 + (s_)) * PER_;      \
-            dstore(std::integral_constant<int, J0_>{});                       \
-            if constexpr (PER_ > 1) dstore(std::integral_constant<int, J0_ + (PER_ > 1 ? 1 : 0)>{}); \
-            if constexpr (PER_ > 2) { dstore(std::integral_constant<int, J0_ + (PER_ > 2 ? 2 : 0)>{}); dstore(std::integral_constant<int, J0_ + (PER_ > 2 ? 3 : 0)>{}); } \
-            if constexpr (PER_ > 4) { dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 4 : 0)>{}); dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 5 : 0)>{}); \
-                                      dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 6 : 0)>{}); dstore(std::integral_constant<int, J0_ + (PER_ > 4 ? 7 : 0)>{}); } \
-            __builtin_amdgcn_sched_barrier(0);                                \
-        }                                                                     \
+#define CX_READS(MMA, f, i0, nxt, rxs, rws, rkk)                                                       \
+    do {                                                                                              \
+        MMA(f, (i0));                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        v6_static_for<0, 16>([&](auto ic_) __attribute__((always_inline)) {                           \
+            read_one(nxt, rxs, rws, rkk, decltype(ic_)::value);                                       \
+            MMA(f, (i0) + 1 + decltype(ic_)::value);                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        });                                                                                           \
+    } while (0)
+#define CX_DMA4(MMA, f, i0, kind, j0)                                                                  \
+    do {                                                                                              \
+        CX_DMA_M0(kind, (j0) + 0);                                                                    \
+        MMA(f, (i0) + 0);                                                                             \
+        CX_DMA_LD(kind, (j0) + 0);                                                                    \
+        CX_DMA_M0(kind, (j0) + 1);                                                                    \
+        MMA(f, (i0) + 1);                                                                             \
+        CX_DMA_LD(kind, (j0) + 1);                                                                    \
+        CX_DMA_M0(kind, (j0) + 2);                                                                    \
+        MMA(f, (i0) + 2);                                                                             \
+        CX_DMA_LD(kind, (j0) + 2);                                                                    \
+        CX_DMA_M0(kind, (j0) + 3);                                                                    \
+        MMA(f, (i0) + 3);                                                                             \
+        CX_DMA_LD(kind, (j0) + 3);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #define CX_DMA_M0(kind, J)                                                       \
     do {                                                                         \
@@ -401,41 +326,52 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) read_one(F0, dsm, dsm + 3 * XS6, 0, i);
+        for (int i = 0; i < 16; ++i) read_one(F0, dsm, dsm + 3 * XS6, 0, i);
     }
 
     // One K-tile of the current output tile.  `first` (compile time) selects the C = 0 MFMA form for its first k-step:
     // the first K-tile of every output tile is a peeled copy of this body, so the accumulators are DEFINED there and
     // only ever updated in place afterwards (no zeroing, no conditional definitions for the register allocator).
+    int cp_kt = 0;
     int pxs_slot = 0, pws_slot = 0;  // slots consumed by the K-tile just finished (the epilogue's staging space)
-    auto kt_body = [&](auto first, auto drk) {
-        constexpr int DRK = decltype(drk)::value;   // DEFER: this K-tile issues stores 4 DRK .. 4 DRK + 3 of the tile in Pd (-1: none)
-        // DMA of this iteration: W of iteration +1 (k-steps 0,1), X of iteration +2 (k-steps 2,3); both target slots
-        // consumed in iteration -1.
+    auto kt_body = [&](auto first) {
+        // DMA of this iteration: W of iteration +1 (k-step 0), X of iteration +2 (k-step 1, half before and half after the barrier);
+        // both target slots consumed in iteration -1.
         if constexpr (DBG != 0) ++n_ktiles;
         const char* xs = dsm + xs_slot * XS6;
         const char* ws = dsm + (3 + ws_slot) * XS6;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
+        // k-step 0 on F0: the 16 fragments of k-step 1 -> F1, then the 8 W instructions
         if constexpr (decltype(first)::value) {
-            CX_KSTEP(mma1z, F0, F1, xs, ws, 1, 1, 0, CX_NOHOOK);
+            CX_READS(mma1z, F0, 0, F1, xs, ws, 1);
+            CX_DMA4(mma1z, F0, 17, 1, 0);
+            CX_DMA4(mma1z, F0, 21, 1, 4);
+            CX_MMAS(mma1z, F0, 25, 64);
         } else {
-            CX_KSTEP(mma1, F0, F1, xs, ws, 1, 1, 0, CX_NOHOOK);
+            CX_READS(mma1, F0, 0, F1, xs, ws, 1);
+            CX_DMA4(mma1, F0, 17, 1, 0);
+            CX_DMA4(mma1, F0, 21, 1, 4);
+            CX_MMAS(mma1, F0, 25, 64);
         }
-        CX_KSTEP(mma1, F1, F0, xs, ws, 2, 1, 4, CX_NOHOOK);
         w_advance();
-        CX_KSTEP(mma1, F0, F1, xs, ws, 3, 2, 0, CX_NOHOOK);
+        // k-step 1 on F1, first half: 4 X instructions
+        CX_DMA4(mma1, F1, 0, 2, 0);
+        CX_MMAS(mma1, F1, 4, 32);
         // this wave's reads of the current slots are complete (F1 has landed) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ... and so are its DMA writes of the next iteration's operands: everything but the 4 X instructions issued in
-        // k-step 2 (the other 4 of that K-tile follow below).  "All but the newest 4" stays correct across a tile end:
-        // the epilogue's global stores are older than the next iteration's newest 4 and retire in order with them (gfx9
-        // has one in-order vmcnt for loads and stores), so they can only make that wait stronger, never weaker.
+        // ... and so are its DMA writes of the next iteration's operands: everything but the 4 X instructions just issued (the
+        // other 4 of that K-tile follow below).  "All but the newest 4" stays correct across a tile end: the epilogue's global
+        // stores are older than the next iteration's newest 4 and retire in order with them (gfx9 has one in-order vmcnt for
+        // loads and stores), so they can only make that wait stronger, never weaker.
         if constexpr ((DBG & 32) == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr ((DBG & 2) == 0) __builtin_amdgcn_s_barrier();
         const char* nxs = dsm + nxs_slot * XS6;
         const char* nws = dsm + (3 + nws_slot) * XS6;
-        // (at a tile end these reads fetch the first fragments of the next tile: its operands have landed too)
-        CX_KSTEP(mma1, F1, F0, nxs, nws, 0, 2, 4, CX_DRAINHOOK);
+        // second half: the fragments of the next K-tile's k-step 0 -> F0 (at a tile end these are the first fragments of the
+        // next tile: its operands have landed too), then the other 4 X instructions
+        CX_READS(mma1, F1, 32, F0, nxs, nws, 0);
+        CX_DMA4(mma1, F1, 49, 2, 4);
+        CX_MMAS(mma1, F1, 53, 64);
         x_advance();
         ++cp_kt;
         pxs_slot = xs_slot;
@@ -447,20 +383,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll 1
     while (cp_tile >= 0) {
         cp_kt = 0;
-        if constexpr (DEFER) {
-            kt_body(std::true_type{}, std::integral_constant<int, 0>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 1>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 2>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 3>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 4>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 5>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 6>{});
-            kt_body(std::false_type{}, std::integral_constant<int, 7>{});
-        } else {
-            kt_body(std::true_type{}, std::integral_constant<int, -1>{});
-        }
+        kt_body(std::true_type{});
 #pragma unroll 1
-        while (cp_kt < nk) kt_body(std::false_type{}, std::integral_constant<int, -1>{});
+        while (cp_kt < nk) kt_body(std::false_type{});
 
         {
             // MFMA results are read by VALU below; the hazard recogniser does not see through the inline asm
@@ -471,54 +396,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const int m0 = tm * BM6 + wm * 128, n0 = tn * BN6 + wn * 128;
             char* my = ((wave < 2) ? dsm + pxs_slot * XS6 : dsm + (3 + pws_slot) * XS6) + (wave & 1) * 16384;
             constexpr int ROWB = 272;  // 32 staged rows x 128 bf16 (+16 B pad) = 8704 B
+            // Where a lane's accumulator registers sit in a 32-row pass (gemm_v6_acc.inc): piece q (4 consecutive columns, registers
+            // 4q .. 4q + 3 of v6_read_block) of the 32-column region a is row prow(q), columns a * 32 + pcol(q) .. + 3.  In a staging
+            // area of `rowb` bytes per row that is base(prow(0), pcol(0)) + a * 64 + qoff(q, rowb) bytes -- one address register and
+            // immediates.  32 lanes of an 8-byte staging write cover 16 rows x 16 bytes at a row stride of 68 / 36 dwords: 64 banks once.
+            auto prow = [&](int q) { return (q >> 1) * 16 + l15; };
+            auto pcol = [&](int q) { return (q & 1) * 16 + 4 * g4; };
+            auto qoff = [](int q, int rowb) { return (q >> 1) * 16 * rowb + (q & 1) * 32; };
             if constexpr ((DBG & 16) != 0) {
                 // ablation: no epilogue
-            } else if constexpr (DEFER && CX_V6_DEFER_MODE == 1) {
-                // (the previous tile's 32 stores were issued during this tile's first K-tiles: Pd is free)
-                // Four passes of 32 rows through the wave's staging rows, software-pipelined like the plain fast path: the 8 row reads
-                // of pass b are in flight while pass b + 1 is rounded; the LDS executes a wave's operations in order, so the staging
-                // writes of pass b + 1 follow the reads of pass b.  What the reads return stays in Pd.
-                const char* rd = my + (lane >> 4) * ROWB + (lane & 15) * 16;
-                char* wr = my + l31 * ROWB + hi * 8;
-                auto stage_pass = [&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        uint32_t p8[8];
-                        v6_pack_block(4 * b + a, p8);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wr + (a * 32 + 8 * q) * 2) = uint2{p8[2 * q], p8[2 * q + 1]};
-                    }
-                };
-#define CX_RD(j_) (*reinterpret_cast<const cx_u32x4*>(rd + 4 * (j_) * ROWB))
-#define CX_DEFER_PASS(b_)                                                                                  \
-    Pd[8 * (b_) + 0] = CX_RD(0); Pd[8 * (b_) + 1] = CX_RD(1); Pd[8 * (b_) + 2] = CX_RD(2); Pd[8 * (b_) + 3] = CX_RD(3);  \
-    Pd[8 * (b_) + 4] = CX_RD(4); Pd[8 * (b_) + 5] = CX_RD(5); Pd[8 * (b_) + 6] = CX_RD(6); Pd[8 * (b_) + 7] = CX_RD(7);  \
-    __builtin_amdgcn_sched_barrier(0);
-                stage_pass(std::integral_constant<int, 0>{});
-                CX_DEFER_PASS(0)
-                stage_pass(std::integral_constant<int, 1>{});
-                CX_DEFER_PASS(1)
-                stage_pass(std::integral_constant<int, 2>{});
-                CX_DEFER_PASS(2)
-                stage_pass(std::integral_constant<int, 3>{});
-                CX_DEFER_PASS(3)
-#undef CX_DEFER_PASS
-#undef CX_RD
-                // the rows must be in the registers before the staging area becomes a DMA target again (the barrier below)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)m0 * p.ldo + n0) * 2;
-            } else if constexpr (DEFER) {
-                // (the previous tile's 32 stores were issued during this tile's K-tiles 0 .. 7: Pd is free)
-                pack_block(std::integral_constant<int, 0>{}); pack_block(std::integral_constant<int, 1>{});
-                pack_block(std::integral_constant<int, 2>{}); pack_block(std::integral_constant<int, 3>{});
-                pack_block(std::integral_constant<int, 4>{}); pack_block(std::integral_constant<int, 5>{});
-                pack_block(std::integral_constant<int, 6>{}); pack_block(std::integral_constant<int, 7>{});
-                pack_block(std::integral_constant<int, 8>{}); pack_block(std::integral_constant<int, 9>{});
-                pack_block(std::integral_constant<int, 10>{}); pack_block(std::integral_constant<int, 11>{});
-                pack_block(std::integral_constant<int, 12>{}); pack_block(std::integral_constant<int, 13>{});
-                pack_block(std::integral_constant<int, 14>{}); pack_block(std::integral_constant<int, 15>{});
-                dbase = reinterpret_cast<const char*>(p.Out) + ((size_t)m0 * p.ldo + n0) * 2;
             } else if constexpr (EPI == GEMM_EPI_NONE || EPI == GEMM_EPI_ACT_BWD || EPI == GEMM_EPI_QACT_BWD) {
                 // ACT_BWD (round 6): the same epilogue with the residual slot holding the saved pre-activation of the plain MLP and
                 // the combine step Out = bf16(bf16(acc) * act'(pre)) instead of an add -- the arithmetic of the standalone
@@ -577,7 +463,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     bf16_t* outp = reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8;
                     const bf16_t* resp = RES ? resid + (size_t)(m0 + rrow) * p.ldo2 + n0 + rch * 8 : nullptr;
                     const char* rd = my + rrow * ROWB + rch * 16;
-                    char* wr = my + l31 * ROWB + hi * 8;
+                    char* wr = my + prow(0) * ROWB + pcol(0) * 2;
                     uint2 pk[16];
                     auto pack_pass = [&](int b) {
 #pragma unroll
@@ -595,7 +481,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wr + (a * 32 + 8 * q) * 2) = pk[a * 4 + q];
+                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wr + a * 64 + qoff(q, ROWB)) = pk[a * 4 + q];
                     };
                     // (named registers and explicit pass constants: a `uint4 rr[8]` carried across the passes of an
                     // unrolled loop is left in scratch memory by the compiler)
@@ -671,7 +557,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     bf16_t* outp = reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8;
                     const bf16_t* resp = resid + (size_t)(m0 + rrow) * p.ldo2 + n0 + rch * 8;
                     const char* rd = my + rrow * ROWB + rch * 16;
-                    char* wr = my + l31 * ROWB + hi * 8;
+                    char* wr = my + prow(0) * ROWB + pcol(0) * 2;
                     auto stage_pass = [&](int b) {
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
@@ -682,7 +568,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 uint2 pk2;
                                 pk2.x = pack_bf16x2(blk[4 * q], blk[4 * q + 1]);
                                 pk2.y = pack_bf16x2(blk[4 * q + 2], blk[4 * q + 3]);
-                                *reinterpret_cast<uint2*>(wr + (a * 32 + 8 * q) * 2) = pk2;
+                                *reinterpret_cast<uint2*>(wr + a * 64 + qoff(q, ROWB)) = pk2;
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -744,7 +630,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             v6_read_block(4 * b + a, blk);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const int nl = a * 32 + 8 * q + 4 * hi;
+                                const int nl = a * 32 + pcol(q);
                                 float v[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = blk[4 * q + e];
@@ -762,7 +648,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 uint2 pk;
                                 pk.x = pack_bf16x2(v[0], v[1]);
                                 pk.y = pack_bf16x2(v[2], v[3]);
-                                *reinterpret_cast<uint2*>(my + l31 * ROWB + nl * 2) = pk;
+                                *reinterpret_cast<uint2*>(my + prow(q) * ROWB + nl * 2) = pk;
                             }
                         }
 #pragma unroll
@@ -882,7 +768,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #if CX_V6_OPAQUE >= 2
                         asm volatile("" : "+v"(lane_p));
 #endif
-                        const int lrow = lane_p >> 5, lch = lane_p & 31, l31 = lane_p & 31, hi = lane_p >> 5;   // (shadow the kernel's)
+                        const int lrow = lane_p >> 5, lch = lane_p & 31, l15 = lane_p & 15, g4 = lane_p >> 4;   // (shadow the kernel's)
                         CX_STAGE_ALL
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (b < 3) { CX_LOAD_LO(b + 1) }  // rows 0..15 of the next pass fly under the arithmetic
@@ -896,8 +782,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             v6_read_block(4 * b + a, da);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                char* py = cell(l31, (a * 64 + 8 * q + 4 * hi) * 2);
-                                char* pg = cell(l31, (a * 64 + 32 + 8 * q + 4 * hi) * 2);
+                                char* py = cell((q >> 1) * 16 + l15, (a * 64 + (q & 1) * 16 + 4 * g4) * 2);
+                                char* pg = cell((q >> 1) * 16 + l15, (a * 64 + 32 + (q & 1) * 16 + 4 * g4) * 2);
                                 const uint2 yy = *reinterpret_cast<const uint2*>(py);
                                 const uint2 gg = *reinterpret_cast<const uint2*>(pg);
                                 const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
@@ -943,7 +829,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll 1
                 for (int b = 0; b < 4; ++b) {
                     // 2 x 8 loads in flight, held in NAMED registers (an L2 prefetch during the last K-tile and 4 x 4 groups measured slower) (a `uint4 in[16]` array lands in scratch memory here)
-                    const int lrow = lane >> 5, lch = lane & 31;
+                    // (edge tiles only: the lane index is made opaque so that this path's ~50 staging addresses are not hoisted out of the
+                    // tile loop, where they would sit in -- or spill from -- the registers of every interior tile's K loop)
+                    int lane_c = lane;
+                    asm volatile("" : "+v"(lane_c));
+                    const int lrow = lane_c >> 5, lch = lane_c & 31, l15 = lane_c & 15, g4 = lane_c >> 4;
 #define CX_YG_LOAD(i)                                                                                   \
     uint4 in##i;                                                                                      \
     {                                                                                                 \
@@ -973,8 +863,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         v6_read_block(4 * b + a, da);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            char* py = cell(l31, (a * 64 + 8 * q + 4 * hi) * 2);
-                            char* pg = cell(l31, (a * 64 + 32 + 8 * q + 4 * hi) * 2);
+                            char* py = cell((q >> 1) * 16 + l15, (a * 64 + (q & 1) * 16 + 4 * g4) * 2);
+                            char* pg = cell((q >> 1) * 16 + l15, (a * 64 + 32 + (q & 1) * 16 + 4 * g4) * 2);
                             const uint2 yy = *reinterpret_cast<const uint2*>(py);
                             const uint2 gg = *reinterpret_cast<const uint2*>(pg);
                             const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
@@ -990,7 +880,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int row = i * 2 + (lane >> 5), ch = lane & 31;
+                        const int row = i * 2 + lrow, ch = lch;
                         const int m = m0 + b * 32 + row;
                         const uint4 vv = *reinterpret_cast<const uint4*>(cell(row, ch * 16));
                         if (m < p.M) gst(dyg + (size_t)m * p.ldo + c0 + ch * 8, vv);
@@ -1007,7 +897,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         v6_read_block(4 * b + a, pre[a]);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int n = n0 + a * 32 + 8 * q + 4 * hi;
+                            const int n = n0 + a * 32 + pcol(q);
                             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
                             pre[a][4 * q] = bf16_to_f32(f32_to_bf16(pre[a][4 * q] + bv.x));
@@ -1036,7 +926,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 uint2 pk;
                                 pk.x = pack_bf16x2(v[0], v[1]);
                                 pk.y = pack_bf16x2(v[2], v[3]);
-                                *reinterpret_cast<uint2*>(my + l31 * ROWB + (a * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                *reinterpret_cast<uint2*>(my + prow(q) * ROWB + (a * 32 + pcol(q)) * 2) = pk;
                             }
 #pragma unroll
                         for (int ps = 0; ps < 8; ++ps) {
@@ -1068,9 +958,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     const char* rdy = my + rrow * ROWB + rch * 16;
                     const char* rda = mya + arow * AROWB + ach * 16;
                     const char* rdg = my + arow * AROWB + ach * 16;   // (SAVE_G: the (y, gate) staging region holds the gate rows)
-                    char* wry = my + l31 * ROWB + hi * 8;
-                    char* wra = mya + l31 * AROWB + hi * 8;
-                    char* wrg = my + l31 * AROWB + hi * 8;
+                    char* wry = my + prow(0) * ROWB + pcol(0) * 2;
+                    char* wra = mya + prow(0) * AROWB + pcol(0) * 2;
+                    char* wrg = my + prow(0) * AROWB + pcol(0) * 2;
                     uint2 pky[SAVE_YG ? 16 : 1], pkg[SAVE_G ? 8 : 1], pka[8];
                     auto compute_pass = [&](int b) {
 #pragma unroll
@@ -1106,18 +996,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wry + (a * 32 + 8 * q) * 2) = pky[a * 4 + q];
+                                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wry + a * 64 + qoff(q, ROWB)) = pky[a * 4 + q];
                         }
                         if constexpr (SAVE_G) {
 #pragma unroll
                             for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wrg + (pr * 32 + 8 * q) * 2) = pkg[pr * 4 + q];
+                                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wrg + pr * 64 + qoff(q, AROWB)) = pkg[pr * 4 + q];
                         }
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wra + (pr * 32 + 8 * q) * 2) = pka[pr * 4 + q];
+                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wra + pr * 64 + qoff(q, AROWB)) = pka[pr * 4 + q];
                     };
                     auto one_pass = [&](auto bc) {
                         constexpr int b = decltype(bc)::value;
@@ -1190,14 +1080,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                 if constexpr (SAVEG) {   // the gate alone, staged in the activation's row layout
                                     pk.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
                                     pk.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
-                                    *reinterpret_cast<uint2*>(my + l31 * AROWB + (pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                    *reinterpret_cast<uint2*>(my + prow(q) * AROWB + (pr * 32 + pcol(q)) * 2) = pk;
                                 } else {
                                     pk.x = pack_bf16x2(yb[4 * q], yb[4 * q + 1]);
                                     pk.y = pack_bf16x2(yb[4 * q + 2], yb[4 * q + 3]);
-                                    *reinterpret_cast<uint2*>(my + l31 * ROWB + (2 * pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                    *reinterpret_cast<uint2*>(my + prow(q) * ROWB + (2 * pr * 32 + pcol(q)) * 2) = pk;
                                     pk.x = pack_bf16x2(gb[4 * q], gb[4 * q + 1]);
                                     pk.y = pack_bf16x2(gb[4 * q + 2], gb[4 * q + 3]);
-                                    *reinterpret_cast<uint2*>(my + l31 * ROWB + ((2 * pr + 1) * 32 + 8 * q + 4 * hi) * 2) = pk;
+                                    *reinterpret_cast<uint2*>(my + prow(q) * ROWB + ((2 * pr + 1) * 32 + pcol(q)) * 2) = pk;
                                 }
                             }
                         }
@@ -1212,7 +1102,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             }
                             uint2 pk;
                             pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
-                            *reinterpret_cast<uint2*>(mya + l31 * AROWB + (pr * 32 + 8 * q + 4 * hi) * 2) = pk;
+                            *reinterpret_cast<uint2*>(mya + prow(q) * AROWB + (pr * 32 + pcol(q)) * 2) = pk;
                         }
                     }
                     if (p.Out) {
@@ -1255,8 +1145,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             // above) are fetched again here -- their slots are untouched by the staging -- so F0 is dead across the epilogue
             // (~150 cycles of exposed LDS latency per tile against 32 registers); the SwiGLU backward additionally rebuilds
             // its 16 DMA cursor offsets from (round, K-tile).
-            if constexpr ((EPI == GEMM_EPI_NONE || EPI == GEMM_EPI_ACT_BWD || EPI == GEMM_EPI_QACT_BWD || IS_SWIGLU_BWD) && (!DEFER || CX_V6_DEFER_MODE == 1)) {
-                asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]));
+            {
+                asm volatile("" : "=v"(F0.w[0]), "=v"(F0.w[1]), "=v"(F0.w[2]), "=v"(F0.w[3]), "=v"(F0.w[4]), "=v"(F0.w[5]), "=v"(F0.w[6]), "=v"(F0.w[7]));
+                asm volatile("" : "=v"(F0.x[0]), "=v"(F0.x[1]), "=v"(F0.x[2]), "=v"(F0.x[3]), "=v"(F0.x[4]), "=v"(F0.x[5]), "=v"(F0.x[6]), "=v"(F0.x[7]));
                 if constexpr (IS_SWIGLU_BWD) {
                     asm volatile("" : "=v"(xoff[0]), "=v"(xoff[1]), "=v"(xoff[2]), "=v"(xoff[3]), "=v"(xoff[4]), "=v"(xoff[5]), "=v"(xoff[6]), "=v"(xoff[7]));
                     asm volatile("" : "=v"(woff[0]), "=v"(woff[1]), "=v"(woff[2]), "=v"(woff[3]), "=v"(woff[4]), "=v"(woff[5]), "=v"(woff[6]), "=v"(woff[7]));
@@ -1268,20 +1159,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
                 if (cp_tile >= 0) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) read_one(F0, dsm + xs_slot * XS6, dsm + (3 + ws_slot) * XS6, 0, i);
+                    for (int i = 0; i < 16; ++i) read_one(F0, dsm + xs_slot * XS6, dsm + (3 + ws_slot) * XS6, 0, i);
                 }
             }
             // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
-            // (DEFER stages nothing: a tile boundary is an ordinary K-tile boundary)
-            if constexpr (!DEFER || CX_V6_DEFER_MODE == 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
         }
     }
-#undef CX_KSTEP
-#undef CX_NOHOOK
-#undef CX_DRAINHOOK
 #undef CX_DMA_M0
 #undef CX_DMA_LD
-    if constexpr (DEFER) drain_all();   // the workgroup's last tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cursors' dummy DMAs must land before the LDS is handed on
     if constexpr (DBG != 0) {
         if (p.trace && tid == 0) {
@@ -1291,13 +1177,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
-template <int EPI, int DBG = 0, bool DEFER = false>
+template <int EPI, int DBG = 0>
 hipError_t launch6(const GemmParams& p, hipStream_t stream) {
     static CxLdsOptIn lds;
-    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG, DEFER>), LDS6)) return hipErrorInvalidValue;
+    if (!lds.ensure(reinterpret_cast<const void*>(&gemm_bf16_v6_kernel<EPI, DBG>), LDS6)) return hipErrorInvalidValue;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, DBG, DEFER>), dim3(grid), dim3(256), LDS6, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, DBG>), dim3(grid), dim3(256), LDS6, stream, p);
     return hipGetLastError();
 }
 
@@ -1311,26 +1197,17 @@ hipError_t launch6(const GemmParams& p, hipStream_t stream) {
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr6;
 constexpr int TNROW6 = 512;      // bytes per token row of a [64 t][256 f] tile
 
-CX_DEVICE bf16x8_t tn_frag6(const char* tile, int f0, int t0, int lane) {
-    const int g = lane >> 4, p = lane & 15;
-    const int t = t0 + 8 * (g >> 1) + (p >> 2);
-    const int f = f0 + 16 * (g & 1) + 4 * (p & 3);
-    union { bf16x4_t h[2]; bf16x8_t v; } u;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int tt = t + 4 * half;
-        const int chunk = (f >> 3) ^ ((tt & 3) << 2);
-        u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(tile + tt * TNROW6 + chunk * 16 + (f & 4) * 2));
-    }
-    return u.v;
-}
+// 16-byte chunk c of token row t of a tile sits at chunk position c ^ tn_swz(t).  A 16-lane group of a transposing read covers
+// 4 token rows x 32 bytes and the two groups of a 32-lane half sit 8 token rows apart: bits 2..3 of the XOR separate the 4 rows
+// (512 B apart = same banks), bit 1 the two groups.
+CX_DEVICE int tn_swz(int t) { return ((t & 3) << 2) ^ (((t >> 3) & 1) << 1); }
 
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v6tn_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
+    const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
     // An XCD runs a contiguous range of logical ids (xcd_remap), normally one K slice's tiles: the index that varies FASTEST is
@@ -1367,7 +1244,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int t = (j * 4 + wave) * 2 + (lane >> 5);
-        const int c = (lane & 31) ^ ((t & 3) << 2);
+        const int c = (lane & 31) ^ tn_swz(t);
         xo[j] = (uint32_t)t * (uint32_t)p.ldx * 2u + c * 16;
         wo[j] = (uint32_t)t * (uint32_t)p.ldw * 2u + c * 16;
     }
@@ -1402,65 +1279,39 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
     // (An L2 prefetch of the K-tiles 3-4 ahead -- one dword touch per 128-B line -- paid in round 1; with the two-instruction
     // DMA issue of round 2 it costs 5-16 %: removed.  profiles/r2_vendor_blas_calibration.txt has the before / after.)
-    // Fragment addressing (tn_frag6 with everything lane-dependent hoisted): with one wave per SIMD the instruction
-    // stream is issue-bound, so each fragment must cost one VALU add + two transposing reads, not a dozen integer ops.
-    // byte offset inside a tile = tt*512 + chunk*16 + (f&4)*2 with tt = 16*ks + 4*half + tl, (tt&3) == (tl&3):
-    //   lane part  = tl*512 + (((f0 + fl) >> 3) ^ ((tl&3) << 2))*16 + (fl&4)*2   (one VGPR per fragment index)
-    //   immediate  = ks*8192 + half*2048
+    // Fragment addressing: fragment i = features 16 i .. 16 i + 15 of the wave's 128, k-step kk = tokens 32 kk .. 32 kk + 31.  Lane
+    // (p = l15, g = g4) must end up with feature p, tokens 8 g .. 8 g + 7: two transposing reads of 4 tokens each, in which the lane
+    // ADDRESSES token tl = 8 g + (p >> 2) (+ 4 for the second) and features fl = 4 (p & 3) .. + 3 -- the 16 lanes of a group cover
+    // 4 tokens x 16 features and the read hands every lane its feature's 4 tokens.  With one wave per SIMD the instruction stream is
+    // issue-bound, so a fragment costs one VALU add + two reads: everything lane-dependent is hoisted into one VGPR per fragment.
+    //   byte offset inside a tile = tt * 512 + ((f >> 3) ^ tn_swz(tt)) * 16 + (f & 4) * 2,  tt = 32 kk + 4 half + tl, tn_swz(tt) == tn_swz(tl)
+    //   lane part = tl * 512 + (((f0 + fl) >> 3) ^ tn_swz(tl)) * 16 + (fl & 4) * 2;   immediate = kk * 16384 + half * 2048
     Frags6 F0, F1;
-    uint32_t woff[4], xoff[4];
+    uint32_t woff[8], xoff[8];
     {
-        const int g = lane >> 4, pp = lane & 15;
-        const int tl = 8 * (g >> 1) + (pp >> 2), fl = 16 * (g & 1) + 4 * (pp & 3);
+        const int tl = 8 * g4 + (l15 >> 2), fl = 4 * (l15 & 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int fw = wn * 128 + i * 32 + fl, fx = wm * 128 + i * 32 + fl;
-            woff[i] = tl * TNROW6 + (((fw >> 3) ^ ((tl & 3) << 2)) << 4) + (fw & 4) * 2;
-            xoff[i] = tl * TNROW6 + (((fx >> 3) ^ ((tl & 3) << 2)) << 4) + (fx & 4) * 2;
+        for (int i = 0; i < 8; ++i) {
+            const int fw = wn * 128 + i * 16 + fl, fx = wm * 128 + i * 16 + fl;
+            woff[i] = tl * TNROW6 + (((fw >> 3) ^ tn_swz(tl)) << 4) + (fw & 4) * 2;
+            xoff[i] = tl * TNROW6 + (((fx >> 3) ^ tn_swz(tl)) << 4) + (fx & 4) * 2;
         }
     }
-    auto tr_pair = [&](const char* base, int ks) -> bf16x8_t {
+    auto tr_pair = [&](const char* base, int kk) -> bf16x8_t {
         union { bf16x4_t h[2]; bf16x8_t v; } u;
-        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(base + ks * 8192));
-        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(base + ks * 8192 + 2048));
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(base + kk * 16384));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr6)(base + kk * 16384 + 2048));
         return u.v;
     };
-    auto read_one = [&](Frags6& f, int xslot, int wslot, int ks, int i) {
-        if (i < 4)
-            f.w[i] = tr_pair(dsm + (3 + wslot) * XS6 + woff[i], ks);
+    auto read_one = [&](Frags6& f, int xslot, int wslot, int kk, int i) {
+        if (i < 8)
+            f.w[i] = tr_pair(dsm + (3 + wslot) * XS6 + woff[i], kk);
         else
-            f.x[i - 4] = tr_pair(dsm + xslot * XS6 + xoff[i - 4], ks);
+            f.x[i - 8] = tr_pair(dsm + xslot * XS6 + xoff[i - 8], kk);
     };
-    auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 3], f.x[i >> 2]); };
-    auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 3], f.x[i >> 2]); };
-    // one k-step: 16 MFMAs on `cur`; the 8 fragments (16 transposing reads) of the next k-step and 4 DMA instructions
-    // ride between them.  dma_kind: 1 = W instructions j0..j0+3, 2 = X instructions j0..j0+3
-#define CX_TN_KSTEP(MMA, cur, nxt, rx, rw, rks, dma_kind, j0)                                           \
-    do {                                                                                              \
-        MMA(cur, 0);                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                            \
-            read_one(nxt, rx, rw, rks, i_);                                                           \
-            MMA(cur, 1 + i_);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                             \
-        CX_DMA_M0(dma_kind, (j0) + 0);                                                                \
-        MMA(cur, 9);                                                                                  \
-        CX_DMA_LD(dma_kind, (j0) + 0);                                                                \
-        CX_DMA_M0(dma_kind, (j0) + 1);                                                                \
-        MMA(cur, 10);                                                                                 \
-        CX_DMA_LD(dma_kind, (j0) + 1);                                                                \
-        CX_DMA_M0(dma_kind, (j0) + 2);                                                                \
-        MMA(cur, 11);                                                                                 \
-        CX_DMA_LD(dma_kind, (j0) + 2);                                                                \
-        CX_DMA_M0(dma_kind, (j0) + 3);                                                                \
-        MMA(cur, 12);                                                                                 \
-        CX_DMA_LD(dma_kind, (j0) + 3);                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        MMA(cur, 13);                                                                                 \
-        MMA(cur, 14);                                                                                 \
-        MMA(cur, 15);                                                                                 \
-    } while (0)
+    auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 7], f.x[i >> 3]); };
+    auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 7], f.x[i >> 3]); };
+    // (k-step pieces: CX_MMAS / CX_READS / CX_DMA4 of the NT kernel; a fragment read is two transposing reads here)
 #define CX_DMA_M0(kind, J)                                  \
     do {                                                    \
         if constexpr ((kind) == 1) v6_dma_m0<(J)>(w_m0);     \
@@ -1481,27 +1332,35 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) read_one(F0, 0, 0, 0, i);
+    for (int i = 0; i < 16; ++i) read_one(F0, 0, 0, 0, i);
 
     int xs_slot = 0, ws_slot = 0;
-    // K-tile body (see the NT kernel): DMA of this iteration = W of K-tile t+1 (k-steps 0,1) and X of K-tile t+2
-    // (k-step 2 and, after the barrier, k-step 3); `first` selects the C = 0 MFMA form.
+    // K-tile body (see the NT kernel): DMA of this iteration = W of K-tile t+1 (k-step 0) and X of K-tile t+2 (k-step 1, half
+    // before and half after the barrier); `first` selects the C = 0 MFMA form.
     auto kt_body = [&](auto first, int t) {
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
         if constexpr (decltype(first)::value) {
-            CX_TN_KSTEP(mma1z, F0, F1, xs_slot, ws_slot, 1, 1, 0);
+            CX_READS(mma1z, F0, 0, F1, xs_slot, ws_slot, 1);
+            CX_DMA4(mma1z, F0, 17, 1, 0);
+            CX_DMA4(mma1z, F0, 21, 1, 4);
+            CX_MMAS(mma1z, F0, 25, 64);
         } else {
-            CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 1, 1, 0);
+            CX_READS(mma1, F0, 0, F1, xs_slot, ws_slot, 1);
+            CX_DMA4(mma1, F0, 17, 1, 0);
+            CX_DMA4(mma1, F0, 21, 1, 4);
+            CX_MMAS(mma1, F0, 25, 64);
         }
-        CX_TN_KSTEP(mma1, F1, F0, xs_slot, ws_slot, 2, 1, 4);
         w_advance(t + 2);
-        CX_TN_KSTEP(mma1, F0, F1, xs_slot, ws_slot, 3, 2, 0);
+        CX_DMA4(mma1, F1, 0, 2, 0);
+        CX_MMAS(mma1, F1, 4, 32);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the current slots are complete ...
-        // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions of k-step 2
+        // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions just issued
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // (after the last K-tile these reads fetch garbage from a landed slot; F0 is not used again)
-        CX_TN_KSTEP(mma1, F1, F0, nxs_slot, nws_slot, 0, 2, 4);
+        CX_READS(mma1, F1, 32, F0, nxs_slot, nws_slot, 0);
+        CX_DMA4(mma1, F1, 49, 2, 4);
+        CX_MMAS(mma1, F1, 53, 64);
         x_advance(t + 3);
         xs_slot = nxs_slot;
         ws_slot = nws_slot;
@@ -1509,19 +1368,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     kt_body(std::true_type{}, 0);
 #pragma unroll 1
     for (int t = 1; t < nk; ++t) kt_body(std::false_type{}, t);
-#undef CX_TN_KSTEP
+#undef CX_MMAS
+#undef CX_READS
+#undef CX_DMA4
 #undef CX_DMA_M0
 #undef CX_DMA_LD
 
-    // ---- epilogue: fp32 partial slab of this K slice, straight from the AGPRs.  block (a, b): rows m0 + wm*128 + b*32
-    // + l31, columns n0 + wn*128 + a*32 + 8q + 4hi (+0..3)
+    // ---- epilogue: fp32 partial slab of this K slice, straight from the AGPRs.  Region (a, b), piece q: row m0 + wm*128 + b*32
+    // + 16 (q >> 1) + l15, columns n0 + wn*128 + a*32 + 16 (q & 1) + 4 g4 (+0..3): a store writes 16 rows x 64 contiguous bytes
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // MFMA -> VMEM read of the accumulators
     float* part = reinterpret_cast<float*>(p.Out) + (size_t)sk * p.M * p.ldo;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        float* rowp = part + (size_t)(m0 + wm * 128 + b * 32 + l31) * p.ldo + n0 + wn * 128 + 4 * hi;
+        float* rowp = part + (size_t)(m0 + wm * 128 + b * 32 + l15) * p.ldo + n0 + wn * 128 + 4 * g4;
+        float* rowq = rowp + (size_t)16 * p.ldo;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) v6_store_block_f32(4 * b + a, rowp + a * 32);
+        for (int a = 0; a < 4; ++a) v6_store_block_f32(4 * b + a, rowp + a * 32, rowq + a * 32);
     }
 }
 
@@ -1546,26 +1408,6 @@ bool v7_takes(const GemmParams& p, int epi) {
     if (epi == GEMM_EPI_SWIGLU_G) return false;
     const long tiles256 = (long)((p.M + BM6 - 1) / BM6) * ((p.N + BN6 - 1) / BN6);
     return tiles256 <= 400;
-}
-
-// Deferred register stores (the DEFER instantiation): CX_V6_DEFER (build-time) 1 = every plain launch it covers, 0 = never.
-// Measured SLOWER than the staged epilogue at every shape (profiles/r4_gemm_deferred_stores_ab.txt: 1.08-1.10 x at K = 768 in its
-// best form, 1.6 x with non-temporal stores spread over 8 K-tiles): a store instruction of this layout writes 32 rows x 32
-// contiguous bytes, and the CU's write path takes ~2 cycles per 32-byte row piece (16 B/clk against 64 B/clk for whole lines) --
-// the 32 stores of a tile cost more than the LDS round trip they replace.  Routed off; kept as a dev-library A/B.
-#ifndef CX_V6_DEFER
-#define CX_V6_DEFER 0
-#endif
-#ifndef CX_PRODUCT
-int g_v6_defer = -1;           // cx_gemm_v6_set_defer: -1 = CX_V6_DEFER, 0 = never, 1 = every launch it covers
-#else
-constexpr int g_v6_defer = -1;
-#endif
-// plain bf16 output (alpha 1, no bias, no residual), whole tiles only, at least the 8 K-tiles the 32 stores are spread over
-bool defer_takes(const GemmParams& p, int epi) {
-    if (!(g_v6_defer >= 0 ? g_v6_defer != 0 : CX_V6_DEFER != 0)) return false;
-    return epi == GEMM_EPI_NONE && !p.bias && p.alpha == 1.f && !p.Out2 && (p.M % BM6) == 0 && (p.N % BN6) == 0 && p.K >= 8 * BK6 &&
-           (reinterpret_cast<uintptr_t>(p.Out) & 15) == 0 && (p.ldo % 8) == 0;
 }
 
 #ifndef CX_PRODUCT
@@ -1603,7 +1445,6 @@ void cx_gemm_v6_set_trace(long long* buf) { g_v6_trace = buf; }
 void cx_gemm_v6_set_ablate(int mask) { g_v6_dbg = mask; }
 void cx_gemm_v6_force_groups(int gn) { g_v6_force_gn = (gn == 1 || gn == 2 || gn == 4 || gn == 8) ? gn : 0; }
 void cx_gemm_v7_set_mode(int mode) { g_v7_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
-void cx_gemm_v6_set_defer(int mode) { g_v6_defer = mode < 0 ? -1 : (mode ? 1 : 0); }
 #endif
 
 // TN wgrad form: p.X = dY (T, M), p.W = A (T, N), p.K = tokens, p.Out = fp32 partial slabs [split_k][M][ldo];
@@ -1664,7 +1505,6 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
         }
     }
 #endif
-    if (defer_takes(p, epi)) return launch6<GEMM_EPI_NONE, 0, true>(p, stream);
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)
            : epi == GEMM_EPI_SWIGLU_G ? launch6<GEMM_EPI_SWIGLU_G>(p, stream)
            : epi == GEMM_EPI_SWIGLU_BWD_AG ? launch6<GEMM_EPI_SWIGLU_BWD_AG>(p, stream)

@@ -39,7 +39,6 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream);
 void cx_gemm_v6_force_groups(int gn);
 void cx_gemm_v6_set_trace(long long* buf);
 void cx_gemm_v6_set_ablate(int mask);
-void cx_gemm_v6_set_defer(int mode);   // dev library only: -1 = CX_V6_DEFER, 0 = never, 1 = every launch the deferred-store form covers
 hipError_t cx_launch_gemm_v6_tn(GemmParams p, hipStream_t stream);
 // dst[c] += sum_b part[b][c] (fixed order: deterministic), part: fp32 [nblocks][N] -- the ACT_BWD epilogue's bias-gradient partials
 hipError_t cx_launch_colsum_part_reduce(const float* part, float* dst, int nblocks, int N, hipStream_t stream);

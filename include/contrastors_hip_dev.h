@@ -30,7 +30,6 @@ void cx_gemm_v6_ablate(int mask);
 void cx_gemm_v6_trace(void* buf);
 /* deferred register stores of the one-wave-per-SIMD kernel's plain form (gemm_bf16_v6.hip, DEFER): -1 = the shipped policy
    (default), 0 = never, 1 = every launch the form covers (A/B, parity tests) */
-void cx_gemm_v6_defer(int mode);
 
 /* routing between the one-wave-per-SIMD kernel (gemm_bf16_v6.hip) and the two-workgroups-per-CU kernel
    (gemm_bf16_v7.hip): -1 = the shipped policy (default), 0 = never v7, 1 = every launch v7 covers (A/B, parity tests) */
