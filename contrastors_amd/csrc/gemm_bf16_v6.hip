@@ -274,41 +274,33 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         v6_mfma_z(i, f.w[i & 7], f.x[i >> 3]);
     };
 
-    // Pieces of a K-tile's instruction stream (64 MFMAs of 16 cycles per k-step, 128 per K-tile).  A fragment read or an LDS-DMA
-    // (M0 write | MFMA | load, see the cursors) rides behind an MFMA; nothing else sits between two MFMAs.
-    //   CX_MMAS(MMA, f, i0, i1)           MFMAs i0 .. i1 - 1 of the k-step on fragments f, back to back
-    //   CX_READS(MMA, f, i0, nxt, ...)    MFMA i0, then 16 x (one fragment read of k-step `rkk` into nxt | MFMA): i0 .. i0 + 16
-    //   CX_DMA4(MMA, f, i0, kind, j0)     4 x (M0 | MFMA | load): MFMAs i0 .. i0 + 3, DMA instructions j0 .. j0 + 3 of W (1) / X (2)
-#define CX_MMAS(MMA, f, i0, i1)                                                                        \
+    // A K-tile's instruction stream: 64 MFMAs of 16 cycles per k-step, 128 per K-tile; a fragment read or an LDS-DMA (M0 write | MFMA |
+    // load, see the cursors) rides with an MFMA, nothing else sits between two MFMAs.
+#ifndef CX_V6_DMA_SPREAD
+#define CX_V6_DMA_SPREAD 4   // MFMAs per LDS-DMA (1 = back to back)
+#endif
+#ifndef CX_V6_RD_SPREAD
+#define CX_V6_RD_SPREAD 2    // MFMAs per fragment read (1: the 16 reads of a k-step behind 16 consecutive MFMAs)
+#endif
+// CX_SEG: MFMAs i0 .. i1 - 1 of a k-step on fragments f.  Fragment read r (0 .. 15) of k-step `rkk` into `nxt` rides in front of MFMA
+// R0 + RSP * r (RSP = 0: no reads); DMA instruction J0 + d (d = 0 .. ND - 1) of operand `kind` brackets MFMA D0 + DSP * d (M0 | MFMA |
+// load).  The four waves leave every barrier in step and share one LDS and one vector-memory front end: requests of the same kind
+// issued behind CONSECUTIVE MFMAs by all four queue up (a 1-KiB LDS-DMA keeps the front end busy for ~16 cycles = one MFMA, so four
+// of them fill four MFMA slots), and an in-order wave stalls behind its own queued request -- 300 cycles of a 2640-cycle K-tile for
+// the 16 DMAs back to back, 62 one per four MFMAs (scripts/gemm_ablate.py, profiles/r6_gemm_v6_m16_ablation.txt).
+#define CX_SEG(MMA, f, i0, i1, nxt, rxs, rws, rkk, R0, RSP, kind, D0, DSP, J0, ND)                     \
     do {                                                                                              \
-        v6_static_for<(i0), (i1)>([&](auto ic_) __attribute__((always_inline)) { MMA(f, decltype(ic_)::value); }); \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-#define CX_READS(MMA, f, i0, nxt, rxs, rws, rkk)                                                       \
-    do {                                                                                              \
-        MMA(f, (i0));                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        v6_static_for<0, 16>([&](auto ic_) __attribute__((always_inline)) {                           \
-            read_one(nxt, rxs, rws, rkk, decltype(ic_)::value);                                       \
-            MMA(f, (i0) + 1 + decltype(ic_)::value);                                                  \
+        v6_static_for<(i0), (i1)>([&](auto ic_) __attribute__((always_inline)) {                      \
+            constexpr int I_ = decltype(ic_)::value;                                                  \
+            constexpr bool RD_ = (RSP) > 0 && I_ >= (R0) && (I_ - (R0)) % ((RSP) > 0 ? (RSP) : 1) == 0 && (I_ - (R0)) / ((RSP) > 0 ? (RSP) : 1) < 16; \
+            constexpr bool DM_ = (ND) > 0 && I_ >= (D0) && (I_ - (D0)) % (DSP) == 0 && (I_ - (D0)) / (DSP) < (ND); \
+            constexpr int J_ = DM_ ? (J0) + (I_ - (D0)) / (DSP) : 0;                                  \
+            if constexpr (RD_) read_one(nxt, rxs, rws, rkk, (I_ - (R0)) / ((RSP) > 0 ? (RSP) : 1));   \
+            if constexpr (DM_) CX_DMA_M0(kind, J_);                                                   \
+            MMA(f, I_);                                                                               \
+            if constexpr (DM_) CX_DMA_LD(kind, J_);                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                        \
         });                                                                                           \
-    } while (0)
-#define CX_DMA4(MMA, f, i0, kind, j0)                                                                  \
-    do {                                                                                              \
-        CX_DMA_M0(kind, (j0) + 0);                                                                    \
-        MMA(f, (i0) + 0);                                                                             \
-        CX_DMA_LD(kind, (j0) + 0);                                                                    \
-        CX_DMA_M0(kind, (j0) + 1);                                                                    \
-        MMA(f, (i0) + 1);                                                                             \
-        CX_DMA_LD(kind, (j0) + 1);                                                                    \
-        CX_DMA_M0(kind, (j0) + 2);                                                                    \
-        MMA(f, (i0) + 2);                                                                             \
-        CX_DMA_LD(kind, (j0) + 2);                                                                    \
-        CX_DMA_M0(kind, (j0) + 3);                                                                    \
-        MMA(f, (i0) + 3);                                                                             \
-        CX_DMA_LD(kind, (j0) + 3);                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #define CX_DMA_M0(kind, J)                                                       \
     do {                                                                         \
@@ -338,25 +330,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // DMA of this iteration: W of iteration +1 (k-step 0), X of iteration +2 (k-step 1, half before and half after the barrier);
         // both target slots consumed in iteration -1.
         if constexpr (DBG != 0) ++n_ktiles;
+        constexpr int RS_ = CX_V6_RD_SPREAD, DS_ = CX_V6_DMA_SPREAD;
         const char* xs = dsm + xs_slot * XS6;
         const char* ws = dsm + (3 + ws_slot) * XS6;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
         // k-step 0 on F0: the 16 fragments of k-step 1 -> F1, then the 8 W instructions
         if constexpr (decltype(first)::value) {
-            CX_READS(mma1z, F0, 0, F1, xs, ws, 1);
-            CX_DMA4(mma1z, F0, 17, 1, 0);
-            CX_DMA4(mma1z, F0, 21, 1, 4);
-            CX_MMAS(mma1z, F0, 25, 64);
+            CX_SEG(mma1z, F0, 0, 64, F1, xs, ws, 1, RS_ == 2 ? 0 : 1, RS_, 1, RS_ == 2 ? 1 : 17, DS_, 0, 8);
         } else {
-            CX_READS(mma1, F0, 0, F1, xs, ws, 1);
-            CX_DMA4(mma1, F0, 17, 1, 0);
-            CX_DMA4(mma1, F0, 21, 1, 4);
-            CX_MMAS(mma1, F0, 25, 64);
+            CX_SEG(mma1, F0, 0, 64, F1, xs, ws, 1, RS_ == 2 ? 0 : 1, RS_, 1, RS_ == 2 ? 1 : 17, DS_, 0, 8);
         }
         w_advance();
         // k-step 1 on F1, first half: 4 X instructions
-        CX_DMA4(mma1, F1, 0, 2, 0);
-        CX_MMAS(mma1, F1, 4, 32);
+        CX_SEG(mma1, F1, 0, 32, F0, xs, ws, 0, 0, 0, 2, 0, RS_ == 2 ? 8 : DS_, 0, 4);
         // this wave's reads of the current slots are complete (F1 has landed) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ... and so are its DMA writes of the next iteration's operands: everything but the 4 X instructions just issued (the
@@ -369,9 +355,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const char* nws = dsm + (3 + nws_slot) * XS6;
         // second half: the fragments of the next K-tile's k-step 0 -> F0 (at a tile end these are the first fragments of the
         // next tile: its operands have landed too), then the other 4 X instructions
-        CX_READS(mma1, F1, 32, F0, nxs, nws, 0);
-        CX_DMA4(mma1, F1, 49, 2, 4);
-        CX_MMAS(mma1, F1, 53, 64);
+        CX_SEG(mma1, F1, 32, 64, F0, nxs, nws, 0, RS_ == 2 ? 32 : 33, RS_, 2, RS_ == 2 ? 33 : 49, RS_ == 2 ? 8 : DS_, 4, 4);
         x_advance();
         ++cp_kt;
         pxs_slot = xs_slot;
@@ -1311,7 +1295,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
     auto mma1 = [&](const Frags6& f, int i) { v6_mfma(i, f.w[i & 7], f.x[i >> 3]); };
     auto mma1z = [&](const Frags6& f, int i) { v6_mfma_z(i, f.w[i & 7], f.x[i >> 3]); };
-    // (k-step pieces: CX_MMAS / CX_READS / CX_DMA4 of the NT kernel; a fragment read is two transposing reads here)
+    // (k-step pieces: CX_SEG of the NT kernel; a fragment read is two transposing reads here)
 #define CX_DMA_M0(kind, J)                                  \
     do {                                                    \
         if constexpr ((kind) == 1) v6_dma_m0<(J)>(w_m0);     \
@@ -1338,29 +1322,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // K-tile body (see the NT kernel): DMA of this iteration = W of K-tile t+1 (k-step 0) and X of K-tile t+2 (k-step 1, half
     // before and half after the barrier); `first` selects the C = 0 MFMA form.
     auto kt_body = [&](auto first, int t) {
+        constexpr int RS_ = CX_V6_RD_SPREAD, DS_ = CX_V6_DMA_SPREAD;
         const int nxs_slot = xs_slot == 2 ? 0 : xs_slot + 1, nws_slot = ws_slot ^ 1;
         if constexpr (decltype(first)::value) {
-            CX_READS(mma1z, F0, 0, F1, xs_slot, ws_slot, 1);
-            CX_DMA4(mma1z, F0, 17, 1, 0);
-            CX_DMA4(mma1z, F0, 21, 1, 4);
-            CX_MMAS(mma1z, F0, 25, 64);
+            CX_SEG(mma1z, F0, 0, 64, F1, xs_slot, ws_slot, 1, RS_ == 2 ? 0 : 1, RS_, 1, RS_ == 2 ? 1 : 17, DS_, 0, 8);
         } else {
-            CX_READS(mma1, F0, 0, F1, xs_slot, ws_slot, 1);
-            CX_DMA4(mma1, F0, 17, 1, 0);
-            CX_DMA4(mma1, F0, 21, 1, 4);
-            CX_MMAS(mma1, F0, 25, 64);
+            CX_SEG(mma1, F0, 0, 64, F1, xs_slot, ws_slot, 1, RS_ == 2 ? 0 : 1, RS_, 1, RS_ == 2 ? 1 : 17, DS_, 0, 8);
         }
         w_advance(t + 2);
-        CX_DMA4(mma1, F1, 0, 2, 0);
-        CX_MMAS(mma1, F1, 4, 32);
+        CX_SEG(mma1, F1, 0, 32, F0, xs_slot, ws_slot, 0, 0, 0, 2, 0, RS_ == 2 ? 8 : DS_, 0, 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the current slots are complete ...
         // ... and so are its DMA writes of K-tile t+1: everything but the 4 X instructions just issued
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // (after the last K-tile these reads fetch garbage from a landed slot; F0 is not used again)
-        CX_READS(mma1, F1, 32, F0, nxs_slot, nws_slot, 0);
-        CX_DMA4(mma1, F1, 49, 2, 4);
-        CX_MMAS(mma1, F1, 53, 64);
+        CX_SEG(mma1, F1, 32, 64, F0, nxs_slot, nws_slot, 0, RS_ == 2 ? 32 : 33, RS_, 2, RS_ == 2 ? 33 : 49, RS_ == 2 ? 8 : DS_, 4, 4);
         x_advance(t + 3);
         xs_slot = nxs_slot;
         ws_slot = nws_slot;
@@ -1368,9 +1344,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     kt_body(std::true_type{}, 0);
 #pragma unroll 1
     for (int t = 1; t < nk; ++t) kt_body(std::false_type{}, t);
-#undef CX_MMAS
-#undef CX_READS
-#undef CX_DMA4
+#undef CX_SEG
 #undef CX_DMA_M0
 #undef CX_DMA_LD
 
