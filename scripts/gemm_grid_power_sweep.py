@@ -4,7 +4,7 @@
    time per launch, shader clock and socket power sampled through librocm_smi64 DURING ~1.5 s of back-to-back launches.
 With --pmc CASE GN the script only issues 4 launches of that (case, grid) so that
    rocprofv3 --pmc FETCH_SIZE --kernel-trace ... python scripts/gemm_grid_power_sweep.py --pmc fc1_swiglu_save 4
-attributes the counter to that grid (scripts/gpu_r5_b.sh loops over the grids and joins both tables).
+attributes the counter to that grid (round 5's driver script, since removed, looped over the grids and joined both tables).
 usage: python scripts/gemm_grid_power_sweep.py [--chunk 2048] [--seconds 1.5]"""
 import argparse
 import sys

@@ -88,3 +88,28 @@ def test_engine_refuses_cpu():
 def test_product_never_imports_oracle():
     for p in (ROOT / "contrastors_amd").rglob("*.py"):
         assert "oracle" not in re.sub(r'""".*?"""', "", p.read_text(), flags=re.S).replace("# oracle", ""), p
+
+
+def test_v6_accumulator_map_is_a_bijection_and_the_generated_file_is_current():
+    """scripts/gen_v6_acc.py: the 8 x 8 blocks of 16 x 16 of a wave's sub-tile cover AGPRs 0 .. 255 exactly once in quads, region
+    i = 4b + a (32 x 32) owns a[16i : 16i + 15] with piece q = 2 (mb & 1) + (nb & 1) in its q-th quad, and the committed
+    gemm_v6_acc.inc is what the generator writes."""
+    import importlib.util
+    import re
+    root = Path(__file__).resolve().parent.parent
+    inc = root / "contrastors_amd" / "csrc" / "gemm_v6_acc.inc"
+    before = inc.read_text()
+    spec = importlib.util.spec_from_file_location("gen_v6_acc", root / "scripts" / "gen_v6_acc.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)          # (re-writes the file: must be a no-op)
+    assert inc.read_text() == before, "gemm_v6_acc.inc is stale: run scripts/gen_v6_acc.py"
+    seen = set()
+    for mb in range(8):
+        for nb in range(8):
+            lo = mod.base(mb, nb)
+            assert lo % 4 == 0 and lo // 16 == 4 * (mb >> 1) + (nb >> 1) and (lo % 16) // 4 == 2 * (mb & 1) + (nb & 1)
+            seen.update(range(lo, lo + 4))
+    assert seen == set(range(256))
+    cases = re.findall(r"case (\d+): asm volatile\(\"v_mfma_f32_16x16x32_bf16 a\[(\d+):(\d+)\], %0, %1, a\[(\d+):(\d+)\]\"", before)
+    assert len(cases) == 64 and all(int(lo) == mod.base(int(i) >> 3, int(i) & 7) == int(clo) and int(hi) == int(lo) + 3 == int(chi)
+                                    for i, lo, hi, clo, chi in cases)
