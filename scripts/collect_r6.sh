@@ -17,17 +17,25 @@ grep -v amdgpu.ids $O/attn_microbench_dropout.txt > profiles/r6_microbench_atten
 grep -v amdgpu.ids $O/attn_bwd_s128_phase_trace.txt > profiles/r6_attn_bwd_s128_phase_trace.txt
 tail -3 $O/gpu_tests.txt > profiles/r6_gpu_tests.txt; tail -1 $O/smoke.log >> profiles/r6_gpu_tests.txt
 cp $O/box_calibration.json profiles/r6_box_calibration.json
-{ echo "# Same-box A/B of the config legs: the product library against variant r5routes (round 5's kernel routing: round 1's streaming attention"
-  echo "# kernels beyond S = 128 incl. the delta pass, no K/V-resident S <= 256 forward, standalone GELU backward + bias colsum; host code identical),"
-  echo "# alternating runs of bench.py --only-config-legs cfg1,lit,clip,cfg3 --steps 3 (scripts/gpu_r6_final.sh)."
-  for v in base r5routes; do for f in $O/legs_ab_${v}*.log; do [[ -f $f ]] && python3 - "$v" "$f" <<'PY'
+grep -v amdgpu.ids $O/v6_vs_vendor_time.txt > profiles/r6_v6_vs_vendor_time.txt
+{ echo "# Same-box A/B at the round's last code state: the product library (16x16x32 main loop, LDS-DMA / fragment reads spread over the K-tile) against"
+  echo "# variant m32 = the library of commit ee8a813 (32x32x16 main loop, requests back to back); host code identical, alternating runs"
+  echo "# (scripts/gpu_r6_final.sh): bench.py --steps 3 --warmup 1 on the headline step, then --only-config-legs cfg1,lit,clip,cfg3."
+  for v in base m32; do for f in $O/step_ab_${v}_*.log; do [[ -f $f ]] && python3 - "$v" "$f" <<'PY'
+import json,sys
+v,f=sys.argv[1],sys.argv[2]
+d=json.loads([l for l in open(f) if l.startswith('{')][-1])
+print(f"{v:5s} headline {d['value']:.1f} pairs/s, {d['ms_per_step']:.1f} ms/step, GEMM family {d['roofline']['achieved']:.1f} TFLOP/s")
+PY
+  done; done
+  for v in base m32; do for f in $O/legs_ab_${v}_*.log; do [[ -f $f ]] && python3 - "$v" "$f" <<'PY'
 import json,sys
 v,f=sys.argv[1],sys.argv[2]
 d=json.loads([l for l in open(f) if l.startswith('{')][-1])
 def sel(k):
     s=(d[k].get('selective_checkpointing') or {}).get('value')
     return f" (selective checkpointing {s:.1f})" if s else ""
-print(f"{v:9s}", "   ".join(f"{k} {d[k]['value']:.1f} {d[k]['unit'].split()[0]}/s, {d[k]['ms_per_step']:.1f} ms{sel(k)}" for k in ("cfg1","cfg3","lit","clip") if k in d))
+print(f"{v:5s}", "   ".join(f"{k} {d[k]['value']:.1f} {d[k]['unit'].split()[0]}/s, {d[k]['ms_per_step']:.1f} ms{sel(k)}" for k in ("cfg1","cfg3","lit","clip") if k in d))
 PY
-  done; done; } > profiles/r6_legs_ab_r6_vs_r5_routes.txt
+  done; done; } > profiles/r6_step_legs_ab_m16_vs_m32.txt
 ls profiles | grep r6_

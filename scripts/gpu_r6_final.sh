@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-6 evidence run (one gpurun call) of the code state at the time of the call: smoke, the GPU suite, the calibrated bench line with
 # every leg, rocprofv3 kernel stats of the headline leg and of the cfg1 / lit / clip / cfg3 legs, PMC traffic + SQ counters, microbenchmarks
-# (warm clocks), the phase trace of the fused S <= 128 attention backward, and the same-box A/B of the config legs against round 5's kernel
-# routing (variant r5routes: round-1 streaming attention beyond S = 128, standalone GELU backward).  Everything lands in gpurun_out/final6/;
+# (warm clocks), the phase trace of the fused S <= 128 attention backward, the plain GEMM against the vendor BLAS on the seven shapes, and the
+# same-box A/B of the headline step and the config legs against the 32x32x16 GEMMs (variant m32).  Everything lands in gpurun_out/final6/;
 # scripts/collect_r6.sh copies the summaries to profiles/r6_*.
 set -u
 mkdir -p gpurun_out/final6
@@ -41,6 +41,7 @@ for leg in cfg1 lit clip cfg3; do
 done
 # --- microbenchmarks (warm clocks: every shape runs >= 0.5 s before it is timed)
 timeout 400 python scripts/gemm_microbench.py --chunk 2048 --reps 10 > $O/gemm_microbench.txt 2>&1; tail -10 $O/gemm_microbench.txt
+timeout 300 python scripts/v6_vs_vendor.py time --seconds 1.0 --rounds 2 > $O/v6_vs_vendor_time.txt 2>&1; tail -9 $O/v6_vs_vendor_time.txt
 { echo "## shipped kernels, no rotation tables (what the engine passes beyond S = 128; image towers): S <= 128 single pass, S <= 256 K/V-resident forward, second-generation streaming kernels"; timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 128,197,256,512,2048,8192 --rotary 0;
   echo "## round 1's streaming kernels on the same box (cx_attn_set_fwd_long(0), cx_attn_set_bwd_long(0); 197 / 256: max_seqlen padded past 256 for the forward)"; timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 512,2048,8192 --rotary 0 --fwd-long 0 --bwd-long 0; timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 197,256 --rotary 0 --fwd-long 0 --bwd-long 0 --max-seqlen-pad 100;
   echo "## with rotation tables (S = 128: the metric's kernels rotate on load; beyond 128 the API's rotate-on-load path keeps round 1's kernels -- the engine pre-rotates instead)"; timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 128,2048 --rotary 1; } > $O/attn_microbench.txt 2>&1
@@ -50,15 +51,17 @@ timeout 300 python scripts/attn_microbench.py --tokens 262144 --seqs 128,197,204
 if [[ -f contrastors_amd/lib/variants/libcontrastors_hip_dev_attntrace.so ]]; then
   CONTRASTORS_HIP_DEV_LIB=contrastors_amd/lib/variants/libcontrastors_hip_dev_attntrace.so timeout 200 python scripts/attn_trace.py > $O/attn_bwd_s128_phase_trace.txt 2>&1
 fi
-# --- the config legs against round 5's kernel routing, same box, alternating libraries (host code identical)
+# --- the headline step and the config legs with the 32x32x16 GEMMs of commit ee8a813 (variant m32, see scripts/gpu_r6_m16.sh), same box,
+#     alternating libraries (host code identical).  (The A/B against round 5's attention / fusion routing -- variant r5routes -- was taken at
+#     ee8a813 and is on file: profiles/r6_legs_ab_r6_vs_r5_routes.txt.)
 L=contrastors_amd/lib
-if [[ -f $L/variants/libcontrastors_hip_r5routes.so ]]; then
-  cp $L/libcontrastors_hip.so /tmp/base.so
+if [[ -f $L/variants/libcontrastors_hip_m32.so ]]; then
   i=0
-  for v in base r5routes base r5routes; do
+  for v in base m32 base m32; do
     i=$((i+1))
-    if [[ $v == base ]]; then cp /tmp/base.so $L/libcontrastors_hip.so; else cp $L/variants/libcontrastors_hip_$v.so $L/libcontrastors_hip.so; fi
+    if [[ $v == base ]]; then unset CONTRASTORS_HIP_LIB; else export CONTRASTORS_HIP_LIB=$L/variants/libcontrastors_hip_$v.so; fi
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --no-config-legs --no-calibration > $O/step_ab_${v}_$i.log 2>&1
     timeout 900 python bench.py --steps 3 --warmup 1 --only-config-legs cfg1,lit,clip,cfg3 > $O/legs_ab_${v}_$i.log 2>&1
   done
-  cp /tmp/base.so $L/libcontrastors_hip.so
+  unset CONTRASTORS_HIP_LIB
 fi
