@@ -55,8 +55,8 @@ int cx_prof_gemm_config(int enable, int stride);
 int cx_prof_gemm_collect(double* total_ms, double* total_flop, long* launches_timed, long* launches_total);
 /* Per-box calibration for bench.py (cx_abi_version >= 9; measurement aids, no product kernel calls them): the pool's boxes differ
  * by +-3 % in sustained matrix-core clock at their power limit, so a roofline fraction is also reported against what THIS box
- * sustains.  cx_calib_mfma_bf16: register-only v_mfma_f32_32x32x16_bf16 loop, `nwg` workgroups of one wave per SIMD, each wave
- * `iters` x 8 MFMAs on fragments from seed (1024 x 16 B, random bf16): FLOPs = nwg * 4 * iters * 8 * 32768; cycles (NULL ok):
+ * sustains.  cx_calib_mfma_bf16: register-only v_mfma_f32_16x16x32_bf16 loop (the GEMMs' instruction), `nwg` workgroups of one wave per SIMD, each wave
+ * `iters` x 16 MFMAs (16 KFLOP each) on fragments from seed (1024 x 16 B, random bf16): FLOPs = nwg * 4 * iters * 8 * 32768; cycles (NULL ok):
  * nwg x 4 s_memtime deltas.  cx_calib_copy: 16 B per lane grid-stride copy, bytes % 16 == 0 (HBM stream rate). */
 int cx_calib_mfma_bf16(const void* seed_1024x16B, int iters, int nwg, long long* cycles_nwg_x4, float* sink, void* stream);
 int cx_calib_copy(const void* src, void* dst, long bytes, void* stream);

@@ -19,6 +19,7 @@ ap.add_argument("--max-seqlen-pad", type=int, default=0, help="pass max_seqlen =
 ap.add_argument("--warm-seconds", type=float, default=0.6, help="back-to-back launches before the first timed shape: the package at its sustained clock, not its boost clock (VERDICT r5 item 5a)")
 ap.add_argument("--pdrop", type=float, default=0.0, help="> 0: the attention-dropout entry points (cx_attn_varlen_dropout_fwd / _bwd)")
 ap.add_argument("--fwd-mode", type=int, default=None, help="cx_attn_set_fwd_s128 (dev library); with --pdrop: 0 = general kernel")
+ap.add_argument("--power", type=float, default=0.0, help="> 0: after timing a kernel, this many seconds of back-to-back launches with socket power / shader clock sampled (librocm_smi64)")
 ap.add_argument("--rotary", type=int, default=1, help="0: no rotation tables (image towers; what the engine passes for pre-rotated long sequences)")
 ap.add_argument("--fwd-long", type=int, default=None, help="cx_attn_set_fwd_long (dev library): 0 = round 1's streaming forward for S > 256")
 ap.add_argument("--bwd-long", type=int, default=None, help="cx_attn_set_bwd_long (dev library): 0 = round 1's delta + dQ + dK/dV kernels for S > 128")
@@ -79,5 +80,15 @@ for S in [int(x) for x in a.seqs.split(",")]:
         e1.record()
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) * 1e3 / a.reps)
+        if a.power > 0:
+            from scripts.box_calibration import SmiSampler
+            smp = SmiSampler(torch.cuda.current_device(), hz=20.0).start()
+            t_end = time.perf_counter() + a.power
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    fn()
+                torch.cuda.synchronize()
+            smi = smp.stop()
+            print(f"#   S = {S} {'fwd' if len(res) == 1 else 'bwd'}: {smi.get('mean_power_w', float('nan')):.0f} W, {smi.get('mean_sclk_mhz', float('nan')):.0f} MHz over {a.power:.1f} s of back-to-back launches")
     fl = 4.0 * S * S * D * B * H
     print(f"{S:5d} {B:5d} {res[0]:9.1f} {fl/res[0]/1e6:8.1f} {res[1]:9.1f} {2.5*fl/res[1]/1e6:8.1f}")

@@ -79,7 +79,7 @@ def calibrate(dev=None, mfma_seconds: float = 2.0, copy_gb: float = 2.0) -> dict
             out[prefix + "_ms"] = med
             out[prefix + "_launches"] = len(evs)
             out[prefix + "_clock_mhz"] = mean_cyc / (med * 1e-3) / 1e6 if med > 0 else None   # s_memtime ticks per wall second of the last launch
-            out[prefix + "_cycles_per_mfma"] = mean_cyc / (iters * 8)
+            out[prefix + "_cycles_per_mfma"] = mean_cyc / (iters * 8)   # per 32 KFLOP: two v_mfma_f32_16x16x32_bf16 since round 6 (one 32x32x16 before)
             out[prefix + "_power_w"] = smi["mean_power_w"]
             out[prefix + "_sclk_mhz"] = smi["mean_sclk_mhz"]
 
