@@ -29,9 +29,12 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(const uint4* __restrict
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)   // 16 x 16 KFLOP = the 8 x 32 KFLOP of the 32x32x16 form this probe used until round 5
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((i & 1) ? fa1 : fa0, (i & 2) ? fb1 : fb0, acc[i], 0, 0, 0);
+            // (inline asm, accumulator tied in place: through the builtin the compiler rotates the 16 small accumulators between
+            // iterations -- register copies and s_nop between the MFMAs, 27 cycles each instead of 17)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"((i & 1) ? fa1 : fa0), "v"((i & 2) ? fb1 : fb0));
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results read by VALU below: the hazard recogniser does not see into the asm
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
