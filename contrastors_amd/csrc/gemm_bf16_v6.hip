@@ -119,6 +119,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     constexpr bool SAVEG = EPI == GEMM_EPI_SWIGLU_G;        // the forward's optional save is the gate alone
     long long t_begin = 0, n_ktiles = 0;
     if constexpr (DBG != 0) t_begin = (long long)__builtin_amdgcn_s_memtime();
+    // DBG & 128 (trace builds): s_memtime phase sums of wave 0 over all of the workgroup's tiles -> p.trace[16 b + 2 ..]: 2 K loop, 3 epilogue
+    // prologue (first pass's arithmetic + staging), 4 row-read issue, 5 next pass's arithmetic, 6 its staging writes, 7 stores, 8 tile tail
+    // (fragment re-read, barrier).  An in-order wave's stamp between two groups is the issue time of the first, stalls included.
+    long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_begin;
+#define CX_PH(i_)                                                              \
+    do {                                                                       \
+        if constexpr ((DBG & 128) != 0) {                                      \
+            const long long now_ = (long long)__builtin_amdgcn_s_memtime();    \
+            ph[(i_)] += now_ - t_last;                                         \
+            t_last = now_;                                                     \
+        }                                                                      \
+    } while (0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,7 +361,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // other 4 of that K-tile follow below).  "All but the newest 4" stays correct across a tile end: the epilogue's global
         // stores are older than the next iteration's newest 4 and retire in order with them (gfx9 has one in-order vmcnt for
         // loads and stores), so they can only make that wait stronger, never weaker.
-        if constexpr ((DBG & 32) == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr ((DBG & 128) != 0) {   // trace builds: the counted DMA wait of a tile's FIRST K-tile (ph[0]: it also waits for the previous
+            // tile's stores, older on gfx9's one in-order vmcnt) and of the others (ph[1]), separately; their sum stays inside ph[2]
+            const long long w0_ = (long long)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            const long long w1_ = (long long)__builtin_amdgcn_s_memtime();
+            ph[decltype(first)::value ? 0 : 1] += w1_ - w0_;
+        } else if constexpr ((DBG & 32) == 0) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
         if constexpr ((DBG & 2) == 0) __builtin_amdgcn_s_barrier();
         const char* nxs = dsm + nxs_slot * XS6;
         const char* nws = dsm + (3 + nws_slot) * XS6;
@@ -372,6 +392,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         while (cp_kt < nk) kt_body(std::false_type{});
 
         {
+            CX_PH(2);
             // MFMA results are read by VALU below; the hazard recogniser does not see through the inline asm
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
             // ---- epilogue.  Free LDS: the X slot and the W slot just consumed (32 KiB each); waves 0,1 stage in the
@@ -755,23 +776,32 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         const int lrow = lane_p >> 5, lch = lane_p & 31, l15 = lane_p & 15, g4 = lane_p >> 4;   // (shadow the kernel's)
                         CX_STAGE_ALL
                         __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(4);
                         if constexpr (b < 3) { CX_LOAD_LO(b + 1) }  // rows 0..15 of the next pass fly under the arithmetic
 #if CX_V6_HI_EARLY
                         if constexpr (b < 3) { CX_LOAD_HI(b + 1) }  // ... and rows 16..31 with them (round 5)
 #endif
                         __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(5);
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             float da[16];
                             v6_read_block(4 * b + a, da);
+                            // (round 6: the block's 8 cells are read up front -- a lane reads and writes only its own cells, so nothing orders
+                            // a quad's reads behind the previous quad's writes but the compiler's alias analysis; read / wait / compute / write
+                            // per quad exposed an LDS round trip 16 times per pass: ~30 % of this phase, scripts/gemm_swiglu_trace.py)
+                            uint2 yy[4], gg[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                yy[q] = *reinterpret_cast<const uint2*>(cell((q >> 1) * 16 + l15, (a * 64 + (q & 1) * 16 + 4 * g4) * 2));
+                                gg[q] = *reinterpret_cast<const uint2*>(cell((q >> 1) * 16 + l15, (a * 64 + 32 + (q & 1) * 16 + 4 * g4) * 2));
+                            }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 char* py = cell((q >> 1) * 16 + l15, (a * 64 + (q & 1) * 16 + 4 * g4) * 2);
                                 char* pg = cell((q >> 1) * 16 + l15, (a * 64 + 32 + (q & 1) * 16 + 4 * g4) * 2);
-                                const uint2 yy = *reinterpret_cast<const uint2*>(py);
-                                const uint2 gg = *reinterpret_cast<const uint2*>(pg);
-                                const float y[4] = {bf16lo_to_f32(yy.x), bf16hi_to_f32(yy.x), bf16lo_to_f32(yy.y), bf16hi_to_f32(yy.y)};
-                                const float g[4] = {bf16lo_to_f32(gg.x), bf16hi_to_f32(gg.x), bf16lo_to_f32(gg.y), bf16hi_to_f32(gg.y)};
+                                const float y[4] = {bf16lo_to_f32(yy[q].x), bf16hi_to_f32(yy[q].x), bf16lo_to_f32(yy[q].y), bf16hi_to_f32(yy[q].y)};
+                                const float g[4] = {bf16lo_to_f32(gg[q].x), bf16hi_to_f32(gg[q].x), bf16lo_to_f32(gg[q].y), bf16hi_to_f32(gg[q].y)};
                                 float dy[4], dg[4];
                                 bwd_quad(y, g, &da[4 * q], dy, dg);
                                 uint2 o;
@@ -786,6 +816,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         if constexpr (b < 3) { CX_LOAD_HI(b + 1) }  // rows 16..31: still ahead of this pass's stores
 #endif
                         __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(6);
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {  // (named registers: a small uint4 array lands in scratch memory here)
                             const uint4 v0 = *reinterpret_cast<const uint4*>(cell((h * 4 + 0) * 2 + lrow, lch * 16));
@@ -798,8 +829,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                             gst(o + (size_t)4 * p.ldo, v2);
                             gst(o + (size_t)6 * p.ldo, v3);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(7);
                     };
                     CX_LOAD_LO(0) CX_LOAD_HI(0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    CX_PH(3);
                     one_pass(std::integral_constant<int, 0>{});
                     one_pass(std::integral_constant<int, 1>{});
                     one_pass(std::integral_constant<int, 2>{});
@@ -1009,9 +1044,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         const uint4 a0 = *reinterpret_cast<const uint4*>(rda + 0 * AROWB), a1 = *reinterpret_cast<const uint4*>(rda + 8 * AROWB),
                                     a2 = *reinterpret_cast<const uint4*>(rda + 16 * AROWB), a3 = *reinterpret_cast<const uint4*>(rda + 24 * AROWB);
                         __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(4);
                         if constexpr (b < 3) compute_pass(b + 1);
                         __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(5);
                         if constexpr (b < 3) stage();  // the LDS executes a wave's operations in order: these follow the row reads
+                        __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(6);
                         if constexpr (SAVE_YG) {
                             bf16_t* o = ygp + (size_t)(b * 32) * p.ldo;
                             gst(o, v0);
@@ -1035,9 +1074,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         gst(oa + (size_t)8 * p.ldo2, a1);
                         gst(oa + (size_t)16 * p.ldo2, a2);
                         gst(oa + (size_t)24 * p.ldo2, a3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        CX_PH(7);
                     };
                     compute_pass(0);
                     stage();
+                    __builtin_amdgcn_sched_barrier(0);
+                    CX_PH(3);
                     one_pass(std::integral_constant<int, 0>{});
                     one_pass(std::integral_constant<int, 1>{});
                     one_pass(std::integral_constant<int, 2>{});
@@ -1148,15 +1191,23 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
             // the staging areas are the DMA targets of the next iteration: nobody may still be reading them
             __builtin_amdgcn_s_barrier();
+            CX_PH(8);
         }
     }
+#undef CX_PH
 #undef CX_DMA_M0
 #undef CX_DMA_LD
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cursors' dummy DMAs must land before the LDS is handed on
     if constexpr (DBG != 0) {
         if (p.trace && tid == 0) {
-            p.trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
-            p.trace[2 * blockIdx.x + 1] = n_ktiles;
+            p.trace[16 * blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+            p.trace[16 * blockIdx.x + 1] = n_ktiles;
+            if constexpr ((DBG & 128) != 0) {
+#pragma unroll
+                for (int i = 2; i < 9; ++i) p.trace[16 * blockIdx.x + i] = ph[i];
+                p.trace[16 * blockIdx.x + 9] = ph[0];
+                p.trace[16 * blockIdx.x + 10] = ph[1];
+            }
         }
     }
 }
@@ -1477,6 +1528,13 @@ hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream) {
             case 128: return launch6<GEMM_EPI_NONE, 128>(p, stream);  // trace only
             default: break;
         }
+    }
+#endif
+#ifndef CX_PRODUCT
+    if (g_v6_dbg == 128 && (epi == GEMM_EPI_SWIGLU_G || epi == GEMM_EPI_SWIGLU || epi == GEMM_EPI_SWIGLU_BWD_AG)) {   // phase traces of the fused SwiGLU epilogues
+        p.trace = g_v6_trace;
+        return epi == GEMM_EPI_SWIGLU_G ? launch6<GEMM_EPI_SWIGLU_G, 128>(p, stream)
+               : epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU, 128>(p, stream) : launch6<GEMM_EPI_SWIGLU_BWD_AG, 128>(p, stream);
     }
 #endif
     return epi == GEMM_EPI_SWIGLU ? launch6<GEMM_EPI_SWIGLU>(p, stream)

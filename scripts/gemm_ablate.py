@@ -22,7 +22,7 @@ masks = [(128, "full kernel (trace only)"), (128, "full kernel again"), (64, "ep
          (32, "no DMA wait"), (33, "no DMA, no wait"), (35, "no DMA/wait/barrier"), (39, "MFMA only (+epilogue)"),
          (55, "MFMA only, no epilogue"), (59, "reads only: no DMA/wait/barrier/MFMA/epilogue")]
 s = torch.cuda.current_stream().cuda_stream
-trace = torch.zeros(256 * 2, dtype=torch.int64, device="cuda")
+trace = torch.zeros(256 * 16, dtype=torch.int64, device="cuda")
 lib.cx_gemm_v6_trace(trace.data_ptr())
 for name, (M, N, K) in shapes.items():
     x = torch.randn(M, K, device="cuda").bfloat16()
@@ -41,7 +41,7 @@ for name, (M, N, K) in shapes.items():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.reps
-        tr = trace.view(256, 2).cpu()
+        tr = trace.view(256, 16).cpu()
         cyc, kt = tr[:, 0].double(), tr[:, 1].double()
         per_kt = float((cyc / kt.clamp(min=1)).mean())
         nk = K // 64
