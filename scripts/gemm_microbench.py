@@ -119,6 +119,13 @@ if not a.shape and not a.only:
     fused["fc2 dgrad + gelu bwd + db (fused)"] = (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_act_bwd(
         x.data_ptr(), w2t.data_ptr(), act.data_ptr(), dpre.data_ptr(), dbias.data_ptr(), wsb.data_ptr(), wsb.numel(), T, I, d, d, d, I, I, 0, s))
     fused["fc2 dgrad, then gelu bwd + db"] = (2.0 * T * I * d, two_kernels)
+    # the plain MLP's forward: fc1 + bias + erf-GELU (BERT-base / ViT towers), pre-activation kept (training) or not (no-grad pass)
+    wg = (torch.randn(I, d, device=dev) * 0.05).bfloat16()
+    bg = torch.randn(I, device=dev) * 0.1
+    pre = torch.empty(T, I, device=dev, dtype=torch.bfloat16)
+    fused["fc1 + bias + gelu (save pre)"] = (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_bias_gelu(x.data_ptr(), wg.data_ptr(), bg.data_ptr(), pre.data_ptr(), dact.data_ptr(), T, I, d, d, d, I, I, s))
+    fused["fc1 + bias + gelu (no save)"] = (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_bias_gelu(x.data_ptr(), wg.data_ptr(), bg.data_ptr(), None, dact.data_ptr(), T, I, d, d, d, I, I, s))
+    fused["fc1 plain (same shape)"] = (2.0 * T * I * d, lambda: lib.cx_gemm_bf16_nt(x.data_ptr(), wg.data_ptr(), dact.data_ptr(), None, T, I, d, d, d, I, 0, 1, 1.0, s))
     for name, (fl, run) in fused.items():
         for _ in range(3):
             assert run() == 0, name
