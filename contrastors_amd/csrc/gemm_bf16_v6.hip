@@ -908,6 +908,117 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             } else if constexpr (EPI == GEMM_EPI_GELU || EPI == GEMM_EPI_QGELU) {
                 // fc1 of the plain MLP (sc/layers/mlp.py:30-34): pre = acc + bias (bf16, kept for backward when p.Out is
                 // set), act = gelu_erf(pre).  The standalone op sees the bf16-rounded pre-activation; so does this one.
+                constexpr int act_kind = EPI == GEMM_EPI_QGELU ? CX_ACT_QUICK_GELU : CX_ACT_GELU;
+                // ---- fast path (interior tiles; round 6).  The first version below costs the launch +39 ... +49 % over the plain GEMM of the same
+                // shape (profiles/r6_microbench_gemm2048.txt): per pass it re-loads its 16 bias quads from global memory (the compiler cannot
+                // carry them across the stores), and each of its two outputs goes stage -> wait -> 8 x (row read -> predicated store) with the
+                // LDS round trip exposed.  Here: the bias in registers once per tile (a lane has only 8 distinct quads: piece q and q + 2 share
+                // their columns), the outputs as half-passes through ONE staging region -- the rows of a half-pass are read, the next half-pass's
+                // arithmetic runs under the read latency (the erf arithmetic of this pass under the pre-activation rows; the next pass's
+                // accumulator read + bias + rounding under the activation rows), its staging writes queue behind the reads, stores unpredicated.
+                auto fast_gelu = [&](auto save_c) {
+                    constexpr bool SAVE = decltype(save_c)::value;
+                    const int rrow = lane >> 4, rch = lane & 15;
+                    bf16_t* prep = SAVE ? reinterpret_cast<bf16_t*>(p.Out) + (size_t)(m0 + rrow) * p.ldo + n0 + rch * 8 : nullptr;
+                    bf16_t* actp = reinterpret_cast<bf16_t*>(p.Out2) + (size_t)(m0 + rrow) * p.ldo2 + n0 + rch * 8;
+                    const char* rd = my + rrow * ROWB + rch * 16;
+                    char* wr = my + prow(0) * ROWB + pcol(0) * 2;
+                    float4 bq[8];   // [2 a + (q & 1)]
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            bq[2 * a + h] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + a * 32 + pcol(h)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    uint2 pkp[16], pka[16];
+                    // part A of a pass: accumulators + bias, rounded to bf16 (the packed words ARE the pre-activation that is stored)
+                    auto part_a = [&](int b) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            float blk[16];
+                            v6_read_block(4 * b + a, blk);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 bv = bq[2 * a + (q & 1)];
+                                pkp[a * 4 + q].x = pack_bf16x2(blk[4 * q] + bv.x, blk[4 * q + 1] + bv.y);
+                                pkp[a * 4 + q].y = pack_bf16x2(blk[4 * q + 2] + bv.z, blk[4 * q + 3] + bv.w);
+                            }
+                        }
+                    };
+                    // part B: the activation of the rounded pre-activation
+                    auto part_b = [&]() {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float v0 = bf16lo_to_f32(pkp[i].x), v1 = bf16hi_to_f32(pkp[i].x), v2 = bf16lo_to_f32(pkp[i].y), v3 = bf16hi_to_f32(pkp[i].y);
+                            pka[i].x = pack_bf16x2(act_val(v0, act_kind), act_val(v1, act_kind));
+                            pka[i].y = pack_bf16x2(act_val(v2, act_kind), act_val(v3, act_kind));
+                        }
+                    };
+                    auto stage = [&](const uint2 (&pk)[16]) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(wr + a * 64 + qoff(q, ROWB)) = pk[a * 4 + q];
+                    };
+#define CX_ROWS8                                                                                                      \
+    uint4 v0 = *reinterpret_cast<const uint4*>(rd + 0 * ROWB), v1 = *reinterpret_cast<const uint4*>(rd + 4 * ROWB),    \
+          v2 = *reinterpret_cast<const uint4*>(rd + 8 * ROWB), v3 = *reinterpret_cast<const uint4*>(rd + 12 * ROWB),   \
+          v4 = *reinterpret_cast<const uint4*>(rd + 16 * ROWB), v5 = *reinterpret_cast<const uint4*>(rd + 20 * ROWB),  \
+          v6 = *reinterpret_cast<const uint4*>(rd + 24 * ROWB), v7 = *reinterpret_cast<const uint4*>(rd + 28 * ROWB);  \
+    __builtin_amdgcn_sched_barrier(0);
+#define CX_STORE8(o_, ld_)                                                                                            \
+    gst(o_, v0); gst(o_ + (size_t)4 * (ld_), v1); gst(o_ + (size_t)8 * (ld_), v2); gst(o_ + (size_t)12 * (ld_), v3);   \
+    gst(o_ + (size_t)16 * (ld_), v4); gst(o_ + (size_t)20 * (ld_), v5); gst(o_ + (size_t)24 * (ld_), v6); gst(o_ + (size_t)28 * (ld_), v7);
+                    auto one_pass = [&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        if constexpr (SAVE) {   // on entry: the pre-activation rows of pass b are staged, pkp holds them
+                            {
+                                CX_ROWS8
+                                part_b();
+                                __builtin_amdgcn_sched_barrier(0);
+                                stage(pka);   // (the LDS executes a wave's operations in order: behind the row reads)
+                                bf16_t* o = prep + (size_t)(b * 32) * p.ldo;
+                                CX_STORE8(o, p.ldo)
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            {
+                                CX_ROWS8
+                                if constexpr (b < 3) part_a(b + 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (b < 3) stage(pkp);
+                                bf16_t* o = actp + (size_t)(b * 32) * p.ldo2;
+                                CX_STORE8(o, p.ldo2)
+                            }
+                        } else {                // on entry: the activation rows of pass b are staged
+                            CX_ROWS8
+                            if constexpr (b < 3) { part_a(b + 1); part_b(); }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (b < 3) stage(pka);
+                            bf16_t* o = actp + (size_t)(b * 32) * p.ldo2;
+                            CX_STORE8(o, p.ldo2)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    part_a(0);
+                    if constexpr (SAVE) {
+                        stage(pkp);
+                    } else {
+                        part_b();
+                        stage(pka);
+                    }
+                    one_pass(std::integral_constant<int, 0>{});
+                    one_pass(std::integral_constant<int, 1>{});
+                    one_pass(std::integral_constant<int, 2>{});
+                    one_pass(std::integral_constant<int, 3>{});
+#undef CX_ROWS8
+#undef CX_STORE8
+                };
+                if (m0 + 128 <= p.M && n0 + 128 <= p.N) {
+                    if (p.Out) {
+                        fast_gelu(std::true_type{});
+                    } else {
+                        fast_gelu(std::false_type{});
+                    }
+                } else
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     float pre[4][16];
