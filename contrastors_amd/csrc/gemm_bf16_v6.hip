@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // DBG & 128 (trace builds): s_memtime phase sums of wave 0 over all of the workgroup's tiles -> p.trace[16 b + 2 ..]: 2 K loop, 3 epilogue
     // prologue (first pass's arithmetic + staging), 4 row-read issue, 5 next pass's arithmetic, 6 its staging writes, 7 stores, 8 tile tail
     // (fragment re-read, barrier).  An in-order wave's stamp between two groups is the issue time of the first, stalls included.
-    long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_begin;
+    long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_begin, kt0_cyc = 0;
 #define CX_PH(i_)                                                              \
     do {                                                                       \
         if constexpr ((DBG & 128) != 0) {                                      \
@@ -377,6 +377,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // next tile: its operands have landed too), then the other 4 X instructions
         CX_SEG(mma1, F1, 32, 64, F0, nxs, nws, 0, RS_ == 2 ? 32 : 33, RS_, 2, RS_ == 2 ? 33 : 49, RS_ == 2 ? 8 : DS_, 4, 4);
         x_advance();
+        if constexpr ((DBG & 128) != 0 && decltype(first)::value) {   // trace builds: the tile's first K-tile on its own (ph[0] reused: see below)
+            const long long now_ = (long long)__builtin_amdgcn_s_memtime();
+            kt0_cyc += now_ - t_last;
+        }
         ++cp_kt;
         pxs_slot = xs_slot;
         pws_slot = ws_slot;
@@ -1318,6 +1322,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 for (int i = 2; i < 9; ++i) p.trace[16 * blockIdx.x + i] = ph[i];
                 p.trace[16 * blockIdx.x + 9] = ph[0];
                 p.trace[16 * blockIdx.x + 10] = ph[1];
+                p.trace[16 * blockIdx.x + 11] = kt0_cyc;   // the first K-tile of every tile (part of ph[2])
             }
         }
     }

@@ -47,7 +47,7 @@ for save in (True, False):
     for i in range(2, 9):
         v = float((tr[:, i] / tiles).mean())
         print(f"    {names[i]:52s} {v:8.0f}  {100 * v / float((tot / tiles).mean()):5.1f} %")
-    print(f"    (inside the K loop: the counted DMA wait of the tile's first K-tile {float((tr[:, 9] / tiles).mean()):.0f}, of the other 11 together {float((tr[:, 10] / tiles).mean()):.0f}; an s_memtime pair alone reads ~{40})")
+    print(f"    (inside the K loop: the counted DMA wait of the tile's first K-tile {float((tr[:, 9] / tiles).mean()):.0f}, of the other 11 together {float((tr[:, 10] / tiles).mean()):.0f}; an s_memtime pair alone reads ~{40}; the first K-tile as a whole {float((tr[:, 11] / tiles).mean()):.0f} cycles, the other 11 {float(((tr[:, 2] - tr[:, 11]) / tiles).mean()) / 11:.0f} each)")
 # ---- fc2 dgrad + SwiGLU backward from (act, gate): gemm_bf16_v6_kernel<SWIGLU_BWD_AG>
 dy = torch.randn(T, d, device="cuda").bfloat16()
 w2t = (torch.randn(I, d, device="cuda") * 0.05).bfloat16()
