@@ -34,7 +34,7 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-DEV_ONLY = {"gemm_bf16.hip", "gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "probe.hip"}   # earlier GEMM generations, probes
+DEV_ONLY = {"gemm_bf16.hip", "probe.hip"}   # earlier GEMM generations (v1 / v2 + the dev dispatch), probes
 PRODUCT_ONLY = {"gemm_api.hip"}                                                      # the product's GEMM entry points
 DEV_LIB = LIBDIR / "libcontrastors_hip_dev.so"
 

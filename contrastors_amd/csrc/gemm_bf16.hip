@@ -609,7 +609,7 @@ hipError_t launch_v2(const GemmParams& p_in, int out_mode, hipStream_t stream) {
 }
 
 int g_dbg = 0;
-int g_variant = 5;  // 5: v5 256x256x64 (default);  3: v3 persistent 256x256x32;  2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
+int g_variant = 5;  // 5: v5 256x256x64 (default; 3 and 4 -- generations deleted in round 6 -- alias to it);  2: v2 (256x128, 3-stage ring);  1: v1 (128x128, 2-stage)
 
 int g_use_glds = 1;
 
@@ -675,10 +675,8 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
     GemmParams p;
     p.X = X; p.W = W; p.Out = Out; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
-    const bool v5 = (g_variant == 5) && g_use_glds && out_mode != OUT_F32_ATOMIC;
-    const bool v4 = (g_variant == 4) && g_use_glds && out_mode != OUT_F32_ATOMIC;
-    const bool v3 = (g_variant == 3) && g_use_glds && out_mode != OUT_F32_ATOMIC;
-    const bool v2 = ((g_variant == 2) || (g_variant >= 3 && !v3 && !v4 && !v5)) && g_use_glds;
+    const bool v5 = (g_variant >= 3) && g_use_glds && out_mode != OUT_F32_ATOMIC;
+    const bool v2 = ((g_variant == 2) || (g_variant >= 3 && !v5)) && g_use_glds;
     p.tiles_m = v2 ? (M + V2_BM - 1) / V2_BM : (M + BM - 1) / BM;
     p.tiles_n = v2 ? (N + V2_BN - 1) / V2_BN : (N + BN - 1) / BN;
     const int nk = K / BK;
@@ -706,8 +704,6 @@ int cx_gemm_bf16_nt(const uint16_t* X, const uint16_t* W, void* Out, const float
         ++g_prof.launches;
     }
     hipError_t e = v5 ? cx_launch_gemm_v5(p, 0, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
-                   : v4 ? cx_launch_gemm_v4(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
-                   : v3 ? cx_launch_gemm_v3(p, out_mode, GEMM_EPI_NONE, (hipStream_t)stream)
                    : v2 ? launch_v2(p, out_mode, (hipStream_t)stream)
                       : (g_use_glds ? launch_mode<true>(p, out_mode, (hipStream_t)stream)
                                     : launch_mode<false>(p, out_mode, (hipStream_t)stream));
@@ -725,26 +721,24 @@ int cx_gemm_bf16_nt_accum(const uint16_t* X, const uint16_t* W, float* Out, floa
     if (!ws || !Out) return CX_ERR_ARG;
     const long slab = (long)M * N;
     if (ws_floats < slab) return CX_ERR_SHAPE;
-    const bool v5 = (g_variant == 5) && g_use_glds;
-    const bool v3 = (g_variant == 3 || v5) && g_use_glds;  // same 256x256 tile count
-    const bool v2 = (g_variant == 2 || g_variant == 4) && g_use_glds;
-    const long tiles = v3 ? (long)((M + 255) / 256) * ((N + 255) / 256)
+    const bool v5 = (g_variant >= 3) && g_use_glds;
+    const bool v2 = (g_variant == 2) && g_use_glds;
+    const long tiles = v5 ? (long)((M + 255) / 256) * ((N + 255) / 256)
                      : v2 ? (long)((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN)
                           : (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const long nk = K / BK;
     long max_split = nk / 4;                               // keep >= 4 K-tiles per slice (pipeline depth)
     if (max_split > ws_floats / slab) max_split = ws_floats / slab;
     if (max_split > 16) max_split = 16;
-    long split = choose_split(tiles, max_split, (v2 || v3) ? 256 : 512);
+    long split = choose_split(tiles, max_split, (v2 || v5) ? 256 : 512);
     int rc;
-    if (v3) {
+    if (v5) {
         GemmParams p;
         p.X = X; p.W = W; p.Out = ws; p.bias = nullptr;
         p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldo = N;
         p.tiles_m = p.tiles_n = 0; p.split_k = (int)split; p.alpha = 1.f; p.dbg = g_dbg; p.Out2 = nullptr; p.ldo2 = 0; p.sup_m = p.sup_n = 0;
         split = p.split_k;
-        const hipError_t he = v5 ? cx_launch_gemm_v5(p, 0, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream)
-                                 : cx_launch_gemm_v3(p, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream);
+        const hipError_t he = cx_launch_gemm_v5(p, 0, GEMM_OUT_F32_PARTIAL, GEMM_EPI_NONE, (hipStream_t)stream);
         rc = he == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
     } else if (v2) {
         GemmParams p;
@@ -857,9 +851,7 @@ int cx_gemm_bf16_swiglu(const uint16_t* X, const uint16_t* W, uint16_t* YG, uint
         }
         ++g_prof.launches;
     }
-    hipError_t e = (g_variant == 5) ? cx_launch_gemm_v5(p, 0, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream)
-                   : (g_variant == 4) ? cx_launch_gemm_v4(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream)
-                                    : cx_launch_gemm_v3(p, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream);
+    hipError_t e = cx_launch_gemm_v5(p, 0, GEMM_OUT_BF16, GEMM_EPI_SWIGLU, (hipStream_t)stream);
     if (slot >= 0) (void)hipEventRecord(g_prof.ev1[slot], (hipStream_t)stream);
     return e == hipSuccess ? CX_OK : CX_ERR_LAUNCH;
 }

@@ -32,8 +32,6 @@ struct GemmParams {
     long long* trace;  // v5p only (set by its launcher): per-workgroup phase cycle counters, or nullptr
 };
 
-hipError_t cx_launch_gemm_v3(GemmParams p, int out_mode, int epi, hipStream_t stream);
-hipError_t cx_launch_gemm_v4(GemmParams p, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v5(GemmParams p, int form, int out_mode, int epi, hipStream_t stream);
 hipError_t cx_launch_gemm_v6(GemmParams p, int epi, hipStream_t stream);
 void cx_gemm_v6_force_groups(int gn);

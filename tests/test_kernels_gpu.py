@@ -50,7 +50,7 @@ def _gemm_lib(variant):
     if variant in ("product", 6):
         return L()
     lib = LD()
-    lib.cx_gemm_set_variant({"v6": 6, "v5": 5, "v4": 4, "v3": 3, "v2": 2}.get(variant, variant if isinstance(variant, int) else 1))
+    lib.cx_gemm_set_variant({"v6": 6, "v5": 5, "v2": 2}.get(variant, variant if isinstance(variant, int) else 1))
     lib.cx_gemm_set_glds(0 if variant == "v1_reg" else 1)
     return lib
 
@@ -60,7 +60,7 @@ def _gemm_lib_reset():
     LD().cx_gemm_set_glds(1)
 
 
-@pytest.mark.parametrize("variant", ["product", "v6", "v5", "v4", "v3", "v2", "v1_glds", "v1_reg"])
+@pytest.mark.parametrize("variant", ["product", "v6", "v5", "v2", "v1_glds", "v1_reg"])
 @pytest.mark.parametrize("M,N,K", [(8192, 2304, 768), (8192, 768, 3072), (1000, 768, 768), (130, 132, 64),
                                    (257, 6144, 768), (300, 768, 128)])
 def test_gemm_bf16_nt(variant, M, N, K):
@@ -95,11 +95,11 @@ def test_gemm_bf16_nt(variant, M, N, K):
         _gemm_lib_reset()
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5, 6])
+@pytest.mark.parametrize("variant", [5, 6])
 @pytest.mark.parametrize("M,I,K", [(8192, 3072, 768), (300, 512, 256), (257, 96, 64)])
 def test_gemm_swiglu_fused(M, I, K, variant):
     """fc11 || fc12 GEMM with SwiGLU in the epilogue == standalone GEMM + swiglu (interleaved-by-32 weight rows)."""
-    lib = _gemm_lib(variant)  # 6 -> product library; 2 -> fused epilogue on the v3 kernel, 4 -> v4, 5 -> v5/v6 (dev library)
+    lib = _gemm_lib(variant)  # 6 -> product library; 5 -> the v5 kernel's fused epilogue (dev library)
     x = bf(_randn(M, K, seed=90))
     w11, w12 = bf(_randn(I, K, seed=91, std=0.05)), bf(_randn(I, K, seed=92, std=0.05))
     wi = torch.stack([w11.view(I // 32, 32, K), w12.view(I // 32, 32, K)], 1).reshape(2 * I, K).contiguous()
