@@ -350,5 +350,14 @@ def test_two_tenants_at_the_metric_per_rank_shape(tmp_path):
     for k in range(2):
         assert all(np.isfinite(s["loss"]) for s in r[k]["steps"]), r[k]
     assert abs(r[0]["grad_abs_sum"] - r[1]["grad_abs_sum"]) <= 1e-6 * r[0]["grad_abs_sum"]
-    assert r[0]["steps"][0]["agreed_free_gb"] == r[1]["steps"][0]["agreed_free_gb"] > 0, r
+    # step 0: the figure the ranks agreed on -- except that a rank which ran out of memory has clamped ITS copy to what it measured then
+    # (loss.note_local_memory_shortfall, round 6: no collective inside a fallback), so it may only be smaller; step 1 starts with the
+    # second agreement of the process group: identical again on both ranks
+    a0 = [r[k]["steps"][0]["agreed_free_gb"] for k in range(2)]
+    fb0 = [bool(r[k]["steps"][0]["fell_back"]) for k in range(2)]
+    if not any(fb0):
+        assert a0[0] == a0[1] > 0, r
+    else:
+        assert all(0 < a0[k] <= max(a0) for k in range(2)) and all(a0[k] == max(a0) for k in range(2) if not fb0[k]), r
+    assert r[0]["steps"][1]["agreed_free_gb"] == r[1]["steps"][1]["agreed_free_gb"] > 0, r
     assert [s["schedule"] for s in r[0]["steps"]] == [s["schedule"] for s in r[1]["steps"]] or any(s["fell_back"] for k in range(2) for s in r[k]["steps"]), r
